@@ -1,0 +1,298 @@
+"""CPU oracle for ALADIN's alignment-scoring / matching-retrieval hot path.  TEST INFRASTRUCTURE.
+
+This file is the checker, never the product: only ``tests/``, ``__graft_entry__.smoke()`` and
+``bench.py``'s ``cpu_baseline`` leg may import it.  The product path (``aladin_amd``) runs the
+HIP kernels in ``aladin_amd/csrc`` and raises if the extension is missing.
+
+It is a numpy restatement (closed forms) of the reference's algorithm; each
+function cites the reference lines (relative to /root/reference) it follows.  The reference is pure
+Python/PyTorch and holds no tests or golden vectors of its own, so parity is PINNED against outputs
+of the reference itself: ``tests/golden/make_golden.py`` imports ``alad.loss`` /
+``alad.recall_auxiliary`` / ``alad.evaluation`` / ``alad.alad_model`` from /root/reference (in the
+build container only) and commits their outputs as ``tests/golden/*.npz``;
+``tests/test_oracle_golden.py`` checks every function below against those fixtures.
+"""
+import numpy as np
+
+F_EPS = 1e-12          # torch.nn.functional.normalize default eps (alad/loss.py:80-81)
+
+
+# ----------------------------------------------------------------------------------------------
+# normalisation
+# ----------------------------------------------------------------------------------------------
+def normalize_rows(x, eps=F_EPS):
+    """x / max(||x||_2, eps) along the last axis -- F.normalize(p=2, dim=2), alad/loss.py:80-81."""
+    n = np.sqrt(np.sum(x.astype(np.float64) ** 2, axis=-1, keepdims=True))
+    return (x / np.maximum(n, eps)).astype(x.dtype)
+
+
+def l2norm(x):
+    """X / sqrt(sum_dim1 X^2), NO eps (zero rows -> NaN) -- alad/utils.py:134-139."""
+    with np.errstate(invalid='ignore', divide='ignore'):
+        n = np.sqrt(np.sum(x * x, axis=1, keepdims=True))
+        return x / n
+
+
+# ----------------------------------------------------------------------------------------------
+# alignment scores (alad/loss.py:79-135)
+# ----------------------------------------------------------------------------------------------
+def masked_alignments(im_set, s_seq, im_len, s_len, dtype=np.float32):
+    """The (Bi, Bc, R', T') tensor of alad/loss.py:97-116: region x word cosines after dropping
+    region 0 / token 0 / the last two token columns (:87-88), zero where r >= im_len-1 or
+    w >= s_len-3 (:89-90,103-116).  Materialises Bi*Bc*R'*T' floats: small cases only."""
+    im = normalize_rows(np.asarray(im_set, dtype))[:, 1:, :]
+    s = normalize_rows(np.asarray(s_seq, dtype))[:, 1:-2, :]
+    Bi, Rp, D = im.shape
+    Bc, Tp, _ = s.shape
+    A = (im.reshape(Bi * Rp, D) @ s.reshape(Bc * Tp, D).T).reshape(Bi, Rp, Bc, Tp)
+    A = np.ascontiguousarray(A.transpose(0, 2, 1, 3))
+    Li = np.asarray(im_len) - 1
+    Lj = np.asarray(s_len) - 3
+    rmask = np.arange(Rp)[None, :] >= Li[:, None]          # (Bi, R')
+    wmask = np.arange(Tp)[None, :] >= Lj[:, None]          # (Bc, T')
+    A[np.broadcast_to(rmask[:, None, :, None] | wmask[None, :, None, :], A.shape)] = 0
+    return A
+
+
+def alignment_scores(im_set, s_seq, im_len, s_len, aggregation='MrSw', dtype=np.float32,
+                     block=32):
+    """S (Bi, Bc) for the pooling modes of alad/loss.py:120-135.  Blocked over images so that
+    B=256 needs ~50 MB instead of the reference's 16 GB of expanded operands."""
+    im_set = np.asarray(im_set)
+    Bi = im_set.shape[0]
+    out = []
+    for i0 in range(0, Bi, block):
+        A = masked_alignments(im_set[i0:i0 + block], s_seq, im_len[i0:i0 + block], s_len, dtype)
+        if aggregation == 'MrSw':                       # :124-125
+            S = A.max(2).sum(2)
+        elif aggregation == 'MrAVGw':                   # :126-129
+            S = A.max(2).sum(2) / (np.asarray(s_len, dtype) - 3)[None, :]
+        elif aggregation == 'MwSr':                     # :134-135
+            S = A.max(3).sum(2)
+        elif aggregation == 'symm':                     # :130-133
+            S = A.max(2).sum(2) + A.max(3).sum(2)
+        elif aggregation == 'sum':                      # :120-121
+            S = A.sum((2, 3))
+        elif aggregation == 'mean':                     # :122-123 (divides by the padded sizes)
+            S = A.mean((2, 3))
+        else:
+            raise ValueError('aggregation %r not restated' % (aggregation,))
+        out.append(S)
+    return np.concatenate(out, 0).astype(dtype)
+
+
+# ----------------------------------------------------------------------------------------------
+# hinge / VSE++ (alad/loss.py:42-67)
+# ----------------------------------------------------------------------------------------------
+def hinge_loss(S, margin, max_violation, return_grad=False):
+    """loss (and dloss/dS) of Contrastive.compute_contrastive_loss, alad/loss.py:42-67."""
+    S = np.asarray(S)
+    if S.shape[0] != S.shape[1]:
+        raise ValueError('hinge loss needs a square score matrix')
+    B = S.shape[0]
+    d = np.diag(S)
+    cs = np.clip(margin + S - d[:, None], 0, None)        # :49   compare with the row's diagonal
+    ci = np.clip(margin + S - d[None, :], 0, None)        # :52   compare with the column's diagonal
+    np.fill_diagonal(cs, 0)
+    np.fill_diagonal(ci, 0)                               # :55-60
+    dS = np.zeros_like(S)
+    if max_violation:                                     # :63-65
+        loss = cs.max(1).sum() + ci.max(0).sum()
+        if return_grad:
+            js = cs.argmax(1)
+            for i in range(B):
+                if cs[i, js[i]] > 0:
+                    dS[i, js[i]] += 1
+                    dS[i, i] -= 1
+            is_ = ci.argmax(0)
+            for j in range(B):
+                if ci[is_[j], j] > 0:
+                    dS[is_[j], j] += 1
+                    dS[j, j] -= 1
+    else:
+        loss = cs.sum() + ci.sum()                        # :67
+        if return_grad:
+            P = (cs > 0).astype(S.dtype)
+            Q = (ci > 0).astype(S.dtype)
+            dS = P + Q - np.diag(P.sum(1)) - np.diag(Q.sum(0))
+    loss = S.dtype.type(loss)
+    return (loss, dS) if return_grad else loss
+
+
+# ----------------------------------------------------------------------------------------------
+# backward of S w.r.t. the raw sets (autograd of alad/loss.py:80-125), MrSw only
+# ----------------------------------------------------------------------------------------------
+def alignment_scores_backward(im_set, s_seq, im_len, s_len, dS, dtype=np.float64):
+    """(d im_set, d s_seq) for upstream gradient dS (Bi, Bc).  Python loops: small cases only."""
+    im_set = np.asarray(im_set, dtype)
+    s_seq = np.asarray(s_seq, dtype)
+    Bi, R, D = im_set.shape
+    Bc, T, _ = s_seq.shape
+    Rp, Tp = R - 1, T - 3
+    n_im = np.maximum(np.sqrt((im_set ** 2).sum(-1, keepdims=True)), F_EPS)
+    n_s = np.maximum(np.sqrt((s_seq ** 2).sum(-1, keepdims=True)), F_EPS)
+    ih, sh = im_set / n_im, s_seq / n_s
+    dih, dsh = np.zeros_like(ih), np.zeros_like(sh)
+    for i in range(Bi):
+        Li = im_len[i] - 1
+        for j in range(Bc):
+            g = dS[i, j]
+            if g == 0:
+                continue
+            Lj = s_len[j] - 3
+            A = ih[i, 1:1 + Li] @ sh[j, 1:1 + Lj].T            # (Li, Lj)
+            rstar = A.argmax(0)
+            for w in range(Lj):
+                r = rstar[w]
+                if Li < Rp and A[r, w] <= 0:                   # the zero fill of :116 won the max
+                    continue
+                dih[i, 1 + r] += g * sh[j, 1 + w]
+                dsh[j, 1 + w] += g * ih[i, 1 + r]
+    dim = (dih - ih * (ih * dih).sum(-1, keepdims=True)) / n_im      # normalize backward
+    ds = (dsh - sh * (sh * dsh).sum(-1, keepdims=True)) / n_s
+    return dim, ds
+
+
+# ----------------------------------------------------------------------------------------------
+# matching head (alad/loss.py:8-11,179-186) and listnet distillation (alad/loss.py:369-370,427-447)
+# ----------------------------------------------------------------------------------------------
+def dot_scores(im, s):
+    """im @ s.T -- dot_sim, alad/loss.py:8-11 (also recall_auxiliary.py:30, evaluation.py:196)."""
+    return np.asarray(im) @ np.asarray(s).T
+
+
+def _softmax(x, axis):
+    m = x.max(axis=axis, keepdims=True)
+    e = np.exp(x - m)
+    return e / e.sum(axis=axis, keepdims=True)
+
+
+def listnet_loss(teacher, student, return_grad=False, temperature=6.0, eps=1e-10):
+    """DistillationLoss(mode='listnet'), alad/loss.py:427-445.  Gradient w.r.t. the student only
+    (the teacher is detached at :370)."""
+    T = np.asarray(teacher)
+    M = np.asarray(student)
+    B = M.shape[0]
+    loss = 0.0
+    dM = np.zeros(M.shape, np.float64)
+    for axis in (1, 0):                                        # :431-436 rows, :438-443 columns
+        Q = _softmax(M.astype(np.float64) * temperature, axis)
+        P = _softmax(T.astype(np.float64), axis)
+        loss += np.mean(-np.sum(P * np.log(Q + eps), axis=axis))
+        if return_grad:
+            W = P * Q / (Q + eps)
+            n = M.shape[axis]
+            dM += temperature / (M.shape[1 - axis]) * (Q * W.sum(axis=axis, keepdims=True) - W)
+    loss = M.dtype.type(loss)
+    return (loss, dM.astype(M.dtype)) if return_grad else loss
+
+
+# ----------------------------------------------------------------------------------------------
+# loss orchestration (alad/alad_model.py:371-454)
+# ----------------------------------------------------------------------------------------------
+def forward_loss(img_emb, cap_emb, img_set_sbd, cap_seq_sbd, img_len, cap_len, loss_type,
+                 margin=0.2, max_violation=True, aggregation='MrSw'):
+    """Ordered dict of loss terms exactly as ALADModel.forward_loss builds it
+    (alad/alad_model.py:371-428): sets arrive (S, B, D) and are permuted (:377-378); matching is
+    always computed (:380) but only reported when the substring 'matching' is in loss-type (:381);
+    alignment is computed when 'alignment' or 'distillation' is requested (:385-390); listnet
+    distillation uses the alignment scores as teacher (:404-408)."""
+    types = loss_type.split('-')
+    im_set = np.transpose(img_set_sbd, (1, 0, 2))
+    s_seq = np.transpose(cap_seq_sbd, (1, 0, 2))
+    losses = {}
+    M = dot_scores(img_emb, cap_emb)
+    if 'matching' in loss_type:
+        losses['matching'] = hinge_loss(M, margin, max_violation)
+    if 'alignment' in types or 'distillation' in types:
+        S = alignment_scores(im_set, s_seq, img_len, cap_len, aggregation)
+        if 'alignment' in types:
+            losses['alignment'] = hinge_loss(S, margin, max_violation)
+    if 'distillation' in types:
+        losses['distillation'] = listnet_loss(S, M)
+    return losses
+
+
+def total_loss(loss_dict, weights, epoch=0, distill_epoch=2):
+    """ALADModel.forward's combination (alad/alad_model.py:442-454), fixed list weights."""
+    d = dict(loss_dict)
+    if epoch < distill_epoch and len(d) > 1:
+        d.pop('distillation', None)
+    return sum(d[k] * weights[k] for k in d), d
+
+
+# ----------------------------------------------------------------------------------------------
+# retrieval metrics (alad/recall_auxiliary.py:8-69, alad/evaluation.py:158-327)
+# ----------------------------------------------------------------------------------------------
+def _metrics(ranks):
+    r1 = 100.0 * np.sum(ranks < 1) / len(ranks)
+    r5 = 100.0 * np.sum(ranks < 5) / len(ranks)
+    r10 = 100.0 * np.sum(ranks < 10) / len(ranks)
+    medr = np.floor(np.median(ranks)) + 1
+    meanr = ranks.mean() + 1
+    return r1, r5, r10, medr, meanr
+
+
+def ranks_from_scores(d_i2t, caps_per_img=5):
+    """Ranks for both directions from the (n_img, n_cap) score matrix, defined as the number of
+    strictly larger scores (== the argsort position used at recall_auxiliary.py:36-46,52-56 and
+    evaluation.py:213-223,303-308 whenever there are no exact ties)."""
+    n_img, n_cap = d_i2t.shape
+    r_i2t = np.empty(n_img)
+    top1_i2t = d_i2t.argmax(1).astype(np.float64)
+    for i in range(n_img):
+        gt = d_i2t[i, caps_per_img * i:caps_per_img * (i + 1)]
+        r_i2t[i] = (d_i2t[i][None, :] > gt[:, None]).sum(1).min()
+    gt_col = d_i2t[np.arange(n_cap) // caps_per_img, np.arange(n_cap)]
+    r_t2i = (d_i2t > gt_col[None, :]).sum(0).astype(np.float64)
+    top1_t2i = d_i2t.argmax(0).astype(np.float64)
+    return r_i2t, top1_i2t, r_t2i, top1_t2i
+
+
+def recall(images, captions, mode='i2t', return_ranks=False, caps_per_img=5):
+    """recall(), alad/recall_auxiliary.py:8-69: image rows 0::5 are the distinct images (:14-27);
+    i2t ranks the best of the 5 ground-truth captions (:30-46), t2i ranks image k for each of its
+    captions (:47-56); R@K, medr, meanr at :61-65."""
+    ims = np.asarray(images)[0::caps_per_img]
+    d = dot_scores(ims, captions)
+    r_i2t, t_i2t, r_t2i, t_t2i = ranks_from_scores(d, caps_per_img)
+    ranks, top1 = (r_i2t, t_i2t) if mode == 'i2t' else (r_t2i, t_t2i)
+    m = _metrics(ranks)
+    return (m, (ranks, top1)) if return_ranks else m
+
+
+def compute_recall(img_embs, cap_embs):
+    """compute_recall -> recall_test, alad/recall_auxiliary.py:72-86,133-149: 7-tuple."""
+    r1, r5, r10, _, _ = recall(img_embs, cap_embs, 'i2t')
+    r1i, r5i, r10i, _, _ = recall(img_embs, cap_embs, 't2i')
+    return r1, r5, r10, r1i, r5i, r10i, r1 + r5 + r10 + r1i + r5i + r10i
+
+
+def i2t(images, captions, img_len, cap_len, sim='matching', return_ranks=False,
+        aggregation='MrSw'):
+    """alad/evaluation.py:158-241.  sim='matching' is the sim_function=None branch (:196, slot-0
+    global embeddings); sim='alignment' is the alignment_sim_fn branch (:199-211) whose chunking
+    over cap_batches does not change the scores."""
+    images = np.asarray(images)
+    captions = np.asarray(captions)
+    if sim == 'matching':
+        d = dot_scores(images[0::5, 0, :], captions[:, 0, :])
+    else:
+        d = alignment_scores(images[0::5], captions, list(img_len[0::5]), cap_len, aggregation)
+    r, t, _, _ = ranks_from_scores(d)
+    m = _metrics(r) + (0, 0)
+    return (m, (r, t)) if return_ranks else m
+
+
+def t2i(images, captions, img_len, cap_len, sim='matching', return_ranks=False,
+        aggregation='MrSw'):
+    """alad/evaluation.py:244-327 (sim_function=None: :285; alignment: :288-301)."""
+    images = np.asarray(images)
+    captions = np.asarray(captions)
+    if sim == 'matching':
+        d = dot_scores(images[0::5, 0, :], captions[:, 0, :])
+    else:
+        d = alignment_scores(images[0::5], captions, list(img_len[0::5]), cap_len, aggregation)
+    _, _, r, t = ranks_from_scores(d)
+    m = _metrics(r) + (0, 0)
+    return (m, (r, t)) if return_ranks else m

@@ -1,0 +1,48 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, 'oracle')):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+GOLDEN = os.path.join(ROOT, 'tests', 'golden')
+
+
+def pytest_configure(config):
+    config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+
+
+def load_golden(name):
+    return dict(np.load(os.path.join(GOLDEN, name + '.npz'), allow_pickle=False))
+
+
+def golden_alignment_inputs(g):
+    """Regenerate the inputs of an alignment golden from its stored generator arguments and
+    check the stored checksums (pins aladin_amd.synth)."""
+    from aladin_amd import synth
+    kind = str(g['kind'])
+    B, Bc, R, T, D, seed = (int(g[k]) for k in ('B', 'Bc', 'R', 'T', 'D', 'seed'))
+    ragged = bool(g['ragged'])
+    if kind.startswith('structured'):
+        noise = float(kind[len('structured'):] or 1.0)
+        im, s, il, sl = synth.structured_alignment_batch(B, R, T, D, seed, noise, ragged)
+    else:
+        im, s, il, sl = synth.alignment_batch(B, R, T, D, seed, ragged, Bc=Bc)
+    assert il == [int(v) for v in g['im_len']] and sl == [int(v) for v in g['s_len']]
+    assert abs(synth.checksum(im) - float(g['im_checksum'])) <= 1e-6 * max(1.0, abs(float(g['im_checksum'])))
+    assert abs(synth.checksum(s) - float(g['s_checksum'])) <= 1e-6 * max(1.0, abs(float(g['s_checksum'])))
+    return im, s, il, sl
+
+
+ALIGN_GOLDENS = ['align_tiny', 'align_b5_d64', 'align_b12_struct', 'align_b32_d64',
+                 'align_b16_d768', 'align_b8_d768_rag', 'align_rect', 'align_r33']
+SQUARE_ALIGN_GOLDENS = [n for n in ALIGN_GOLDENS if n != 'align_rect']
+
+
+@pytest.fixture(scope='session')
+def golden():
+    return load_golden

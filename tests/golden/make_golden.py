@@ -1,0 +1,258 @@
+"""Generate tests/golden/*.npz by running the REFERENCE (mesnico/ALADIN) on synthetic inputs.
+
+Runs ONLY in the build container (it imports /root/reference read-only; the reference does not
+exist on the GPU box).  The reference holds no tests or fixtures of its own, so these files are
+what pins the oracle and the HIP path.  Each .npz stores the generator arguments of its inputs
+(see aladin_amd/synth.py), a checksum of the inputs, and the reference's outputs -- data only.
+
+    python tests/golden/make_golden.py          # rewrites tests/golden/*.npz
+"""
+import os
+import sys
+import types
+import warnings
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, '/root/reference')
+warnings.filterwarnings('ignore')
+
+import numpy as np
+import torch
+import yaml
+
+from aladin_amd import synth
+
+import alad.loss as ref_loss                      # noqa: E402
+import alad.recall_auxiliary as ref_recall        # noqa: E402
+import alad.evaluation as ref_eval                # noqa: E402
+
+torch.set_num_threads(8)
+
+
+def t(x):
+    return torch.from_numpy(np.ascontiguousarray(x))
+
+
+def save(name, **kw):
+    path = os.path.join(HERE, name + '.npz')
+    np.savez_compressed(path, **kw)
+    print('%-28s %8.1f KB' % (name, os.path.getsize(path) / 1024))
+
+
+# ------------------------------------------------------------------------------ alignment cases
+ALIGN_CASES = [
+    # name, kind, B, Bc, R, T, D, seed, ragged, margin
+    ('align_tiny',      'random',     2,  2,  3,  5,   8,  11, False, 0.2),
+    ('align_b5_d64',    'random',     5,  5, 34, 50,  64,  12, True,  0.2),
+    ('align_b12_struct', 'structured', 12, 12, 20, 30,  64,  13, True,  0.2),
+    ('align_b32_d64',   'random',    32, 32, 34, 50,  64,  14, True,  0.3),
+    ('align_b16_d768',  'random',    16, 16, 34, 50, 768, 1234, False, 0.2),   # BASELINE config 1
+    ('align_b8_d768_rag', 'structured4', 8, 8, 34, 50, 768,  15, True,  0.2),
+    ('align_rect',      'random',     3,  7, 34, 50,  64,  16, True,  0.2),
+    ('align_r33',       'random',     6,  6, 33, 34, 128,  17, True,  0.2),    # R'=32 exactly
+]
+AGG_MODES = ['MrSw', 'MrAVGw', 'MwSr', 'symm', 'sum', 'mean']
+
+
+def make_inputs(kind, B, Bc, R, T, D, seed, ragged):
+    if kind.startswith('structured'):
+        noise = float(kind[len('structured'):] or 1.0)
+        return synth.structured_alignment_batch(B, R, T, D, seed, noise=noise, ragged=ragged)
+    return synth.alignment_batch(B, R, T, D, seed, ragged, Bc=Bc)
+
+
+def gen_alignment():
+    for name, kind, B, Bc, R, T, D, seed, ragged, margin in ALIGN_CASES:
+        im, s, im_len, s_len = make_inputs(kind, B, Bc, R, T, D, seed, ragged)
+        out = dict(kind=kind, B=B, Bc=Bc, R=R, T=T, D=D, seed=seed, ragged=ragged, margin=margin,
+                   im_len=np.array(im_len), s_len=np.array(s_len),
+                   im_checksum=synth.checksum(im), s_checksum=synth.checksum(s))
+        for mode in AGG_MODES:
+            crit = ref_loss.AlignmentContrastiveLoss(margin=margin, measure='dot',
+                                                     max_violation=True, aggregation=mode)
+            with torch.no_grad():
+                S = crit(t(im), t(s), im_len, s_len, return_loss=False, return_similarity_mat=True)
+            out['S_' + mode] = S.numpy()
+        if B == Bc:
+            stride = 16 if D >= 512 else 1
+            out['grad_stride'] = stride
+            for mv in (True, False):
+                crit = ref_loss.AlignmentContrastiveLoss(margin=margin, measure='dot',
+                                                         max_violation=mv, aggregation='MrSw')
+                a = t(im).requires_grad_(True)
+                b = t(s).requires_grad_(True)
+                loss, S = crit(a, b, im_len, s_len, return_similarity_mat=True)
+                loss.backward()
+                tag = 'mv' if mv else 'sum'
+                out['loss_' + tag] = loss.item()
+                out['dim_' + tag] = a.grad.numpy()[:, :, ::stride]
+                out['ds_' + tag] = b.grad.numpy()[:, :, ::stride]
+                out['dim_cs_' + tag] = synth.checksum(a.grad.numpy())
+                out['ds_cs_' + tag] = synth.checksum(b.grad.numpy())
+                out['dim_abs_' + tag] = float(a.grad.abs().sum())
+                out['ds_abs_' + tag] = float(b.grad.abs().sum())
+                # dloss/dS, through a leaf copy of S
+                Sl = S.detach().clone().requires_grad_(True)
+                crit.compute_contrastive_loss(Sl).backward()
+                out['dS_' + tag] = Sl.grad.numpy()
+        save(name, **out)
+
+
+# ------------------------------------------------------------------------- evaluation-shape case
+def gen_eval():
+    n_img, D, seed = 50, 64, 31
+    images, captions, img_len, cap_len = synth.eval_sets(n_img, D, seed)
+    out = dict(n_img=n_img, D=D, seed=seed, images_checksum=synth.checksum(images),
+               captions_checksum=synth.checksum(captions),
+               img_len=np.array(img_len), cap_len=np.array(cap_len))
+    crit = ref_loss.AlignmentContrastiveLoss(aggregation='MrSw')
+    with torch.no_grad():
+        S = crit(t(images[0::5]), t(captions), img_len[0::5], cap_len, return_loss=False,
+                 return_similarity_mat=True)
+    out['S_eval'] = S.numpy()
+
+    def sim_fn(img, cap, il, cl):
+        with torch.no_grad():
+            return crit(img, cap, il, cl, return_loss=False, return_similarity_mat=True)
+
+    saved_cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self          # evaluation.py:179,202 call .cuda()
+    try:
+        for tag, fn in (('match', None), ('align', sim_fn)):
+            m, (ranks, top1) = ref_eval.i2t(t(images), t(captions), img_len, cap_len,
+                                            return_ranks=True, sim_function=fn, cap_batches=5)
+            out['i2t_%s_metrics' % tag] = np.array(m, dtype=np.float64)
+            out['i2t_%s_ranks' % tag] = ranks
+            out['i2t_%s_top1' % tag] = top1
+            m, (ranks, top50) = ref_eval.t2i(t(images), t(captions), img_len, cap_len,
+                                             return_ranks=True, sim_function=fn, im_batches=5)
+            out['t2i_%s_metrics' % tag] = np.array(m, dtype=np.float64)
+            out['t2i_%s_ranks' % tag] = ranks
+            out['t2i_%s_top1' % tag] = top50[:, 0]
+    finally:
+        torch.Tensor.cuda = saved_cuda
+    save('eval_sets', **out)
+
+
+# --------------------------------------------------------------------- matching / distillation
+def gen_matching():
+    for name, B, D, seed, noise in (('match_b16_d768', 16, 768, 21, 1.0), ('match_b7_d64', 7, 64, 22, 0.5)):
+        img, cap = synth.global_embeddings(B, D, seed, noise)
+        out = dict(B=B, D=D, seed=seed, noise=noise, img_checksum=synth.checksum(img))
+        for mv in (True, False):
+            crit = ref_loss.ContrastiveLoss(margin=0.2, measure='dot', max_violation=mv)
+            a = t(img).requires_grad_(True)
+            b = t(cap).requires_grad_(True)
+            loss, M = crit(a, b, return_similarity_mat=True)
+            loss.backward()
+            tag = 'mv' if mv else 'sum'
+            out['M'] = M.detach().numpy()
+            out['loss_' + tag] = loss.item()
+            out['dimg_' + tag] = a.grad.numpy()
+            out['dcap_' + tag] = b.grad.numpy()
+        save(name, **out)
+
+
+def gen_distill():
+    for name, B, seed in (('distill_b16', 16, 41), ('distill_b5', 5, 42)):
+        img, cap = synth.global_embeddings(B, 64, seed, 1.0)
+        teacher = (synth.normal((B, B), seed + 7) * 0.8 + 3.0 * np.eye(B, dtype=np.float32) + 4.0).astype(np.float32)
+        student = (img @ cap.T).astype(np.float32)
+        out = dict(B=B, seed=seed, teacher=teacher, student=student)
+        for mode in ('listnet', 'mse', 'ordinal', 'contrastive'):
+            crit = ref_loss.DistillationLoss(mode=mode)
+            st = t(student).requires_grad_(True)
+            loss = crit(t(teacher.copy()), st)
+            loss.backward()
+            out['loss_' + mode] = loss.item()
+            out['dstudent_' + mode] = st.grad.numpy()
+        save(name, **out)
+
+
+# ------------------------------------------------------------------------- ALADModel orchestration
+def import_alad_model():
+    import oscar, oscar.modeling                                      # noqa: F401
+    stub = types.ModuleType('transformers.pytorch_transformers')
+    stub.BertTokenizer = type('BertTokenizer', (), {})
+    stub.BertConfig = type('BertConfig', (), {})
+    import transformers as _tf
+    sys.modules['transformers.pytorch_transformers'] = stub
+    _tf.pytorch_transformers = stub
+    stub2 = types.ModuleType('oscar.modeling.modeling_bert')
+    stub2.ImageBertForSequenceClassification = type('ImageBertForSequenceClassification', (), {})
+    sys.modules['oscar.modeling.modeling_bert'] = stub2
+    import alad.alad_model as am
+    return am
+
+
+def gen_model():
+    am = import_alad_model()
+    cfg_dir = '/root/reference/alad/configs'
+    B, R, T, D, seed = 8, 34, 50, 64, 51
+    im, s, im_len, s_len = synth.structured_alignment_batch(B, R, T, D, seed, 1.0, True)
+    img_emb, cap_emb = synth.global_embeddings(B, D, seed + 1, 1.0)
+    out = dict(B=B, R=R, T=T, D=D, seed=seed, im_len=np.array(im_len), s_len=np.array(s_len))
+    names = []
+    for fn in sorted(os.listdir(cfg_dir)):
+        if not fn.endswith('.yaml'):
+            continue
+        with open(os.path.join(cfg_dir, fn)) as f:
+            config = yaml.safe_load(f)
+        tr = config['training']
+        m = am.ALADModel.__new__(am.ALADModel)
+        torch.nn.Module.__init__(m)
+        m.losses_types = tr['loss-type'].split('-')
+        m.losses_weights = {k: v for k, v in zip(m.losses_types, tr['loss-weights'])}
+        m.auto_weight = False
+        m.config = config
+        m.alignment_criterion = ref_loss.AlignmentContrastiveLoss(
+            margin=tr['margin'], measure=tr['measure'], max_violation=tr['max-violation'],
+            aggregation=tr['alignment-mode'])
+        m.matching_criterion = ref_loss.ContrastiveLoss(
+            margin=tr['margin'], measure=tr['measure'], max_violation=tr['max-violation'])
+        m.distillation_loss = ref_loss.DistillationLoss(mode=tr['distillation-mode'])
+        m.logger = ref_eval.LogCollector()
+        m.Eiters = 0
+        sets = (t(img_emb), t(cap_emb), t(im).permute(1, 0, 2), t(s).permute(1, 0, 2), im_len, s_len, 0)
+        m.forward_emb = lambda a, b, _sets=sets: _sets
+        key = fn[:-5].replace('-', '_').replace('.', '_')
+        names.append(fn)
+        out[key + '__loss_type'] = tr['loss-type']
+        out[key + '__weights'] = np.array(tr['loss-weights'], dtype=np.float64)
+        for epoch in (0, 5):
+            loss, d = m.forward(None, None, epoch=epoch, distill_epoch=2)
+            out['%s__e%d_total' % (key, epoch)] = float(loss)
+            out['%s__e%d_keys' % (key, epoch)] = np.array(list(d.keys()))
+            out['%s__e%d_vals' % (key, epoch)] = np.array([float(v) for v in d.values()])
+        out[key + '__logged'] = np.array(list(m.logger.meters.keys()))
+        out[key + '__eiters'] = m.Eiters
+    out['configs'] = np.array(names)
+    save('model_forward', **out)
+
+
+# --------------------------------------------------------------------------------------- recall
+def gen_recall():
+    for name, n_img, D, seed, sigma in (('recall_n500', 100, 64, 61, 3.5),
+                                        ('recall_n5000', 1000, 768, 62, 9.0)):
+        img, cap = synth.retrieval_embeddings(n_img, D, seed, sigma)
+        out = dict(n_img=n_img, D=D, seed=seed, sigma=sigma, img_checksum=synth.checksum(img),
+                   cap_checksum=synth.checksum(cap))
+        out['compute_recall'] = np.array(ref_recall.compute_recall(t(img), t(cap)), dtype=np.float64)
+        for mode in ('i2t', 't2i'):
+            m, (ranks, top1) = ref_recall.recall(t(img), t(cap), None, mode=mode, return_ranks=True)
+            out[mode + '_metrics'] = np.array(m, dtype=np.float64)
+            out[mode + '_ranks'] = ranks
+            out[mode + '_top1'] = top1
+        save(name, **out)
+
+
+if __name__ == '__main__':
+    gen_alignment()
+    gen_eval()
+    gen_matching()
+    gen_distill()
+    gen_model()
+    gen_recall()

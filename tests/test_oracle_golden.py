@@ -1,0 +1,132 @@
+"""CPU tier: the oracle (oracle/alad_oracle.py, oracle/faithful_torch.py) against the golden
+fixtures produced by the reference itself (tests/golden/make_golden.py).  This is what pins the
+oracle; the -m gpu tests then compare the HIP path with the pinned oracle and the same fixtures."""
+import numpy as np
+import pytest
+
+from conftest import (ALIGN_GOLDENS, SQUARE_ALIGN_GOLDENS, golden_alignment_inputs, load_golden)
+import alad_oracle as O
+
+RTOL = 1e-3          # north_star tolerance; the oracle itself lands around 1e-6
+
+
+def close(a, b, rtol=2e-5, atol=2e-5):
+    np.testing.assert_allclose(np.asarray(a, np.float64), np.asarray(b, np.float64), rtol=rtol, atol=atol)
+
+
+@pytest.mark.parametrize('name', ALIGN_GOLDENS)
+@pytest.mark.parametrize('mode', ['MrSw', 'MrAVGw', 'MwSr', 'symm', 'sum', 'mean'])
+def test_alignment_scores(name, mode):
+    g = load_golden(name)
+    im, s, il, sl = golden_alignment_inputs(g)
+    S = O.alignment_scores(im, s, il, sl, mode)
+    close(S, g['S_' + mode])
+
+
+@pytest.mark.parametrize('name', SQUARE_ALIGN_GOLDENS)
+@pytest.mark.parametrize('tag', ['mv', 'sum'])
+def test_hinge_and_grad_wrt_scores(name, tag):
+    g = load_golden(name)
+    loss, dS = O.hinge_loss(g['S_MrSw'], float(g['margin']), tag == 'mv', return_grad=True)
+    close(loss, g['loss_' + tag], rtol=1e-5, atol=1e-5)
+    close(dS, g['dS_' + tag], rtol=0, atol=0)
+
+
+@pytest.mark.parametrize('name', ['align_tiny', 'align_b5_d64', 'align_b12_struct', 'align_r33',
+                                  'align_b8_d768_rag'])
+@pytest.mark.parametrize('tag', ['mv', 'sum'])
+def test_alignment_backward(name, tag):
+    g = load_golden(name)
+    im, s, il, sl = golden_alignment_inputs(g)
+    dim, ds = O.alignment_scores_backward(im, s, il, sl, g['dS_' + tag])
+    st = int(g['grad_stride'])
+    scale = max(1e-6, float(np.abs(g['dim_' + tag]).max()))
+    close(dim[:, :, ::st], g['dim_' + tag], rtol=1e-4, atol=1e-5 * scale)
+    scale = max(1e-6, float(np.abs(g['ds_' + tag]).max()))
+    close(ds[:, :, ::st], g['ds_' + tag], rtol=1e-4, atol=1e-5 * scale)
+    from aladin_amd import synth
+    assert abs(np.abs(dim).sum() - float(g['dim_abs_' + tag])) <= 1e-4 * float(g['dim_abs_' + tag]) + 1e-6
+
+
+@pytest.mark.parametrize('name', SQUARE_ALIGN_GOLDENS)
+def test_faithful_torch_matches_reference(name):
+    import torch
+    import faithful_torch as FT
+    g = load_golden(name)
+    im, s, il, sl = golden_alignment_inputs(g)
+    for tag, mv in (('mv', True), ('sum', False)):
+        loss, S, dim, ds = FT.alignment_triplet_step(torch.from_numpy(im), torch.from_numpy(s), il, sl,
+                                                     float(g['margin']), mv)
+        close(S.numpy(), g['S_MrSw'])
+        close(loss.item(), g['loss_' + tag], rtol=1e-5, atol=1e-5)
+        st = int(g['grad_stride'])
+        close(dim.numpy()[:, :, ::st], g['dim_' + tag], rtol=1e-4, atol=1e-6)
+        close(ds.numpy()[:, :, ::st], g['ds_' + tag], rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize('name', ['match_b16_d768', 'match_b7_d64'])
+def test_matching(name):
+    g = load_golden(name)
+    from aladin_amd import synth
+    img, cap = synth.global_embeddings(int(g['B']), int(g['D']), int(g['seed']), float(g['noise']))
+    M = O.dot_scores(img, cap)
+    close(M, g['M'], rtol=1e-5, atol=1e-6)
+    for tag, mv in (('mv', True), ('sum', False)):
+        loss, dM = O.hinge_loss(M, 0.2, mv, return_grad=True)
+        close(loss, g['loss_' + tag], rtol=1e-5, atol=1e-6)
+        close(dM @ cap, g['dimg_' + tag], rtol=1e-4, atol=1e-6)
+        close(dM.T @ img, g['dcap_' + tag], rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize('name', ['distill_b16', 'distill_b5'])
+def test_listnet(name):
+    g = load_golden(name)
+    loss, dM = O.listnet_loss(g['teacher'], g['student'], return_grad=True)
+    close(loss, g['loss_listnet'], rtol=1e-5, atol=1e-6)
+    close(dM, g['dstudent_listnet'], rtol=1e-4, atol=1e-7)
+
+
+def test_model_forward_dicts():
+    g = load_golden('model_forward')
+    from aladin_amd import synth
+    B, R, T, D, seed = (int(g[k]) for k in ('B', 'R', 'T', 'D', 'seed'))
+    im, s, il, sl = synth.structured_alignment_batch(B, R, T, D, seed, 1.0, True)
+    img_emb, cap_emb = synth.global_embeddings(B, D, seed + 1, 1.0)
+    for fn in g['configs']:
+        key = str(fn)[:-5].replace('-', '_').replace('.', '_')
+        lt = str(g[key + '__loss_type'])
+        w = dict(zip(lt.split('-'), g[key + '__weights']))
+        d = O.forward_loss(img_emb, cap_emb, im.transpose(1, 0, 2), s.transpose(1, 0, 2), il, sl, lt)
+        for epoch in (0, 5):
+            total, kept = O.total_loss(d, w, epoch, 2)
+            assert list(kept.keys()) == [str(k) for k in g['%s__e%d_keys' % (key, epoch)]]
+            close(list(kept.values()), g['%s__e%d_vals' % (key, epoch)], rtol=1e-5, atol=1e-6)
+            close(total, g['%s__e%d_total' % (key, epoch)], rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize('name', ['recall_n500', 'recall_n5000'])
+def test_recall(name):
+    g = load_golden(name)
+    from aladin_amd import synth
+    img, cap = synth.retrieval_embeddings(int(g['n_img']), int(g['D']), int(g['seed']), float(g['sigma']))
+    close(O.compute_recall(img, cap), g['compute_recall'], rtol=0, atol=1e-9)
+    for mode in ('i2t', 't2i'):
+        m, (ranks, top1) = O.recall(img, cap, mode, return_ranks=True)
+        close(m, g[mode + '_metrics'], rtol=0, atol=1e-9)
+        assert np.array_equal(ranks, g[mode + '_ranks'])
+        assert np.array_equal(top1, g[mode + '_top1'])
+
+
+def test_eval_i2t_t2i():
+    g = load_golden('eval_sets')
+    from aladin_amd import synth
+    images, captions, il, cl = synth.eval_sets(int(g['n_img']), int(g['D']), int(g['seed']))
+    S = O.alignment_scores(images[0::5], captions, il[0::5], cl)
+    close(S, g['S_eval'])
+    for tag, sim in (('match', 'matching'), ('align', 'alignment')):
+        m, (r, t1) = O.i2t(images, captions, il, cl, sim, return_ranks=True)
+        close(m, g['i2t_%s_metrics' % tag], rtol=0, atol=1e-9)
+        assert np.array_equal(r, g['i2t_%s_ranks' % tag]) and np.array_equal(t1, g['i2t_%s_top1' % tag])
+        m, (r, t1) = O.t2i(images, captions, il, cl, sim, return_ranks=True)
+        close(m, g['t2i_%s_metrics' % tag], rtol=0, atol=1e-9)
+        assert np.array_equal(r, g['t2i_%s_ranks' % tag]) and np.array_equal(t1, g['t2i_%s_top1' % tag])
