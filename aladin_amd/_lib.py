@@ -1,0 +1,86 @@
+"""ctypes binding of libaladin_hip.so (the C ABI declared in include/aladin_hip.h).
+
+This is the whole FFI surface: plain pointers, sizes and a hipStream_t.  There is no CPU fallback:
+if the shared library is missing or an entry point fails, a RuntimeError is raised.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'lib', 'libaladin_hip.so')
+
+ABI_VERSION = 1
+
+# every symbol include/aladin_hip.h declares (tests check that the library exports all of them)
+SYMBOLS = [
+    'aladin_version', 'aladin_last_error', 'aladin_align_geometry', 'aladin_align_pack_images',
+    'aladin_align_pack_captions', 'aladin_align_scores', 'aladin_align_scores_ex',
+    'aladin_align_bwd_workspace_bytes',
+    'aladin_align_bwd', 'aladin_hinge_workspace_bytes', 'aladin_hinge_fwd_bwd',
+    'aladin_listnet_workspace_bytes', 'aladin_listnet_fwd_bwd', 'aladin_sgemm_strided',
+    'aladin_sim_workspace_bytes', 'aladin_sim_matrix', 'aladin_recall_workspace_bytes',
+    'aladin_recall_ranks',
+]
+
+
+class AlignGeom(C.Structure):
+    """struct aladin_align_geom."""
+    _fields_ = [(n, C.c_int32) for n in ('Bi', 'Bc', 'R', 'T', 'D', 'Rq', 'Tq', 'mtiles', 'rem', 'tp16', 'Dp',
+                                         'img_unit', 'cap_unit', 'Bi_pad', 'Bc_pad')] + \
+               [(n, C.c_int64) for n in ('xm_rows', 'xe_rows', 'y_rows', 'xm_bytes', 'xe_bytes', 'y_bytes',
+                                         'e_bytes')]
+
+
+_lib = None
+
+
+def _declare(lib):
+    p, i32, i64, f32, sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
+    G = C.POINTER(AlignGeom)
+    sig = {
+        'aladin_version': (C.c_int, []),
+        'aladin_last_error': (C.c_char_p, []),
+        'aladin_align_geometry': (C.c_int, [i32, i32, i32, i32, i32, G]),
+        'aladin_align_pack_images': (C.c_int, [p, i64, i64, p, G, p, p, p]),
+        'aladin_align_pack_captions': (C.c_int, [p, i64, i64, p, G, p, p]),
+        'aladin_align_scores': (C.c_int, [p, p, p, G, p, p, i64, p]),
+        'aladin_align_scores_ex': (C.c_int, [p, p, p, G, p, p, i64, i32, p]),
+        'aladin_align_bwd_workspace_bytes': (sz, [i32, i32, i32, i32, i32]),
+        'aladin_align_bwd': (C.c_int, [p, i64, i64, p, p, i64, i64, p, i32, i32, i32, i32, i32, p, i64, p, p, p, p, p]),
+        'aladin_hinge_workspace_bytes': (sz, [i32]),
+        'aladin_hinge_fwd_bwd': (C.c_int, [p, i64, i32, f32, i32, p, p, p, p]),
+        'aladin_listnet_workspace_bytes': (sz, [i32]),
+        'aladin_listnet_fwd_bwd': (C.c_int, [p, i64, p, i64, i32, f32, f32, p, p, p, p]),
+        'aladin_sgemm_strided': (C.c_int, [i32, i32, i32, p, i64, i64, p, i64, i64, p, i64, p]),
+        'aladin_sim_workspace_bytes': (sz, [i32, i32, i32]),
+        'aladin_sim_matrix': (C.c_int, [p, i64, p, i64, i32, i32, i32, p, i64, p, p]),
+        'aladin_recall_workspace_bytes': (sz, [i32]),
+        'aladin_recall_ranks': (C.c_int, [p, i64, i32, i32, i32, p, p, p, p, p, p]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+
+
+def load():
+    """Load (once) and return the ctypes handle; raises RuntimeError if the extension is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                'aladin_amd: HIP extension %s is missing -- build it with `python -c "import __graft_entry__ as g; '
+                'g.build()"` (or `make -C aladin_amd/csrc`).  There is no CPU fallback.' % LIB_PATH)
+        lib = C.CDLL(LIB_PATH)
+        _declare(lib)
+        if lib.aladin_version() != ABI_VERSION:
+            raise RuntimeError('aladin_amd: ABI version mismatch (library %d, binding %d)'
+                               % (lib.aladin_version(), ABI_VERSION))
+        _lib = lib
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().aladin_last_error()
+        raise RuntimeError('aladin_hip %s failed (status %d): %s' % (what, rc, msg.decode() if msg else ''))

@@ -1,0 +1,149 @@
+"""ALADModel-compatible loss orchestration (reference alad/alad_model.py:250-454) over the HIP
+criteria of aladin_amd.loss.
+
+Scope: `forward`, `forward_loss` and the attribute protocol
+(`logger`, `Eiters`, `losses_types`, `losses_weights`, `*_criterion`, `distillation_loss`) are
+re-stated; the VinVL/Oscar backbone (`JointTextImageTransformerEncoder`, alad_model.py:29-247) is
+host PyTorch code outside the hot path and is INJECTED as `encoder` -- any module returning the
+reference's 7-tuple (img_glob (B,D), cap_glob (B,D), img_set (R,B,D), cap_seq (T,B,D), img_len,
+cap_len, reg_loss).  `StandInEncoder` is a random-init substitute used by smoke tests and bench.
+"""
+import torch
+from torch import nn
+
+from .loss import AlignmentContrastiveLoss, ContrastiveLoss, DistillationLoss, l2norm
+
+
+class ALADModel(nn.Module):
+    def __init__(self, config, oscar_checkpoint=None, encoder=None):
+        super().__init__()
+        self.img_txt_enc = encoder                                   # alad_model.py:259 (injected here)
+        training = config['training']
+        self.losses_types = training['loss-type'].split('-')          # :265
+        self.losses_weights = training['loss-weights']                # :266
+        if isinstance(self.losses_weights, list):                     # :267-270
+            assert len(self.losses_types) == len(self.losses_weights)
+            self.losses_weights = {k: v for k, v in zip(self.losses_types, self.losses_weights)}
+            self.auto_weight = False
+        else:                                                         # :271-273 ('auto': unregistered parameters)
+            dev = 'cuda' if torch.cuda.is_available() else 'cpu'
+            self.losses_weights = {k: nn.Parameter(-2.3 * torch.ones(1)).to(dev) for k in self.losses_types}
+            self.auto_weight = True
+        if 'distillation' in self.losses_types:                       # :275-276
+            self.distillation_loss = DistillationLoss(mode=training['distillation-mode'])
+        if 'attdistillation' in self.losses_types:
+            raise NotImplementedError("aladin_amd: 'attdistillation' is constructed but never used by the "
+                                      "reference's forward_loss (alad_model.py:278-279); not provided")
+        if 'alignment' in self.losses_types or 'distillation' in self.losses_types:    # :285-288
+            self.alignment_criterion = AlignmentContrastiveLoss(
+                margin=training['margin'], measure=training['measure'],
+                max_violation=training['max-violation'], aggregation=training['alignment-mode'])
+        self.matching_criterion = ContrastiveLoss(                    # :289-292 (the `if` there is always true)
+            margin=training['margin'], measure=training['measure'], max_violation=training['max-violation'])
+        self.Eiters = 0
+        self.config = config
+        self.logger = None
+
+    def forward_emb(self, example_imgs, example_txts):
+        """reference alad_model.py:325-348 (host->device copies + encoder call)."""
+        if self.img_txt_enc is None:
+            raise RuntimeError('aladin_amd.ALADModel: no encoder injected (the VinVL backbone is outside the '
+                               'accelerated path; pass encoder=...)')
+        if torch.cuda.is_available():
+            example_imgs = [c.cuda() if isinstance(c, torch.Tensor) else c for c in example_imgs]
+            example_txts = [c.cuda() if isinstance(c, torch.Tensor) else c for c in example_txts]
+        return self.img_txt_enc(example_imgs, example_txts)
+
+    def forward_loss(self, img_emb, cap_emb, img_emb_set, cap_emb_seq, img_lengths, cap_lengths, reg_loss):
+        """reference alad_model.py:371-428.  Same terms, same insertion order, same logger keys; the
+        per-term `.item()` host syncs of the reference are batched into one device->host copy."""
+        losses = {}
+        logged = []                                                   # (key, tensor, n)
+        img_emb_set = img_emb_set.permute(1, 0, 2)                    # :377-378  (S,B,D) -> (B,S,D) views
+        cap_emb_seq = cap_emb_seq.permute(1, 0, 2)
+
+        matching_loss, matching_mat = self.matching_criterion(img_emb, cap_emb, return_similarity_mat=True)   # :380
+        if 'matching' in self.config['training']['loss-type']:        # :381 (substring test on the string)
+            losses['matching'] = matching_loss
+            logged.append(('matching_loss', matching_loss, img_emb.size(0)))
+
+        if 'alignment' in self.losses_types or 'distillation' in self.losses_types:       # :385-390
+            alignment_loss, teacher_scores = self.alignment_criterion(
+                img_emb_set, cap_emb_seq, img_lengths, cap_lengths, return_similarity_mat=True)
+            if 'alignment' in self.losses_types:
+                losses['alignment'] = alignment_loss
+                logged.append(('alignment_loss', alignment_loss, img_emb_set.size(0)))
+
+        if 'selfaggregation' in self.losses_types:                    # :397-402
+            matching_loss, matching_mat = self.matching_criterion(img_emb, cap_emb, return_similarity_mat=True)
+            losses['selfaggregation'] = matching_loss
+            logged.append(('self_attention_loss', matching_loss, img_emb.size(0)))
+
+        if 'distillation' in self.losses_types:                       # :404-408
+            distillation_loss = self.distillation_loss(teacher_scores, matching_mat)
+            losses['distillation'] = distillation_loss
+            logged.append(('distillation_loss', distillation_loss, img_emb.size(0)))
+
+        if 'entropy' in self.losses_types:
+            raise NotImplementedError("aladin_amd: the 'entropy' term (alad_model.py:410-421) is not provided")
+
+        if 'regularizehidden' in self.losses_types:                   # :423-425
+            losses['regularizehidden'] = reg_loss
+            logged.append(('regularize_hidden_loss', reg_loss, img_emb.size(0)))
+
+        if self.logger is not None and logged:
+            vals = torch.stack([t.detach().reshape(()).to(torch.float32) for _, t, _ in logged]).tolist()
+            for (key, _, n), v in zip(logged, vals):
+                self.logger.update(key, v, n)
+        return losses
+
+    def forward(self, example_imgs, example_txts, epoch=0, distill_epoch=2):
+        """reference alad_model.py:430-454."""
+        self.Eiters += 1
+        if self.logger is not None:
+            self.logger.update('Eit', self.Eiters)
+        img_emb_aggr, cap_emb_aggr, img_feats, cap_feats, img_lengths, cap_lengths, regul_loss = \
+            self.forward_emb(example_imgs, example_txts)
+        loss_dict = self.forward_loss(img_emb_aggr, cap_emb_aggr, img_feats, cap_feats, img_lengths, cap_lengths,
+                                      regul_loss)
+        if epoch < distill_epoch and len(loss_dict) > 1:              # :442-444
+            loss_dict.pop('distillation', None)
+        if self.auto_weight:                                          # :445-449
+            loss = 0
+            for k in loss_dict:
+                loss += loss_dict[k] * torch.exp(-self.losses_weights[k]) + self.losses_weights[k]
+            loss *= 0.5
+        else:                                                         # :450-453
+            loss = 0
+            for k in loss_dict:
+                loss += loss_dict[k] * self.losses_weights[k]
+        return loss, loss_dict
+
+
+class StandInEncoder(nn.Module):
+    """Random-init substitute for JointTextImageTransformerEncoder with the same OUTPUT contract
+    (reference alad_model.py:121-247): region features (B,R,F) + box counts, token ids (B,T) +
+    token counts -> the 7-tuple, sets L2-normalised (:237-238), globals l2norm'd (:240-241).
+    It exists so that ALADModel.forward can be exercised end to end without the VinVL checkpoint;
+    it is NOT a model of the backbone."""
+
+    def __init__(self, feat_dim=2054, embed=768, vocab=30522, seed=0):
+        super().__init__()
+        g = torch.Generator().manual_seed(seed)
+        self.img_proj = nn.Linear(feat_dim, embed)
+        self.tok_emb = nn.Embedding(vocab, embed)
+        with torch.no_grad():
+            self.img_proj.weight.copy_(torch.randn(embed, feat_dim, generator=g) / feat_dim ** 0.5)
+            self.img_proj.bias.zero_()
+            self.tok_emb.weight.copy_(torch.randn(vocab, embed, generator=g))
+
+    def forward(self, example_imgs, example_txts):
+        img_feat, img_len = example_imgs
+        tok_ids, cap_len = example_txts
+        i_emb = self.img_proj(img_feat)[:, :max(img_len)]             # slice to the batch maximum (:174-175)
+        c_emb = self.tok_emb(tok_ids)[:, :max(cap_len)]
+        img_glob = l2norm(i_emb.mean(1))
+        cap_glob = l2norm(c_emb.mean(1))
+        i_set = nn.functional.normalize(i_emb, p=2, dim=2).permute(1, 0, 2)     # (R,B,D)
+        c_seq = nn.functional.normalize(c_emb, p=2, dim=2).permute(1, 0, 2)     # (T,B,D)
+        return img_glob, cap_glob, i_set, c_seq, list(img_len), list(cap_len), 0

@@ -1,0 +1,360 @@
+// Alignment scores S[i][j] = sum_w max_r <im^[i,r], s^[j,w]>  ('MrSw', reference
+// alad/loss.py:79-125) for gfx950.
+//
+// pack kernels   fp32 sets -> L2-normalised fp16 MFMA operands.  All masking of the reference
+//                (alad/loss.py:103-116) is folded into the packed data, so the score kernel is
+//                mask-free:
+//                  * padded regions (r >= im_len-1) and padded words (w >= s_len-3) become ZERO
+//                    rows: their dot products are exactly 0, which is what masked_fill_(.., 0)
+//                    leaves in the reference before max / sum;
+//                  * rows that exist only to fill a 32-row MFMA tile are COPIES of the image's
+//                    first region (max is idempotent), never zeros: a zero would wrongly clamp
+//                    the max of an image without padded regions.
+// score kernel   one (8 images x 4 captions)-class tile per workgroup: LDS-staged fp16 MFMA GEMM
+//                (gemm_core.hpp) with regions on the MFMA row axis and words on the lane axis, so
+//                max-over-regions is an in-lane max over the 16 accumulator registers plus one
+//                half-wave exchange, and sum-over-words is a 32-lane shuffle reduction.  The
+//                B x B x R' x T' tensor of the reference never exists.
+// side GEMM      R' = 33 = 32 + 1: the 33rd region of every image is gathered into one extra
+//                operand (one row per image) whose plain GEMM against the captions (E) is folded
+//                into the max by the score kernel -- 33/32 of the MFMA work instead of 64/32.
+#include <math.h>
+#include <string.h>
+
+#include "../../include/aladin_hip.h"
+#include "gemm_core.hpp"
+
+// ------------------------------------------------------------------------------------------------
+// geometry
+// ------------------------------------------------------------------------------------------------
+extern "C" int aladin_align_geometry(int Bi, int Bc, int R, int T, int D, aladin_align_geom* g) {
+  if (!g || Bi < 1 || Bc < 1 || D < 1) { aladin_set_error("align_geometry: bad sizes Bi=%d Bc=%d D=%d", Bi, Bc, D); return ALADIN_ERR_ARG; }
+  if (R < 2 || T < 4) { aladin_set_error("align_geometry: need R >= 2 and T >= 4 (got R=%d T=%d): region 0, token 0 and the last two tokens are dropped", R, T); return ALADIN_ERR_ARG; }
+  memset(g, 0, sizeof(*g));
+  g->Bi = Bi; g->Bc = Bc; g->R = R; g->T = T; g->D = D;
+  g->Rq = R - 1; g->Tq = T - 3;
+  if (g->Rq > 96 || g->Tq > 96) { aladin_set_error("align_geometry: at most 97 regions / 99 tokens supported (got R=%d T=%d)", R, T); return ALADIN_ERR_UNSUPPORTED; }
+  if (g->Rq > 32 && g->Rq % 32 == 1 && g->Rq < 96) { g->mtiles = g->Rq / 32; g->rem = 1; }
+  else { g->mtiles = cdiv(g->Rq, 32); g->rem = 0; }
+  g->tp16 = cdiv(g->Tq, 16);
+  if (g->tp16 == 5) g->tp16 = 6;
+  g->Dp = round_up(D, 64);
+  const int imgs_per_wave = (g->mtiles == 1) ? 2 : 1;
+  g->img_unit = 4 * imgs_per_wave;
+  g->cap_unit = 2 * ((g->tp16 & 1) ? 2 : 1);
+  g->Bi_pad = round_up(Bi, g->img_unit);
+  g->Bc_pad = round_up(Bc, g->cap_unit);
+  g->xm_rows = (int64_t)g->Bi_pad * 32 * g->mtiles;
+  g->xe_rows = g->rem ? round_up(g->Bi_pad, 64) : 0;
+  g->y_rows = (int64_t)g->Bc_pad * 16 * g->tp16;
+  g->xm_bytes = g->xm_rows * g->Dp * 2;
+  g->xe_bytes = g->xe_rows * g->Dp * 2;
+  g->y_bytes = g->y_rows * g->Dp * 2;
+  g->e_bytes = g->xe_rows * g->y_rows * 4;
+  return ALADIN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// pack: one wave per destination row
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void pack_row(const float* __restrict__ src, half_t* __restrict__ dst, int D, int Dp,
+                                         int lane, bool vec4) {
+  // src == nullptr -> zero row
+  if (src == nullptr) {
+    for (int c = lane * 8; c < Dp; c += 64 * 8) *reinterpret_cast<half8*>(dst + c) = half8{0, 0, 0, 0, 0, 0, 0, 0};
+    return;
+  }
+  float ss = 0.f;
+  if (vec4) {
+    for (int c = lane * 4; c < D; c += 256) {
+      const float4 v = *reinterpret_cast<const float4*>(src + c);
+      ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    }
+  } else {
+    for (int c = lane; c < D; c += 64) ss += src[c] * src[c];
+  }
+  ss = wave_sum(ss);
+  const float inv = 1.0f / fmaxf(sqrtf(ss), 1e-12f);        // F.normalize eps (alad/loss.py:80-81)
+  if (vec4) {
+    for (int c = lane * 4; c < Dp; c += 256) {
+      half4 h = {0, 0, 0, 0};
+      if (c < D) {
+        const float4 v = *reinterpret_cast<const float4*>(src + c);
+        h = half4{(half_t)(v.x * inv), (half_t)(v.y * inv), (half_t)(v.z * inv), (half_t)(v.w * inv)};
+      }
+      *reinterpret_cast<half4*>(dst + c) = h;
+    }
+  } else {
+    for (int c = lane; c < Dp; c += 64) dst[c] = (c < D) ? (half_t)(src[c] * inv) : (half_t)0;
+  }
+}
+
+__global__ __launch_bounds__(256) void pack_images_kernel(const float* __restrict__ im, int64_t sb, int64_t sr,
+                                                          const int32_t* __restrict__ im_len, int Bi, int Rq, int D,
+                                                          int Dp, int mtiles, int rem, int64_t xm_rows,
+                                                          int64_t total_rows, half_t* __restrict__ xm,
+                                                          half_t* __restrict__ xe, int vec4) {
+  const int lane = threadIdx.x & 63;
+  const int64_t d = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (d >= total_rows) return;
+  int i, rho;
+  half_t* dst;
+  if (d < xm_rows) {
+    const int rows_per_img = 32 * mtiles;
+    i = (int)(d / rows_per_img);
+    rho = (int)(d % rows_per_img);
+    if (rho >= Rq) rho = 0;                       // tile-filling copy of the first region
+    dst = xm + d * Dp;
+  } else {
+    i = (int)(d - xm_rows);
+    rho = 32 * mtiles;                            // the leftover (last) region
+    dst = xe + (d - xm_rows) * Dp;
+  }
+  const float* src = nullptr;
+  if (i < Bi) {
+    int Li = im_len[i] - 1;                       // alad/loss.py:89
+    Li = Li < 0 ? 0 : (Li > Rq ? Rq : Li);
+    if (rho < Li) src = im + i * sb + (int64_t)(rho + 1) * sr;     // region 0 dropped (alad/loss.py:87)
+  }
+  pack_row(src, dst, D, Dp, lane, vec4 != 0);
+}
+
+__global__ __launch_bounds__(256) void pack_captions_kernel(const float* __restrict__ s, int64_t sb, int64_t st,
+                                                            const int32_t* __restrict__ s_len, int Bc, int Tq, int D,
+                                                            int Dp, int tpad, int64_t total_rows,
+                                                            half_t* __restrict__ y, int vec4) {
+  const int lane = threadIdx.x & 63;
+  const int64_t d = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (d >= total_rows) return;
+  const int j = (int)(d / tpad), w = (int)(d % tpad);
+  const float* src = nullptr;
+  if (j < Bc) {
+    int Lj = s_len[j] - 3;                        // alad/loss.py:90
+    Lj = Lj < 0 ? 0 : (Lj > Tq ? Tq : Lj);
+    if (w < Lj) src = s + j * sb + (int64_t)(w + 1) * st;          // token 0 dropped (alad/loss.py:88)
+  }
+  pack_row(src, y + d * Dp, D, Dp, lane, vec4 != 0);
+}
+
+static int is_vec4_ok(const void* p, int64_t s0, int64_t s1, int D) {
+  return (D % 4 == 0) && (s0 % 4 == 0) && (s1 % 4 == 0) && (((uintptr_t)p & 15) == 0);
+}
+
+extern "C" int aladin_align_pack_images(const float* im, int64_t stride_b, int64_t stride_r, const int32_t* im_len,
+                                        const aladin_align_geom* g, void* xm, void* xe, void* stream) {
+  if (!im || !im_len || !g || !xm || (g->rem && !xe)) { aladin_set_error("align_pack_images: null argument"); return ALADIN_ERR_ARG; }
+  const int64_t total = g->xm_rows + g->xe_rows;
+  const unsigned grid = (unsigned)((total + 3) / 4);
+  hipLaunchKernelGGL(pack_images_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, im, stride_b, stride_r, im_len,
+                     g->Bi, g->Rq, g->D, g->Dp, g->mtiles, g->rem, g->xm_rows, total, (half_t*)xm, (half_t*)xe,
+                     is_vec4_ok(im, stride_b, stride_r, g->D));
+  return aladin_check_launch("pack_images_kernel");
+}
+
+extern "C" int aladin_align_pack_captions(const float* s, int64_t stride_b, int64_t stride_t, const int32_t* s_len,
+                                          const aladin_align_geom* g, void* y, void* stream) {
+  if (!s || !s_len || !g || !y) { aladin_set_error("align_pack_captions: null argument"); return ALADIN_ERR_ARG; }
+  const unsigned grid = (unsigned)((g->y_rows + 3) / 4);
+  hipLaunchKernelGGL(pack_captions_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, s, stride_b, stride_t, s_len,
+                     g->Bc, g->Tq, g->D, g->Dp, 16 * g->tp16, g->y_rows, (half_t*)y,
+                     is_vec4_ok(s, stride_b, stride_t, g->D));
+  return aladin_check_launch("pack_captions_kernel");
+}
+
+// ------------------------------------------------------------------------------------------------
+// side GEMM: E[i][col] = <last region of image i, word col>   (fp32, xe_rows x y_rows)
+// ------------------------------------------------------------------------------------------------
+template <int NT>
+__global__ __launch_bounds__(256) void align_side_gemm_kernel(const half_t* __restrict__ xe, const half_t* __restrict__ y,
+                                                              float* __restrict__ E, int64_t ldE, int64_t ldk,
+                                                              int ktiles, int n_nblk) {
+  using Cfg = GemmCfg<2, 2, 1, NT>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int mb = blockIdx.x / n_nblk, nb = blockIdx.x % n_nblk;
+  f32x16 acc[1][NT];
+#pragma unroll
+  for (int n = 0; n < NT; ++n)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[0][n][r] = 0.f;
+  gemm_mainloop<Cfg>(xe + (int64_t)mb * Cfg::BM * ldk, y + (int64_t)nb * Cfg::BN * ldk, ldk, ktiles, smem, acc);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wm = wave / 2, wn = wave % 2;
+  const int64_t row0 = (int64_t)mb * Cfg::BM + wm * 32 + 4 * (lane >> 5);
+  const int64_t col0 = (int64_t)nb * Cfg::BN + wn * NT * 32 + (lane & 31);
+#pragma unroll
+  for (int n = 0; n < NT; ++n)
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      E[(row0 + (r & 3) + 8 * (r >> 2)) * ldE + col0 + n * 32] = acc[0][n][r];
+}
+
+// ------------------------------------------------------------------------------------------------
+// score kernel
+//   WM   M-tiles (32 rows) per wave;  Q  M-tiles per image;  images per wave = WM / Q  (2 or 1)
+//   TP16 padded words per caption / 16;  a wave's column strip holds CPS = 1 or 2 whole captions
+// ------------------------------------------------------------------------------------------------
+template <int WM, int Q, int TP16, bool HAS_E>
+__global__ __launch_bounds__(512) void align_scores_kernel(const half_t* __restrict__ xm, const half_t* __restrict__ y,
+                                                           const float* __restrict__ E, int64_t ldE,
+                                                           float* __restrict__ S, int64_t ldS, int Bi, int Bc,
+                                                           int64_t ldk, int ktiles, int n_nblk, int n_blocks) {
+  constexpr int NT = (TP16 & 1) ? TP16 : TP16 / 2;
+  constexpr int CPS = (TP16 & 1) ? 2 : 1;
+  constexpr int IPW = WM / Q;
+  static_assert(IPW == 1 || IPW == 2, "one or two images per wave");
+  using Cfg = GemmCfg<4, 2, WM, NT>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int bid = xcd_remap(blockIdx.x, n_blocks);
+  const int mb = bid / n_nblk, nb = bid % n_nblk;
+
+  f32x16 acc[WM][NT];
+#pragma unroll
+  for (int a = 0; a < WM; ++a)
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][n][r] = 0.f;
+
+  gemm_mainloop<Cfg>(xm + (int64_t)mb * Cfg::BM * ldk, y + (int64_t)nb * Cfg::BN * ldk, ldk, ktiles, smem, acc);
+
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wm = wave / 2, wn = wave % 2;
+  const int half = lane >> 5, l5 = lane & 31;
+
+  // max over regions: 16 accumulator rows per lane, then the other half-wave's 16 rows
+  float m[NT];
+  if constexpr (IPW == 2) {
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      float p0 = acc[0][n][0], p1 = acc[1][n][0];
+#pragma unroll
+      for (int r = 1; r < 16; ++r) { p0 = fmaxf(p0, acc[0][n][r]); p1 = fmaxf(p1, acc[1][n][r]); }
+      // lanes 0-31 end up with image 0's two partial maxima, lanes 32-63 with image 1's
+      auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(p0), __float_as_uint(p1), false, false);
+      m[n] = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+    }
+  } else {
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      float p = acc[0][n][0];
+#pragma unroll
+      for (int a = 0; a < WM; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) p = fmaxf(p, acc[a][n][r]);
+      m[n] = fmaxf(p, __shfl_xor(p, 32, 64));
+    }
+  }
+  const int img = (mb * 4 + wm) * IPW + (IPW == 2 ? half : 0);
+  if constexpr (HAS_E) {
+    const float* e = E + (int64_t)img * ldE + (int64_t)nb * Cfg::BN + wn * NT * 32 + l5;
+#pragma unroll
+    for (int n = 0; n < NT; ++n) m[n] = fmaxf(m[n], e[n * 32]);
+  }
+
+  // sum over words: 16-lane groups map to captions at compile time
+  float v0 = 0.f, v1 = 0.f;
+#pragma unroll
+  for (int n = 0; n < NT; ++n) {
+    constexpr int dummy = 0; (void)dummy;
+    const int c_lo = (2 * n) / TP16, c_hi = (2 * n + 1) / TP16;
+    const float lo = (c_lo == c_hi || l5 < 16) ? m[n] : 0.f;      // contribution to caption c_lo
+    const float hi = (c_lo != c_hi && l5 >= 16) ? m[n] : 0.f;     // contribution to caption c_hi (straddling tile)
+    if (c_lo == 0) v0 += lo; else v1 += lo;
+    if (c_hi == 0) v0 += hi; else v1 += hi;
+  }
+  v0 = half_wave_sum(v0);
+  if constexpr (CPS == 2) v1 = half_wave_sum(v1);
+  const int cap = (nb * 2 + wn) * CPS;
+  if (l5 == 0 && (IPW == 2 || half == 0) && img < Bi) {
+    if (cap < Bc) S[(int64_t)img * ldS + cap] = v0;
+    if (CPS == 2 && cap + 1 < Bc) S[(int64_t)img * ldS + cap + 1] = v1;
+  }
+}
+
+template <int WM, int Q, int TP16, bool HAS_E>
+static int launch_scores(const aladin_align_geom* g, const half_t* xm, const half_t* y, const float* E, float* S,
+                         int64_t ldS, hipStream_t stream) {
+  constexpr int NT = (TP16 & 1) ? TP16 : TP16 / 2;
+  using Cfg = GemmCfg<4, 2, WM, NT>;
+  const int n_mblk = (int)(g->xm_rows / Cfg::BM), n_nblk = (int)(g->y_rows / Cfg::BN);
+  if ((int64_t)n_mblk * Cfg::BM != g->xm_rows || (int64_t)n_nblk * Cfg::BN != g->y_rows) {
+    aladin_set_error("align_scores: packed rows (%lld, %lld) do not tile by (%d, %d)", (long long)g->xm_rows,
+                     (long long)g->y_rows, Cfg::BM, Cfg::BN);
+    return ALADIN_ERR_ARG;
+  }
+  auto kern = align_scores_kernel<WM, Q, TP16, HAS_E>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES) != hipSuccess) {
+      aladin_set_error("align_scores: cannot reserve %d B of LDS", Cfg::LDS_BYTES);
+      return ALADIN_ERR_HIP;
+    }
+    attr_done = true;
+  }
+  const int n_blocks = n_mblk * n_nblk;
+  hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(Cfg::THREADS), Cfg::LDS_BYTES, stream, xm, y, E, g->y_rows, S, ldS, g->Bi,
+                     g->Bc, (int64_t)g->Dp, g->Dp / 64, n_nblk, n_blocks);
+  return aladin_check_launch("align_scores_kernel");
+}
+
+template <int NT>
+static int launch_side(const aladin_align_geom* g, const half_t* xe, const half_t* y, float* E, hipStream_t stream) {
+  using Cfg = GemmCfg<2, 2, 1, NT>;
+  const int n_mblk = (int)(g->xe_rows / Cfg::BM), n_nblk = (int)(g->y_rows / Cfg::BN);
+  auto kern = align_side_gemm_kernel<NT>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES) != hipSuccess) {
+      aladin_set_error("align_side_gemm: cannot reserve %d B of LDS", Cfg::LDS_BYTES);
+      return ALADIN_ERR_HIP;
+    }
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(n_mblk * n_nblk), dim3(Cfg::THREADS), Cfg::LDS_BYTES, stream, xe, y, E, g->y_rows,
+                     (int64_t)g->Dp, g->Dp / 64, n_nblk);
+  return aladin_check_launch("align_side_gemm_kernel");
+}
+
+template <int TP16>
+static int dispatch_tp(const aladin_align_geom* g, const half_t* xm, const half_t* xe, const half_t* y, float* E,
+                       float* S, int64_t ldS, int flags, hipStream_t stream) {
+  constexpr int NT = (TP16 & 1) ? TP16 : TP16 / 2;
+  if (g->rem) {
+    if (!(flags & ALADIN_SCORES_REUSE_SIDE)) {
+      int rc = launch_side<NT>(g, xe, y, E, stream);
+      if (rc) return rc;
+    }
+    if (g->mtiles == 1) return launch_scores<2, 1, TP16, true>(g, xm, y, E, S, ldS, stream);
+    if (g->mtiles == 2) return launch_scores<2, 2, TP16, true>(g, xm, y, E, S, ldS, stream);
+  } else {
+    if (g->mtiles == 1) return launch_scores<2, 1, TP16, false>(g, xm, y, E, S, ldS, stream);
+    if (g->mtiles == 2) return launch_scores<2, 2, TP16, false>(g, xm, y, E, S, ldS, stream);
+    if (g->mtiles == 3) return launch_scores<3, 3, TP16, false>(g, xm, y, E, S, ldS, stream);
+  }
+  aladin_set_error("align_scores: unsupported tiling mtiles=%d rem=%d", g->mtiles, g->rem);
+  return ALADIN_ERR_UNSUPPORTED;
+}
+
+extern "C" int aladin_align_scores(const void* xm, const void* xe, const void* y, const aladin_align_geom* g,
+                                   void* e_scratch, float* S, int64_t ldS, void* stream) {
+  return aladin_align_scores_ex(xm, xe, y, g, e_scratch, S, ldS, 0, stream);
+}
+
+extern "C" int aladin_align_scores_ex(const void* xm, const void* xe, const void* y, const aladin_align_geom* g,
+                                      void* e_scratch, float* S, int64_t ldS, int flags, void* stream) {
+  if (!xm || !y || !g || !S || (g->rem && (!xe || !e_scratch))) { aladin_set_error("align_scores: null argument"); return ALADIN_ERR_ARG; }
+  if (ldS < g->Bc) { aladin_set_error("align_scores: ldS %lld < Bc %d", (long long)ldS, g->Bc); return ALADIN_ERR_ARG; }
+  hipStream_t st = (hipStream_t)stream;
+  const half_t* a = (const half_t*)xm; const half_t* b = (const half_t*)xe; const half_t* c = (const half_t*)y;
+  float* E = (float*)e_scratch;
+  switch (g->tp16) {
+    case 1: return dispatch_tp<1>(g, a, b, c, E, S, ldS, flags, st);
+    case 2: return dispatch_tp<2>(g, a, b, c, E, S, ldS, flags, st);
+    case 3: return dispatch_tp<3>(g, a, b, c, E, S, ldS, flags, st);
+    case 4: return dispatch_tp<4>(g, a, b, c, E, S, ldS, flags, st);
+    case 6: return dispatch_tp<6>(g, a, b, c, E, S, ldS, flags, st);
+  }
+  aladin_set_error("align_scores: unsupported padded caption length %d", 16 * g->tp16);
+  return ALADIN_ERR_UNSUPPORTED;
+}

@@ -1,0 +1,277 @@
+// Loss reductions on the B x B score matrices (tiny next to the score kernel; one pass of row/column
+// statistics + one element-wise pass, no atomics, bitwise reproducible):
+//   hinge    VSE++ triplet loss, reference alad/loss.py:42-67
+//   listnet  score distillation, reference alad/loss.py:369-370,427-445
+//   sgemm    C = A * B with arbitrary strides on the exact-fp32 MFMA (dot_sim alad/loss.py:8-11 and
+//            its two backward products)
+#include "../../include/aladin_hip.h"
+#include "common.hpp"
+
+// ------------------------------------------------------------------------------------------------
+// block-wide reductions (256 threads = 4 waves)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float block_sum(float v, float* red) {
+  v = wave_sum(v);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  __syncthreads();
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  float t = 0.f;
+  for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += red[w];
+  return t;
+}
+__device__ __forceinline__ float block_max(float v, float* red) {
+  v = wave_max(v);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  __syncthreads();
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  float t = red[0];
+  for (int w = 1; w < (int)(blockDim.x >> 6); ++w) t = fmaxf(t, red[w]);
+  return t;
+}
+// (max value, smallest index attaining it)
+__device__ __forceinline__ void block_argmax(float& v, int& idx, float* redv, int* redi) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(v, o, 64);
+    const int oi = __shfl_xor(idx, o, 64);
+    if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
+  }
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  __syncthreads();
+  if (lane == 0) { redv[wave] = v; redi[wave] = idx; }
+  __syncthreads();
+  v = redv[0]; idx = redi[0];
+  for (int w = 1; w < (int)(blockDim.x >> 6); ++w)
+    if (redv[w] > v || (redv[w] == v && redi[w] < idx)) { v = redv[w]; idx = redi[w]; }
+}
+
+// ------------------------------------------------------------------------------------------------
+// hinge: stats[b] for rows (b < B) and columns (b >= B)
+//   max_violation: val = max_j cost, arg = argmax          (alad/loss.py:63-65)
+//   sum mode     : val = sum_j cost, arg = #(cost > 0)     (alad/loss.py:67)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void hinge_stats_kernel(const float* __restrict__ S, int64_t ld, int B, float margin,
+                                                          int max_violation, float* __restrict__ val,
+                                                          int* __restrict__ arg) {
+  __shared__ float redv[4];
+  __shared__ int redi[4];
+  const int b = blockIdx.x;
+  const bool is_row = b < B;
+  const int q = is_row ? b : b - B;
+  const float diag = S[(int64_t)q * ld + q];
+  float best = 0.f, sum = 0.f;
+  int besti = 0x7fffffff, cnt = 0;
+  for (int t = threadIdx.x; t < B; t += blockDim.x) {
+    const float s = is_row ? S[(int64_t)q * ld + t] : S[(int64_t)t * ld + q];
+    float c = fmaxf(margin + s - diag, 0.f);              // :49 / :52
+    if (t == q) c = 0.f;                                  // :55-60
+    if (c > best || (c == best && t < besti)) { best = c; besti = t; }
+    sum += c;
+    cnt += (c > 0.f);
+  }
+  if (max_violation) {
+    block_argmax(best, besti, redv, redi);
+    if (threadIdx.x == 0) { val[b] = best; arg[b] = besti; }
+  } else {
+    sum = block_sum(sum, redv);
+    const float fc = block_sum((float)cnt, redv);
+    if (threadIdx.x == 0) { val[b] = sum; arg[b] = (int)fc; }
+  }
+}
+
+__global__ __launch_bounds__(256) void hinge_finish_kernel(const float* __restrict__ S, int64_t ld, int B, float margin,
+                                                           int max_violation, const float* __restrict__ val,
+                                                           const int* __restrict__ arg, float* __restrict__ loss,
+                                                           float* __restrict__ dS) {
+  __shared__ float red[4];
+  if (blockIdx.x == 0) {
+    float rs = 0.f, cs = 0.f;                             // rows first, then columns, fixed order
+    for (int t = threadIdx.x; t < B; t += blockDim.x) { rs += val[t]; cs += val[B + t]; }
+    rs = block_sum(rs, red);
+    cs = block_sum(cs, red);
+    if (threadIdx.x == 0) *loss = rs + cs;
+  }
+  if (dS == nullptr) return;
+  const int64_t n = (int64_t)B * B;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+    const int i = (int)(e / B), j = (int)(e % B);
+    float g;
+    if (max_violation) {
+      if (i == j) g = -(float)((val[i] > 0.f) + (val[B + i] > 0.f));
+      else g = (float)((val[i] > 0.f && arg[i] == j) + (val[B + j] > 0.f && arg[B + j] == i));
+    } else {
+      if (i == j) g = -(float)(arg[i] + arg[B + i]);
+      else {
+        const float s = S[(int64_t)i * ld + j];
+        g = (float)((margin + s - S[(int64_t)i * ld + i] > 0.f) + (margin + s - S[(int64_t)j * ld + j] > 0.f));
+      }
+    }
+    dS[e] = g;
+  }
+}
+
+extern "C" size_t aladin_hinge_workspace_bytes(int B) { return (size_t)(B > 0 ? B : 0) * 16 + 256; }
+
+extern "C" int aladin_hinge_fwd_bwd(const float* S, int64_t ldS, int B, float margin, int max_violation, float* loss,
+                                    float* dS, void* workspace, void* stream) {
+  if (!S || !loss || !workspace || B < 1 || ldS < B) { aladin_set_error("hinge_fwd_bwd: bad argument (B=%d ldS=%lld)", B, (long long)ldS); return ALADIN_ERR_ARG; }
+  float* val = (float*)workspace;
+  int* arg = (int*)(val + 2 * (size_t)B);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(hinge_stats_kernel, dim3(2 * B), dim3(256), 0, st, S, ldS, B, margin, max_violation, val, arg);
+  int rc = aladin_check_launch("hinge_stats_kernel");
+  if (rc) return rc;
+  const int64_t n = (int64_t)B * B;
+  const int grid = dS ? (int)((n + 1023) / 1024 < 2048 ? (n + 1023) / 1024 : 2048) : 1;
+  hipLaunchKernelGGL(hinge_finish_kernel, dim3(grid < 1 ? 1 : grid), dim3(256), 0, st, S, ldS, B, margin, max_violation, val,
+                     arg, loss, dS);
+  return aladin_check_launch("hinge_finish_kernel");
+}
+
+// ------------------------------------------------------------------------------------------------
+// listnet.  stats[b][6] = {t_max, t_sumexp, s_max, s_sumexp, W_sum, loss_term}, rows then columns.
+//   P = softmax(T), Q = softmax(tau*M), loss_term = -sum P log(Q + eps), W = P Q / (Q + eps)
+//   dM = (tau / B) [ Q^r Wsum^r - W^r + Q^c Wsum^c - W^c ]           
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void listnet_stats_kernel(const float* __restrict__ T, int64_t ldt,
+                                                            const float* __restrict__ M, int64_t ldm, int B, float tau,
+                                                            float eps, float* __restrict__ stats) {
+  __shared__ float red[4];
+  const int b = blockIdx.x;
+  const bool is_row = b < B;
+  const int q = is_row ? b : b - B;
+  float tmax = -INFINITY, smax = -INFINITY;
+  for (int t = threadIdx.x; t < B; t += blockDim.x) {
+    const int64_t ot = is_row ? (int64_t)q * ldt + t : (int64_t)t * ldt + q;
+    const int64_t om = is_row ? (int64_t)q * ldm + t : (int64_t)t * ldm + q;
+    tmax = fmaxf(tmax, T[ot]);
+    smax = fmaxf(smax, tau * M[om]);
+  }
+  tmax = block_max(tmax, red);
+  smax = block_max(smax, red);
+  float tsum = 0.f, ssum = 0.f;
+  for (int t = threadIdx.x; t < B; t += blockDim.x) {
+    const int64_t ot = is_row ? (int64_t)q * ldt + t : (int64_t)t * ldt + q;
+    const int64_t om = is_row ? (int64_t)q * ldm + t : (int64_t)t * ldm + q;
+    tsum += expf(T[ot] - tmax);
+    ssum += expf(tau * M[om] - smax);
+  }
+  tsum = block_sum(tsum, red);
+  ssum = block_sum(ssum, red);
+  float wsum = 0.f, lterm = 0.f;
+  for (int t = threadIdx.x; t < B; t += blockDim.x) {
+    const int64_t ot = is_row ? (int64_t)q * ldt + t : (int64_t)t * ldt + q;
+    const int64_t om = is_row ? (int64_t)q * ldm + t : (int64_t)t * ldm + q;
+    const float P = expf(T[ot] - tmax) / tsum;
+    const float Q = expf(tau * M[om] - smax) / ssum;
+    lterm -= P * logf(Q + eps);
+    wsum += P * Q / (Q + eps);
+  }
+  lterm = block_sum(lterm, red);
+  wsum = block_sum(wsum, red);
+  if (threadIdx.x == 0) {
+    float* s = stats + (size_t)b * 6;
+    s[0] = tmax; s[1] = tsum; s[2] = smax; s[3] = ssum; s[4] = wsum; s[5] = lterm;
+  }
+}
+
+__global__ __launch_bounds__(256) void listnet_finish_kernel(const float* __restrict__ T, int64_t ldt,
+                                                             const float* __restrict__ M, int64_t ldm, int B, float tau,
+                                                             float eps, const float* __restrict__ stats,
+                                                             float* __restrict__ loss, float* __restrict__ dM) {
+  __shared__ float red[4];
+  if (blockIdx.x == 0) {
+    float rs = 0.f, cs = 0.f;
+    for (int t = threadIdx.x; t < B; t += blockDim.x) { rs += stats[(size_t)t * 6 + 5]; cs += stats[(size_t)(B + t) * 6 + 5]; }
+    rs = block_sum(rs, red);
+    cs = block_sum(cs, red);
+    if (threadIdx.x == 0) *loss = cs / (float)B + rs / (float)B;       // im_cost + s_cost (alad/loss.py:445)
+  }
+  if (dM == nullptr) return;
+  const int64_t n = (int64_t)B * B;
+  const float k = tau / (float)B;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+    const int i = (int)(e / B), j = (int)(e % B);
+    const float t = T[(int64_t)i * ldt + j], m = tau * M[(int64_t)i * ldm + j];
+    const float* r = stats + (size_t)i * 6;
+    const float* c = stats + (size_t)(B + j) * 6;
+    const float Pr = expf(t - r[0]) / r[1], Qr = expf(m - r[2]) / r[3];
+    const float Pc = expf(t - c[0]) / c[1], Qc = expf(m - c[2]) / c[3];
+    const float Wr = Pr * Qr / (Qr + eps), Wc = Pc * Qc / (Qc + eps);
+    dM[e] = k * (Qr * r[4] - Wr + Qc * c[4] - Wc);
+  }
+}
+
+extern "C" size_t aladin_listnet_workspace_bytes(int B) { return (size_t)(B > 0 ? B : 0) * 2 * 6 * 4 + 256; }
+
+extern "C" int aladin_listnet_fwd_bwd(const float* teacher, int64_t ld_t, const float* student, int64_t ld_s, int B,
+                                      float temperature, float eps, float* loss, float* d_student, void* workspace,
+                                      void* stream) {
+  if (!teacher || !student || !loss || !workspace || B < 1 || ld_t < B || ld_s < B) { aladin_set_error("listnet_fwd_bwd: bad argument (B=%d)", B); return ALADIN_ERR_ARG; }
+  float* stats = (float*)workspace;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(listnet_stats_kernel, dim3(2 * B), dim3(256), 0, st, teacher, ld_t, student, ld_s, B, temperature, eps,
+                     stats);
+  int rc = aladin_check_launch("listnet_stats_kernel");
+  if (rc) return rc;
+  const int64_t n = (int64_t)B * B;
+  const int grid = d_student ? (int)((n + 1023) / 1024 < 2048 ? (n + 1023) / 1024 : 2048) : 1;
+  hipLaunchKernelGGL(listnet_finish_kernel, dim3(grid < 1 ? 1 : grid), dim3(256), 0, st, teacher, ld_t, student, ld_s, B,
+                     temperature, eps, stats, loss, d_student);
+  return aladin_check_launch("listnet_finish_kernel");
+}
+
+// ------------------------------------------------------------------------------------------------
+// strided fp32 GEMM on v_mfma_f32_32x32x2_f32 (exact fp32 fma chain).  64 x 64 tile per workgroup
+// (4 waves, one 32x32 accumulator each), 32-deep K slabs staged through LDS with bounds checks.
+// ------------------------------------------------------------------------------------------------
+#define SG_KB 32
+__global__ __launch_bounds__(256) void sgemm_strided_kernel(int M, int N, int K, const float* __restrict__ A, int64_t a_rs,
+                                                            int64_t a_cs, const float* __restrict__ Bm, int64_t b_rs,
+                                                            int64_t b_cs, float* __restrict__ C, int64_t ldc) {
+  __shared__ float As[SG_KB][65];      // [k][m]
+  __shared__ float Bs[SG_KB][65];      // [k][n]
+  const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wm = wave >> 1, wn = wave & 1;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const bool a_kfast = (a_cs == 1), b_kfast = (b_rs == 1);
+  for (int k0 = 0; k0 < K; k0 += SG_KB) {
+    __syncthreads();
+    for (int e = threadIdx.x; e < 64 * SG_KB; e += 256) {
+      int m, k;
+      if (a_kfast) { k = e % SG_KB; m = e / SG_KB; } else { m = e % 64; k = e / 64; }
+      const int gm = m0 + m, gk = k0 + k;
+      As[k][m] = (gm < M && gk < K) ? A[gm * a_rs + gk * a_cs] : 0.f;
+      int n, kb;
+      if (b_kfast) { kb = e % SG_KB; n = e / SG_KB; } else { n = e % 64; kb = e / 64; }
+      const int gn = n0 + n, gkb = k0 + kb;
+      Bs[kb][n] = (gn < N && gkb < K) ? Bm[gkb * b_rs + gn * b_cs] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < SG_KB; kk += 2) {
+      const float a = As[kk + (lane >> 5)][wm * 32 + (lane & 31)];
+      const float b = Bs[kk + (lane >> 5)][wn * 32 + (lane & 31)];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    }
+  }
+  const int col = n0 + wn * 32 + (lane & 31);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    if (row < M && col < N) C[(int64_t)row * ldc + col] = acc[r];
+  }
+}
+
+extern "C" int aladin_sgemm_strided(int M, int N, int K, const float* A, int64_t a_rs, int64_t a_cs, const float* B,
+                                    int64_t b_rs, int64_t b_cs, float* C, int64_t ldc, void* stream) {
+  if (!A || !B || !C || M < 1 || N < 1 || K < 1 || ldc < N) { aladin_set_error("sgemm_strided: bad argument (M=%d N=%d K=%d)", M, N, K); return ALADIN_ERR_ARG; }
+  hipLaunchKernelGGL(sgemm_strided_kernel, dim3(cdiv(N, 64), cdiv(M, 64)), dim3(256), 0, (hipStream_t)stream, M, N, K, A,
+                     a_rs, a_cs, B, b_rs, b_cs, C, ldc);
+  return aladin_check_launch("sgemm_strided_kernel");
+}

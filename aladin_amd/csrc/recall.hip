@@ -1,0 +1,261 @@
+// Matching-head retrieval at evaluation scale: sim = img @ cap.T and COCO-protocol ranks.
+// Replaces ims.mm(caps.t()) + numpy argsort/where, reference alad/recall_auxiliary.py:30-56 and
+// alad/evaluation.py:196,213-223,285,303-308.
+//
+// Ranks must agree with the fp32 reference, so the 16-bit MFMA path uses a hi/lo split:
+//   x * 2^e = hi + lo (both fp16),  <a,b> ~ (ah.bh + al.bh + ah.bl) * 2^-(ea+eb)
+// i.e. three fp16 MFMA products accumulated in fp32 (~2^-21 relative operand error, the level of
+// fp32 rounding in the reference's own sgemm).  It is expressed as ONE ordinary GEMM over a
+// K-concatenated operand pair  A'' = [ah | al | ah],  B'' = [bh | bh | bl]  so the LDS-staged
+// main loop of gemm_core.hpp is reused unchanged.  The power-of-two scale 2^e (from the operand's
+// absmax) keeps lo in fp16's normal range; undoing it is exact.
+#include "../../include/aladin_hip.h"
+#include "gemm_core.hpp"
+
+using SimCfg = GemmCfg<4, 2, 2, 4>;       // 256 x 256 tile, 8 waves, 128 accumulator VGPRs per lane
+
+struct SimWs {
+  float* scale;      // [0] = 2^ea, [1] = 2^eb, [2] = absmax(img), [3] = absmax(cap)  (256 B block)
+  half_t* a;         // Mp x 3Dp
+  half_t* b;         // Np x 3Dp
+};
+
+static size_t sim_ws_layout(int n_img, int n_cap, int D, char* base, SimWs* ws, int* Mp_, int* Np_, int* Dp_) {
+  const int Mp = round_up(n_img, SimCfg::BM), Np = round_up(n_cap, SimCfg::BN), Dp = round_up(D, 64);
+  if (Mp_) *Mp_ = Mp;
+  if (Np_) *Np_ = Np;
+  if (Dp_) *Dp_ = Dp;
+  size_t off = 0;
+  if (ws) ws->scale = (float*)(base + off);
+  off += 256;
+  if (ws) ws->a = (half_t*)(base + off);
+  off += (size_t)Mp * 3 * Dp * 2;
+  if (ws) ws->b = (half_t*)(base + off);
+  off += (size_t)Np * 3 * Dp * 2;
+  return off;
+}
+
+extern "C" size_t aladin_sim_workspace_bytes(int n_img, int n_cap, int D) {
+  if (n_img < 1 || n_cap < 1 || D < 1) return 0;
+  return sim_ws_layout(n_img, n_cap, D, nullptr, nullptr, nullptr, nullptr, nullptr);
+}
+
+// absmax as an integer max on the (non-negative) float bit pattern: order preserving, deterministic
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, int64_t rs, int rows, int D,
+                                                     unsigned* __restrict__ out) {
+  float m = 0.f;
+  const int64_t n = (int64_t)rows * D;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+    const float v = fabsf(x[(e / D) * rs + (e % D)]);
+    if (v > m) m = v;                                   // NaN never wins
+  }
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));
+}
+
+__global__ void sim_scale_kernel(float* __restrict__ sc) {
+  for (int t = 0; t < 2; ++t) {
+    const float am = sc[2 + t];
+    int e = 0;
+    if (am > 0.f && am < INFINITY) {
+      int ex;
+      frexpf(am, &ex);                                  // am = f * 2^ex, f in [0.5, 1)
+      e = 14 - ex;                                      // |x| * 2^e < 2^14
+      e = e > 100 ? 100 : (e < -100 ? -100 : e);
+    }
+    sc[t] = ldexpf(1.f, e);
+  }
+}
+
+// one wave per row: dst row = [hi | lo | hi] (kind 0, images) or [hi | hi | lo] (kind 1, captions)
+__global__ __launch_bounds__(256) void sim_pack_kernel(const float* __restrict__ x, int64_t rs, int rows, int D, int Dp,
+                                                       int rows_p, const float* __restrict__ scale, int kind,
+                                                       half_t* __restrict__ dst) {
+  const int lane = threadIdx.x & 63;
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows_p) return;
+  const float sc = scale[kind];
+  half_t* d = dst + r * 3 * Dp;
+  const int lo_slot = kind == 0 ? 1 : 2, hi2_slot = kind == 0 ? 2 : 1;
+  for (int c = lane; c < Dp; c += 64) {
+    float v = 0.f;
+    if (r < rows && c < D) v = x[r * rs + c] * sc;
+    const half_t hi = (half_t)v;
+    const half_t lo = (half_t)(v - (float)hi);
+    d[c] = hi;
+    d[lo_slot * Dp + c] = lo;
+    d[hi2_slot * Dp + c] = hi;
+  }
+}
+
+__global__ __launch_bounds__(512) void sim_gemm_kernel(const half_t* __restrict__ a, const half_t* __restrict__ b,
+                                                       const float* __restrict__ scale, float* __restrict__ sim,
+                                                       int64_t ld, int n_img, int n_cap, int64_t ldk, int ktiles,
+                                                       int n_nblk, int n_blocks) {
+  using Cfg = SimCfg;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int bid = xcd_remap(blockIdx.x, n_blocks);
+  const int mb = bid / n_nblk, nb = bid % n_nblk;
+  f32x16 acc[Cfg::WM][Cfg::WN];
+#pragma unroll
+  for (int m = 0; m < Cfg::WM; ++m)
+#pragma unroll
+    for (int n = 0; n < Cfg::WN; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+  gemm_mainloop<Cfg>(a + (int64_t)mb * Cfg::BM * ldk, b + (int64_t)nb * Cfg::BN * ldk, ldk, ktiles, smem, acc);
+  const float unscale = 1.0f / (scale[0] * scale[1]);   // exact: powers of two
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wm = wave / Cfg::WGN, wn = wave % Cfg::WGN;
+#pragma unroll
+  for (int m = 0; m < Cfg::WM; ++m)
+#pragma unroll
+    for (int n = 0; n < Cfg::WN; ++n) {
+      const int col = nb * Cfg::BN + (wn * Cfg::WN + n) * 32 + (lane & 31);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = mb * Cfg::BM + (wm * Cfg::WM + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (row < n_img && col < n_cap) sim[(int64_t)row * ld + col] = acc[m][n][r] * unscale;
+      }
+    }
+}
+
+extern "C" int aladin_sim_matrix(const float* img, int64_t img_rs, const float* cap, int64_t cap_rs, int n_img, int n_cap,
+                                 int D, float* sim, int64_t ld_sim, void* workspace, void* stream) {
+  if (!img || !cap || !sim || !workspace || n_img < 1 || n_cap < 1 || D < 1 || ld_sim < n_cap || img_rs < D || cap_rs < D) {
+    aladin_set_error("sim_matrix: bad argument (n_img=%d n_cap=%d D=%d)", n_img, n_cap, D);
+    return ALADIN_ERR_ARG;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  SimWs ws;
+  int Mp, Np, Dp;
+  sim_ws_layout(n_img, n_cap, D, (char*)workspace, &ws, &Mp, &Np, &Dp);
+  if (hipMemsetAsync(ws.scale, 0, 256, st) != hipSuccess) { aladin_set_error("sim_matrix: memset failed"); return ALADIN_ERR_HIP; }
+  hipLaunchKernelGGL(absmax_kernel, dim3(512), dim3(256), 0, st, img, img_rs, n_img, D, (unsigned*)(ws.scale + 2));
+  hipLaunchKernelGGL(absmax_kernel, dim3(1024), dim3(256), 0, st, cap, cap_rs, n_cap, D, (unsigned*)(ws.scale + 3));
+  hipLaunchKernelGGL(sim_scale_kernel, dim3(1), dim3(1), 0, st, ws.scale);
+  hipLaunchKernelGGL(sim_pack_kernel, dim3((Mp + 3) / 4), dim3(256), 0, st, img, img_rs, n_img, D, Dp, Mp, ws.scale, 0, ws.a);
+  hipLaunchKernelGGL(sim_pack_kernel, dim3((Np + 3) / 4), dim3(256), 0, st, cap, cap_rs, n_cap, D, Dp, Np, ws.scale, 1, ws.b);
+  int rc = aladin_check_launch("sim_pack_kernel");
+  if (rc) return rc;
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute((const void*)sim_gemm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SimCfg::LDS_BYTES) != hipSuccess) {
+      aladin_set_error("sim_matrix: cannot reserve %d B of LDS", SimCfg::LDS_BYTES);
+      return ALADIN_ERR_HIP;
+    }
+    attr_done = true;
+  }
+  const int n_mblk = Mp / SimCfg::BM, n_nblk = Np / SimCfg::BN;
+  hipLaunchKernelGGL(sim_gemm_kernel, dim3(n_mblk * n_nblk), dim3(SimCfg::THREADS), SimCfg::LDS_BYTES, st, ws.a, ws.b,
+                     ws.scale, sim, ld_sim, n_img, n_cap, (int64_t)3 * Dp, 3 * Dp / 64, n_nblk, n_mblk * n_nblk);
+  return aladin_check_launch("sim_gemm_kernel");
+}
+
+// ------------------------------------------------------------------------------------------------
+// ranks.  rank = number of strictly larger scores (argsort position unless scores tie exactly).
+// ------------------------------------------------------------------------------------------------
+#define MAX_CPI 8
+__global__ __launch_bounds__(256) void rank_i2t_kernel(const float* __restrict__ sim, int64_t ld, int n_cap, int cpi,
+                                                       int32_t* __restrict__ rank, int32_t* __restrict__ top1) {
+  __shared__ int red[4][MAX_CPI];
+  __shared__ float redv[4];
+  __shared__ int redi[4];
+  const int i = blockIdx.x;
+  const float* row = sim + (int64_t)i * ld;
+  float gt[MAX_CPI];
+  int cnt[MAX_CPI];
+#pragma unroll
+  for (int g = 0; g < MAX_CPI; ++g) { gt[g] = (g < cpi) ? row[(int64_t)i * cpi + g] : INFINITY; cnt[g] = 0; }
+  float best = -INFINITY;
+  int besti = 0x7fffffff;
+  for (int c = threadIdx.x; c < n_cap; c += blockDim.x) {
+    const float v = row[c];
+#pragma unroll
+    for (int g = 0; g < MAX_CPI; ++g) cnt[g] += (v > gt[g]);
+    if (v > best) { best = v; besti = c; }
+  }
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+  for (int g = 0; g < MAX_CPI; ++g) {
+    int c = cnt[g];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+    if (lane == 0) red[wave][g] = c;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(best, o, 64);
+    const int oi = __shfl_xor(besti, o, 64);
+    if (ov > best || (ov == best && oi < besti)) { best = ov; besti = oi; }
+  }
+  if (lane == 0) { redv[wave] = best; redi[wave] = besti; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int r = 0x7fffffff;
+    for (int g = 0; g < cpi; ++g) {
+      const int c = red[0][g] + red[1][g] + red[2][g] + red[3][g];
+      r = c < r ? c : r;
+    }
+    rank[i] = r;                                         // best of the image's captions (recall_auxiliary.py:38-44)
+    for (int w = 1; w < 4; ++w)
+      if (redv[w] > best || (redv[w] == best && redi[w] < besti)) { best = redv[w]; besti = redi[w]; }
+    top1[i] = besti;
+  }
+}
+
+// columns: thread per caption, rows split over blockIdx.y; integer atomics (order independent)
+__global__ __launch_bounds__(256) void rank_t2i_kernel(const float* __restrict__ sim, int64_t ld, int n_img, int n_cap,
+                                                       int cpi, int rows_per_block, int32_t* __restrict__ rank,
+                                                       unsigned long long* __restrict__ best_packed) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= n_cap) return;
+  const float gt = sim[(int64_t)(c / cpi) * ld + c];
+  const int r0 = blockIdx.y * rows_per_block;
+  const int r1 = (r0 + rows_per_block < n_img) ? r0 + rows_per_block : n_img;
+  int cnt = 0;
+  float best = -INFINITY;
+  int besti = 0;
+  for (int i = r0; i < r1; ++i) {
+    const float v = sim[(int64_t)i * ld + c];
+    cnt += (v > gt);
+    if (v > best) { best = v; besti = i; }
+  }
+  if (r1 > r0) {
+    atomicAdd(&rank[c], cnt);
+    unsigned u = __float_as_uint(best);
+    u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);      // order-preserving map float -> uint
+    atomicMax(&best_packed[c], ((unsigned long long)u << 32) | (unsigned)(0x7fffffff - besti));
+  }
+}
+
+__global__ __launch_bounds__(256) void unpack_top1_kernel(const unsigned long long* __restrict__ packed, int n,
+                                                          int32_t* __restrict__ top1) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < n) top1[c] = 0x7fffffff - (int)(unsigned)(packed[c] & 0xffffffffull);
+}
+
+extern "C" size_t aladin_recall_workspace_bytes(int n_cap) { return n_cap > 0 ? (size_t)n_cap * 8 : 0; }
+
+extern "C" int aladin_recall_ranks(const float* sim, int64_t ld_sim, int n_img, int n_cap, int caps_per_img,
+                                   int32_t* rank_i2t, int32_t* top1_i2t, int32_t* rank_t2i, int32_t* top1_t2i,
+                                   void* workspace, void* stream) {
+  if (!sim || !rank_i2t || !top1_i2t || !rank_t2i || !top1_t2i || !workspace) { aladin_set_error("recall_ranks: null argument"); return ALADIN_ERR_ARG; }
+  if (n_img < 1 || caps_per_img < 1 || caps_per_img > MAX_CPI || n_cap != n_img * caps_per_img || ld_sim < n_cap) {
+    aladin_set_error("recall_ranks: need n_cap == n_img * caps_per_img, caps_per_img <= %d (n_img=%d n_cap=%d cpi=%d)", MAX_CPI, n_img, n_cap, caps_per_img);
+    return ALADIN_ERR_ARG;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(rank_i2t_kernel, dim3(n_img), dim3(256), 0, st, sim, ld_sim, n_cap, caps_per_img, rank_i2t, top1_i2t);
+  int rc = aladin_check_launch("rank_i2t_kernel");
+  if (rc) return rc;
+  unsigned long long* packed = (unsigned long long*)workspace;
+  hipMemsetAsync(packed, 0, (size_t)n_cap * 8, st);
+  hipMemsetAsync(rank_t2i, 0, (size_t)n_cap * 4, st);
+  const int ysplit = n_img >= 2048 ? 16 : (n_img >= 256 ? 4 : 1);
+  const int rpb = cdiv(n_img, ysplit);
+  hipLaunchKernelGGL(rank_t2i_kernel, dim3(cdiv(n_cap, 256), ysplit), dim3(256), 0, st, sim, ld_sim, n_img, n_cap,
+                     caps_per_img, rpb, rank_t2i, packed);
+  hipLaunchKernelGGL(unpack_top1_kernel, dim3(cdiv(n_cap, 256)), dim3(256), 0, st, packed, n_cap, top1_t2i);
+  return aladin_check_launch("rank_t2i_kernel");
+}

@@ -1,0 +1,187 @@
+"""Retrieval evaluation with the reference's call surface, scored and ranked on the GPU.
+
+    compute_sim_matrix                       new name for the sites
+                                             recall_auxiliary.py:30,51, evaluation.py:196,285 and
+                                             the alignment_sim_fn closures train.py:495-498 / test.py:260-263
+    recall / recall_test / compute_recall    <- alad/recall_auxiliary.py:8-149
+    i2t / t2i                                <- alad/evaluation.py:158-327
+    AverageMeter / LogCollector              <- alad/evaluation.py:22-77 (host bookkeeping)
+
+The per-query Python loops, per-iteration host->device copies and numpy argsort of the reference
+are replaced by one score-matrix launch plus one rank launch per direction; only the rank vectors
+come back to the host.  Rank = number of strictly larger scores, which equals the reference's
+argsort position except on exact ties (whose order numpy leaves unspecified).
+"""
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from . import ops
+
+CAPS_PER_IMG = 5
+
+
+class AverageMeter(object):
+    """reference alad/evaluation.py:22-47."""
+
+    def __init__(self):
+        self.reset()
+
+    def reset(self):
+        self.val = 0
+        self.avg = 0
+        self.sum = 0
+        self.count = 0
+
+    def update(self, val, n=0):
+        self.val = val
+        self.sum += val * n
+        self.count += n
+        self.avg = self.sum / (.0001 + self.count)
+
+    def __str__(self):
+        if self.count == 0:
+            return str(self.val)
+        return '%.4f (%.4f)' % (self.val, self.avg)
+
+
+class LogCollector(object):
+    """reference alad/evaluation.py:50-77."""
+
+    def __init__(self):
+        self.meters = OrderedDict()
+
+    def update(self, k, v, n=0):
+        if k not in self.meters:
+            self.meters[k] = AverageMeter()
+        self.meters[k].update(v, n)
+
+    def __str__(self):
+        return '  '.join(k + ' ' + str(v) for k, v in self.meters.items())
+
+    def tb_log(self, tb_logger, prefix='', step=None):
+        for k, v in self.meters.items():
+            tb_logger.add_scalar(prefix + k, v.val, global_step=step)
+
+
+def _device():
+    if not torch.cuda.is_available():
+        raise RuntimeError('aladin_amd: retrieval scoring runs in HIP kernels on an MI355X only (no GPU visible)')
+    return torch.device('cuda', torch.cuda.current_device())
+
+
+def compute_sim_matrix(img, cap, img_len=None, cap_len=None, mode='matching'):
+    """(N_img, N_cap) score matrix on the GPU.
+
+    mode='matching'  : img (N_img, D), cap (N_cap, D) global embeddings -> img @ cap.T
+    mode='alignment' : img (N_img, R, D), cap (N_cap, T, D) sets with length lists -> MrSw scores
+    """
+    dev = _device()
+    img = torch.as_tensor(img).to(dev, torch.float32)
+    cap = torch.as_tensor(cap).to(dev, torch.float32)
+    with torch.no_grad():
+        if mode == 'matching':
+            return ops.sim_matrix(img, cap)
+        if mode == 'alignment':
+            if img_len is None or cap_len is None:
+                raise ValueError("compute_sim_matrix(mode='alignment') needs img_len and cap_len")
+            return ops.alignment_scores(img, cap, img_len, cap_len)
+    raise ValueError("mode must be 'matching' or 'alignment'")
+
+
+def _metrics(ranks):
+    ranks = np.asarray(ranks, dtype=np.float64)
+    r1 = 100.0 * len(np.where(ranks < 1)[0]) / len(ranks)
+    r5 = 100.0 * len(np.where(ranks < 5)[0]) / len(ranks)
+    r10 = 100.0 * len(np.where(ranks < 10)[0]) / len(ranks)
+    medr = np.floor(np.median(ranks)) + 1
+    meanr = ranks.mean() + 1
+    return r1, r5, r10, medr, meanr
+
+
+def _ranks(sim):
+    r_i2t, t_i2t, r_t2i, t_t2i = ops.recall_ranks(sim, CAPS_PER_IMG)
+    both = torch.cat([r_i2t, t_i2t, r_t2i, t_t2i]).cpu().numpy().astype(np.float64)      # one D2H copy
+    n_img, n_cap = sim.shape
+    return both[:n_img], both[n_img:2 * n_img], both[2 * n_img:2 * n_img + n_cap], both[2 * n_img + n_cap:]
+
+
+def recall(images, captions, model=None, mode='i2t', lenghts=None, return_ranks=False):
+    """reference alad/recall_auxiliary.py:8-69: rows 0::5 of `images` are the distinct images."""
+    if mode not in ('i2t', 't2i'):
+        raise ValueError('mode not correct')
+    sim = compute_sim_matrix(torch.as_tensor(images)[0::CAPS_PER_IMG], captions)
+    r_i2t, t_i2t, r_t2i, t_t2i = _ranks(sim)
+    ranks, top1 = (r_i2t, t_i2t) if mode == 'i2t' else (r_t2i, t_t2i)
+    m = _metrics(ranks)
+    return (m, (ranks, top1)) if return_ranks else m
+
+
+def recall_test(img_embs, cap_embs, tot_lengths=None, model=None):
+    """reference alad/recall_auxiliary.py:72-86; both directions from one score matrix."""
+    sim = compute_sim_matrix(torch.as_tensor(img_embs)[0::CAPS_PER_IMG], cap_embs)
+    r_i2t, _, r_t2i, _ = _ranks(sim)
+    r1, r5, r10, _, _ = _metrics(r_i2t)
+    r1i, r5i, r10i, _, _ = _metrics(r_t2i)
+    return r1, r5, r10, r1i, r5i, r10i, r1 + r5 + r10 + r1i + r5i + r10i
+
+
+def compute_recall(img_embs, cap_embs, tot_lengths=None, model=None, verbose=True):
+    """reference alad/recall_auxiliary.py:133-149."""
+    r1, r5, r10, r1i, r5i, r10i, _ = recall_test(img_embs, cap_embs)
+    rsum = r1 + r5 + r10 + r1i + r5i + r10i
+    if verbose:
+        print("Recall Image to text: %.2f, %.2f, %.2f" % (r1, r5, r10))
+        print("Recall Text to image: %.2f, %.2f, %.2f" % (r1i, r5i, r10i))
+        print('Sum score: %.2f' % rsum)
+    return r1, r5, r10, r1i, r5i, r10i, rsum
+
+
+def recall_1k_5fold_test(img_embs, cap_embs, tot_lengths=None, model=None):
+    """reference alad/recall_auxiliary.py:90-130: mean over five 5000-row folds."""
+    img_folds = torch.split(torch.as_tensor(img_embs), 5000, dim=0)
+    cap_folds = torch.split(torch.as_tensor(cap_embs), 5000, dim=0)
+    res = np.array([recall_test(img_folds[i], cap_folds[i])[:6] for i in range(5)], dtype=np.float64)
+    r1, r5, r10, r1i, r5i, r10i = (float(v) for v in res.mean(0))
+    return r1, r5, r10, r1i, r5i, r10i, r1 + r5 + r10 + r1i + r5i + r10i
+
+
+def _eval_scores(images, captions, img_lenghts, cap_lenghts, measure, sim_function):
+    if measure == 'order':
+        raise NotImplementedError("aladin_amd: measure='order' is not on the accelerated path")
+    images = torch.as_tensor(images)
+    captions = torch.as_tensor(captions)
+    ims = images[0::CAPS_PER_IMG]
+    if sim_function is None:                      # matching head on the slot-0 global embeddings (:196, :285)
+        return compute_sim_matrix(ims[:, 0, :], captions[:, 0, :])
+    ims_len = list(img_lenghts[0::CAPS_PER_IMG])
+    if sim_function == 'alignment':
+        return compute_sim_matrix(ims, captions, ims_len, list(cap_lenghts), mode='alignment')
+    dev = _device()
+    return sim_function(ims.to(dev), captions.to(dev), ims_len, list(cap_lenghts)).to(torch.float32)
+
+
+def i2t(images, captions, img_lenghts, cap_lenghts, npts=None, return_ranks=False, ndcg_scorer=None, fold_index=0,
+        measure='dot', sim_function=None, cap_batches=1):
+    """reference alad/evaluation.py:158-241.  sim_function may be None (matching head), the string
+    'alignment' (HIP alignment scores) or a callable (img, cap, img_len, cap_len) -> scores; it is
+    called ONCE on the whole (n_img x n_cap) grid instead of once per query and caption chunk
+    (cap_batches is accepted and ignored)."""
+    if ndcg_scorer is not None:
+        raise NotImplementedError('aladin_amd: ndcg_scorer is out of scope (None at every reference call site)')
+    sim = _eval_scores(images, captions, img_lenghts, cap_lenghts, measure, sim_function)
+    ranks, top1, _, _ = _ranks(sim)
+    m = _metrics(ranks) + (0, 0)
+    return (m, (ranks, top1)) if return_ranks else m
+
+
+def t2i(images, captions, img_lenghts, cap_lenghts, npts=None, return_ranks=False, ndcg_scorer=None, fold_index=0,
+        measure='dot', sim_function=None, im_batches=1):
+    """reference alad/evaluation.py:244-327 (returns (ranks, top1) instead of the top-50 table)."""
+    if ndcg_scorer is not None:
+        raise NotImplementedError('aladin_amd: ndcg_scorer is out of scope (None at every reference call site)')
+    sim = _eval_scores(images, captions, img_lenghts, cap_lenghts, measure, sim_function)
+    _, _, ranks, top1 = _ranks(sim)
+    m = _metrics(ranks) + (0, 0)
+    return (m, (ranks, top1)) if return_ranks else m

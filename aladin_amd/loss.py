@@ -1,0 +1,106 @@
+"""Drop-in loss modules with the reference's names, constructor arguments and forward signatures
+(reference alad/loss.py), computed by the HIP kernels behind include/aladin_hip.h.
+
+    AlignmentContrastiveLoss  <- alad/loss.py:70-159
+    ContrastiveLoss           <- alad/loss.py:162-186
+    DistillationLoss          <- alad/loss.py:359-447
+    Contrastive               <- alad/loss.py:29-67 (shared hinge)
+
+None of them holds parameters or buffers (DistillationLoss only in the unsupported 'mse' mode), so
+state dicts saved by the reference load unchanged (checkpoint row).
+Modes outside the shipped configs raise NotImplementedError rather
+than fall back to eager PyTorch.
+"""
+import torch
+from torch import nn
+
+from . import ops
+
+
+def l2norm(X):
+    """X / sqrt(sum_dim1 X^2), no eps -- reference alad/utils.py:134-139 (zero rows give NaN)."""
+    norm = torch.pow(X, 2).sum(dim=1, keepdim=True).sqrt()
+    return torch.div(X, norm)
+
+
+def dot_sim(im, s):
+    """reference alad/loss.py:8-11."""
+    return ops.dot_scores(im, s)
+
+
+def cosine_sim(im, s):
+    """reference alad/loss.py:13-18."""
+    return ops.dot_scores(l2norm(im), l2norm(s))
+
+
+class Contrastive(nn.Module):
+    """reference alad/loss.py:29-67."""
+
+    def __init__(self, margin=0, measure=False, max_violation=False):
+        super().__init__()
+        self.margin = margin
+        if measure == 'order':
+            raise NotImplementedError("aladin_amd: measure='order' is not on the accelerated path "
+                                      "(no shipped ALADIN config uses it)")
+        elif measure == 'cosine':
+            self.sim = cosine_sim
+        elif measure == 'dot':
+            self.sim = dot_sim
+        self.max_violation = max_violation
+
+    def compute_contrastive_loss(self, scores):
+        return ops.hinge_loss(scores, self.margin, self.max_violation)
+
+
+class AlignmentContrastiveLoss(Contrastive):
+    """reference alad/loss.py:70-159.  aggregation: 'MrSw' (all shipped configs) and 'MrAVGw'
+    (= MrSw divided by the caption length, :126-129)."""
+
+    def __init__(self, margin=0, measure=False, max_violation=False, aggregation='sum-max-sentences'):
+        super().__init__(margin, measure, max_violation)
+        self.aggregation = aggregation
+
+    def forward(self, im_set, s_seq, im_len, s_len, return_loss=True, return_similarity_mat=False):
+        if self.aggregation not in ('MrSw', 'MrAVGw'):
+            raise NotImplementedError("aladin_amd: alignment aggregation %r is not implemented in HIP yet "
+                                      "(supported: 'MrSw', 'MrAVGw')" % (self.aggregation,))
+        aggr_similarity = ops.alignment_scores(im_set, s_seq, im_len, s_len)
+        if self.aggregation == 'MrAVGw':
+            lens = ops.lengths_tensor(s_len, aggr_similarity.device).to(torch.float32) - 3.0
+            aggr_similarity = aggr_similarity / lens.unsqueeze(0)
+        if return_loss:
+            loss = self.compute_contrastive_loss(aggr_similarity)
+        if return_loss and return_similarity_mat:
+            return loss, aggr_similarity
+        elif return_loss:
+            return loss
+        elif return_similarity_mat:
+            return aggr_similarity
+
+
+class ContrastiveLoss(Contrastive):
+    """reference alad/loss.py:162-186."""
+
+    def forward(self, im, s, return_similarity_mat=False):
+        scores = self.sim(im, s)
+        loss = self.compute_contrastive_loss(scores)
+        if return_similarity_mat:
+            return loss, scores
+        return loss
+
+
+class DistillationLoss(nn.Module):
+    """reference alad/loss.py:359-447; mode 'listnet' (every shipped config)."""
+
+    def __init__(self, mode='mse', margin=0.2, threshold=0.1, stride=3):
+        super().__init__()
+        if mode != 'listnet':
+            raise NotImplementedError("aladin_amd: distillation mode %r is not implemented in HIP yet "
+                                      "(supported: 'listnet')" % (mode,))
+        self.mode = mode
+        self.margin = margin
+        self.threshold = threshold
+        self.stride = stride
+
+    def forward(self, teacher_scores, student_scores):
+        return ops.listnet_loss(teacher_scores, student_scores, temperature=6.0, eps=1e-10)

@@ -1,0 +1,276 @@
+"""Tensor-level entry points over the C ABI (include/aladin_hip.h): device memory, streams and
+autograd plumbing only -- all arithmetic of the hot path happens in the HIP kernels.
+
+Every function requires float32 tensors on an AMD GPU ("cuda" device of PyTorch-ROCm) and raises
+otherwise; there is no CPU or eager-PyTorch fallback.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _require_gpu(*tensors):
+    for t in tensors:
+        if not isinstance(t, torch.Tensor):
+            raise TypeError('aladin_amd: expected a torch.Tensor, got %r' % type(t))
+        if not t.is_cuda:
+            raise RuntimeError('aladin_amd: the alignment/matching path runs in HIP kernels on an MI355X only; '
+                               'got a %s tensor (no CPU fallback exists)' % t.device)
+        if t.dtype != torch.float32:
+            raise TypeError('aladin_amd: float32 expected, got %s' % t.dtype)
+
+
+def _rows_inner_contig(t):
+    """Keep permuted (S,B,D)->(B,S,D) views (reference alad/alad_model.py:377-378) without a copy
+    as long as the feature axis is contiguous and rows stay 16-byte aligned."""
+    if t.stride(-1) != 1 or any(st % 4 for st in t.stride()[:-1]) or t.data_ptr() % 16:
+        return t.contiguous()
+    return t
+
+
+def lengths_tensor(lens, device):
+    """Python list / tensor of lengths -> int32 device tensor (the reference passes lists)."""
+    if isinstance(lens, torch.Tensor):
+        return lens.to(device=device, dtype=torch.int32, non_blocking=True)
+    return torch.tensor([int(v) for v in lens], dtype=torch.int32).to(device, non_blocking=True)
+
+
+def _workspace(nbytes, device):
+    return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
+
+
+# ------------------------------------------------------------------------------------------------
+# alignment scores
+# ------------------------------------------------------------------------------------------------
+def align_geometry(Bi, Bc, R, T, D):
+    g = _lib.AlignGeom()
+    _lib.check(_lib.load().aladin_align_geometry(Bi, Bc, R, T, D, C.byref(g)), 'align_geometry')
+    return g
+
+
+def pack_images(im, im_len_t, geom):
+    """(xm, xe): L2-normalised, sliced, length-masked fp16 MFMA operands of the image sets."""
+    lib = _lib.load()
+    im = _rows_inner_contig(im)
+    xm = torch.empty(geom.xm_bytes // 2, dtype=torch.float16, device=im.device)
+    xe = torch.empty(max(geom.xe_bytes // 2, 8), dtype=torch.float16, device=im.device)
+    _lib.check(lib.aladin_align_pack_images(_ptr(im), im.stride(0), im.stride(1), _ptr(im_len_t), C.byref(geom),
+                                            _ptr(xm), _ptr(xe), _stream()), 'align_pack_images')
+    return xm, xe
+
+
+def pack_captions(s, s_len_t, geom):
+    lib = _lib.load()
+    s = _rows_inner_contig(s)
+    y = torch.empty(geom.y_bytes // 2, dtype=torch.float16, device=s.device)
+    _lib.check(lib.aladin_align_pack_captions(_ptr(s), s.stride(0), s.stride(1), _ptr(s_len_t), C.byref(geom),
+                                              _ptr(y), _stream()), 'align_pack_captions')
+    return y
+
+
+def scores_from_packed(xm, xe, y, geom, out=None, e_scratch=None, reuse_side=False):
+    lib = _lib.load()
+    S = out if out is not None else torch.empty((geom.Bi, geom.Bc), dtype=torch.float32, device=xm.device)
+    e = e_scratch if e_scratch is not None else _workspace(geom.e_bytes, xm.device)
+    _lib.check(lib.aladin_align_scores_ex(_ptr(xm), _ptr(xe), _ptr(y), C.byref(geom), _ptr(e), _ptr(S), S.stride(0),
+                                          1 if reuse_side else 0, _stream()), 'align_scores')
+    return S
+
+
+def _align_forward(im, s, im_len_t, s_len_t):
+    Bi, R, D = im.shape
+    Bc, T, D2 = s.shape
+    if D != D2:
+        raise ValueError('aladin_amd: feature sizes differ (%d vs %d)' % (D, D2))
+    geom = align_geometry(Bi, Bc, R, T, D)
+    xm, xe = pack_images(im, im_len_t, geom)
+    y = pack_captions(s, s_len_t, geom)
+    return scores_from_packed(xm, xe, y, geom)
+
+
+def _align_backward(im, s, im_len_t, s_len_t, dS, gscale=None):
+    lib = _lib.load()
+    im = _rows_inner_contig(im)
+    s = _rows_inner_contig(s)
+    dS = dS.contiguous()
+    Bi, R, D = im.shape
+    Bc, T, _ = s.shape
+    d_im = torch.empty((Bi, R, D), dtype=torch.float32, device=im.device)
+    d_s = torch.empty((Bc, T, D), dtype=torch.float32, device=im.device)
+    ws = _workspace(lib.aladin_align_bwd_workspace_bytes(Bi, Bc, R, T, D), im.device)
+    _lib.check(lib.aladin_align_bwd(_ptr(im), im.stride(0), im.stride(1), _ptr(im_len_t),
+                                    _ptr(s), s.stride(0), s.stride(1), _ptr(s_len_t), Bi, Bc, R, T, D,
+                                    _ptr(dS), dS.stride(0), _ptr(gscale), _ptr(d_im), _ptr(d_s), _ptr(ws), _stream()),
+               'align_bwd')
+    return d_im, d_s
+
+
+class _AlignScores(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, im, s, im_len_t, s_len_t):
+        ctx.save_for_backward(im, s, im_len_t, s_len_t)
+        return _align_forward(im, s, im_len_t, s_len_t)
+
+    @staticmethod
+    def backward(ctx, dS):
+        im, s, im_len_t, s_len_t = ctx.saved_tensors
+        d_im, d_s = _align_backward(im, s, im_len_t, s_len_t, dS)
+        return d_im, d_s, None, None
+
+
+def alignment_scores(im_set, s_seq, im_len, s_len):
+    """S (Bi, Bc) = sum over words of max over regions of the cosine ('MrSw'), differentiable.
+    Replaces reference alad/loss.py:80-125."""
+    _require_gpu(im_set, s_seq)
+    if im_set.dim() != 3 or s_seq.dim() != 3:
+        raise ValueError('aladin_amd: im_set (B,R,D) and s_seq (B,T,D) expected')
+    if len(im_len) != im_set.shape[0] or len(s_len) != s_seq.shape[0]:
+        raise ValueError('aladin_amd: one length per sample expected')
+    im_len_t = lengths_tensor(im_len, im_set.device)
+    s_len_t = lengths_tensor(s_len, im_set.device)
+    return _AlignScores.apply(im_set, s_seq, im_len_t, s_len_t)
+
+
+# ------------------------------------------------------------------------------------------------
+# hinge / listnet
+# ------------------------------------------------------------------------------------------------
+class _Hinge(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, scores, margin, max_violation):
+        lib = _lib.load()
+        B = scores.shape[0]
+        sc = scores if scores.stride(1) == 1 else scores.contiguous()
+        loss = torch.empty((), dtype=torch.float32, device=scores.device)
+        need = ctx.needs_input_grad[0]
+        dS = torch.empty((B, B), dtype=torch.float32, device=scores.device) if need else None
+        ws = _workspace(lib.aladin_hinge_workspace_bytes(B), scores.device)
+        _lib.check(lib.aladin_hinge_fwd_bwd(_ptr(sc), sc.stride(0), B, float(margin), int(bool(max_violation)),
+                                            _ptr(loss), _ptr(dS), _ptr(ws), _stream()), 'hinge_fwd_bwd')
+        ctx.dS = dS
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        return (ctx.dS * g if ctx.dS is not None else None), None, None
+
+
+def hinge_loss(scores, margin, max_violation):
+    """VSE++ hinge on a square score matrix; replaces reference alad/loss.py:42-67."""
+    _require_gpu(scores)
+    if scores.dim() != 2 or scores.shape[0] != scores.shape[1]:
+        raise ValueError('aladin_amd: the contrastive loss needs a square score matrix, got %s '
+                         '(the reference fails in diag/expand_as, alad/loss.py:43-45)' % (tuple(scores.shape),))
+    return _Hinge.apply(scores, margin, max_violation)
+
+
+class _ListNet(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, teacher, student, temperature, eps):
+        lib = _lib.load()
+        B = student.shape[0]
+        t = teacher if teacher.stride(1) == 1 else teacher.contiguous()
+        m = student if student.stride(1) == 1 else student.contiguous()
+        loss = torch.empty((), dtype=torch.float32, device=student.device)
+        dM = torch.empty((B, B), dtype=torch.float32, device=student.device) if ctx.needs_input_grad[1] else None
+        ws = _workspace(lib.aladin_listnet_workspace_bytes(B), student.device)
+        _lib.check(lib.aladin_listnet_fwd_bwd(_ptr(t), t.stride(0), _ptr(m), m.stride(0), B, float(temperature),
+                                              float(eps), _ptr(loss), _ptr(dM), _ptr(ws), _stream()), 'listnet_fwd_bwd')
+        ctx.dM = dM
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        return None, (ctx.dM * g if ctx.dM is not None else None), None, None
+
+
+def listnet_loss(teacher_scores, student_scores, temperature=6.0, eps=1e-10):
+    """ListNet distillation; replaces reference alad/loss.py:427-445 (teacher detached, :370)."""
+    _require_gpu(teacher_scores, student_scores)
+    if teacher_scores.shape != student_scores.shape or student_scores.dim() != 2 \
+            or student_scores.shape[0] != student_scores.shape[1]:
+        raise ValueError('aladin_amd: listnet needs two square score matrices of equal shape')
+    return _ListNet.apply(teacher_scores.detach(), student_scores, temperature, eps)
+
+
+# ------------------------------------------------------------------------------------------------
+# dot-product scores (matching head)
+# ------------------------------------------------------------------------------------------------
+def _sgemm(M, N, K, A, a_rs, a_cs, B, b_rs, b_cs, out):
+    _lib.check(_lib.load().aladin_sgemm_strided(M, N, K, _ptr(A), a_rs, a_cs, _ptr(B), b_rs, b_cs, _ptr(out),
+                                                out.stride(0), _stream()), 'sgemm_strided')
+    return out
+
+
+class _DotScores(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, im, s):
+        ctx.save_for_backward(im, s)
+        out = torch.empty((im.shape[0], s.shape[0]), dtype=torch.float32, device=im.device)
+        # C[m][n] = sum_k im[m,k] * s[n,k]
+        return _sgemm(im.shape[0], s.shape[0], im.shape[1], im, im.stride(0), im.stride(1), s, s.stride(1), s.stride(0), out)
+
+    @staticmethod
+    def backward(ctx, dM):
+        im, s = ctx.saved_tensors
+        dM = dM.contiguous()
+        Bi, Bc, D = im.shape[0], s.shape[0], im.shape[1]
+        d_im = torch.empty((Bi, D), dtype=torch.float32, device=im.device)
+        d_s = torch.empty((Bc, D), dtype=torch.float32, device=im.device)
+        _sgemm(Bi, D, Bc, dM, dM.stride(0), 1, s, s.stride(0), s.stride(1), d_im)        # dM @ s
+        _sgemm(Bc, D, Bi, dM, 1, dM.stride(0), im, im.stride(0), im.stride(1), d_s)      # dM.T @ im
+        return d_im, d_s
+
+
+def dot_scores(im, s):
+    """im @ s.T in exact fp32 on the MFMA; replaces dot_sim, reference alad/loss.py:8-11."""
+    _require_gpu(im, s)
+    if im.dim() != 2 or s.dim() != 2 or im.shape[1] != s.shape[1]:
+        raise ValueError('aladin_amd: (Bi,D) and (Bc,D) embeddings expected')
+    return _DotScores.apply(im, s)
+
+
+# ------------------------------------------------------------------------------------------------
+# retrieval
+# ------------------------------------------------------------------------------------------------
+def sim_matrix(img, cap):
+    """(n_img, n_cap) = img @ cap.T on the split-fp16 MFMA path (no autograd); replaces
+    ims.mm(caps.t()), reference alad/recall_auxiliary.py:30 and alad/evaluation.py:196,285."""
+    _require_gpu(img, cap)
+    lib = _lib.load()
+    img = img if img.stride(1) == 1 else img.contiguous()
+    cap = cap if cap.stride(1) == 1 else cap.contiguous()
+    n_img, D = img.shape
+    n_cap = cap.shape[0]
+    sim = torch.empty((n_img, n_cap), dtype=torch.float32, device=img.device)
+    ws = _workspace(lib.aladin_sim_workspace_bytes(n_img, n_cap, D), img.device)
+    _lib.check(lib.aladin_sim_matrix(_ptr(img), img.stride(0), _ptr(cap), cap.stride(0), n_img, n_cap, D, _ptr(sim),
+                                     sim.stride(0), _ptr(ws), _stream()), 'sim_matrix')
+    return sim
+
+
+def recall_ranks(sim, caps_per_img=5):
+    """(rank_i2t, top1_i2t, rank_t2i, top1_t2i) int32 device tensors from a (n_img, 5*n_img) score
+    matrix; replaces the argsort/where loops of reference alad/recall_auxiliary.py:34-56."""
+    _require_gpu(sim)
+    lib = _lib.load()
+    sim = sim if sim.stride(1) == 1 else sim.contiguous()
+    n_img, n_cap = sim.shape
+    dev = sim.device
+    r_i2t = torch.empty(n_img, dtype=torch.int32, device=dev)
+    t_i2t = torch.empty(n_img, dtype=torch.int32, device=dev)
+    r_t2i = torch.empty(n_cap, dtype=torch.int32, device=dev)
+    t_t2i = torch.empty(n_cap, dtype=torch.int32, device=dev)
+    ws = _workspace(lib.aladin_recall_workspace_bytes(n_cap), dev)
+    _lib.check(lib.aladin_recall_ranks(_ptr(sim), sim.stride(0), n_img, n_cap, caps_per_img, _ptr(r_i2t), _ptr(t_i2t),
+                                       _ptr(r_t2i), _ptr(t_t2i), _ptr(ws), _stream()), 'recall_ranks')
+    return r_i2t, t_i2t, r_t2i, t_t2i

@@ -1,0 +1,145 @@
+/*
+ * aladin_hip.h -- C ABI of libaladin_hip.so: ALADIN's fine-grained alignment-scoring and
+ * matching-retrieval hot path as hand-written HIP kernels for gfx950 (MI355X, CDNA4).
+ *
+ * The reference (mesnico/ALADIN) is pure Python/PyTorch and has no FFI of its own; the boundary
+ * this library slots under is the Python call surface of alad/loss.py, alad/recall_auxiliary.py
+ * and alad/evaluation.py.  Each entry point below names the reference
+ * lines it replaces.  INTEGRATION.md shows the ctypes binding a maintainer would add there;
+ * aladin_amd/_lib.py is that binding as shipped.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (HBM) unless a parameter says "host";
+ *   - `stream` is a hipStream_t (PyTorch: torch.cuda.current_stream().cuda_stream); all work is
+ *     enqueued asynchronously on it, nothing synchronises, nothing is allocated: outputs and
+ *     workspaces are caller-owned, and no pointer is retained after return;
+ *   - return value: 0 = ok, 1 = bad argument, 2 = unsupported shape, 3 = HIP launch error;
+ *     aladin_last_error() gives the message (thread-local).  Never aborts.
+ *   - float = IEEE binary32.  16-bit packed operands are IEEE binary16 (fp16): the MFMA path
+ *     multiplies fp16 operands and accumulates in fp32 (see DESIGN.md for why not bf16).
+ */
+#ifndef ALADIN_HIP_H
+#define ALADIN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ALADIN_ABI_VERSION 1
+
+int aladin_version(void);
+const char* aladin_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Alignment scores  S[i][j] = sum_w max_r <im^[i,r], s^[j,w]>      (aggregation 'MrSw')
+ * replaces AlignmentContrastiveLoss.forward, reference alad/loss.py:79-125 (normalise :80-81,
+ * drop region 0 / token 0 / last two tokens :87-90, B*B batched matmul :97-99, length masks
+ * :103-116, max over regions + sum over words :124-125).
+ *
+ * Three steps so that the packed image operand can be all-gathered between GPUs (RCCL) before
+ * scoring:  pack_images -> [all-gather] -> scores  <- pack_captions.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct aladin_align_geom {
+  int32_t Bi, Bc, R, T, D;      /* inputs: im (Bi,R,D), s (Bc,T,D)                              */
+  int32_t Rq, Tq;               /* R-1 regions and T-3 words take part (alad/loss.py:87-88)     */
+  int32_t mtiles;               /* 32-row MFMA tiles per image in the main operand              */
+  int32_t rem;                  /* 1: the last region of every image goes through the side GEMM */
+  int32_t tp16;                 /* padded words per caption / 16                                */
+  int32_t Dp;                   /* D rounded up to 64 (zero filled)                             */
+  int32_t img_unit, cap_unit;   /* images / captions per workgroup tile                         */
+  int32_t Bi_pad, Bc_pad;       /* batch sizes rounded up to the units (zero rows)              */
+  int64_t xm_rows, xe_rows, y_rows;            /* rows of the packed fp16 operands              */
+  int64_t xm_bytes, xe_bytes, y_bytes;         /* their sizes                                   */
+  int64_t e_bytes;              /* fp32 scratch for the side GEMM, xe_rows x y_rows (0 if !rem) */
+} aladin_align_geom;
+
+/* Host-only: derive the packed layout for a problem. */
+int aladin_align_geometry(int Bi, int Bc, int R, int T, int D, aladin_align_geom* out);
+
+/* L2-normalise (eps 1e-12, F.normalize), slice, length-mask and convert the image sets to the
+ * packed fp16 MFMA operand.  im[(b*stride_b + r*stride_r) + d], innermost stride 1 (the reference
+ * hands a permuted (S,B,D)->(B,S,D) view, alad/alad_model.py:377).  im_len: Bi int32 on device.
+ * xm: geom->xm_bytes, xe: geom->xe_bytes (ignored when !rem). */
+int aladin_align_pack_images(const float* im, int64_t stride_b, int64_t stride_r, const int32_t* im_len,
+                             const aladin_align_geom* geom, void* xm, void* xe, void* stream);
+int aladin_align_pack_captions(const float* s, int64_t stride_b, int64_t stride_t, const int32_t* s_len,
+                               const aladin_align_geom* geom, void* y, void* stream);
+
+/* S (Bi x Bc, row stride ldS floats) from packed operands.  e_scratch: geom->e_bytes. */
+int aladin_align_scores(const void* xm, const void* xe, const void* y, const aladin_align_geom* geom,
+                        void* e_scratch, float* S, int64_t ldS, void* stream);
+/* Same with flags.  ALADIN_SCORES_REUSE_SIDE: e_scratch already holds the side-GEMM result of a
+ * previous call on the same operands, launch the score kernel alone (used by bench.py to time the
+ * dominant kernel in isolation). */
+#define ALADIN_SCORES_REUSE_SIDE 1
+int aladin_align_scores_ex(const void* xm, const void* xe, const void* y, const aladin_align_geom* geom,
+                           void* e_scratch, float* S, int64_t ldS, int flags, void* stream);
+
+/* Backward of S w.r.t. the raw sets (autograd of alad/loss.py:80-125).
+ * dS (Bi x Bc, stride ld_dS) is multiplied by *gscale (device float, may be NULL = 1).  Pairs with
+ * dS == 0 are skipped, so the max_violation=True hinge (<= 3B non-zeros) costs O(B) pair blocks.
+ * The argmax over regions is recomputed in fp32.  d_im (Bi,R,D) and d_s (Bc,T,D) are contiguous
+ * and fully written.  workspace: aladin_align_bwd_workspace_bytes(). */
+size_t aladin_align_bwd_workspace_bytes(int Bi, int Bc, int R, int T, int D);
+int aladin_align_bwd(const float* im, int64_t im_stride_b, int64_t im_stride_r, const int32_t* im_len,
+                     const float* s, int64_t s_stride_b, int64_t s_stride_t, const int32_t* s_len,
+                     int Bi, int Bc, int R, int T, int D,
+                     const float* dS, int64_t ld_dS, const float* gscale,
+                     float* d_im, float* d_s, void* workspace, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * VSE++ hinge loss on a square score matrix -- Contrastive.compute_contrastive_loss,
+ * reference alad/loss.py:42-67.  loss: 1 float.  dS (B x B, contiguous) may be NULL; it receives
+ * dloss/dS (max_violation: +-1 at the hardest negatives and the diagonal, <= 3B non-zeros).
+ * workspace: aladin_hinge_workspace_bytes(B).
+ * ------------------------------------------------------------------------------------------- */
+size_t aladin_hinge_workspace_bytes(int B);
+int aladin_hinge_fwd_bwd(const float* S, int64_t ldS, int B, float margin, int max_violation,
+                         float* loss, float* dS, void* workspace, void* stream);
+
+/* ListNet score distillation -- DistillationLoss(mode='listnet'), reference alad/loss.py:427-445
+ * (teacher detached :370; temperature 6 on the student only; eps 1e-10 inside the log).
+ * d_student (B x B contiguous) may be NULL. */
+size_t aladin_listnet_workspace_bytes(int B);
+int aladin_listnet_fwd_bwd(const float* teacher, int64_t ld_t, const float* student, int64_t ld_s, int B,
+                           float temperature, float eps, float* loss, float* d_student,
+                           void* workspace, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Dot-product scores  C[m][n] = sum_k A[m*a_rs + k*a_cs] * B[k*b_rs + n*b_cs]   (fp32 in/out,
+ * exact-fp32 MFMA).  With a_cs = 1, b_rs = 1 it is dot_sim  im.mm(s.t()), reference
+ * alad/loss.py:8-11; the strides also give the two backward products.
+ * ------------------------------------------------------------------------------------------- */
+int aladin_sgemm_strided(int M, int N, int K, const float* A, int64_t a_rs, int64_t a_cs,
+                         const float* B, int64_t b_rs, int64_t b_cs, float* C, int64_t ldc, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Retrieval similarity matrix  sim = img @ cap.T  at evaluation scale (5000 x 25000 x 768) on the
+ * 16-bit MFMA path with a hi/lo fp16 split (3 MFMAs per product, ~fp32 accuracy so that ranks
+ * agree with the reference).  Replaces ims.mm(caps.t()), reference alad/recall_auxiliary.py:30,51
+ * and torch.mm at alad/evaluation.py:196,285.
+ * workspace: aladin_sim_workspace_bytes(n_img, n_cap, D).
+ * ------------------------------------------------------------------------------------------- */
+size_t aladin_sim_workspace_bytes(int n_img, int n_cap, int D);
+int aladin_sim_matrix(const float* img, int64_t img_rs, const float* cap, int64_t cap_rs,
+                      int n_img, int n_cap, int D, float* sim, int64_t ld_sim,
+                      void* workspace, void* stream);
+
+/* Ranks for both retrieval directions from sim (n_img x n_cap), COCO protocol: captions
+ * caps_per_img*i .. caps_per_img*i + caps_per_img-1 belong to image i.  rank = number of strictly
+ * larger scores (== argsort position, reference alad/recall_auxiliary.py:34-56 and
+ * alad/evaluation.py:213-223,303-308, except on exact ties).
+ *   rank_i2t[n_img]: best rank among the image's captions;  top1_i2t[n_img]: argmax caption
+ *   rank_t2i[n_cap]: rank of the caption's image;           top1_t2i[n_cap]: argmax image */
+size_t aladin_recall_workspace_bytes(int n_cap);
+int aladin_recall_ranks(const float* sim, int64_t ld_sim, int n_img, int n_cap, int caps_per_img,
+                        int32_t* rank_i2t, int32_t* top1_i2t, int32_t* rank_t2i, int32_t* top1_t2i,
+                        void* workspace, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ALADIN_HIP_H */

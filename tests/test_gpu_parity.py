@@ -1,0 +1,300 @@
+"""GPU tier (-m gpu): the HIP path, called through the C ABI (aladin_amd.ops -> ctypes ->
+libaladin_hip.so), against the golden fixtures made from the reference and against the pinned
+oracle on identical seeded inputs.
+
+Tolerance: north_star asks for 1e-3 relative on scores/losses.  Scores come from fp16 MFMA
+operands with fp32 accumulation (measured ~1e-4); everything downstream of the scores (hinge,
+listnet, dot products, backward argmax) is fp32 and is held to 1e-5..1e-4.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import ALIGN_GOLDENS, SQUARE_ALIGN_GOLDENS, golden_alignment_inputs, load_golden
+import alad_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-3
+
+
+def dev():
+    assert torch.cuda.is_available(), 'these tests need the MI355X'
+    return torch.device('cuda:0')
+
+
+def T(x):
+    return torch.from_numpy(np.ascontiguousarray(x)).to(dev())
+
+
+def assert_scores_close(S, ref, rtol=RTOL):
+    S = np.asarray(S, np.float64)
+    ref = np.asarray(ref, np.float64)
+    scale = max(1e-6, np.abs(ref).mean())
+    np.testing.assert_allclose(S, ref, rtol=rtol, atol=2e-4 * scale)
+
+
+def test_extension_is_loaded():
+    from aladin_amd import _lib
+    lib = _lib.load()
+    assert lib.aladin_version() == _lib.ABI_VERSION
+
+
+@pytest.mark.parametrize('name', ALIGN_GOLDENS)
+def test_alignment_scores_vs_reference(name):
+    from aladin_amd import ops
+    g = load_golden(name)
+    im, s, il, sl = golden_alignment_inputs(g)
+    S = ops.alignment_scores(T(im), T(s), il, sl).cpu().numpy()
+    assert_scores_close(S, g['S_MrSw'])
+
+
+@pytest.mark.parametrize('name', ['align_b5_d64', 'align_rect'])
+def test_alignment_module_modes(name):
+    from aladin_amd.loss import AlignmentContrastiveLoss
+    g = load_golden(name)
+    im, s, il, sl = golden_alignment_inputs(g)
+    for mode in ('MrSw', 'MrAVGw'):
+        crit = AlignmentContrastiveLoss(margin=0.2, measure='dot', max_violation=True, aggregation=mode)
+        S = crit(T(im), T(s), il, sl, return_loss=False, return_similarity_mat=True)
+        assert_scores_close(S.cpu().numpy(), g['S_' + mode])
+    with pytest.raises(NotImplementedError):
+        AlignmentContrastiveLoss(aggregation='symm')(T(im), T(s), il, sl, return_loss=False, return_similarity_mat=True)
+
+
+def test_alignment_scores_permuted_view_input():
+    """forward_loss hands (S,B,D)->(B,S,D) permuted views (reference alad_model.py:377-378)."""
+    from aladin_amd import ops
+    g = load_golden('align_b5_d64')
+    im, s, il, sl = golden_alignment_inputs(g)
+    im_v = T(im.transpose(1, 0, 2).copy()).permute(1, 0, 2)
+    s_v = T(s.transpose(1, 0, 2).copy()).permute(1, 0, 2)
+    assert not im_v.is_contiguous()
+    assert_scores_close(ops.alignment_scores(im_v, s_v, il, sl).cpu().numpy(), g['S_MrSw'])
+
+
+@pytest.mark.parametrize('name', SQUARE_ALIGN_GOLDENS)
+@pytest.mark.parametrize('tag', ['mv', 'sum'])
+def test_hinge_on_reference_scores(name, tag):
+    from aladin_amd import ops
+    g = load_golden(name)
+    S = T(g['S_MrSw']).requires_grad_(True)
+    loss = ops.hinge_loss(S, float(g['margin']), tag == 'mv')
+    loss.backward()
+    np.testing.assert_allclose(loss.item(), float(g['loss_' + tag]), rtol=1e-5, atol=1e-5)
+    np.testing.assert_array_equal(S.grad.cpu().numpy(), g['dS_' + tag])
+
+
+@pytest.mark.parametrize('name', SQUARE_ALIGN_GOLDENS)
+@pytest.mark.parametrize('tag', ['mv', 'sum'])
+def test_alignment_backward_kernel_vs_reference(name, tag):
+    """K1b in isolation: the reference's dS in, the reference's input gradients out."""
+    from aladin_amd import ops
+    g = load_golden(name)
+    im, s, il, sl = golden_alignment_inputs(g)
+    d = dev()
+    d_im, d_s = ops._align_backward(T(im), T(s), ops.lengths_tensor(il, d), ops.lengths_tensor(sl, d), T(g['dS_' + tag]))
+    st = int(g['grad_stride'])
+    for got, key in ((d_im, 'dim_'), (d_s, 'ds_')):
+        got = got.cpu().numpy()
+        ref = g[key + tag]
+        scale = max(1e-9, float(np.abs(ref).max()))
+        np.testing.assert_allclose(got[:, :, ::st], ref, rtol=1e-3, atol=2e-5 * scale)
+        np.testing.assert_allclose(np.abs(got).sum(), float(g[key + 'abs_' + tag]), rtol=1e-4)
+    # dropped / padded positions get exactly zero gradient
+    got = d_im.cpu().numpy()
+    assert np.all(got[:, 0, :] == 0)
+    for i, L in enumerate(il):
+        assert np.all(got[i, L:, :] == 0)
+    got = d_s.cpu().numpy()
+    assert np.all(got[:, 0, :] == 0)
+    for j, L in enumerate(sl):
+        assert np.all(got[j, max(L - 2, 1):, :] == 0)
+
+
+@pytest.mark.parametrize('name', ['align_b5_d64', 'align_b12_struct', 'align_b16_d768'])
+def test_alignment_loss_end_to_end(name):
+    """Module forward + autograd backward against the oracle chained on the HIP scores (the hardest
+    negative is an argmax over scores, so the check is made self-consistent with the fp16 S)."""
+    from aladin_amd.loss import AlignmentContrastiveLoss
+    g = load_golden(name)
+    im, s, il, sl = golden_alignment_inputs(g)
+    a, b = T(im).requires_grad_(True), T(s).requires_grad_(True)
+    crit = AlignmentContrastiveLoss(margin=float(g['margin']), measure='dot', max_violation=True, aggregation='MrSw')
+    loss, S = crit(a, b, il, sl, return_similarity_mat=True)
+    loss.backward()
+    np.testing.assert_allclose(loss.item(), float(g['loss_mv']), rtol=RTOL, atol=1e-3)
+    S_np = S.detach().cpu().numpy()
+    _, dS = O.hinge_loss(S_np, float(g['margin']), True, return_grad=True)
+    dim, ds = O.alignment_scores_backward(im, s, il, sl, dS)
+    scale = max(1e-9, float(np.abs(dim).max()))
+    np.testing.assert_allclose(a.grad.cpu().numpy(), dim, rtol=1e-3, atol=2e-5 * scale)
+    scale = max(1e-9, float(np.abs(ds).max()))
+    np.testing.assert_allclose(b.grad.cpu().numpy(), ds, rtol=1e-3, atol=2e-5 * scale)
+
+
+@pytest.mark.parametrize('name', ['match_b16_d768', 'match_b7_d64'])
+def test_matching_head(name):
+    from aladin_amd import synth
+    from aladin_amd.loss import ContrastiveLoss
+    g = load_golden(name)
+    img, cap = synth.global_embeddings(int(g['B']), int(g['D']), int(g['seed']), float(g['noise']))
+    for tag, mv in (('mv', True), ('sum', False)):
+        a, b = T(img).requires_grad_(True), T(cap).requires_grad_(True)
+        loss, M = ContrastiveLoss(margin=0.2, measure='dot', max_violation=mv)(a, b, return_similarity_mat=True)
+        loss.backward()
+        np.testing.assert_allclose(M.detach().cpu().numpy(), g['M'], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(loss.item(), float(g['loss_' + tag]), rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(a.grad.cpu().numpy(), g['dimg_' + tag], rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(b.grad.cpu().numpy(), g['dcap_' + tag], rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize('name', ['distill_b16', 'distill_b5'])
+def test_listnet(name):
+    from aladin_amd.loss import DistillationLoss
+    g = load_golden(name)
+    st = T(g['student']).requires_grad_(True)
+    loss = DistillationLoss(mode='listnet')(T(g['teacher']), st)
+    loss.backward()
+    np.testing.assert_allclose(loss.item(), float(g['loss_listnet']), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(st.grad.cpu().numpy(), g['dstudent_listnet'], rtol=1e-4, atol=1e-7)
+    with pytest.raises(NotImplementedError):
+        DistillationLoss(mode='mse')
+
+
+def test_model_forward_matches_reference_configs():
+    import yaml  # noqa: F401
+    from aladin_amd import synth
+    from aladin_amd.alad_model import ALADModel
+    from aladin_amd.evaluation import LogCollector
+    g = load_golden('model_forward')
+    B, R, Tn, D, seed = (int(g[k]) for k in ('B', 'R', 'T', 'D', 'seed'))
+    im, s, il, sl = synth.structured_alignment_batch(B, R, Tn, D, seed, 1.0, True)
+    img_emb, cap_emb = synth.global_embeddings(B, D, seed + 1, 1.0)
+    sets = (T(img_emb), T(cap_emb), T(im).permute(1, 0, 2), T(s).permute(1, 0, 2), il, sl, 0)
+    for fn in g['configs']:
+        key = str(fn)[:-5].replace('-', '_').replace('.', '_')
+        lt = str(g[key + '__loss_type'])
+        config = {'training': {'loss-type': lt, 'loss-weights': [float(w) for w in g[key + '__weights']],
+                               'margin': 0.2, 'measure': 'dot', 'max-violation': True, 'alignment-mode': 'MrSw',
+                               'distillation-mode': 'listnet'}}
+        m = ALADModel(config)
+        m.logger = LogCollector()
+        m.forward_emb = lambda a, b, _s=sets: _s
+        for epoch in (0, 5):
+            loss, d = m.forward(None, None, epoch=epoch, distill_epoch=2)
+            assert list(d.keys()) == [str(k) for k in g['%s__e%d_keys' % (key, epoch)]]
+            np.testing.assert_allclose([float(v) for v in d.values()], g['%s__e%d_vals' % (key, epoch)], rtol=RTOL, atol=1e-4)
+            np.testing.assert_allclose(float(loss), float(g['%s__e%d_total' % (key, epoch)]), rtol=RTOL, atol=1e-4)
+        assert list(m.logger.meters.keys()) == [str(k) for k in g[key + '__logged']]
+        assert m.Eiters == int(g[key + '__eiters'])
+
+
+@pytest.mark.parametrize('name', ['recall_n500', 'recall_n5000'])
+def test_recall_vs_reference(name):
+    from aladin_amd import synth
+    from aladin_amd import evaluation as E
+    g = load_golden(name)
+    img, cap = synth.retrieval_embeddings(int(g['n_img']), int(g['D']), int(g['seed']), float(g['sigma']))
+    sim = E.compute_sim_matrix(img[0::5], cap).cpu().numpy()
+    np.testing.assert_allclose(sim, img[0::5].astype(np.float64) @ cap.astype(np.float64).T, rtol=0, atol=2e-6)
+    np.testing.assert_allclose(E.compute_recall(img, cap, verbose=False), g['compute_recall'], rtol=0, atol=1e-9)
+    for mode in ('i2t', 't2i'):
+        m, (ranks, top1) = E.recall(img, cap, mode=mode, return_ranks=True)
+        np.testing.assert_allclose(m, g[mode + '_metrics'], rtol=0, atol=1e-9)
+        np.testing.assert_array_equal(ranks, g[mode + '_ranks'])
+        np.testing.assert_array_equal(top1, g[mode + '_top1'])
+
+
+def test_eval_i2t_t2i_vs_reference():
+    from aladin_amd import synth
+    from aladin_amd import evaluation as E
+    from aladin_amd.loss import AlignmentContrastiveLoss
+    g = load_golden('eval_sets')
+    images, captions, il, cl = synth.eval_sets(int(g['n_img']), int(g['D']), int(g['seed']))
+    S = E.compute_sim_matrix(images[0::5], captions, il[0::5], cl, mode='alignment').cpu().numpy()
+    assert_scores_close(S, g['S_eval'])
+    # matching head (sim_function=None): exact ranks
+    m, (r, t1) = E.i2t(images, captions, il, cl, return_ranks=True)
+    np.testing.assert_allclose(m, g['i2t_match_metrics'], atol=1e-9)
+    np.testing.assert_array_equal(r, g['i2t_match_ranks'])
+    m, (r, t1) = E.t2i(images, captions, il, cl, return_ranks=True)
+    np.testing.assert_allclose(m, g['t2i_match_metrics'], atol=1e-9)
+    np.testing.assert_array_equal(r, g['t2i_match_ranks'])
+    # alignment head through the reference-style closure (train.py:493-500 / test.py:259-264)
+    crit = AlignmentContrastiveLoss(aggregation='MrSw')
+
+    def alignment_sim_fn(img, cap, img_len, cap_len):
+        with torch.no_grad():
+            return crit(img, cap, img_len, cap_len, return_loss=False, return_similarity_mat=True)
+
+    for fn in (alignment_sim_fn, 'alignment'):
+        m, (r, t1) = E.i2t(images, captions, il, cl, return_ranks=True, sim_function=fn, cap_batches=5)
+        assert np.mean(r == g['i2t_align_ranks']) >= 0.98
+        np.testing.assert_allclose(m[:3], g['i2t_align_metrics'][:3], atol=2.01)
+        m, (r, t1) = E.t2i(images, captions, il, cl, return_ranks=True, sim_function=fn, im_batches=5)
+        assert np.mean(r == g['t2i_align_ranks']) >= 0.98
+        np.testing.assert_allclose(m[:3], g['t2i_align_metrics'][:3], atol=0.81)
+
+
+# ------------------------------------------------------------------ BASELINE-size property tests
+def test_b256_scores_vs_oracle_and_properties():
+    from aladin_amd import ops, synth
+    B = 256
+    im, s, il, sl = synth.alignment_batch(B, 34, 50, 768, seed=1234, ragged=False)
+    a, b = T(im), T(s)
+    S = ops.alignment_scores(a, b, il, sl)
+    ref = O.alignment_scores(im, s, il, sl)
+    assert_scores_close(S.cpu().numpy(), ref)
+    # permutation equivariance under a batch permutation of images and captions (bit exact:
+    # every (i, j) block sees the same operands in the same order)
+    pi = torch.from_numpy(np.random.RandomState(0).permutation(B)).to(dev())
+    pj = torch.from_numpy(np.random.RandomState(1).permutation(B)).to(dev())
+    Sp = ops.alignment_scores(a[pi].contiguous(), b[pj].contiguous(), il, sl)
+    assert torch.equal(Sp, S[pi][:, pj])
+    # ragged: content of masked positions is irrelevant
+    im2, s2, il2, sl2 = synth.alignment_batch(B, 34, 50, 768, seed=99, ragged=True)
+    S1 = ops.alignment_scores(T(im2), T(s2), il2, sl2)
+    im3, s3 = im2.copy(), s2.copy()
+    for i, L in enumerate(il2):
+        im3[i, L:] = 1e3
+    for j, L in enumerate(sl2):
+        s3[j, L - 2:] = -7.0
+    S2 = ops.alignment_scores(T(im3), T(s3), il2, sl2)
+    assert torch.equal(S1, S2)
+    assert_scores_close(S1.cpu().numpy(), O.alignment_scores(im2, s2, il2, sl2))
+
+
+def test_b256_triplet_step_gradient_sparsity():
+    from aladin_amd import synth
+    from aladin_amd.loss import AlignmentContrastiveLoss
+    B = 256
+    im, s, il, sl = synth.alignment_batch(B, 34, 50, 768, seed=7, ragged=True)
+    a, b = T(im).requires_grad_(True), T(s).requires_grad_(True)
+    crit = AlignmentContrastiveLoss(margin=0.2, measure='dot', max_violation=True, aggregation='MrSw')
+    loss, S = crit(a, b, il, sl, return_similarity_mat=True)
+    loss.backward()
+    S_np = S.detach().cpu().numpy()
+    ref_loss, dS = O.hinge_loss(S_np, 0.2, True, return_grad=True)
+    np.testing.assert_allclose(loss.item(), ref_loss, rtol=1e-5)
+    assert (dS != 0).sum() <= 3 * B
+    ga, gb = a.grad.cpu().numpy(), b.grad.cpu().numpy()
+    assert np.isfinite(ga).all() and np.isfinite(gb).all()
+    assert np.all(ga[:, 0] == 0) and np.all(gb[:, 0] == 0)
+    # gradients are tangent to the unit sphere: <x, dx> = 0 for every row (normalise backward)
+    dots = np.abs((ga * im).sum(-1))
+    assert dots.max() <= 1e-3 * max(1e-6, np.abs(ga).sum(-1).max() * np.abs(im).max())
+
+
+def test_error_behaviour():
+    from aladin_amd import ops
+    from aladin_amd.loss import AlignmentContrastiveLoss
+    g = load_golden('align_rect')
+    im, s, il, sl = golden_alignment_inputs(g)
+    crit = AlignmentContrastiveLoss(margin=0.2, measure='dot', max_violation=True, aggregation='MrSw')
+    with pytest.raises(ValueError):                      # non-square S into the hinge (reference: diag/expand_as fails)
+        crit(T(im), T(s), il, sl)
+    with pytest.raises(RuntimeError):                    # CPU tensors: no fallback
+        ops.alignment_scores(torch.from_numpy(im), torch.from_numpy(s), il, sl)
+    with pytest.raises(ValueError):
+        ops.alignment_scores(T(im), T(s), il[:-1], sl)
