@@ -63,10 +63,22 @@ def _declare(lib):
         fn.argtypes = args
 
 
+def _preload_torch_hip_runtime():
+    """PyTorch-ROCm ships its own libamdhip64.so (SONAME libamdhip64.so.7) and asks for it by the
+    unversioned name; this library asks for libamdhip64.so.7.  If ours were loaded first the loader
+    would map a SECOND HIP runtime for torch and streams/devices would not be shared.  Loading
+    torch's copy first makes the loader reuse it for us (same SONAME)."""
+    import torch
+    cand = os.path.join(os.path.dirname(torch.__file__), 'lib', 'libamdhip64.so')
+    if os.path.exists(cand):
+        C.CDLL(cand, mode=C.RTLD_GLOBAL)
+
+
 def load():
     """Load (once) and return the ctypes handle; raises RuntimeError if the extension is absent."""
     global _lib
     if _lib is None:
+        _preload_torch_hip_runtime()
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(
                 'aladin_amd: HIP extension %s is missing -- build it with `python -c "import __graft_entry__ as g; '

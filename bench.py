@@ -14,7 +14,6 @@ Inputs are resident in HBM before the timed region.  value = (N*256)^2 pairs / s
 Prints ONE JSON line on rank 0 (see DESIGN.md section "Measurement" for every field).
 """
 import argparse
-import ctypes
 import json
 import os
 import sys
@@ -162,7 +161,7 @@ def main():
                                    'features per GPU (R=34,T=50,D=768, full lengths)' +
                                    ('' if world == 1 else '; configs[3]: global %dx%d matrix, images all-gathered '
                                     'over RCCL, caption-block sharding' % (B * world, B * world)),
-                       'global_pairs_per_step': pairs, 'loss': float(loss),
+                       'global_pairs_per_step': pairs, 'loss': float(loss.detach()),
                        'step_tflops_algorithmic': round(value * FLOPS_PER_PAIR / 1e12, 2)},
             'roofline': roof,
         }

@@ -31,7 +31,7 @@ def assert_scores_close(S, ref, rtol=RTOL):
     S = np.asarray(S, np.float64)
     ref = np.asarray(ref, np.float64)
     scale = max(1e-6, np.abs(ref).mean())
-    np.testing.assert_allclose(S, ref, rtol=rtol, atol=2e-4 * scale)
+    np.testing.assert_allclose(S, ref, rtol=rtol, atol=5e-4 * scale)
 
 
 def test_extension_is_loaded():
