@@ -16,7 +16,7 @@ SYMBOLS = [
     'aladin_version', 'aladin_last_error', 'aladin_align_geometry', 'aladin_align_pack_images',
     'aladin_align_pack_captions', 'aladin_align_scores', 'aladin_align_scores_ex',
     'aladin_align_bwd_workspace_bytes',
-    'aladin_align_bwd', 'aladin_hinge_workspace_bytes', 'aladin_hinge_fwd_bwd',
+    'aladin_align_bwd', 'aladin_align_bwd_packed', 'aladin_hinge_workspace_bytes', 'aladin_hinge_fwd_bwd',
     'aladin_listnet_workspace_bytes', 'aladin_listnet_fwd_bwd', 'aladin_sgemm_strided',
     'aladin_sim_workspace_bytes', 'aladin_sim_matrix', 'aladin_recall_workspace_bytes',
     'aladin_recall_ranks',
@@ -47,6 +47,7 @@ def _declare(lib):
         'aladin_align_scores_ex': (C.c_int, [p, p, p, G, p, p, i64, i32, p]),
         'aladin_align_bwd_workspace_bytes': (sz, [i32, i32, i32, i32, i32]),
         'aladin_align_bwd': (C.c_int, [p, i64, i64, p, p, i64, i64, p, i32, i32, i32, i32, i32, p, i64, p, p, p, p, p]),
+        'aladin_align_bwd_packed': (C.c_int, [p, i64, i64, p, p, i64, i64, p, p, i64, p, p, p, p, G, p, p, p, p]),
         'aladin_hinge_workspace_bytes': (sz, [i32]),
         'aladin_hinge_fwd_bwd': (C.c_int, [p, i64, i32, f32, i32, p, p, p, p]),
         'aladin_listnet_workspace_bytes': (sz, [i32]),

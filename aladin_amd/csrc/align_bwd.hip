@@ -4,10 +4,16 @@
 //   dS is sparse in practice: the max_violation hinge has <= 3B non-zeros.  So the backward never
 //   builds the dense (B,B,R',T') gradient the reference's autograd differentiates through:
 //     1. compact      non-zero (i,j) pairs of dS -> pair list (order irrelevant)
-//     2. pair argmax  per listed pair recompute the R' x T' block in exact fp32
-//                     (v_mfma_f32_32x32x2_f32 straight from the raw rows) and record, per word, the
-//                     winning region (or 255 = no gradient: padded word, or the zero fill of
-//                     alad/loss.py:116 won the max)
+//     2. pair argmax  per listed pair recompute the R' x T' block and record, per word, the winning
+//                     region (or 255 = no gradient: padded word, or the zero fill of
+//                     alad/loss.py:116 won the max).  The winner must be the fp32 winner (a flipped
+//                     argmax moves a whole gradient row), so:
+//                       fast path  (forward's packed fp16 operands available): fp16 MFMA block, whose
+//                         entries are within 2^-10 of the fp32 cosines (unit vectors, one rounding per
+//                         operand); every word whose top candidates lie within a 2.1e-3 margin -- or
+//                         whose maximum is that close to 0 when the zero fill competes -- is
+//                         re-decided with exact fp32 dot products of just those candidates;
+//                       fallback   v_mfma_f32_32x32x2_f32 straight from the raw rows.
 //     3. row gather   one wave per OUTPUT row (every (image, region) and (caption, token)):
 //                     sum the partner rows the argmax table points at, then apply the
 //                     normalise-backward dx = (dxh - xh <xh, dxh>) / ||x|| and store.  No atomics:
@@ -15,15 +21,16 @@
 //                     (rows outside the alignment -- region 0, token 0, the last two tokens, padding
 //                     -- get exact zeros, as in the reference).
 #include "../../include/aladin_hip.h"
-#include "common.hpp"
+#include "gemm_core.hpp"
 
 #define NO_GRAD 255
 
 struct BwdWs {
   int* counter;      // [64] ints, [0] = number of listed pairs
   int* pairs;        // Bi*Bc
-  uint8_t* table;    // Bi*Bc*Tq
+  uint8_t* table;    // Bi*Bc rows of TQP = round_up(Tq,16) bytes
 };
+static inline int table_stride(int Tq) { return (Tq + 15) / 16 * 16; }
 
 static size_t bwd_ws_layout(int Bi, int Bc, int Tq, char* base, BwdWs* ws) {
   size_t off = 0;
@@ -32,7 +39,7 @@ static size_t bwd_ws_layout(int Bi, int Bc, int Tq, char* base, BwdWs* ws) {
   if (ws) ws->pairs = (int*)(base + off);
   off += ((size_t)Bi * Bc * 4 + 255) / 256 * 256;
   if (ws) ws->table = (uint8_t*)(base + off);
-  off += ((size_t)Bi * Bc * Tq + 255) / 256 * 256;
+  off += ((size_t)Bi * Bc * table_stride(Tq) + 255) / 256 * 256;
   return off;
 }
 
@@ -69,7 +76,7 @@ __global__ __launch_bounds__(256) void bwd_compact_kernel(const float* __restric
 __global__ __launch_bounds__(256) void bwd_pair_argmax_kernel(
     const float* __restrict__ im, int64_t im_sb, int64_t im_sr, const int32_t* __restrict__ im_len,
     const float* __restrict__ s, int64_t s_sb, int64_t s_st, const int32_t* __restrict__ s_len, int Bc, int Rq, int Tq,
-    int D, const int* __restrict__ counter, const int* __restrict__ pairs, uint8_t* __restrict__ table) {
+    int D, const int* __restrict__ counter, const int* __restrict__ pairs, uint8_t* __restrict__ table, int tstride) {
   __shared__ float blk[PA_MAXR][PA_MAXT + 1];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int h = lane >> 5, l5 = lane & 31;
@@ -123,8 +130,8 @@ __global__ __launch_bounds__(256) void bwd_pair_argmax_kernel(
       }
     }
     __syncthreads();
-    uint8_t* trow = table + ((int64_t)i * Bc + j) * Tq;
-    for (int w = threadIdx.x; w < Tq; w += blockDim.x) {
+    uint8_t* trow = table + ((int64_t)i * Bc + j) * tstride;
+    for (int w = threadIdx.x; w < tstride; w += blockDim.x) {
       uint8_t res = NO_GRAD;
       if (w < Lj && Li > 0) {
         float best = blk[0][w];
@@ -141,22 +148,216 @@ __global__ __launch_bounds__(256) void bwd_pair_argmax_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------
+// 2b. fast path: fp16 MFMA block from the packed operands + exact re-decision of close calls
+// ------------------------------------------------------------------------------------------------
+#define CAND_MAX 512
+#define AMBIG_MARGIN 2.2e-3f      // > 2 * 2^-10: two fp16-operand cosines of unit vectors
+
+using PairCfg = GemmCfg<2, 2, 1, 1>;      // 64 x 64 block per pair: [32 main regions | extra-region segment] x 64 word rows
+#define PAIR_STAGES 3
+
+// Requires mtiles == 1 and 16*tp16 <= 64 (every training shape); other shapes use the fp32 kernel.
+__global__ __launch_bounds__(256) void bwd_pair_argmax16_kernel(
+    const half_t* __restrict__ xm, const half_t* __restrict__ xe, const half_t* __restrict__ y, int Dp, int rem,
+    int tpad, int xe_rows, int y_rows, const float* __restrict__ im, int64_t im_sb, int64_t im_sr,
+    const int32_t* __restrict__ im_len, const float* __restrict__ s, int64_t s_sb, int64_t s_st,
+    const int32_t* __restrict__ s_len, int Bc, int Rq, int Tq, int D, const int* __restrict__ counter,
+    const int* __restrict__ pairs, uint8_t* __restrict__ table, int tstride, int blk_rows, int blk_ld) {
+  // dynamic LDS: the operand ring of the MFMA phase, re-used afterwards as the score block
+  // blk[(blk_rows + 2) x blk_ld] (the two extra rows carry per-word scratch).
+  extern __shared__ __attribute__((aligned(16))) char pair_smem[];
+  float* blk_mem = reinterpret_cast<float*>(pair_smem);
+#define BLK(r, c) blk_mem[(r) * blk_ld + (c)]
+  __shared__ float cand_val[CAND_MAX];
+  __shared__ uint8_t cand_w[CAND_MAX], cand_r[CAND_MAX];
+  __shared__ int ncand;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int h = lane >> 5, l5 = lane & 31;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int count = *counter;
+  for (int p = blockIdx.x; p < count; p += gridDim.x) {
+    const int i = pairs[p] / Bc, j = pairs[p] % Bc;
+    int Li = im_len[i] - 1; Li = Li < 0 ? 0 : (Li > Rq ? Rq : Li);
+    int Lj = s_len[j] - 3; Lj = Lj < 0 ? 0 : (Lj > Tq ? Tq : Lj);
+    __syncthreads();                                   // everyone is done with the previous pair's blk
+    if (threadIdx.x == 0) ncand = 0;
+    // operand panels: rows [0,32) = the image's 32 main regions, rows [32,64) = 32 consecutive rows
+    // of the extra-region operand containing image i's row at offset eo; 64 caption-word rows
+    // starting at by (the caption's words sit at column offset co)
+    const int be = rem ? (i < xe_rows - 32 ? i : xe_rows - 32) : 0;
+    const int eo = i - be;
+    const int64_t yrow = (int64_t)j * tpad;
+    const int64_t by = yrow < (int64_t)y_rows - 64 ? yrow : (int64_t)y_rows - 64;
+    const int co = (int)(yrow - by);
+    const half_t* a1 = xm + (int64_t)i * 32 * Dp;
+    const half_t* a2 = rem ? xe + (int64_t)be * Dp : a1;
+    f32x16 acc[1][1];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[0][0][r] = 0.f;
+    gemm_mainloop<PairCfg, PAIR_STAGES>(a1, y + by * Dp, Dp, Dp / 64, pair_smem, acc, a2, 32);
+    __syncthreads();                                   // ring no longer read: re-use it as blk
+    {
+      const int w = wn * 32 + l5 - co;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (w >= 0 && w < blk_ld) {
+          if (wm == 0) BLK(row, w) = acc[0][0][r];
+          else if (rem && row == eo) BLK(32, w) = acc[0][0][r];
+        }
+      }
+    }
+    __syncthreads();
+    // per word: approximate winner, runner-up, and the list of candidates that need an exact look
+    uint8_t res = NO_GRAD;
+    bool ambiguous = false;
+    const int w = threadIdx.x;
+    if (w < Lj && Li > 0) {
+      float b1 = BLK(0, w), b2 = -INFINITY;
+      int a1 = 0;
+      for (int r = 1; r < Li; ++r) {
+        const float v = BLK(r, w);
+        if (v > b1) { b2 = b1; b1 = v; a1 = r; }
+        else if (v > b2) b2 = v;
+      }
+      ambiguous = (b1 - b2 < AMBIG_MARGIN) || (Li < Rq && fabsf(b1) < AMBIG_MARGIN);
+      if (!ambiguous) res = (Li < Rq && b1 <= 0.f) ? NO_GRAD : (uint8_t)a1;
+      else {
+        float best = -INFINITY;
+        int arg = 0;
+        for (int r = 0; r < Li; ++r) {
+          if (BLK(r, w) > b1 - AMBIG_MARGIN) {
+            const int slot = atomicAdd(&ncand, 1);
+            if (slot < CAND_MAX) { cand_w[slot] = (uint8_t)w; cand_r[slot] = (uint8_t)r; }
+            else {                                       // list full (degenerate inputs): decide here, serially
+              const float* x = im + i * im_sb + (int64_t)(r + 1) * im_sr;
+              const float* yv = s + j * s_sb + (int64_t)(w + 1) * s_st;
+              float sxy = 0.f, sxx = 0.f;
+              for (int c = 0; c < D; ++c) { sxy += x[c] * yv[c]; sxx += x[c] * x[c]; }
+              const float v = sxy / fmaxf(sqrtf(sxx), 1e-12f);
+              if (v > best) { best = v; arg = r; }
+            }
+          }
+        }
+        BLK(blk_rows + 1, w) = best;                     // stash the serial part's result in the scratch rows
+        BLK(blk_rows, w) = (float)arg;
+      }
+    }
+    __syncthreads();
+    const int nc = ncand < CAND_MAX ? ncand : CAND_MAX;
+    // exact fp32 cosines of the listed candidates, four per wave per trip (eight rows in flight)
+    for (int e0 = wave * 4; e0 < nc; e0 += 16) {
+      float sxy[4] = {0.f, 0.f, 0.f, 0.f}, sxx[4] = {0.f, 0.f, 0.f, 0.f};
+      const float* xp[4];
+      const float* yp[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int e = (e0 + q < nc) ? e0 + q : e0;
+        xp[q] = im + i * im_sb + (int64_t)(cand_r[e] + 1) * im_sr;
+        yp[q] = s + j * s_sb + (int64_t)(cand_w[e] + 1) * s_st;
+      }
+      for (int c = lane * 4; c < D; c += 256) {
+        float4 a[4], b[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { a[q] = *reinterpret_cast<const float4*>(xp[q] + c); b[q] = *reinterpret_cast<const float4*>(yp[q] + c); }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          sxy[q] += a[q].x * b[q].x + a[q].y * b[q].y + a[q].z * b[q].z + a[q].w * b[q].w;
+          sxx[q] += a[q].x * a[q].x + a[q].y * a[q].y + a[q].z * a[q].z + a[q].w * a[q].w;
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float xy = wave_sum(sxy[q]), xx = wave_sum(sxx[q]);
+        if (lane == 0 && e0 + q < nc) cand_val[e0 + q] = xy / fmaxf(sqrtf(xx), 1e-12f);
+      }
+    }
+    __syncthreads();
+    if (ambiguous) {
+      float best = BLK(blk_rows + 1, w);
+      int arg = (int)BLK(blk_rows, w);
+      for (int e = 0; e < nc; ++e)
+        if (cand_w[e] == (uint8_t)w) {
+          const float v = cand_val[e];
+          const int r = cand_r[e];
+          if (v > best || (v == best && r < arg)) { best = v; arg = r; }
+        }
+      res = (Li < Rq && best <= 0.f) ? NO_GRAD : (uint8_t)arg;
+    }
+    if (w < tstride) table[((int64_t)i * Bc + j) * tstride + w] = res;
+  }
+}
+#undef BLK
+
+// ------------------------------------------------------------------------------------------------
 // 3. row gather + normalise backward.  One wave per output row; lane owns float4 columns
 //    lane*4 + 256*c.  grid rows: [0, Bi*R) image rows, then [Bi*R, Bi*R + Bc*T) caption rows.
+//    Structured for memory-level parallelism: (a) the row's own x is fetched first, (b) the
+//    non-zero partners of the row are compacted into a per-wave list, (c) every listed partner's
+//    argmax-table entry is fetched by its own lane in ONE load, (d) partner rows are gathered two
+//    at a time.
 // ------------------------------------------------------------------------------------------------
+#define ROWS_LIST 64
+
+template <int NCH>
+struct RowAcc {
+  float4 a[NCH];
+  __device__ __forceinline__ void zero() {
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) a[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+};
+
+template <int NCH>
+__device__ __forceinline__ void load_row(const float* __restrict__ p, int D, int lane, float4 (&v)[NCH]) {
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int col = lane * 4 + 256 * c;
+    v[c] = (col < D) ? *reinterpret_cast<const float4*>(p + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+}
+template <int NCH>
+__device__ __forceinline__ float row_sumsq(const float4 (&v)[NCH]) {
+  float ss = 0.f;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) ss += v[c].x * v[c].x + v[c].y * v[c].y + v[c].z * v[c].z + v[c].w * v[c].w;
+  return ss;
+}
+template <int NCH>
+__device__ __forceinline__ void axpy_row(float f, const float4 (&v)[NCH], RowAcc<NCH>& acc) {
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) { acc.a[c].x += f * v[c].x; acc.a[c].y += f * v[c].y; acc.a[c].z += f * v[c].z; acc.a[c].w += f * v[c].w; }
+}
+
+// gather one or two partner rows (r1 == nullptr: one); both loads are issued before either is used
+template <int NCH>
+__device__ __forceinline__ void gather2(const float* __restrict__ r0, float g0, const float* __restrict__ r1, float g1, int D,
+                                        int lane, RowAcc<NCH>& acc) {
+  float4 v0[NCH], v1[NCH];
+  load_row<NCH>(r0, D, lane, v0);
+  if (r1 != nullptr) {                                   // wave-uniform
+    load_row<NCH>(r1, D, lane, v1);
+    const float n1 = wave_sum(row_sumsq<NCH>(v1));
+    axpy_row<NCH>(g1 / fmaxf(sqrtf(n1), 1e-12f), v1, acc);
+  }
+  const float n0 = wave_sum(row_sumsq<NCH>(v0));
+  axpy_row<NCH>(g0 / fmaxf(sqrtf(n0), 1e-12f), v0, acc);
+}
+
 template <int NCH>
 __global__ __launch_bounds__(256) void bwd_rows_kernel(
     const float* __restrict__ im, int64_t im_sb, int64_t im_sr, const int32_t* __restrict__ im_len,
     const float* __restrict__ s, int64_t s_sb, int64_t s_st, const int32_t* __restrict__ s_len, int Bi, int Bc, int R,
     int T, int D, const float* __restrict__ dS, int64_t ld, const float* __restrict__ gscale,
-    const uint8_t* __restrict__ table, float* __restrict__ d_im, float* __restrict__ d_s) {
-  const int lane = threadIdx.x & 63;
-  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const uint8_t* __restrict__ table, int tstride, float* __restrict__ d_im, float* __restrict__ d_s) {
+  __shared__ int lst_p[4][ROWS_LIST];
+  __shared__ float lst_g[4][ROWS_LIST];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t row = (int64_t)blockIdx.x * 4 + wave;
   const int64_t n_im_rows = (int64_t)Bi * R;
   if (row >= n_im_rows + (int64_t)Bc * T) return;
   const bool is_img = row < n_im_rows;
   const int Rq = R - 1, Tq = T - 3;
-  const float gs = gscale ? *gscale : 1.f;
 
   int own_b, own_p;           // owner sample and position inside it
   float* out;
@@ -168,66 +369,109 @@ __global__ __launch_bounds__(256) void bwd_rows_kernel(
   if (is_img) { L = im_len[own_b] - 1; L = L < 0 ? 0 : (L > Rq ? Rq : L); }
   else { L = s_len[own_b] - 3; L = L < 0 ? 0 : (L > Tq ? Tq : L); }
 
-  float4 acc[NCH];
-#pragma unroll
-  for (int c = 0; c < NCH; ++c) acc[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+  RowAcc<NCH> acc;
+  acc.zero();
   bool any = false;
+  float4 xv[NCH];
 
   if (idx >= 0 && idx < L) {
-    const int nb = is_img ? Bc : Bi;                       // partners
-    for (int p0 = 0; p0 < nb; p0 += 64) {
-      const int pl = p0 + lane;
-      float g = 0.f;
-      if (pl < nb) g = is_img ? dS[(int64_t)own_b * ld + pl] : dS[(int64_t)pl * ld + own_b];
-      unsigned long long mask = __ballot(g != 0.f);
-      while (mask) {
-        const int bit = __ffsll((long long)mask) - 1;
-        mask &= mask - 1;
-        const int partner = p0 + bit;
-        const float gp = __shfl(g, bit, 64) * gs;
-        if (is_img) {
-          // image row (i, rho): every word w of caption `partner` whose argmax is rho
-          const uint8_t* trow = table + ((int64_t)own_b * Bc + partner) * Tq;
-          for (int w0 = 0; w0 < Tq; w0 += 64) {
-            const int w = w0 + lane;
-            const bool hit = (w < Tq) && (trow[w] == (uint8_t)idx);
-            unsigned long long wm = __ballot(hit);
-            while (wm) {
-              const int wb = __ffsll((long long)wm) - 1;
-              wm &= wm - 1;
-              const float* y = s + partner * s_sb + (int64_t)(w0 + wb + 1) * s_st;
-              float4 v[NCH];
-              float ss = 0.f;
+    load_row<NCH>(xrow, D, lane, xv);                               // (a) own row, needed last
+    const float gs = gscale ? *gscale : 1.f;
+    const int nb = is_img ? Bc : Bi;                                // partners
+    int* lp = lst_p[wave];
+    float* lg = lst_g[wave];
+    int p0 = 0;
+    while (true) {
+      int cnt = 0;
+      while (p0 < nb) {                                             // (b) compact non-zero partners, 4 blocks of 64 per trip
+        float g4[4];
 #pragma unroll
-              for (int c = 0; c < NCH; ++c) {
-                const int col = lane * 4 + 256 * c;
-                v[c] = (col < D) ? *reinterpret_cast<const float4*>(y + col) : make_float4(0.f, 0.f, 0.f, 0.f);
-                ss += v[c].x * v[c].x + v[c].y * v[c].y + v[c].z * v[c].z + v[c].w * v[c].w;
+        for (int q = 0; q < 4; ++q) {
+          const int pl = p0 + 64 * q + lane;
+          g4[q] = 0.f;
+          if (pl < nb) g4[q] = is_img ? dS[(int64_t)own_b * ld + pl] : dS[(int64_t)pl * ld + own_b];
+        }
+        bool full = false;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          if (full || p0 >= nb) continue;
+          const unsigned long long mask = __ballot(g4[q] != 0.f);
+          const int m = __popcll(mask);
+          if (cnt + m > ROWS_LIST) { full = true; continue; }       // drain first (dense dS); an empty list always fits a block
+          if (g4[q] != 0.f) { const int slot = cnt + __popcll(mask & ((1ull << lane) - 1)); lp[slot] = p0 + lane; lg[slot] = g4[q] * gs; }
+          cnt += m;
+          p0 += 64;
+        }
+        if (full) break;
+      }
+      if (cnt == 0) break;
+      // ---- drain the list: lane k owns partner k
+      const int my_p = lane < cnt ? lp[lane] : 0;
+      const float my_g = lane < cnt ? lg[lane] : 0.f;
+      if (!is_img) {
+        // (c) caption row (j, w): the winning region of every listed image, one load
+        const uint8_t my_rho = lane < cnt ? table[((int64_t)my_p * Bc + own_b) * tstride + idx] : NO_GRAD;
+        const unsigned long long live = __ballot(my_rho != NO_GRAD);
+        unsigned long long todo = live;
+        while (todo) {                                              // (d) two partner rows per trip
+          const int k0 = __ffsll((long long)todo) - 1; todo &= todo - 1;
+          int k1 = -1;
+          if (todo) { k1 = __ffsll((long long)todo) - 1; todo &= todo - 1; }
+          const int p_0 = __shfl(my_p, k0, 64), r_0 = __shfl((int)my_rho, k0, 64);
+          const float g_0 = __shfl(my_g, k0, 64);
+          const int kk1 = k1 < 0 ? k0 : k1;
+          const int p_1 = __shfl(my_p, kk1, 64), r_1 = __shfl((int)my_rho, kk1, 64);
+          const float g_1 = k1 < 0 ? 0.f : __shfl(my_g, kk1, 64);
+          const float* x0 = im + p_0 * im_sb + (int64_t)(r_0 + 1) * im_sr;
+          const float* x1 = k1 < 0 ? nullptr : im + p_1 * im_sb + (int64_t)(r_1 + 1) * im_sr;
+          gather2<NCH>(x0, g_0, x1, g_1, D, lane, acc);
+          any = true;
+        }
+      } else {
+        // (c) image row (i, rho): lane k scans partner k's table row for words whose argmax is rho
+        unsigned long long hit_lo = 0, hit_hi = 0;                  // words 0..63 / 64..127
+        if (lane < cnt) {
+          const uint4* trow = reinterpret_cast<const uint4*>(table + ((int64_t)own_b * Bc + my_p) * tstride);
+          for (int q = 0; q < tstride / 16; ++q) {
+            const uint4 t4 = trow[q];
+            const unsigned wds[4] = {t4.x, t4.y, t4.z, t4.w};
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+              for (int b = 0; b < 4; ++b)
+                if (((wds[u] >> (8 * b)) & 0xffu) == (unsigned)idx) {
+                  const int wpos = q * 16 + u * 4 + b;
+                  if (wpos < 64) hit_lo |= 1ull << wpos; else hit_hi |= 1ull << (wpos - 64);
+                }
+          }
+        }
+        unsigned long long live = __ballot((hit_lo | hit_hi) != 0);
+        // flatten (partner, word) hits and gather two rows per trip
+        int pend_p = -1, pend_w = 0;
+        float pend_g = 0.f;
+        while (live) {
+          const int k = __ffsll((long long)live) - 1; live &= live - 1;
+          const int pk = __shfl(my_p, k, 64);
+          const float gk = __shfl(my_g, k, 64);
+          unsigned long long lo = __shfl((unsigned)(hit_lo & 0xffffffffu), k, 64) | ((unsigned long long)__shfl((unsigned)(hit_lo >> 32), k, 64) << 32);
+          unsigned long long hi = __shfl((unsigned)(hit_hi & 0xffffffffu), k, 64) | ((unsigned long long)__shfl((unsigned)(hit_hi >> 32), k, 64) << 32);
+          for (int part = 0; part < 2; ++part) {
+            unsigned long long bits = part == 0 ? lo : hi;
+            while (bits) {
+              const int wb = __ffsll((long long)bits) - 1 + 64 * part; bits &= bits - 1;
+              if (pend_p < 0) { pend_p = pk; pend_w = wb; pend_g = gk; }
+              else {
+                gather2<NCH>(s + pend_p * s_sb + (int64_t)(pend_w + 1) * s_st, pend_g,
+                             s + pk * s_sb + (int64_t)(wb + 1) * s_st, gk, D, lane, acc);
+                pend_p = -1;
+                any = true;
               }
-              const float f = gp / fmaxf(sqrtf(wave_sum(ss)), 1e-12f);
-#pragma unroll
-              for (int c = 0; c < NCH; ++c) { acc[c].x += f * v[c].x; acc[c].y += f * v[c].y; acc[c].z += f * v[c].z; acc[c].w += f * v[c].w; }
-              any = true;
             }
           }
-        } else {
-          // caption row (j, w): the winning region of image `partner`
-          const uint8_t rho = table[((int64_t)partner * Bc + own_b) * Tq + idx];
-          if (rho != NO_GRAD) {
-            const float* x = im + partner * im_sb + (int64_t)(rho + 1) * im_sr;
-            float4 v[NCH];
-            float ss = 0.f;
-#pragma unroll
-            for (int c = 0; c < NCH; ++c) {
-              const int col = lane * 4 + 256 * c;
-              v[c] = (col < D) ? *reinterpret_cast<const float4*>(x + col) : make_float4(0.f, 0.f, 0.f, 0.f);
-              ss += v[c].x * v[c].x + v[c].y * v[c].y + v[c].z * v[c].z + v[c].w * v[c].w;
-            }
-            const float f = gp / fmaxf(sqrtf(wave_sum(ss)), 1e-12f);
-#pragma unroll
-            for (int c = 0; c < NCH; ++c) { acc[c].x += f * v[c].x; acc[c].y += f * v[c].y; acc[c].z += f * v[c].z; acc[c].w += f * v[c].w; }
-            any = true;
-          }
+        }
+        if (pend_p >= 0) {
+          gather2<NCH>(s + pend_p * s_sb + (int64_t)(pend_w + 1) * s_st, pend_g, nullptr, 0.f, D, lane, acc);
+          any = true;
         }
       }
     }
@@ -242,14 +486,11 @@ __global__ __launch_bounds__(256) void bwd_rows_kernel(
     return;
   }
   // normalise backward: xh = x / n, dx = (dxh - xh <xh, dxh>) / n
-  float4 xv[NCH];
   float ss = 0.f, dot = 0.f;
 #pragma unroll
   for (int c = 0; c < NCH; ++c) {
-    const int col = lane * 4 + 256 * c;
-    xv[c] = (col < D) ? *reinterpret_cast<const float4*>(xrow + col) : make_float4(0.f, 0.f, 0.f, 0.f);
     ss += xv[c].x * xv[c].x + xv[c].y * xv[c].y + xv[c].z * xv[c].z + xv[c].w * xv[c].w;
-    dot += xv[c].x * acc[c].x + xv[c].y * acc[c].y + xv[c].z * acc[c].z + xv[c].w * acc[c].w;
+    dot += xv[c].x * acc.a[c].x + xv[c].y * acc.a[c].y + xv[c].z * acc.a[c].z + xv[c].w * acc.a[c].w;
   }
   ss = wave_sum(ss);
   dot = wave_sum(dot);
@@ -260,29 +501,36 @@ __global__ __launch_bounds__(256) void bwd_rows_kernel(
     const int col = lane * 4 + 256 * c;
     if (col < D) {
       float4 o;
-      o.x = (acc[c].x - xv[c].x * proj) * inv;
-      o.y = (acc[c].y - xv[c].y * proj) * inv;
-      o.z = (acc[c].z - xv[c].z * proj) * inv;
-      o.w = (acc[c].w - xv[c].w * proj) * inv;
+      o.x = (acc.a[c].x - xv[c].x * proj) * inv;
+      o.y = (acc.a[c].y - xv[c].y * proj) * inv;
+      o.z = (acc.a[c].z - xv[c].z * proj) * inv;
+      o.w = (acc.a[c].w - xv[c].w * proj) * inv;
       *reinterpret_cast<float4*>(out + col) = o;
     }
   }
 }
 
-extern "C" int aladin_align_bwd(const float* im, int64_t im_sb, int64_t im_sr, const int32_t* im_len, const float* s,
-                                int64_t s_sb, int64_t s_st, const int32_t* s_len, int Bi, int Bc, int R, int T, int D,
-                                const float* dS, int64_t ld_dS, const float* gscale, float* d_im, float* d_s,
-                                void* workspace, void* stream) {
+static int align_bwd_impl(const float* im, int64_t im_sb, int64_t im_sr, const int32_t* im_len, const float* s,
+                          int64_t s_sb, int64_t s_st, const int32_t* s_len, int Bi, int Bc, int R, int T, int D,
+                          const float* dS, int64_t ld_dS, const float* gscale, const void* xm, const void* xe,
+                          const void* y, const aladin_align_geom* g, float* d_im, float* d_s, void* workspace,
+                          void* stream) {
   if (!im || !s || !im_len || !s_len || !dS || !d_im || !d_s || !workspace) { aladin_set_error("align_bwd: null argument"); return ALADIN_ERR_ARG; }
   if (Bi < 1 || Bc < 1 || R < 2 || T < 4 || D < 1 || ld_dS < Bc) { aladin_set_error("align_bwd: bad sizes"); return ALADIN_ERR_ARG; }
-  if (R - 1 > PA_MAXR || R - 1 >= NO_GRAD || T - 3 > PA_MAXT) { aladin_set_error("align_bwd: at most %d regions / %d words", PA_MAXR, PA_MAXT); return ALADIN_ERR_UNSUPPORTED; }
+  if (R - 1 > PA_MAXR - 2 || R - 1 >= NO_GRAD || T - 3 > PA_MAXT) { aladin_set_error("align_bwd: at most %d regions / %d words", PA_MAXR - 2, PA_MAXT); return ALADIN_ERR_UNSUPPORTED; }
   if (D % 4 != 0 || D > 1024 || im_sb % 4 || im_sr % 4 || s_sb % 4 || s_st % 4 || ((uintptr_t)im & 15) || ((uintptr_t)s & 15)) {
     aladin_set_error("align_bwd: needs D %% 4 == 0, D <= 1024 and 16-byte aligned rows (D=%d)", D);
     return ALADIN_ERR_UNSUPPORTED;
   }
+  const bool packed = xm && y && g && g->mtiles == 1 && g->tp16 <= 4;   // shapes the fp16 pair kernel covers
+  if (xm && y && g && (g->Bi != Bi || g->Bc != Bc || g->R != R || g->T != T || g->D != D || (g->rem && !xe))) {
+    aladin_set_error("align_bwd: packed operands do not belong to this problem");
+    return ALADIN_ERR_ARG;
+  }
   hipStream_t st = (hipStream_t)stream;
   BwdWs ws;
-  bwd_ws_layout(Bi, Bc, T - 3, (char*)workspace, &ws);
+  const int Tq = T - 3, tstride = table_stride(Tq);
+  bwd_ws_layout(Bi, Bc, Tq, (char*)workspace, &ws);
   if (hipMemsetAsync(ws.counter, 0, 256, st) != hipSuccess) { aladin_set_error("align_bwd: memset failed"); return ALADIN_ERR_HIP; }
   const int64_t n = (int64_t)Bi * Bc;
   int grid = (int)((n + 255) / 256); if (grid > 1024) grid = 1024;
@@ -290,16 +538,28 @@ extern "C" int aladin_align_bwd(const float* im, int64_t im_sb, int64_t im_sr, c
   int rc = aladin_check_launch("bwd_compact_kernel");
   if (rc) return rc;
   int pgrid = (int)(n < 2048 ? n : 2048);
-  hipLaunchKernelGGL(bwd_pair_argmax_kernel, dim3(pgrid), dim3(256), 0, st, im, im_sb, im_sr, im_len, s, s_sb, s_st, s_len,
-                     Bc, R - 1, T - 3, D, ws.counter, ws.pairs, ws.table);
-  rc = aladin_check_launch("bwd_pair_argmax_kernel");
+  if (packed) {
+    const int blk_rows = 32 + g->rem;
+    const int blk_ld = 65;
+    size_t lds = (size_t)(blk_rows + 2) * blk_ld * 4;
+    if (lds < (size_t)PAIR_STAGES * PairCfg::STAGE_BYTES) lds = (size_t)PAIR_STAGES * PairCfg::STAGE_BYTES;
+    hipLaunchKernelGGL(bwd_pair_argmax16_kernel, dim3(pgrid), dim3(256), lds, st, (const half_t*)xm, (const half_t*)xe,
+                       (const half_t*)y, g->Dp, g->rem, 16 * g->tp16, (int)g->xe_rows, (int)g->y_rows, im, im_sb, im_sr,
+                       im_len, s, s_sb, s_st, s_len, Bc, R - 1, Tq, D, ws.counter, ws.pairs, ws.table, tstride, blk_rows,
+                       blk_ld);
+    rc = aladin_check_launch("bwd_pair_argmax16_kernel");
+  } else {
+    hipLaunchKernelGGL(bwd_pair_argmax_kernel, dim3(pgrid), dim3(256), 0, st, im, im_sb, im_sr, im_len, s, s_sb, s_st,
+                       s_len, Bc, R - 1, Tq, D, ws.counter, ws.pairs, ws.table, tstride);
+    rc = aladin_check_launch("bwd_pair_argmax_kernel");
+  }
   if (rc) return rc;
   const int64_t rows = (int64_t)Bi * R + (int64_t)Bc * T;
   const unsigned rgrid = (unsigned)((rows + 3) / 4);
   const int nch = (D + 255) / 256;
 #define LAUNCH_ROWS(N)                                                                                                  \
   hipLaunchKernelGGL(bwd_rows_kernel<N>, dim3(rgrid), dim3(256), 0, st, im, im_sb, im_sr, im_len, s, s_sb, s_st, s_len, \
-                     Bi, Bc, R, T, D, dS, ld_dS, gscale, ws.table, d_im, d_s)
+                     Bi, Bc, R, T, D, dS, ld_dS, gscale, ws.table, tstride, d_im, d_s)
   switch (nch) {
     case 1: LAUNCH_ROWS(1); break;
     case 2: LAUNCH_ROWS(2); break;
@@ -308,4 +568,22 @@ extern "C" int aladin_align_bwd(const float* im, int64_t im_sb, int64_t im_sr, c
   }
 #undef LAUNCH_ROWS
   return aladin_check_launch("bwd_rows_kernel");
+}
+
+extern "C" int aladin_align_bwd(const float* im, int64_t im_sb, int64_t im_sr, const int32_t* im_len, const float* s,
+                                int64_t s_sb, int64_t s_st, const int32_t* s_len, int Bi, int Bc, int R, int T, int D,
+                                const float* dS, int64_t ld_dS, const float* gscale, float* d_im, float* d_s,
+                                void* workspace, void* stream) {
+  return align_bwd_impl(im, im_sb, im_sr, im_len, s, s_sb, s_st, s_len, Bi, Bc, R, T, D, dS, ld_dS, gscale, nullptr,
+                        nullptr, nullptr, nullptr, d_im, d_s, workspace, stream);
+}
+
+extern "C" int aladin_align_bwd_packed(const float* im, int64_t im_sb, int64_t im_sr, const int32_t* im_len, const float* s,
+                                       int64_t s_sb, int64_t s_st, const int32_t* s_len, const float* dS, int64_t ld_dS,
+                                       const float* gscale, const void* xm, const void* xe, const void* y,
+                                       const aladin_align_geom* geom, float* d_im, float* d_s, void* workspace,
+                                       void* stream) {
+  if (!geom) { aladin_set_error("align_bwd_packed: null geometry"); return ALADIN_ERR_ARG; }
+  return align_bwd_impl(im, im_sb, im_sr, im_len, s, s_sb, s_st, s_len, geom->Bi, geom->Bc, geom->R, geom->T, geom->D, dS,
+                        ld_dS, gscale, xm, xe, y, geom, d_im, d_s, workspace, stream);
 }

@@ -19,6 +19,7 @@
 //                operand (one row per image) whose plain GEMM against the captions (E) is folded
 //                into the max by the score kernel -- 33/32 of the MFMA work instead of 64/32.
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "../../include/aladin_hip.h"
@@ -27,6 +28,14 @@
 // ------------------------------------------------------------------------------------------------
 // geometry
 // ------------------------------------------------------------------------------------------------
+// Column-strip multiplier of the score kernel: 2 doubles the captions per wave (256 x 384 tile for
+// 48-word captions: 1.43x less LDS-DMA traffic per flop, half the barriers per MFMA).
+static int scores_strip_mult(int tp16, int mtiles) {
+  static int env = -1;
+  if (env < 0) { const char* e = getenv("ALADIN_ALIGN_STRIP"); env = e ? atoi(e) : 2; }
+  return (env == 2 && tp16 == 3 && mtiles == 1) ? 2 : 1;
+}
+
 extern "C" int aladin_align_geometry(int Bi, int Bc, int R, int T, int D, aladin_align_geom* g) {
   if (!g || Bi < 1 || Bc < 1 || D < 1) { aladin_set_error("align_geometry: bad sizes Bi=%d Bc=%d D=%d", Bi, Bc, D); return ALADIN_ERR_ARG; }
   if (R < 2 || T < 4) { aladin_set_error("align_geometry: need R >= 2 and T >= 4 (got R=%d T=%d): region 0, token 0 and the last two tokens are dropped", R, T); return ALADIN_ERR_ARG; }
@@ -41,7 +50,7 @@ extern "C" int aladin_align_geometry(int Bi, int Bc, int R, int T, int D, aladin
   g->Dp = round_up(D, 64);
   const int imgs_per_wave = (g->mtiles == 1) ? 2 : 1;
   g->img_unit = 4 * imgs_per_wave;
-  g->cap_unit = 2 * ((g->tp16 & 1) ? 2 : 1);
+  g->cap_unit = 2 * ((g->tp16 & 1) ? 2 : 1) * scores_strip_mult(g->tp16, g->mtiles);
   g->Bi_pad = round_up(Bi, g->img_unit);
   g->Bc_pad = round_up(Bc, g->cap_unit);
   g->xm_rows = (int64_t)g->Bi_pad * 32 * g->mtiles;
@@ -164,6 +173,7 @@ extern "C" int aladin_align_pack_captions(const float* s, int64_t stride_b, int6
 // ------------------------------------------------------------------------------------------------
 // side GEMM: E[i][col] = <last region of image i, word col>   (fp32, xe_rows x y_rows)
 // ------------------------------------------------------------------------------------------------
+#define SIDE_STAGES 4
 template <int NT>
 __global__ __launch_bounds__(256) void align_side_gemm_kernel(const half_t* __restrict__ xe, const half_t* __restrict__ y,
                                                               float* __restrict__ E, int64_t ldE, int64_t ldk,
@@ -176,7 +186,7 @@ __global__ __launch_bounds__(256) void align_side_gemm_kernel(const half_t* __re
   for (int n = 0; n < NT; ++n)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[0][n][r] = 0.f;
-  gemm_mainloop<Cfg>(xe + (int64_t)mb * Cfg::BM * ldk, y + (int64_t)nb * Cfg::BN * ldk, ldk, ktiles, smem, acc);
+  gemm_mainloop<Cfg, SIDE_STAGES>(xe + (int64_t)mb * Cfg::BM * ldk, y + (int64_t)nb * Cfg::BN * ldk, ldk, ktiles, smem, acc);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int wm = wave / 2, wn = wave % 2;
   const int64_t row0 = (int64_t)mb * Cfg::BM + wm * 32 + 4 * (lane >> 5);
@@ -193,20 +203,20 @@ __global__ __launch_bounds__(256) void align_side_gemm_kernel(const half_t* __re
 //   WM   M-tiles (32 rows) per wave;  Q  M-tiles per image;  images per wave = WM / Q  (2 or 1)
 //   TP16 padded words per caption / 16;  a wave's column strip holds CPS = 1 or 2 whole captions
 // ------------------------------------------------------------------------------------------------
-template <int WM, int Q, int TP16, bool HAS_E>
-__global__ __launch_bounds__(512) void align_scores_kernel(const half_t* __restrict__ xm, const half_t* __restrict__ y,
+template <int WGM, int WM, int Q, int TP16, bool HAS_E, int SM>
+__global__ __launch_bounds__(WGM * 128) void align_scores_kernel(const half_t* __restrict__ xm, const half_t* __restrict__ y,
                                                            const float* __restrict__ E, int64_t ldE,
                                                            float* __restrict__ S, int64_t ldS, int Bi, int Bc,
                                                            int64_t ldk, int ktiles, int n_nblk, int n_blocks) {
-  constexpr int NT = (TP16 & 1) ? TP16 : TP16 / 2;
-  constexpr int CPS = (TP16 & 1) ? 2 : 1;
+  constexpr int NT = ((TP16 & 1) ? TP16 : TP16 / 2) * SM;
+  constexpr int CPS = ((TP16 & 1) ? 2 : 1) * SM;
   constexpr int IPW = WM / Q;
   static_assert(IPW == 1 || IPW == 2, "one or two images per wave");
-  using Cfg = GemmCfg<4, 2, WM, NT>;
+  using Cfg = GemmCfg<WGM, 2, WM, NT>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
-  const int bid = xcd_remap(blockIdx.x, n_blocks);
-  const int mb = bid / n_nblk, nb = bid % n_nblk;
+  int mb, nb;
+  tile_coords(blockIdx.x, n_blocks / n_nblk, n_nblk, 4, mb, nb);
 
   f32x16 acc[WM][NT];
 #pragma unroll
@@ -245,7 +255,7 @@ __global__ __launch_bounds__(512) void align_scores_kernel(const half_t* __restr
       m[n] = fmaxf(p, __shfl_xor(p, 32, 64));
     }
   }
-  const int img = (mb * 4 + wm) * IPW + (IPW == 2 ? half : 0);
+  const int img = (mb * WGM + wm) * IPW + (IPW == 2 ? half : 0);
   if constexpr (HAS_E) {
     const float* e = E + (int64_t)img * ldE + (int64_t)nb * Cfg::BN + wn * NT * 32 + l5;
 #pragma unroll
@@ -253,37 +263,41 @@ __global__ __launch_bounds__(512) void align_scores_kernel(const half_t* __restr
   }
 
   // sum over words: 16-lane groups map to captions at compile time
-  float v0 = 0.f, v1 = 0.f;
+  float v[CPS];
+#pragma unroll
+  for (int c = 0; c < CPS; ++c) v[c] = 0.f;
 #pragma unroll
   for (int n = 0; n < NT; ++n) {
-    constexpr int dummy = 0; (void)dummy;
-    const int c_lo = (2 * n) / TP16, c_hi = (2 * n + 1) / TP16;
-    const float lo = (c_lo == c_hi || l5 < 16) ? m[n] : 0.f;      // contribution to caption c_lo
-    const float hi = (c_lo != c_hi && l5 >= 16) ? m[n] : 0.f;     // contribution to caption c_hi (straddling tile)
-    if (c_lo == 0) v0 += lo; else v1 += lo;
-    if (c_hi == 0) v0 += hi; else v1 += hi;
+    const int c_lo = (2 * n) / TP16, c_hi = (2 * n + 1) / TP16;       // captions of the tile's two 16-column groups
+    if (c_lo == c_hi) v[c_lo] += m[n];
+    else { v[c_lo] += (l5 < 16) ? m[n] : 0.f; v[c_hi] += (l5 >= 16) ? m[n] : 0.f; }
   }
-  v0 = half_wave_sum(v0);
-  if constexpr (CPS == 2) v1 = half_wave_sum(v1);
   const int cap = (nb * 2 + wn) * CPS;
-  if (l5 == 0 && (IPW == 2 || half == 0) && img < Bi) {
-    if (cap < Bc) S[(int64_t)img * ldS + cap] = v0;
-    if (CPS == 2 && cap + 1 < Bc) S[(int64_t)img * ldS + cap + 1] = v1;
+#pragma unroll
+  for (int c = 0; c < CPS; ++c) {
+    const float t = half_wave_sum(v[c]);
+    if (l5 == 0 && (IPW == 2 || half == 0) && img < Bi && cap + c < Bc) S[(int64_t)img * ldS + cap + c] = t;
   }
 }
 
-template <int WM, int Q, int TP16, bool HAS_E>
-static int launch_scores(const aladin_align_geom* g, const half_t* xm, const half_t* y, const float* E, float* S,
-                         int64_t ldS, hipStream_t stream) {
-  constexpr int NT = (TP16 & 1) ? TP16 : TP16 / 2;
-  using Cfg = GemmCfg<4, 2, WM, NT>;
+static int scores_wgm() {
+  static int v = 0;
+  if (!v) { const char* e = getenv("ALADIN_ALIGN_WGM"); v = (e && atoi(e) == 2) ? 2 : 4; }
+  return v;
+}
+
+template <int WGM, int WM, int Q, int TP16, bool HAS_E, int SM>
+static int launch_scores_w(const aladin_align_geom* g, const half_t* xm, const half_t* y, const float* E, float* S,
+                           int64_t ldS, hipStream_t stream) {
+  constexpr int NT = ((TP16 & 1) ? TP16 : TP16 / 2) * SM;
+  using Cfg = GemmCfg<WGM, 2, WM, NT>;
   const int n_mblk = (int)(g->xm_rows / Cfg::BM), n_nblk = (int)(g->y_rows / Cfg::BN);
   if ((int64_t)n_mblk * Cfg::BM != g->xm_rows || (int64_t)n_nblk * Cfg::BN != g->y_rows) {
     aladin_set_error("align_scores: packed rows (%lld, %lld) do not tile by (%d, %d)", (long long)g->xm_rows,
                      (long long)g->y_rows, Cfg::BM, Cfg::BN);
     return ALADIN_ERR_ARG;
   }
-  auto kern = align_scores_kernel<WM, Q, TP16, HAS_E>;
+  auto kern = align_scores_kernel<WGM, WM, Q, TP16, HAS_E, SM>;
   static bool attr_done = false;
   if (!attr_done) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES) != hipSuccess) {
@@ -298,20 +312,30 @@ static int launch_scores(const aladin_align_geom* g, const half_t* xm, const hal
   return aladin_check_launch("align_scores_kernel");
 }
 
+template <int WM, int Q, int TP16, bool HAS_E>
+static int launch_scores(const aladin_align_geom* g, const half_t* xm, const half_t* y, const float* E, float* S,
+                         int64_t ldS, hipStream_t stream) {
+  if constexpr (TP16 == 3 && Q == 1)
+    if (scores_strip_mult(TP16, g->mtiles) == 2) return launch_scores_w<4, WM, Q, TP16, HAS_E, 2>(g, xm, y, E, S, ldS, stream);
+  if (scores_wgm() == 4) return launch_scores_w<4, WM, Q, TP16, HAS_E, 1>(g, xm, y, E, S, ldS, stream);
+  return launch_scores_w<2, WM, Q, TP16, HAS_E, 1>(g, xm, y, E, S, ldS, stream);
+}
+
 template <int NT>
 static int launch_side(const aladin_align_geom* g, const half_t* xe, const half_t* y, float* E, hipStream_t stream) {
   using Cfg = GemmCfg<2, 2, 1, NT>;
   const int n_mblk = (int)(g->xe_rows / Cfg::BM), n_nblk = (int)(g->y_rows / Cfg::BN);
   auto kern = align_side_gemm_kernel<NT>;
+  constexpr int lds_bytes = SIDE_STAGES * Cfg::STAGE_BYTES;
   static bool attr_done = false;
   if (!attr_done) {
-    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES) != hipSuccess) {
-      aladin_set_error("align_side_gemm: cannot reserve %d B of LDS", Cfg::LDS_BYTES);
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess) {
+      aladin_set_error("align_side_gemm: cannot reserve %d B of LDS", lds_bytes);
       return ALADIN_ERR_HIP;
     }
     attr_done = true;
   }
-  hipLaunchKernelGGL(kern, dim3(n_mblk * n_nblk), dim3(Cfg::THREADS), Cfg::LDS_BYTES, stream, xe, y, E, g->y_rows,
+  hipLaunchKernelGGL(kern, dim3(n_mblk * n_nblk), dim3(Cfg::THREADS), lds_bytes, stream, xe, y, E, g->y_rows,
                      (int64_t)g->Dp, g->Dp / 64, n_nblk);
   return aladin_check_launch("align_side_gemm_kernel");
 }

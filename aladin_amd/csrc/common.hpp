@@ -49,5 +49,17 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   return base + (bid >> 3);
 }
 
+// Tile order: logical ids are contiguous per XCD (xcd_remap) and walk the tile grid in groups of
+// GM block-rows, column-major inside a group, so the ~32 workgroups an XCD runs at a time cover a
+// compact GM x (32/GM) patch of tiles whose operand panels fit its 4 MiB L2 and are re-used there.
+__device__ __forceinline__ void tile_coords(int bid, int n_mblk, int n_nblk, int GM, int& mb, int& nb) {
+  const int L = xcd_remap(bid, n_mblk * n_nblk);
+  const int per_group = GM * n_nblk;
+  const int g = L / per_group, r = L % per_group;
+  const int gm = (n_mblk - g * GM) < GM ? (n_mblk - g * GM) : GM;
+  mb = g * GM + r % gm;
+  nb = r / gm;
+}
+
 static inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }

@@ -26,19 +26,24 @@ struct GemmCfg {
   static constexpr int STAGE_BYTES = ROWS * 128;
   static constexpr int CHUNKS = ROWS / 8;
   static constexpr int CHUNKS_PER_WAVE = CHUNKS / NWAVES;
-  static constexpr int LDS_BYTES = 2 * STAGE_BYTES;
+  static constexpr int LDS_BYTES = 2 * STAGE_BYTES;      // for the default 2-stage ring
   static_assert(CHUNKS % NWAVES == 0, "stage chunks must divide over the waves");
 };
 
+// One K-step (64 deep) of both panels -> LDS.  The A panel may come from two row segments
+// (rows [0,a_split) from a_rows, rows [a_split,BM) from a_rows2) -- used by the backward pair kernel.
 template <class Cfg>
-__device__ __forceinline__ void gemm_stage(const half_t* __restrict__ a_rows, const half_t* __restrict__ b_rows,
-                                           int64_t ldk, int kt, char* stage, int wave, int lane) {
+__device__ __forceinline__ void gemm_stage(const half_t* __restrict__ a_rows, const half_t* __restrict__ a_rows2, int a_split,
+                                           const half_t* __restrict__ b_rows, int64_t ldk, int kt, char* stage, int wave,
+                                           int lane) {
 #pragma unroll
   for (int c = 0; c < Cfg::CHUNKS_PER_WAVE; ++c) {
     const int chunk = wave + c * Cfg::NWAVES;
     const int row = chunk * 8 + (lane >> 3);
     const int logical = (lane & 7) ^ ((row >> 1) & 7);
-    const half_t* src = (row < Cfg::BM) ? a_rows + (int64_t)row * ldk : b_rows + (int64_t)(row - Cfg::BM) * ldk;
+    const half_t* src;
+    if (row < Cfg::BM) src = (row < a_split) ? a_rows + (int64_t)row * ldk : a_rows2 + (int64_t)(row - a_split) * ldk;
+    else src = b_rows + (int64_t)(row - Cfg::BM) * ldk;
     src += (int64_t)kt * 64 + logical * 8;
     __builtin_amdgcn_global_load_lds(GLOBAL_PTR(src), LDS_PTR(stage + chunk * 1024), 16, 0, 0);
   }
@@ -50,24 +55,49 @@ __device__ __forceinline__ half8 lds_frag(const char* stage, int row, int kk, in
   return *reinterpret_cast<const half8*>(stage + row * 128 + phys * 16);
 }
 
-// acc must be zero-initialised (or hold a running sum) by the caller.
-template <class Cfg>
+// s_waitcnt vmcnt(n) with a run-time n <= 32 (the instruction needs an immediate)
+__device__ __forceinline__ void wait_vmcnt(int n) {
+  switch (n) {
+#define ALADIN_VMCNT_CASE(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
+    ALADIN_VMCNT_CASE(0) ALADIN_VMCNT_CASE(1) ALADIN_VMCNT_CASE(2) ALADIN_VMCNT_CASE(3) ALADIN_VMCNT_CASE(4)
+    ALADIN_VMCNT_CASE(5) ALADIN_VMCNT_CASE(6) ALADIN_VMCNT_CASE(7) ALADIN_VMCNT_CASE(8) ALADIN_VMCNT_CASE(9)
+    ALADIN_VMCNT_CASE(10) ALADIN_VMCNT_CASE(11) ALADIN_VMCNT_CASE(12) ALADIN_VMCNT_CASE(13) ALADIN_VMCNT_CASE(14)
+    ALADIN_VMCNT_CASE(15) ALADIN_VMCNT_CASE(16) ALADIN_VMCNT_CASE(17) ALADIN_VMCNT_CASE(18) ALADIN_VMCNT_CASE(19)
+    ALADIN_VMCNT_CASE(20) ALADIN_VMCNT_CASE(21) ALADIN_VMCNT_CASE(22) ALADIN_VMCNT_CASE(23) ALADIN_VMCNT_CASE(24)
+    ALADIN_VMCNT_CASE(25) ALADIN_VMCNT_CASE(26) ALADIN_VMCNT_CASE(27) ALADIN_VMCNT_CASE(28) ALADIN_VMCNT_CASE(29)
+    ALADIN_VMCNT_CASE(30) ALADIN_VMCNT_CASE(31) ALADIN_VMCNT_CASE(32)
+#undef ALADIN_VMCNT_CASE
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+  }
+}
+
+// NS-stage LDS ring (smem: NS * Cfg::STAGE_BYTES).  K-step kt lives in buffer kt % NS; steps
+// kt+1 .. kt+NS-2 are in flight while kt is consumed.  Per K-step: a counted vmcnt (only this
+// wave's older LDS-DMA groups must have landed), ONE raw s_barrier (publishes step kt to every
+// wave and proves every wave is done reading buffer (kt-1) % NS), then the refill of that buffer
+// is issued before the MFMAs of step kt.  acc must be initialised by the caller.
+template <class Cfg, int NS = 2>
 __device__ __forceinline__ void gemm_mainloop(const half_t* __restrict__ a_rows, const half_t* __restrict__ b_rows,
-                                              int64_t ldk, int ktiles, char* smem,
-                                              f32x16 (&acc)[Cfg::WM][Cfg::WN]) {
+                                              int64_t ldk, int ktiles, char* smem, f32x16 (&acc)[Cfg::WM][Cfg::WN],
+                                              const half_t* __restrict__ a_rows2 = nullptr, int a_split = Cfg::BM) {
+  static_assert(NS >= 2 && Cfg::CHUNKS_PER_WAVE * (NS - 2) <= 32, "ring too deep for the vmcnt dispatcher");
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   const int wm = wave / Cfg::WGN, wn = wave % Cfg::WGN;
   const int a_row0 = wm * Cfg::WM * 32 + (lane & 31);
   const int b_row0 = Cfg::BM + wn * Cfg::WN * 32 + (lane & 31);
 
-  gemm_stage<Cfg>(a_rows, b_rows, ldk, 0, smem, wave, lane);
+#pragma unroll
+  for (int st = 0; st < NS - 1; ++st)
+    if (st < ktiles) gemm_stage<Cfg>(a_rows, a_rows2, a_split, b_rows, ldk, st, smem + st * Cfg::STAGE_BYTES, wave, lane);
   for (int kt = 0; kt < ktiles; ++kt) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    char* cur = smem + (kt & 1) * Cfg::STAGE_BYTES;
-    if (kt + 1 < ktiles)
-      gemm_stage<Cfg>(a_rows, b_rows, ldk, kt + 1, smem + ((kt + 1) & 1) * Cfg::STAGE_BYTES, wave, lane);
+    const int ahead = ktiles - 1 - kt;                                   // groups issued after step kt's
+    wait_vmcnt(Cfg::CHUNKS_PER_WAVE * (ahead < NS - 2 ? ahead : NS - 2));
+    __builtin_amdgcn_s_barrier();
+    const char* cur = smem + (kt % NS) * Cfg::STAGE_BYTES;
+    if (kt + NS - 1 < ktiles)
+      gemm_stage<Cfg>(a_rows, a_rows2, a_split, b_rows, ldk, kt + NS - 1, smem + ((kt + NS - 1) % NS) * Cfg::STAGE_BYTES,
+                      wave, lane);
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
       half8 af[Cfg::WM], bf[Cfg::WN];

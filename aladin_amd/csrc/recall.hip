@@ -94,8 +94,8 @@ __global__ __launch_bounds__(512) void sim_gemm_kernel(const half_t* __restrict_
                                                        int n_nblk, int n_blocks) {
   using Cfg = SimCfg;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int bid = xcd_remap(blockIdx.x, n_blocks);
-  const int mb = bid / n_nblk, nb = bid % n_nblk;
+  int mb, nb;
+  tile_coords(blockIdx.x, n_blocks / n_nblk, n_nblk, 4, mb, nb);
   f32x16 acc[Cfg::WM][Cfg::WN];
 #pragma unroll
   for (int m = 0; m < Cfg::WM; ++m)

@@ -64,6 +64,11 @@ class AlignmentContrastiveLoss(Contrastive):
         if self.aggregation not in ('MrSw', 'MrAVGw'):
             raise NotImplementedError("aladin_amd: alignment aggregation %r is not implemented in HIP yet "
                                       "(supported: 'MrSw', 'MrAVGw')" % (self.aggregation,))
+        if return_loss and self.aggregation == 'MrSw':
+            # fused scores + hinge node; the returned matrix is detached (see ops.alignment_triplet_loss)
+            loss, aggr_similarity = ops.alignment_triplet_loss(im_set, s_seq, im_len, s_len, self.margin,
+                                                               self.max_violation)
+            return (loss, aggr_similarity) if return_similarity_mat else loss
         aggr_similarity = ops.alignment_scores(im_set, s_seq, im_len, s_len)
         if self.aggregation == 'MrAVGw':
             lens = ops.lengths_tensor(s_len, aggr_similarity.device).to(torch.float32) - 3.0

@@ -38,11 +38,22 @@ def _rows_inner_contig(t):
     return t
 
 
+_LEN_CACHE = {}
+
+
 def lengths_tensor(lens, device):
-    """Python list / tensor of lengths -> int32 device tensor (the reference passes lists)."""
+    """Python list / tensor of lengths -> int32 device tensor (the reference passes lists).
+    Lists are cached by value so that a repeated batch shape costs no host->device copy."""
     if isinstance(lens, torch.Tensor):
         return lens.to(device=device, dtype=torch.int32, non_blocking=True)
-    return torch.tensor([int(v) for v in lens], dtype=torch.int32).to(device, non_blocking=True)
+    key = (tuple(int(v) for v in lens), str(device))
+    t = _LEN_CACHE.get(key)
+    if t is None:
+        if len(_LEN_CACHE) >= 256:
+            _LEN_CACHE.clear()
+        t = torch.tensor(key[0], dtype=torch.int32).to(device, non_blocking=True)
+        _LEN_CACHE[key] = t
+    return t
 
 
 def _workspace(nbytes, device):
@@ -88,6 +99,7 @@ def scores_from_packed(xm, xe, y, geom, out=None, e_scratch=None, reuse_side=Fal
 
 
 def _align_forward(im, s, im_len_t, s_len_t):
+    """-> (S, packed) where packed = (geom, xm, xe, y) is kept for the backward pass."""
     Bi, R, D = im.shape
     Bc, T, D2 = s.shape
     if D != D2:
@@ -95,10 +107,10 @@ def _align_forward(im, s, im_len_t, s_len_t):
     geom = align_geometry(Bi, Bc, R, T, D)
     xm, xe = pack_images(im, im_len_t, geom)
     y = pack_captions(s, s_len_t, geom)
-    return scores_from_packed(xm, xe, y, geom)
+    return scores_from_packed(xm, xe, y, geom), (geom, xm, xe, y)
 
 
-def _align_backward(im, s, im_len_t, s_len_t, dS, gscale=None):
+def _align_backward(im, s, im_len_t, s_len_t, dS, gscale=None, packed=None):
     lib = _lib.load()
     im = _rows_inner_contig(im)
     s = _rows_inner_contig(s)
@@ -108,36 +120,97 @@ def _align_backward(im, s, im_len_t, s_len_t, dS, gscale=None):
     d_im = torch.empty((Bi, R, D), dtype=torch.float32, device=im.device)
     d_s = torch.empty((Bc, T, D), dtype=torch.float32, device=im.device)
     ws = _workspace(lib.aladin_align_bwd_workspace_bytes(Bi, Bc, R, T, D), im.device)
-    _lib.check(lib.aladin_align_bwd(_ptr(im), im.stride(0), im.stride(1), _ptr(im_len_t),
-                                    _ptr(s), s.stride(0), s.stride(1), _ptr(s_len_t), Bi, Bc, R, T, D,
-                                    _ptr(dS), dS.stride(0), _ptr(gscale), _ptr(d_im), _ptr(d_s), _ptr(ws), _stream()),
-               'align_bwd')
+    if packed is not None:
+        geom, xm, xe, y = packed
+        _lib.check(lib.aladin_align_bwd_packed(_ptr(im), im.stride(0), im.stride(1), _ptr(im_len_t),
+                                               _ptr(s), s.stride(0), s.stride(1), _ptr(s_len_t),
+                                               _ptr(dS), dS.stride(0), _ptr(gscale), _ptr(xm), _ptr(xe), _ptr(y),
+                                               C.byref(geom), _ptr(d_im), _ptr(d_s), _ptr(ws), _stream()),
+                   'align_bwd_packed')
+    else:
+        _lib.check(lib.aladin_align_bwd(_ptr(im), im.stride(0), im.stride(1), _ptr(im_len_t),
+                                        _ptr(s), s.stride(0), s.stride(1), _ptr(s_len_t), Bi, Bc, R, T, D,
+                                        _ptr(dS), dS.stride(0), _ptr(gscale), _ptr(d_im), _ptr(d_s), _ptr(ws),
+                                        _stream()), 'align_bwd')
     return d_im, d_s
 
 
 class _AlignScores(torch.autograd.Function):
     @staticmethod
     def forward(ctx, im, s, im_len_t, s_len_t):
-        ctx.save_for_backward(im, s, im_len_t, s_len_t)
-        return _align_forward(im, s, im_len_t, s_len_t)
+        S, packed = _align_forward(im, s, im_len_t, s_len_t)
+        if any(ctx.needs_input_grad[:2]):
+            ctx.save_for_backward(im, s, im_len_t, s_len_t, packed[1], packed[2], packed[3])
+            ctx.geom = packed[0]
+        return S
 
     @staticmethod
     def backward(ctx, dS):
-        im, s, im_len_t, s_len_t = ctx.saved_tensors
-        d_im, d_s = _align_backward(im, s, im_len_t, s_len_t, dS)
+        im, s, im_len_t, s_len_t, xm, xe, y = ctx.saved_tensors
+        d_im, d_s = _align_backward(im, s, im_len_t, s_len_t, dS, packed=(ctx.geom, xm, xe, y))
         return d_im, d_s, None, None
 
 
-def alignment_scores(im_set, s_seq, im_len, s_len):
-    """S (Bi, Bc) = sum over words of max over regions of the cosine ('MrSw'), differentiable.
-    Replaces reference alad/loss.py:80-125."""
+def _hinge_raw(scores, margin, max_violation, want_grad):
+    lib = _lib.load()
+    B = scores.shape[0]
+    sc = scores if scores.stride(1) == 1 else scores.contiguous()
+    loss = torch.empty((), dtype=torch.float32, device=scores.device)
+    dS = torch.empty((B, B), dtype=torch.float32, device=scores.device) if want_grad else None
+    ws = _workspace(lib.aladin_hinge_workspace_bytes(B), scores.device)
+    _lib.check(lib.aladin_hinge_fwd_bwd(_ptr(sc), sc.stride(0), B, float(margin), int(bool(max_violation)),
+                                        _ptr(loss), _ptr(dS), _ptr(ws), _stream()), 'hinge_fwd_bwd')
+    return loss, dS
+
+
+class _AlignTriplet(torch.autograd.Function):
+    """scores + hinge in one autograd node (reference alad/loss.py:79-159 with return_loss=True):
+    dloss/dS never leaves the device-side workspace and the upstream scalar gradient is handed to
+    the backward kernels as a device pointer (no element-wise scaling launch)."""
+
+    @staticmethod
+    def forward(ctx, im, s, im_len_t, s_len_t, margin, max_violation):
+        S, packed = _align_forward(im, s, im_len_t, s_len_t)
+        need = any(ctx.needs_input_grad[:2])
+        loss, dS = _hinge_raw(S, margin, max_violation, need)
+        if need:
+            ctx.save_for_backward(im, s, im_len_t, s_len_t, packed[1], packed[2], packed[3], dS)
+            ctx.geom = packed[0]
+        ctx.mark_non_differentiable(S)
+        return loss, S
+
+    @staticmethod
+    def backward(ctx, g_loss, _g_scores):
+        im, s, im_len_t, s_len_t, xm, xe, y, dS = ctx.saved_tensors
+        g = g_loss.to(torch.float32).contiguous()
+        d_im, d_s = _align_backward(im, s, im_len_t, s_len_t, dS, gscale=g, packed=(ctx.geom, xm, xe, y))
+        return d_im, d_s, None, None, None, None
+
+
+def _check_sets(im_set, s_seq, im_len, s_len):
     _require_gpu(im_set, s_seq)
     if im_set.dim() != 3 or s_seq.dim() != 3:
         raise ValueError('aladin_amd: im_set (B,R,D) and s_seq (B,T,D) expected')
     if len(im_len) != im_set.shape[0] or len(s_len) != s_seq.shape[0]:
         raise ValueError('aladin_amd: one length per sample expected')
-    im_len_t = lengths_tensor(im_len, im_set.device)
-    s_len_t = lengths_tensor(s_len, im_set.device)
+    return lengths_tensor(im_len, im_set.device), lengths_tensor(s_len, im_set.device)
+
+
+def alignment_triplet_loss(im_set, s_seq, im_len, s_len, margin, max_violation):
+    """(loss, S.detach()) of AlignmentContrastiveLoss(aggregation='MrSw') in one fused node.
+    The returned score matrix carries no gradient (the reference only ever feeds it, detached, to
+    the distillation loss -- alad/loss.py:370); use alignment_scores() for a differentiable S."""
+    im_len_t, s_len_t = _check_sets(im_set, s_seq, im_len, s_len)
+    if im_set.shape[0] != s_seq.shape[0]:
+        raise ValueError('aladin_amd: the contrastive loss needs a square score matrix, got (%d, %d) '
+                         '(the reference fails in diag/expand_as, alad/loss.py:43-45)' % (im_set.shape[0], s_seq.shape[0]))
+    return _AlignTriplet.apply(im_set, s_seq, im_len_t, s_len_t, margin, max_violation)
+
+
+def alignment_scores(im_set, s_seq, im_len, s_len):
+    """S (Bi, Bc) = sum over words of max over regions of the cosine ('MrSw'), differentiable.
+    Replaces reference alad/loss.py:80-125."""
+    im_len_t, s_len_t = _check_sets(im_set, s_seq, im_len, s_len)
     return _AlignScores.apply(im_set, s_seq, im_len_t, s_len_t)
 
 
@@ -147,16 +220,7 @@ def alignment_scores(im_set, s_seq, im_len, s_len):
 class _Hinge(torch.autograd.Function):
     @staticmethod
     def forward(ctx, scores, margin, max_violation):
-        lib = _lib.load()
-        B = scores.shape[0]
-        sc = scores if scores.stride(1) == 1 else scores.contiguous()
-        loss = torch.empty((), dtype=torch.float32, device=scores.device)
-        need = ctx.needs_input_grad[0]
-        dS = torch.empty((B, B), dtype=torch.float32, device=scores.device) if need else None
-        ws = _workspace(lib.aladin_hinge_workspace_bytes(B), scores.device)
-        _lib.check(lib.aladin_hinge_fwd_bwd(_ptr(sc), sc.stride(0), B, float(margin), int(bool(max_violation)),
-                                            _ptr(loss), _ptr(dS), _ptr(ws), _stream()), 'hinge_fwd_bwd')
-        ctx.dS = dS
+        loss, ctx.dS = _hinge_raw(scores, margin, max_violation, ctx.needs_input_grad[0])
         return loss
 
     @staticmethod

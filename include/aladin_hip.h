@@ -90,6 +90,15 @@ int aladin_align_bwd(const float* im, int64_t im_stride_b, int64_t im_stride_r, 
                      const float* dS, int64_t ld_dS, const float* gscale,
                      float* d_im, float* d_s, void* workspace, void* stream);
 
+/* Same, given the packed fp16 operands of the forward pass (aladin_align_pack_*): the per-pair
+ * argmax recompute then runs on the fp16 MFMA and only words whose top candidates are closer than
+ * the fp16 error bound are re-decided with exact fp32 dot products (same result, ~8x cheaper). */
+int aladin_align_bwd_packed(const float* im, int64_t im_stride_b, int64_t im_stride_r, const int32_t* im_len,
+                            const float* s, int64_t s_stride_b, int64_t s_stride_t, const int32_t* s_len,
+                            const float* dS, int64_t ld_dS, const float* gscale,
+                            const void* xm, const void* xe, const void* y, const aladin_align_geom* geom,
+                            float* d_im, float* d_s, void* workspace, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * VSE++ hinge loss on a square score matrix -- Contrastive.compute_contrastive_loss,
  * reference alad/loss.py:42-67.  loss: 1 float.  dS (B x B, contiguous) may be NULL; it receives

@@ -87,13 +87,22 @@ def test_hinge_on_reference_scores(name, tag):
 
 @pytest.mark.parametrize('name', SQUARE_ALIGN_GOLDENS)
 @pytest.mark.parametrize('tag', ['mv', 'sum'])
-def test_alignment_backward_kernel_vs_reference(name, tag):
-    """K1b in isolation: the reference's dS in, the reference's input gradients out."""
+@pytest.mark.parametrize('path', ['f32', 'packed'])
+def test_alignment_backward_kernel_vs_reference(name, tag, path):
+    """K1b in isolation: the reference's dS in, the reference's input gradients out.  'f32' is the
+    stand-alone entry point (fp32 MFMA argmax recompute), 'packed' the one used by autograd (fp16
+    MFMA block + exact fp32 re-decision of close calls); both must give the fp32 argmax."""
     from aladin_amd import ops
     g = load_golden(name)
     im, s, il, sl = golden_alignment_inputs(g)
     d = dev()
-    d_im, d_s = ops._align_backward(T(im), T(s), ops.lengths_tensor(il, d), ops.lengths_tensor(sl, d), T(g['dS_' + tag]))
+    a, b, ilt, slt = T(im), T(s), ops.lengths_tensor(il, d), ops.lengths_tensor(sl, d)
+    packed = None
+    if path == 'packed':
+        geom = ops.align_geometry(a.shape[0], b.shape[0], a.shape[1], b.shape[1], a.shape[2])
+        xm, xe = ops.pack_images(a, ilt, geom)
+        packed = (geom, xm, xe, ops.pack_captions(b, slt, geom))
+    d_im, d_s = ops._align_backward(a, b, ilt, slt, T(g['dS_' + tag]), packed=packed)
     st = int(g['grad_stride'])
     for got, key in ((d_im, 'dim_'), (d_s, 'ds_')):
         got = got.cpu().numpy()
