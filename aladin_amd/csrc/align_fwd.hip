@@ -207,7 +207,7 @@ template <int WGM, int WM, int Q, int TP16, bool HAS_E, int SM>
 __global__ __launch_bounds__(WGM * 128) void align_scores_kernel(const half_t* __restrict__ xm, const half_t* __restrict__ y,
                                                            const float* __restrict__ E, int64_t ldE,
                                                            float* __restrict__ S, int64_t ldS, int Bi, int Bc,
-                                                           int64_t ldk, int ktiles, int n_nblk, int n_blocks) {
+                                                           int64_t ldk, int ktiles, int n_nblk, int n_blocks, int spread) {
   constexpr int NT = ((TP16 & 1) ? TP16 : TP16 / 2) * SM;
   constexpr int CPS = ((TP16 & 1) ? 2 : 1) * SM;
   constexpr int IPW = WM / Q;
@@ -226,7 +226,8 @@ __global__ __launch_bounds__(WGM * 128) void align_scores_kernel(const half_t* _
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][n][r] = 0.f;
 
-  gemm_mainloop<Cfg>(xm + (int64_t)mb * Cfg::BM * ldk, y + (int64_t)nb * Cfg::BN * ldk, ldk, ktiles, smem, acc);
+  if (spread) gemm_mainloop<Cfg, 2, true>(xm + (int64_t)mb * Cfg::BM * ldk, y + (int64_t)nb * Cfg::BN * ldk, ldk, ktiles, smem, acc);
+  else gemm_mainloop<Cfg, 2, false>(xm + (int64_t)mb * Cfg::BM * ldk, y + (int64_t)nb * Cfg::BN * ldk, ldk, ktiles, smem, acc);
 
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int wm = wave / 2, wn = wave % 2;
@@ -280,6 +281,12 @@ __global__ __launch_bounds__(WGM * 128) void align_scores_kernel(const half_t* _
   }
 }
 
+static int scores_spread() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("ALADIN_ALIGN_SPREAD"); v = e ? atoi(e) : 1; }
+  return v;
+}
+
 static int scores_wgm() {
   static int v = 0;
   if (!v) { const char* e = getenv("ALADIN_ALIGN_WGM"); v = (e && atoi(e) == 2) ? 2 : 4; }
@@ -308,7 +315,7 @@ static int launch_scores_w(const aladin_align_geom* g, const half_t* xm, const h
   }
   const int n_blocks = n_mblk * n_nblk;
   hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(Cfg::THREADS), Cfg::LDS_BYTES, stream, xm, y, E, g->y_rows, S, ldS, g->Bi,
-                     g->Bc, (int64_t)g->Dp, g->Dp / 64, n_nblk, n_blocks);
+                     g->Bc, (int64_t)g->Dp, g->Dp / 64, n_nblk, n_blocks, scores_spread());
   return aladin_check_launch("align_scores_kernel");
 }
 

@@ -32,12 +32,12 @@ struct GemmCfg {
 
 // One K-step (64 deep) of both panels -> LDS.  The A panel may come from two row segments
 // (rows [0,a_split) from a_rows, rows [a_split,BM) from a_rows2) -- used by the backward pair kernel.
-template <class Cfg>
+template <class Cfg, int C0 = 0, int C1 = Cfg::CHUNKS_PER_WAVE>
 __device__ __forceinline__ void gemm_stage(const half_t* __restrict__ a_rows, const half_t* __restrict__ a_rows2, int a_split,
                                            const half_t* __restrict__ b_rows, int64_t ldk, int kt, char* stage, int wave,
                                            int lane) {
 #pragma unroll
-  for (int c = 0; c < Cfg::CHUNKS_PER_WAVE; ++c) {
+  for (int c = C0; c < C1; ++c) {
     const int chunk = wave + c * Cfg::NWAVES;
     const int row = chunk * 8 + (lane >> 3);
     const int logical = (lane & 7) ^ ((row >> 1) & 7);
@@ -76,7 +76,7 @@ __device__ __forceinline__ void wait_vmcnt(int n) {
 // wave's older LDS-DMA groups must have landed), ONE raw s_barrier (publishes step kt to every
 // wave and proves every wave is done reading buffer (kt-1) % NS), then the refill of that buffer
 // is issued before the MFMAs of step kt.  acc must be initialised by the caller.
-template <class Cfg, int NS = 2>
+template <class Cfg, int NS = 2, bool SPREAD = false>
 __device__ __forceinline__ void gemm_mainloop(const half_t* __restrict__ a_rows, const half_t* __restrict__ b_rows,
                                               int64_t ldk, int ktiles, char* smem, f32x16 (&acc)[Cfg::WM][Cfg::WN],
                                               const half_t* __restrict__ a_rows2 = nullptr, int a_split = Cfg::BM) {
@@ -95,9 +95,9 @@ __device__ __forceinline__ void gemm_mainloop(const half_t* __restrict__ a_rows,
     wait_vmcnt(Cfg::CHUNKS_PER_WAVE * (ahead < NS - 2 ? ahead : NS - 2));
     __builtin_amdgcn_s_barrier();
     const char* cur = smem + (kt % NS) * Cfg::STAGE_BYTES;
-    if (kt + NS - 1 < ktiles)
-      gemm_stage<Cfg>(a_rows, a_rows2, a_split, b_rows, ldk, kt + NS - 1, smem + ((kt + NS - 1) % NS) * Cfg::STAGE_BYTES,
-                      wave, lane);
+    const bool refill = kt + NS - 1 < ktiles;
+    char* nxt = smem + ((kt + NS - 1) % NS) * Cfg::STAGE_BYTES;
+    if (!SPREAD && refill) gemm_stage<Cfg>(a_rows, a_rows2, a_split, b_rows, ldk, kt + NS - 1, nxt, wave, lane);
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
       half8 af[Cfg::WM], bf[Cfg::WN];
@@ -105,6 +105,14 @@ __device__ __forceinline__ void gemm_mainloop(const half_t* __restrict__ a_rows,
       for (int a = 0; a < Cfg::WM; ++a) af[a] = lds_frag(cur, a_row0 + a * 32, kk, lane);
 #pragma unroll
       for (int n = 0; n < Cfg::WN; ++n) bf[n] = lds_frag(cur, b_row0 + n * 32, kk, lane);
+      if (SPREAD && refill) {
+        // a quarter of the refill per MFMA group instead of one burst after the barrier
+        constexpr int CPW = Cfg::CHUNKS_PER_WAVE;
+        if (kk == 0) gemm_stage<Cfg, 0, (CPW + 3) / 4>(a_rows, a_rows2, a_split, b_rows, ldk, kt + NS - 1, nxt, wave, lane);
+        if (kk == 1) gemm_stage<Cfg, (CPW + 3) / 4, (2 * CPW + 3) / 4>(a_rows, a_rows2, a_split, b_rows, ldk, kt + NS - 1, nxt, wave, lane);
+        if (kk == 2) gemm_stage<Cfg, (2 * CPW + 3) / 4, (3 * CPW + 3) / 4>(a_rows, a_rows2, a_split, b_rows, ldk, kt + NS - 1, nxt, wave, lane);
+        if (kk == 3) gemm_stage<Cfg, (3 * CPW + 3) / 4, CPW>(a_rows, a_rows2, a_split, b_rows, ldk, kt + NS - 1, nxt, wave, lane);
+      }
 #pragma unroll
       for (int a = 0; a < Cfg::WM; ++a)
 #pragma unroll

@@ -65,9 +65,28 @@ def kernel_roofline(im, s, il, sl, iters=50):
     ms = e0.elapsed_time(e1) / iters
     flops = B * B * 2 * 32 * (T - 3) * D
     achieved = flops / (ms * 1e-3) / 1e12
-    return {'bound': 'mfma', 'kernel': 'align_scores_kernel<2,1,3,true>', 'achieved': round(achieved, 2), 'peak': PEAK_TFLOPS,
-            'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_TFLOPS, 4), 'traffic': None,
+    traffic, src = pmc_traffic('align_scores_kernel')
+    return {'bound': 'mfma', 'traffic_source': src, 'kernel': 'align_scores_kernel<4,2,1,3,true,2> (256x384 tile)', 'achieved': round(achieved, 2), 'peak': PEAK_TFLOPS,
+            'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_TFLOPS, 4), 'traffic': traffic,
             'kernel_us': round(ms * 1e3, 2), 'flops_per_launch': flops}
+
+
+def pmc_traffic(kernel_substr):
+    """HBM-side bytes per launch of the dominant kernel from the newest committed PMC summary
+    (profiles/*_pmc.json, written by tools/collect_pmc.sh from separate rocprofv3 --pmc passes with
+    the gfx950 FETCH_SIZE x2 correction).  bench.py cannot run the profiler on itself, so it
+    reports the committed measurement and names its file; None if there is none."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc.json')), key=os.path.getmtime)
+    for f in reversed(files):
+        try:
+            ks = json.load(open(f))['kernels']
+        except Exception:
+            continue
+        for name, d in ks.items():
+            if kernel_substr in name and 'ELi2EE' in name.replace(' ', '') + 'ELi2EE' and 'hbm_bytes_corrected' in d:
+                return int(d['hbm_bytes_corrected']), os.path.relpath(f, ROOT)
+    return None, None
 
 
 def cpu_baseline(batch):
