@@ -307,3 +307,40 @@ def test_error_behaviour():
         ops.alignment_scores(torch.from_numpy(im), torch.from_numpy(s), il, sl)
     with pytest.raises(ValueError):
         ops.alignment_scores(T(im), T(s), il[:-1], sl)
+
+
+def test_config3_full_size_retrieval_ranks():
+    """BASELINE configs[2]: 5000 images x 25000 captions, D=768.  Ranks from the HIP split-fp16 sim
+    matrix + rank kernels must equal ranks computed on the host in float64 from the same embeddings
+    (ties aside), and Recall@K must match exactly."""
+    from aladin_amd import evaluation as E, synth
+    n_img = 5000
+    img, cap = synth.retrieval_embeddings(n_img, 768, seed=303, sigma=12.0)
+    sim = E.compute_sim_matrix(img[0::5], cap)
+    r_i2t, t_i2t, r_t2i, t_t2i = (x.cpu().numpy() for x in __import__('aladin_amd').ops.recall_ranks(sim))
+    ims = img[0::5].astype(np.float64)
+    capd = cap.astype(np.float64)
+    ref_i2t = np.empty(n_img, np.int64)
+    ref_t2i = np.empty(5 * n_img, np.int64)
+    max_err = 0.0
+    sim_h = sim.cpu().numpy()
+    for i0 in range(0, n_img, 500):
+        d = ims[i0:i0 + 500] @ capd.T                                   # (500, 25000) float64
+        max_err = max(max_err, float(np.abs(d - sim_h[i0:i0 + 500]).max()))
+        for k in range(d.shape[0]):
+            i = i0 + k
+            gt = d[k, 5 * i:5 * i + 5]
+            ref_i2t[i] = (d[k][None, :] > gt[:, None]).sum(1).min()
+    for c0 in range(0, 5 * n_img, 2500):
+        d = ims @ capd[c0:c0 + 2500].T                                  # (5000, 2500)
+        gt = d[np.arange(c0, c0 + 2500) // 5, np.arange(2500)]
+        ref_t2i[c0:c0 + 2500] = (d > gt[None, :]).sum(0)
+    assert max_err < 3e-6
+    # float64 host ranks vs the ~fp32-accurate device scores: only near-ties (|delta| < 3e-6) may move, by a few places
+    assert np.mean(r_i2t == ref_i2t) > 0.998 and np.mean(r_t2i == ref_t2i) > 0.998
+    assert np.abs(r_i2t - ref_i2t).max() <= 3 and np.abs(r_t2i - ref_t2i).max() <= 3
+    for K in (1, 5, 10):
+        assert abs(100.0 * np.mean(r_i2t < K) - 100.0 * np.mean(ref_i2t < K)) <= 0.1
+        assert abs(100.0 * np.mean(r_t2i < K) - 100.0 * np.mean(ref_t2i < K)) <= 0.1
+    m = E.compute_recall(img, cap, verbose=False)
+    assert 5.0 < m[0] < 95.0                                            # non-degenerate

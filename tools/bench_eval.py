@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""Timing of BASELINE configs[2] (evaluation): 5000 x 25000 x 768 matching-head similarity + ranks,
+and the alignment-head grid 1000 x 5000 at padded length 71.  Prints one JSON line per workload.
+Not the driver's bench (that is bench.py); used for DESIGN.md / profiles."""
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+from aladin_amd import ops, synth
+
+
+def timed(fn, iters=10, warm=2):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / iters * 1e3
+
+
+def main():
+    dev = torch.device('cuda:0')
+    n_img = 5000
+    img, cap = synth.retrieval_embeddings(n_img, 768, seed=303, sigma=12.0)
+    a = torch.from_numpy(img[0::5]).to(dev)
+    b = torch.from_numpy(cap).to(dev)
+    sim = ops.sim_matrix(a, b)
+    ms_sim = timed(lambda: ops.sim_matrix(a, b))
+    ms_rank = timed(lambda: ops.recall_ranks(sim))
+    ms_torch = timed(lambda: torch.mm(a, b.t()))
+    flops = 2.0 * n_img * 5 * n_img * 768
+    print(json.dumps({'workload': 'configs[2] matching head 5000x25000x768', 'sim_ms': round(ms_sim, 3),
+                      'rank_ms': round(ms_rank, 3), 'torch_mm_fp32_ms': round(ms_torch, 3),
+                      'sim_tflops_algorithmic': round(flops / ms_sim / 1e9, 1)}))
+    n = 1000
+    images, captions, il, cl = synth.eval_sets(n, 768, seed=9)
+    ia = torch.from_numpy(images[0::5]).to(dev)
+    ca = torch.from_numpy(captions).to(dev)
+    ilen = il[0::5]
+    ms_align = timed(lambda: ops.alignment_scores(ia, ca, ilen, cl), iters=5)
+    pairs = n * 5 * n
+    print(json.dumps({'workload': 'alignment-head grid 1000x5000 at L=71 (70x68 after slicing)', 'ms': round(ms_align, 3),
+                      'pairs_per_s': round(pairs / ms_align * 1e3, 1)}))
+
+
+if __name__ == '__main__':
+    main()
