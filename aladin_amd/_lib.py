@@ -14,9 +14,10 @@ ABI_VERSION = 1
 # every symbol include/aladin_hip.h declares (tests check that the library exports all of them)
 SYMBOLS = [
     'aladin_version', 'aladin_last_error', 'aladin_align_geometry', 'aladin_align_pack_images',
-    'aladin_align_pack_captions', 'aladin_align_scores', 'aladin_align_scores_ex',
+    'aladin_align_pack_captions', 'aladin_align_pack_both', 'aladin_align_scores', 'aladin_align_scores_ex',
     'aladin_align_bwd_workspace_bytes',
     'aladin_align_bwd', 'aladin_align_bwd_packed', 'aladin_hinge_workspace_bytes', 'aladin_hinge_fwd_bwd',
+    'aladin_hinge_fused',
     'aladin_listnet_workspace_bytes', 'aladin_listnet_fwd_bwd', 'aladin_sgemm_strided',
     'aladin_sim_workspace_bytes', 'aladin_sim_matrix', 'aladin_recall_workspace_bytes',
     'aladin_recall_ranks',
@@ -43,13 +44,15 @@ def _declare(lib):
         'aladin_align_geometry': (C.c_int, [i32, i32, i32, i32, i32, G]),
         'aladin_align_pack_images': (C.c_int, [p, i64, i64, p, G, p, p, p]),
         'aladin_align_pack_captions': (C.c_int, [p, i64, i64, p, G, p, p]),
+        'aladin_align_pack_both': (C.c_int, [p, i64, i64, p, p, i64, i64, p, G, p, p, p, p]),
         'aladin_align_scores': (C.c_int, [p, p, p, G, p, p, i64, p]),
         'aladin_align_scores_ex': (C.c_int, [p, p, p, G, p, p, i64, i32, p]),
         'aladin_align_bwd_workspace_bytes': (sz, [i32, i32, i32, i32, i32]),
         'aladin_align_bwd': (C.c_int, [p, i64, i64, p, p, i64, i64, p, i32, i32, i32, i32, i32, p, i64, p, p, p, p, p]),
-        'aladin_align_bwd_packed': (C.c_int, [p, i64, i64, p, p, i64, i64, p, p, i64, p, p, p, p, G, p, p, p, p]),
+        'aladin_align_bwd_packed': (C.c_int, [p, i64, i64, p, p, i64, i64, p, p, i64, p, p, p, p, G, p, p, p, p, p, p]),
         'aladin_hinge_workspace_bytes': (sz, [i32]),
         'aladin_hinge_fwd_bwd': (C.c_int, [p, i64, i32, f32, i32, p, p, p, p]),
+        'aladin_hinge_fused': (C.c_int, [p, i64, i32, f32, i32, p, p, p, p, p, p]),
         'aladin_listnet_workspace_bytes': (sz, [i32]),
         'aladin_listnet_fwd_bwd': (C.c_int, [p, i64, p, i64, i32, f32, f32, p, p, p, p]),
         'aladin_sgemm_strided': (C.c_int, [i32, i32, i32, p, i64, i64, p, i64, i64, p, i64, p]),

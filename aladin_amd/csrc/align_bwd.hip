@@ -513,8 +513,8 @@ __global__ __launch_bounds__(256) void bwd_rows_kernel(
 static int align_bwd_impl(const float* im, int64_t im_sb, int64_t im_sr, const int32_t* im_len, const float* s,
                           int64_t s_sb, int64_t s_st, const int32_t* s_len, int Bi, int Bc, int R, int T, int D,
                           const float* dS, int64_t ld_dS, const float* gscale, const void* xm, const void* xe,
-                          const void* y, const aladin_align_geom* g, float* d_im, float* d_s, void* workspace,
-                          void* stream) {
+                          const void* y, const aladin_align_geom* g, const int32_t* pairs_in, const int32_t* count_in,
+                          float* d_im, float* d_s, void* workspace, void* stream) {
   if (!im || !s || !im_len || !s_len || !dS || !d_im || !d_s || !workspace) { aladin_set_error("align_bwd: null argument"); return ALADIN_ERR_ARG; }
   if (Bi < 1 || Bc < 1 || R < 2 || T < 4 || D < 1 || ld_dS < Bc) { aladin_set_error("align_bwd: bad sizes"); return ALADIN_ERR_ARG; }
   if (R - 1 > PA_MAXR - 2 || R - 1 >= NO_GRAD || T - 3 > PA_MAXT) { aladin_set_error("align_bwd: at most %d regions / %d words", PA_MAXR - 2, PA_MAXT); return ALADIN_ERR_UNSUPPORTED; }
@@ -531,12 +531,18 @@ static int align_bwd_impl(const float* im, int64_t im_sb, int64_t im_sr, const i
   BwdWs ws;
   const int Tq = T - 3, tstride = table_stride(Tq);
   bwd_ws_layout(Bi, Bc, Tq, (char*)workspace, &ws);
-  if (hipMemsetAsync(ws.counter, 0, 256, st) != hipSuccess) { aladin_set_error("align_bwd: memset failed"); return ALADIN_ERR_HIP; }
   const int64_t n = (int64_t)Bi * Bc;
-  int grid = (int)((n + 255) / 256); if (grid > 1024) grid = 1024;
-  hipLaunchKernelGGL(bwd_compact_kernel, dim3(grid), dim3(256), 0, st, dS, ld_dS, Bi, Bc, ws.counter, ws.pairs);
-  int rc = aladin_check_launch("bwd_compact_kernel");
-  if (rc) return rc;
+  int rc = ALADIN_OK;
+  if (pairs_in && count_in) {                           // list already built by aladin_hinge_fused
+    ws.pairs = const_cast<int*>(pairs_in);
+    ws.counter = const_cast<int*>(count_in);
+  } else {
+    if (hipMemsetAsync(ws.counter, 0, 256, st) != hipSuccess) { aladin_set_error("align_bwd: memset failed"); return ALADIN_ERR_HIP; }
+    int grid = (int)((n + 255) / 256); if (grid > 1024) grid = 1024;
+    hipLaunchKernelGGL(bwd_compact_kernel, dim3(grid), dim3(256), 0, st, dS, ld_dS, Bi, Bc, ws.counter, ws.pairs);
+    rc = aladin_check_launch("bwd_compact_kernel");
+    if (rc) return rc;
+  }
   int pgrid = (int)(n < 2048 ? n : 2048);
   if (packed) {
     const int blk_rows = 32 + g->rem;
@@ -575,15 +581,15 @@ extern "C" int aladin_align_bwd(const float* im, int64_t im_sb, int64_t im_sr, c
                                 const float* dS, int64_t ld_dS, const float* gscale, float* d_im, float* d_s,
                                 void* workspace, void* stream) {
   return align_bwd_impl(im, im_sb, im_sr, im_len, s, s_sb, s_st, s_len, Bi, Bc, R, T, D, dS, ld_dS, gscale, nullptr,
-                        nullptr, nullptr, nullptr, d_im, d_s, workspace, stream);
+                        nullptr, nullptr, nullptr, nullptr, nullptr, d_im, d_s, workspace, stream);
 }
 
 extern "C" int aladin_align_bwd_packed(const float* im, int64_t im_sb, int64_t im_sr, const int32_t* im_len, const float* s,
                                        int64_t s_sb, int64_t s_st, const int32_t* s_len, const float* dS, int64_t ld_dS,
                                        const float* gscale, const void* xm, const void* xe, const void* y,
-                                       const aladin_align_geom* geom, float* d_im, float* d_s, void* workspace,
-                                       void* stream) {
+                                       const aladin_align_geom* geom, const int32_t* pairs, const int32_t* pair_count,
+                                       float* d_im, float* d_s, void* workspace, void* stream) {
   if (!geom) { aladin_set_error("align_bwd_packed: null geometry"); return ALADIN_ERR_ARG; }
   return align_bwd_impl(im, im_sb, im_sr, im_len, s, s_sb, s_st, s_len, geom->Bi, geom->Bc, geom->R, geom->T, geom->D, dS,
-                        ld_dS, gscale, xm, xe, y, geom, d_im, d_s, workspace, stream);
+                        ld_dS, gscale, xm, xe, y, geom, pairs, pair_count, d_im, d_s, workspace, stream);
 }

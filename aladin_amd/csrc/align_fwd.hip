@@ -145,6 +145,53 @@ __global__ __launch_bounds__(256) void pack_captions_kernel(const float* __restr
   pack_row(src, y + d * Dp, D, Dp, lane, vec4 != 0);
 }
 
+// both operand sets in one launch (rows [0, img_rows) -> images, the rest -> captions)
+__global__ __launch_bounds__(256) void pack_both_kernel(const float* __restrict__ im, int64_t isb, int64_t isr,
+                                                        const int32_t* __restrict__ im_len, const float* __restrict__ s,
+                                                        int64_t ssb, int64_t sst, const int32_t* __restrict__ s_len, int Bi,
+                                                        int Bc, int Rq, int Tq, int D, int Dp, int mtiles, int64_t xm_rows,
+                                                        int64_t img_rows, int64_t total_rows, int tpad,
+                                                        half_t* __restrict__ xm, half_t* __restrict__ xe,
+                                                        half_t* __restrict__ y, int vec_i, int vec_s) {
+  const int lane = threadIdx.x & 63;
+  const int64_t d = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (d >= total_rows) return;
+  const float* src = nullptr;
+  half_t* dst;
+  bool vec;
+  if (d < img_rows) {
+    int i, rho;
+    if (d < xm_rows) {
+      const int rows_per_img = 32 * mtiles;
+      i = (int)(d / rows_per_img);
+      rho = (int)(d % rows_per_img);
+      if (rho >= Rq) rho = 0;
+      dst = xm + d * Dp;
+    } else {
+      i = (int)(d - xm_rows);
+      rho = 32 * mtiles;
+      dst = xe + (d - xm_rows) * Dp;
+    }
+    if (i < Bi) {
+      int Li = im_len[i] - 1;
+      Li = Li < 0 ? 0 : (Li > Rq ? Rq : Li);
+      if (rho < Li) src = im + i * isb + (int64_t)(rho + 1) * isr;
+    }
+    vec = vec_i != 0;
+  } else {
+    const int64_t q = d - img_rows;
+    const int j = (int)(q / tpad), w = (int)(q % tpad);
+    if (j < Bc) {
+      int Lj = s_len[j] - 3;
+      Lj = Lj < 0 ? 0 : (Lj > Tq ? Tq : Lj);
+      if (w < Lj) src = s + j * ssb + (int64_t)(w + 1) * sst;
+    }
+    dst = y + q * Dp;
+    vec = vec_s != 0;
+  }
+  pack_row(src, dst, D, Dp, lane, vec);
+}
+
 static int is_vec4_ok(const void* p, int64_t s0, int64_t s1, int D) {
   return (D % 4 == 0) && (s0 % 4 == 0) && (s1 % 4 == 0) && (((uintptr_t)p & 15) == 0);
 }
@@ -168,6 +215,18 @@ extern "C" int aladin_align_pack_captions(const float* s, int64_t stride_b, int6
                      g->Bc, g->Tq, g->D, g->Dp, 16 * g->tp16, g->y_rows, (half_t*)y,
                      is_vec4_ok(s, stride_b, stride_t, g->D));
   return aladin_check_launch("pack_captions_kernel");
+}
+
+extern "C" int aladin_align_pack_both(const float* im, int64_t im_stride_b, int64_t im_stride_r, const int32_t* im_len,
+                                      const float* s, int64_t s_stride_b, int64_t s_stride_t, const int32_t* s_len,
+                                      const aladin_align_geom* g, void* xm, void* xe, void* y, void* stream) {
+  if (!im || !im_len || !s || !s_len || !g || !xm || !y || (g->rem && !xe)) { aladin_set_error("align_pack_both: null argument"); return ALADIN_ERR_ARG; }
+  const int64_t img_rows = g->xm_rows + g->xe_rows, total = img_rows + g->y_rows;
+  hipLaunchKernelGGL(pack_both_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, (hipStream_t)stream, im, im_stride_b,
+                     im_stride_r, im_len, s, s_stride_b, s_stride_t, s_len, g->Bi, g->Bc, g->Rq, g->Tq, g->D, g->Dp, g->mtiles,
+                     g->xm_rows, img_rows, total, 16 * g->tp16, (half_t*)xm, (half_t*)xe, (half_t*)y,
+                     is_vec4_ok(im, im_stride_b, im_stride_r, g->D), is_vec4_ok(s, s_stride_b, s_stride_t, g->D));
+  return aladin_check_launch("pack_both_kernel");
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -203,15 +262,16 @@ __global__ __launch_bounds__(256) void align_side_gemm_kernel(const half_t* __re
 //   WM   M-tiles (32 rows) per wave;  Q  M-tiles per image;  images per wave = WM / Q  (2 or 1)
 //   TP16 padded words per caption / 16;  a wave's column strip holds CPS = 1 or 2 whole captions
 // ------------------------------------------------------------------------------------------------
-template <int WGM, int WM, int Q, int TP16, bool HAS_E, int SM>
+template <int WGM, int WM, int Q, int TP16, bool HAS_E, int SM, int SCHED>
 __global__ __launch_bounds__(WGM * 128) void align_scores_kernel(const half_t* __restrict__ xm, const half_t* __restrict__ y,
                                                            const float* __restrict__ E, int64_t ldE,
                                                            float* __restrict__ S, int64_t ldS, int Bi, int Bc,
-                                                           int64_t ldk, int ktiles, int n_nblk, int n_blocks, int spread) {
+                                                           int64_t ldk, int ktiles, int n_nblk, int n_blocks) {
   constexpr int NT = ((TP16 & 1) ? TP16 : TP16 / 2) * SM;
   constexpr int CPS = ((TP16 & 1) ? 2 : 1) * SM;
   constexpr int IPW = WM / Q;
-  static_assert(IPW == 1 || IPW == 2, "one or two images per wave");
+  static_assert(IPW == 1 || IPW % 2 == 0, "one image or pairs of images per wave");
+  constexpr int NPAIR = IPW == 1 ? 1 : IPW / 2;
   using Cfg = GemmCfg<WGM, 2, WM, NT>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -226,42 +286,47 @@ __global__ __launch_bounds__(WGM * 128) void align_scores_kernel(const half_t* _
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][n][r] = 0.f;
 
-  if (spread) gemm_mainloop<Cfg, 2, true>(xm + (int64_t)mb * Cfg::BM * ldk, y + (int64_t)nb * Cfg::BN * ldk, ldk, ktiles, smem, acc);
-  else gemm_mainloop<Cfg, 2, false>(xm + (int64_t)mb * Cfg::BM * ldk, y + (int64_t)nb * Cfg::BN * ldk, ldk, ktiles, smem, acc);
+  const half_t* a_rows = xm + (int64_t)mb * Cfg::BM * ldk;
+  const half_t* b_rows = y + (int64_t)nb * Cfg::BN * ldk;
+  // SCHED: 0 = refill burst right after the barrier, 1 = refill spread over the four MFMA groups
+  if constexpr (SCHED == 1) gemm_mainloop<Cfg, 2, true>(a_rows, b_rows, ldk, ktiles, smem, acc);
+  else gemm_mainloop<Cfg, 2, false>(a_rows, b_rows, ldk, ktiles, smem, acc);
 
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int wm = wave / 2, wn = wave % 2;
   const int half = lane >> 5, l5 = lane & 31;
 
-  // max over regions: 16 accumulator rows per lane, then the other half-wave's 16 rows
-  float m[NT];
-  if constexpr (IPW == 2) {
+  // max over regions: 16 accumulator rows per lane, then the other half-wave's 16 rows.  Images are
+  // handled in pairs: one v_permlane32_swap leaves image 2p in lanes 0-31 and image 2p+1 in lanes 32-63.
 #pragma unroll
-    for (int n = 0; n < NT; ++n) {
-      float p0 = acc[0][n][0], p1 = acc[1][n][0];
+  for (int pr = 0; pr < NPAIR; ++pr) {
+    float m[NT];
+    if constexpr (IPW >= 2) {
 #pragma unroll
-      for (int r = 1; r < 16; ++r) { p0 = fmaxf(p0, acc[0][n][r]); p1 = fmaxf(p1, acc[1][n][r]); }
-      // lanes 0-31 end up with image 0's two partial maxima, lanes 32-63 with image 1's
-      auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(p0), __float_as_uint(p1), false, false);
-      m[n] = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+      for (int n = 0; n < NT; ++n) {
+        float p0 = acc[2 * pr][n][0], p1 = acc[2 * pr + 1][n][0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) { p0 = fmaxf(p0, acc[2 * pr][n][r]); p1 = fmaxf(p1, acc[2 * pr + 1][n][r]); }
+        auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(p0), __float_as_uint(p1), false, false);
+        m[n] = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+      }
+    } else {
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        float p = acc[0][n][0];
+#pragma unroll
+        for (int a = 0; a < WM; ++a)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) p = fmaxf(p, acc[a][n][r]);
+        m[n] = fmaxf(p, __shfl_xor(p, 32, 64));
+      }
     }
-  } else {
+    const int img = (mb * WGM + wm) * IPW + (IPW >= 2 ? 2 * pr + half : 0);
+    if constexpr (HAS_E) {
+      const float* e = E + (int64_t)img * ldE + (int64_t)nb * Cfg::BN + wn * NT * 32 + l5;
 #pragma unroll
-    for (int n = 0; n < NT; ++n) {
-      float p = acc[0][n][0];
-#pragma unroll
-      for (int a = 0; a < WM; ++a)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) p = fmaxf(p, acc[a][n][r]);
-      m[n] = fmaxf(p, __shfl_xor(p, 32, 64));
+      for (int n = 0; n < NT; ++n) m[n] = fmaxf(m[n], e[n * 32]);
     }
-  }
-  const int img = (mb * WGM + wm) * IPW + (IPW == 2 ? half : 0);
-  if constexpr (HAS_E) {
-    const float* e = E + (int64_t)img * ldE + (int64_t)nb * Cfg::BN + wn * NT * 32 + l5;
-#pragma unroll
-    for (int n = 0; n < NT; ++n) m[n] = fmaxf(m[n], e[n * 32]);
-  }
 
   // sum over words: 16-lane groups map to captions at compile time
   float v[CPS];
@@ -277,7 +342,8 @@ __global__ __launch_bounds__(WGM * 128) void align_scores_kernel(const half_t* _
 #pragma unroll
   for (int c = 0; c < CPS; ++c) {
     const float t = half_wave_sum(v[c]);
-    if (l5 == 0 && (IPW == 2 || half == 0) && img < Bi && cap + c < Bc) S[(int64_t)img * ldS + cap + c] = t;
+    if (l5 == 0 && (IPW >= 2 || half == 0) && img < Bi && cap + c < Bc) S[(int64_t)img * ldS + cap + c] = t;
+  }
   }
 }
 
@@ -293,7 +359,7 @@ static int scores_wgm() {
   return v;
 }
 
-template <int WGM, int WM, int Q, int TP16, bool HAS_E, int SM>
+template <int WGM, int WM, int Q, int TP16, bool HAS_E, int SM, int SCHED = 1>
 static int launch_scores_w(const aladin_align_geom* g, const half_t* xm, const half_t* y, const float* E, float* S,
                            int64_t ldS, hipStream_t stream) {
   constexpr int NT = ((TP16 & 1) ? TP16 : TP16 / 2) * SM;
@@ -304,7 +370,7 @@ static int launch_scores_w(const aladin_align_geom* g, const half_t* xm, const h
                      (long long)g->y_rows, Cfg::BM, Cfg::BN);
     return ALADIN_ERR_ARG;
   }
-  auto kern = align_scores_kernel<WGM, WM, Q, TP16, HAS_E, SM>;
+  auto kern = align_scores_kernel<WGM, WM, Q, TP16, HAS_E, SM, SCHED>;
   static bool attr_done = false;
   if (!attr_done) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES) != hipSuccess) {
@@ -315,7 +381,7 @@ static int launch_scores_w(const aladin_align_geom* g, const half_t* xm, const h
   }
   const int n_blocks = n_mblk * n_nblk;
   hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(Cfg::THREADS), Cfg::LDS_BYTES, stream, xm, y, E, g->y_rows, S, ldS, g->Bi,
-                     g->Bc, (int64_t)g->Dp, g->Dp / 64, n_nblk, n_blocks, scores_spread());
+                     g->Bc, (int64_t)g->Dp, g->Dp / 64, n_nblk, n_blocks);
   return aladin_check_launch("align_scores_kernel");
 }
 
@@ -323,7 +389,12 @@ template <int WM, int Q, int TP16, bool HAS_E>
 static int launch_scores(const aladin_align_geom* g, const half_t* xm, const half_t* y, const float* E, float* S,
                          int64_t ldS, hipStream_t stream) {
   if constexpr (TP16 == 3 && Q == 1)
-    if (scores_strip_mult(TP16, g->mtiles) == 2) return launch_scores_w<4, WM, Q, TP16, HAS_E, 2>(g, xm, y, E, S, ldS, stream);
+    if (scores_strip_mult(TP16, g->mtiles) == 2) {
+      switch (scores_spread()) {                       // experiment knob (ALADIN_ALIGN_SPREAD); default 1
+        case 0: return launch_scores_w<4, WM, Q, TP16, HAS_E, 2, 0>(g, xm, y, E, S, ldS, stream);
+        default: return launch_scores_w<4, WM, Q, TP16, HAS_E, 2, 1>(g, xm, y, E, S, ldS, stream);
+      }
+    }
   if (scores_wgm() == 4) return launch_scores_w<4, WM, Q, TP16, HAS_E, 1>(g, xm, y, E, S, ldS, stream);
   return launch_scores_w<2, WM, Q, TP16, HAS_E, 1>(g, xm, y, E, S, ldS, stream);
 }

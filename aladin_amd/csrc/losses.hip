@@ -54,10 +54,11 @@ __device__ __forceinline__ void block_argmax(float& v, int& idx, float* redv, in
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void hinge_stats_kernel(const float* __restrict__ S, int64_t ld, int B, float margin,
                                                           int max_violation, float* __restrict__ val,
-                                                          int* __restrict__ arg) {
+                                                          int* __restrict__ arg, int* __restrict__ pair_count) {
   __shared__ float redv[4];
   __shared__ int redi[4];
   const int b = blockIdx.x;
+  if (b == 0 && threadIdx.x == 0 && pair_count) *pair_count = 0;     // consumed by hinge_finish_kernel (next launch)
   const bool is_row = b < B;
   const int q = is_row ? b : b - B;
   const float diag = S[(int64_t)q * ld + q];
@@ -84,7 +85,8 @@ __global__ __launch_bounds__(256) void hinge_stats_kernel(const float* __restric
 __global__ __launch_bounds__(256) void hinge_finish_kernel(const float* __restrict__ S, int64_t ld, int B, float margin,
                                                            int max_violation, const float* __restrict__ val,
                                                            const int* __restrict__ arg, float* __restrict__ loss,
-                                                           float* __restrict__ dS) {
+                                                           float* __restrict__ dS, int* __restrict__ pairs,
+                                                           int* __restrict__ pair_count) {
   __shared__ float red[4];
   if (blockIdx.x == 0) {
     float rs = 0.f, cs = 0.f;                             // rows first, then columns, fixed order
@@ -93,11 +95,14 @@ __global__ __launch_bounds__(256) void hinge_finish_kernel(const float* __restri
     cs = block_sum(cs, red);
     if (threadIdx.x == 0) *loss = rs + cs;
   }
-  if (dS == nullptr) return;
+  if (dS == nullptr && pairs == nullptr) return;
   const int64_t n = (int64_t)B * B;
-  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+  const int lane = threadIdx.x & 63;
+  for (int64_t e0 = (int64_t)blockIdx.x * blockDim.x; e0 < n; e0 += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t e = e0 + threadIdx.x;
+    float g = 0.f;
+    if (e < n) {
     const int i = (int)(e / B), j = (int)(e % B);
-    float g;
     if (max_violation) {
       if (i == j) g = -(float)((val[i] > 0.f) + (val[B + i] > 0.f));
       else g = (float)((val[i] > 0.f && arg[i] == j) + (val[B + j] > 0.f && arg[B + j] == i));
@@ -108,26 +113,47 @@ __global__ __launch_bounds__(256) void hinge_finish_kernel(const float* __restri
         g = (float)((margin + s - S[(int64_t)i * ld + i] > 0.f) + (margin + s - S[(int64_t)j * ld + j] > 0.f));
       }
     }
-    dS[e] = g;
+    if (dS) dS[e] = g;
+    }
+    if (pairs) {                                          // list of non-zero pairs for the alignment backward
+      const unsigned long long mask = __ballot(g != 0.f);
+      if (mask) {
+        int base = 0;
+        if (lane == 0) base = atomicAdd(pair_count, __popcll(mask));
+        base = __shfl(base, 0, 64);
+        if (g != 0.f) pairs[base + __popcll(mask & ((1ull << lane) - 1))] = (int)e;
+      }
+    }
   }
 }
 
 extern "C" size_t aladin_hinge_workspace_bytes(int B) { return (size_t)(B > 0 ? B : 0) * 16 + 256; }
 
-extern "C" int aladin_hinge_fwd_bwd(const float* S, int64_t ldS, int B, float margin, int max_violation, float* loss,
-                                    float* dS, void* workspace, void* stream) {
-  if (!S || !loss || !workspace || B < 1 || ldS < B) { aladin_set_error("hinge_fwd_bwd: bad argument (B=%d ldS=%lld)", B, (long long)ldS); return ALADIN_ERR_ARG; }
+static int hinge_impl(const float* S, int64_t ldS, int B, float margin, int max_violation, float* loss, float* dS,
+                      int32_t* pairs, int32_t* pair_count, void* workspace, void* stream) {
+  if (!S || !loss || !workspace || B < 1 || ldS < B || (pairs && !pair_count)) { aladin_set_error("hinge: bad argument (B=%d ldS=%lld)", B, (long long)ldS); return ALADIN_ERR_ARG; }
   float* val = (float*)workspace;
   int* arg = (int*)(val + 2 * (size_t)B);
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(hinge_stats_kernel, dim3(2 * B), dim3(256), 0, st, S, ldS, B, margin, max_violation, val, arg);
+  hipLaunchKernelGGL(hinge_stats_kernel, dim3(2 * B), dim3(256), 0, st, S, ldS, B, margin, max_violation, val, arg,
+                     pairs ? pair_count : nullptr);
   int rc = aladin_check_launch("hinge_stats_kernel");
   if (rc) return rc;
   const int64_t n = (int64_t)B * B;
-  const int grid = dS ? (int)((n + 1023) / 1024 < 2048 ? (n + 1023) / 1024 : 2048) : 1;
+  const int grid = (dS || pairs) ? (int)((n + 1023) / 1024 < 2048 ? (n + 1023) / 1024 : 2048) : 1;
   hipLaunchKernelGGL(hinge_finish_kernel, dim3(grid < 1 ? 1 : grid), dim3(256), 0, st, S, ldS, B, margin, max_violation, val,
-                     arg, loss, dS);
+                     arg, loss, dS, pairs, pair_count);
   return aladin_check_launch("hinge_finish_kernel");
+}
+
+extern "C" int aladin_hinge_fwd_bwd(const float* S, int64_t ldS, int B, float margin, int max_violation, float* loss,
+                                    float* dS, void* workspace, void* stream) {
+  return hinge_impl(S, ldS, B, margin, max_violation, loss, dS, nullptr, nullptr, workspace, stream);
+}
+
+extern "C" int aladin_hinge_fused(const float* S, int64_t ldS, int B, float margin, int max_violation, float* loss,
+                                  float* dS, int32_t* pairs, int32_t* pair_count, void* workspace, void* stream) {
+  return hinge_impl(S, ldS, B, margin, max_violation, loss, dS, pairs, pair_count, workspace, stream);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -46,12 +46,12 @@ def lengths_tensor(lens, device):
     Lists are cached by value so that a repeated batch shape costs no host->device copy."""
     if isinstance(lens, torch.Tensor):
         return lens.to(device=device, dtype=torch.int32, non_blocking=True)
-    key = (tuple(int(v) for v in lens), str(device))
+    key = (tuple(lens), device)
     t = _LEN_CACHE.get(key)
     if t is None:
         if len(_LEN_CACHE) >= 256:
             _LEN_CACHE.clear()
-        t = torch.tensor(key[0], dtype=torch.int32).to(device, non_blocking=True)
+        t = torch.tensor([int(x) for x in key[0]], dtype=torch.int32).to(device, non_blocking=True)
         _LEN_CACHE[key] = t
     return t
 
@@ -63,9 +63,17 @@ def _workspace(nbytes, device):
 # ------------------------------------------------------------------------------------------------
 # alignment scores
 # ------------------------------------------------------------------------------------------------
+_GEOM_CACHE = {}
+
+
 def align_geometry(Bi, Bc, R, T, D):
-    g = _lib.AlignGeom()
-    _lib.check(_lib.load().aladin_align_geometry(Bi, Bc, R, T, D, C.byref(g)), 'align_geometry')
+    key = (Bi, Bc, R, T, D)
+    g = _GEOM_CACHE.get(key)
+    if g is None:
+        g = _lib.AlignGeom()
+        _lib.check(_lib.load().aladin_align_geometry(Bi, Bc, R, T, D, C.byref(g)), 'align_geometry')
+        if len(_GEOM_CACHE) < 1024:
+            _GEOM_CACHE[key] = g
     return g
 
 
@@ -105,12 +113,18 @@ def _align_forward(im, s, im_len_t, s_len_t):
     if D != D2:
         raise ValueError('aladin_amd: feature sizes differ (%d vs %d)' % (D, D2))
     geom = align_geometry(Bi, Bc, R, T, D)
-    xm, xe = pack_images(im, im_len_t, geom)
-    y = pack_captions(s, s_len_t, geom)
+    im = _rows_inner_contig(im)
+    s = _rows_inner_contig(s)
+    xm = torch.empty(geom.xm_bytes // 2, dtype=torch.float16, device=im.device)
+    xe = torch.empty(max(geom.xe_bytes // 2, 8), dtype=torch.float16, device=im.device)
+    y = torch.empty(geom.y_bytes // 2, dtype=torch.float16, device=im.device)
+    _lib.check(_lib.load().aladin_align_pack_both(_ptr(im), im.stride(0), im.stride(1), _ptr(im_len_t),
+                                                  _ptr(s), s.stride(0), s.stride(1), _ptr(s_len_t), C.byref(geom),
+                                                  _ptr(xm), _ptr(xe), _ptr(y), _stream()), 'align_pack_both')
     return scores_from_packed(xm, xe, y, geom), (geom, xm, xe, y)
 
 
-def _align_backward(im, s, im_len_t, s_len_t, dS, gscale=None, packed=None):
+def _align_backward(im, s, im_len_t, s_len_t, dS, gscale=None, packed=None, pairs=None):
     lib = _lib.load()
     im = _rows_inner_contig(im)
     s = _rows_inner_contig(s)
@@ -125,7 +139,9 @@ def _align_backward(im, s, im_len_t, s_len_t, dS, gscale=None, packed=None):
         _lib.check(lib.aladin_align_bwd_packed(_ptr(im), im.stride(0), im.stride(1), _ptr(im_len_t),
                                                _ptr(s), s.stride(0), s.stride(1), _ptr(s_len_t),
                                                _ptr(dS), dS.stride(0), _ptr(gscale), _ptr(xm), _ptr(xe), _ptr(y),
-                                               C.byref(geom), _ptr(d_im), _ptr(d_s), _ptr(ws), _stream()),
+                                               C.byref(geom), _ptr(pairs[0] if pairs else None),
+                                               _ptr(pairs[1] if pairs else None), _ptr(d_im), _ptr(d_s), _ptr(ws),
+                                               _stream()),
                    'align_bwd_packed')
     else:
         _lib.check(lib.aladin_align_bwd(_ptr(im), im.stride(0), im.stride(1), _ptr(im_len_t),
@@ -151,16 +167,22 @@ class _AlignScores(torch.autograd.Function):
         return d_im, d_s, None, None
 
 
-def _hinge_raw(scores, margin, max_violation, want_grad):
+def _hinge_raw(scores, margin, max_violation, want_grad, want_pairs=False):
+    """-> (loss, dS or None, pairs or None); pairs = (int32 list of non-zero i*B+j, int32 count)."""
     lib = _lib.load()
     B = scores.shape[0]
     sc = scores if scores.stride(1) == 1 else scores.contiguous()
-    loss = torch.empty((), dtype=torch.float32, device=scores.device)
-    dS = torch.empty((B, B), dtype=torch.float32, device=scores.device) if want_grad else None
-    ws = _workspace(lib.aladin_hinge_workspace_bytes(B), scores.device)
-    _lib.check(lib.aladin_hinge_fwd_bwd(_ptr(sc), sc.stride(0), B, float(margin), int(bool(max_violation)),
-                                        _ptr(loss), _ptr(dS), _ptr(ws), _stream()), 'hinge_fwd_bwd')
-    return loss, dS
+    dev = scores.device
+    loss = torch.empty((), dtype=torch.float32, device=dev)
+    dS = torch.empty((B, B), dtype=torch.float32, device=dev) if want_grad else None
+    ws = _workspace(lib.aladin_hinge_workspace_bytes(B), dev)
+    pairs = None
+    if want_grad and want_pairs:
+        pairs = (torch.empty(B * B, dtype=torch.int32, device=dev), torch.empty(1, dtype=torch.int32, device=dev))
+    _lib.check(lib.aladin_hinge_fused(_ptr(sc), sc.stride(0), B, float(margin), int(bool(max_violation)), _ptr(loss),
+                                      _ptr(dS), _ptr(pairs[0] if pairs else None), _ptr(pairs[1] if pairs else None),
+                                      _ptr(ws), _stream()), 'hinge_fused')
+    return loss, dS, pairs
 
 
 class _AlignTriplet(torch.autograd.Function):
@@ -172,18 +194,23 @@ class _AlignTriplet(torch.autograd.Function):
     def forward(ctx, im, s, im_len_t, s_len_t, margin, max_violation):
         S, packed = _align_forward(im, s, im_len_t, s_len_t)
         need = any(ctx.needs_input_grad[:2])
-        loss, dS = _hinge_raw(S, margin, max_violation, need)
+        loss, dS, pairs = _hinge_raw(S, margin, max_violation, need, want_pairs=True)
         if need:
             ctx.save_for_backward(im, s, im_len_t, s_len_t, packed[1], packed[2], packed[3], dS)
             ctx.geom = packed[0]
+            ctx.pairs = pairs
         ctx.mark_non_differentiable(S)
+        ctx.set_materialize_grads(False)
         return loss, S
 
     @staticmethod
     def backward(ctx, g_loss, _g_scores):
+        if g_loss is None:
+            return None, None, None, None, None, None
         im, s, im_len_t, s_len_t, xm, xe, y, dS = ctx.saved_tensors
         g = g_loss.to(torch.float32).contiguous()
-        d_im, d_s = _align_backward(im, s, im_len_t, s_len_t, dS, gscale=g, packed=(ctx.geom, xm, xe, y))
+        d_im, d_s = _align_backward(im, s, im_len_t, s_len_t, dS, gscale=g, packed=(ctx.geom, xm, xe, y),
+                                    pairs=ctx.pairs)
         return d_im, d_s, None, None, None, None
 
 
@@ -220,7 +247,7 @@ def alignment_scores(im_set, s_seq, im_len, s_len):
 class _Hinge(torch.autograd.Function):
     @staticmethod
     def forward(ctx, scores, margin, max_violation):
-        loss, ctx.dS = _hinge_raw(scores, margin, max_violation, ctx.needs_input_grad[0])
+        loss, ctx.dS, _ = _hinge_raw(scores, margin, max_violation, ctx.needs_input_grad[0])
         return loss
 
     @staticmethod

@@ -68,6 +68,11 @@ int aladin_align_pack_images(const float* im, int64_t stride_b, int64_t stride_r
 int aladin_align_pack_captions(const float* s, int64_t stride_b, int64_t stride_t, const int32_t* s_len,
                                const aladin_align_geom* geom, void* y, void* stream);
 
+/* Both packs in one launch (single-GPU path). */
+int aladin_align_pack_both(const float* im, int64_t im_stride_b, int64_t im_stride_r, const int32_t* im_len,
+                           const float* s, int64_t s_stride_b, int64_t s_stride_t, const int32_t* s_len,
+                           const aladin_align_geom* geom, void* xm, void* xe, void* y, void* stream);
+
 /* S (Bi x Bc, row stride ldS floats) from packed operands.  e_scratch: geom->e_bytes. */
 int aladin_align_scores(const void* xm, const void* xe, const void* y, const aladin_align_geom* geom,
                         void* e_scratch, float* S, int64_t ldS, void* stream);
@@ -92,11 +97,14 @@ int aladin_align_bwd(const float* im, int64_t im_stride_b, int64_t im_stride_r, 
 
 /* Same, given the packed fp16 operands of the forward pass (aladin_align_pack_*): the per-pair
  * argmax recompute then runs on the fp16 MFMA and only words whose top candidates are closer than
- * the fp16 error bound are re-decided with exact fp32 dot products (same result, ~8x cheaper). */
+ * the fp16 error bound are re-decided with exact fp32 dot products (same result, cheaper).
+ * pairs / pair_count (both or neither; may be NULL): the non-zero (i*Bc + j) list of dS as
+ * emitted by aladin_hinge_fused -- skips the in-call compaction. */
 int aladin_align_bwd_packed(const float* im, int64_t im_stride_b, int64_t im_stride_r, const int32_t* im_len,
                             const float* s, int64_t s_stride_b, int64_t s_stride_t, const int32_t* s_len,
                             const float* dS, int64_t ld_dS, const float* gscale,
                             const void* xm, const void* xe, const void* y, const aladin_align_geom* geom,
+                            const int32_t* pairs, const int32_t* pair_count,
                             float* d_im, float* d_s, void* workspace, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
@@ -108,6 +116,11 @@ int aladin_align_bwd_packed(const float* im, int64_t im_stride_b, int64_t im_str
 size_t aladin_hinge_workspace_bytes(int B);
 int aladin_hinge_fwd_bwd(const float* S, int64_t ldS, int B, float margin, int max_violation,
                          float* loss, float* dS, void* workspace, void* stream);
+
+/* Same, additionally emitting the list of non-zero pairs of dS (pairs: B*B int32 holding i*B + j in
+ * arbitrary order, pair_count: 1 int32) that aladin_align_bwd_packed can consume directly. */
+int aladin_hinge_fused(const float* S, int64_t ldS, int B, float margin, int max_violation, float* loss,
+                       float* dS, int32_t* pairs, int32_t* pair_count, void* workspace, void* stream);
 
 /* ListNet score distillation -- DistillationLoss(mode='listnet'), reference alad/loss.py:427-445
  * (teacher detached :370; temperature 6 on the student only; eps 1e-10 inside the log).
