@@ -257,6 +257,16 @@ __global__ __launch_bounds__(256) void align_side_gemm_kernel(const half_t* __re
       E[(row0 + (r & 3) + 8 * (r >> 2)) * ldE + col0 + n * 32] = acc[0][n][r];
 }
 
+// Diagnostic only (SCHED == 6 instantiation, never on the product path): per-workgroup shader-clock
+// and 100 MHz real-time deltas around the main loop -> in-kernel clock = d(memtime)/d(memrealtime) * 100 MHz.
+__device__ unsigned long long g_clock_probe[4 * 4096];
+
+extern "C" int aladin_debug_read_clock_probe(unsigned long long* host_out, int n_blocks) {
+  if (!host_out || n_blocks < 1 || n_blocks > 4096) { aladin_set_error("debug_read_clock_probe: bad argument"); return ALADIN_ERR_ARG; }
+  if (hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_clock_probe), (size_t)n_blocks * 32) != hipSuccess) { aladin_set_error("debug_read_clock_probe: copy failed"); return ALADIN_ERR_HIP; }
+  return ALADIN_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // score kernel
 //   WM   M-tiles (32 rows) per wave;  Q  M-tiles per image;  images per wave = WM / Q  (2 or 1)
@@ -289,7 +299,17 @@ __global__ __launch_bounds__(WGM * 128) void align_scores_kernel(const half_t* _
   const half_t* a_rows = xm + (int64_t)mb * Cfg::BM * ldk;
   const half_t* b_rows = y + (int64_t)nb * Cfg::BN * ldk;
   // SCHED: 0 = refill burst right after the barrier, 1 = refill spread over the four MFMA groups
-  if constexpr (SCHED == 1) gemm_mainloop<Cfg, 2, true>(a_rows, b_rows, ldk, ktiles, smem, acc);
+  if constexpr (SCHED == 6) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    gemm_mainloop<Cfg, 2, true, 0, true>(a_rows, b_rows, ldk, ktiles, smem, acc);
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0 && blockIdx.x < 4096) { g_clock_probe[4 * blockIdx.x] = t1 - t0; g_clock_probe[4 * blockIdx.x + 1] = r1 - r0; g_clock_probe[4 * blockIdx.x + 2] = r0; g_clock_probe[4 * blockIdx.x + 3] = r1; }
+  } else if constexpr (SCHED == 2) gemm_mainloop<Cfg, 2, true, 0, true>(a_rows, b_rows, ldk, ktiles, smem, acc);
+  else if constexpr (SCHED == 3) gemm_mainloop<Cfg, 2, true, 0, true, true>(a_rows, b_rows, ldk, ktiles, smem, acc);
+  else if constexpr (SCHED == 7) gemm_mainloop<Cfg, 2, true, 1, true>(a_rows, b_rows, ldk, ktiles, smem, acc);
+  else if constexpr (SCHED == 8) gemm_mainloop<Cfg, 2, true, 1>(a_rows, b_rows, ldk, ktiles, smem, acc);
+  else if constexpr (SCHED == 9) gemm_mainloop<Cfg, 2, true, 2>(a_rows, b_rows, ldk, ktiles, smem, acc);
+  else if constexpr (SCHED == 1) gemm_mainloop<Cfg, 2, true>(a_rows, b_rows, ldk, ktiles, smem, acc);
   else gemm_mainloop<Cfg, 2, false>(a_rows, b_rows, ldk, ktiles, smem, acc);
 
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -345,11 +365,15 @@ __global__ __launch_bounds__(WGM * 128) void align_scores_kernel(const half_t* _
     if (l5 == 0 && (IPW >= 2 || half == 0) && img < Bi && cap + c < Bc) S[(int64_t)img * ldS + cap + c] = t;
   }
   }
+  if constexpr (SCHED == 6) {
+    __syncthreads();
+    if (threadIdx.x == 0 && blockIdx.x < 4096) g_clock_probe[4 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();   // overwrite slot 0 with the exit stamp
+  }
 }
 
 static int scores_spread() {
   static int v = -1;
-  if (v < 0) { const char* e = getenv("ALADIN_ALIGN_SPREAD"); v = e ? atoi(e) : 1; }
+  if (v < 0) { const char* e = getenv("ALADIN_ALIGN_SPREAD"); v = e ? atoi(e) : 3; }
   return v;
 }
 
@@ -390,9 +414,15 @@ static int launch_scores(const aladin_align_geom* g, const half_t* xm, const hal
                          int64_t ldS, hipStream_t stream) {
   if constexpr (TP16 == 3 && Q == 1)
     if (scores_strip_mult(TP16, g->mtiles) == 2) {
-      switch (scores_spread()) {                       // experiment knob (ALADIN_ALIGN_SPREAD); default 1
+      switch (scores_spread()) {                       // schedule knob ALADIN_ALIGN_SPREAD (default 3 = pipelined fragments + setprio)
         case 0: return launch_scores_w<4, WM, Q, TP16, HAS_E, 2, 0>(g, xm, y, E, S, ldS, stream);
-        default: return launch_scores_w<4, WM, Q, TP16, HAS_E, 2, 1>(g, xm, y, E, S, ldS, stream);
+        case 2: return launch_scores_w<4, WM, Q, TP16, HAS_E, 2, 2>(g, xm, y, E, S, ldS, stream);
+        case 6: return launch_scores_w<4, WM, Q, TP16, HAS_E, 2, 6>(g, xm, y, E, S, ldS, stream);
+        case 7: return launch_scores_w<4, WM, Q, TP16, HAS_E, 2, 7>(g, xm, y, E, S, ldS, stream);
+        case 8: return launch_scores_w<4, WM, Q, TP16, HAS_E, 2, 8>(g, xm, y, E, S, ldS, stream);
+        case 9: return launch_scores_w<4, WM, Q, TP16, HAS_E, 2, 9>(g, xm, y, E, S, ldS, stream);
+        case 1: return launch_scores_w<4, WM, Q, TP16, HAS_E, 2, 1>(g, xm, y, E, S, ldS, stream);
+        default: return launch_scores_w<4, WM, Q, TP16, HAS_E, 2, 3>(g, xm, y, E, S, ldS, stream);
       }
     }
   if (scores_wgm() == 4) return launch_scores_w<4, WM, Q, TP16, HAS_E, 1>(g, xm, y, E, S, ldS, stream);

@@ -32,19 +32,33 @@ struct GemmCfg {
 
 // One K-step (64 deep) of both panels -> LDS.  The A panel may come from two row segments
 // (rows [0,a_split) from a_rows, rows [a_split,BM) from a_rows2) -- used by the backward pair kernel.
+//
+// Addressing is split into a WAVE-UNIFORM base per 1-KiB piece (panel pointer + piece row * ldk +
+// kt * 64, all scalar) and ONE per-lane byte offset shared by every piece of the wave
+// (stage_lane_offset): lane -> (row-in-piece r = lane>>3, 16-B chunk).  The XOR swizzle
+// ((row>>1)&7 with row = 8*piece + r) equals (r>>1) ^ 4*(piece&1), and a wave's pieces all have the
+// parity of the wave id (NWAVES is even), so the swizzled chunk is a per-lane constant too.  This
+// keeps the LDS-DMA address state in one VGPR instead of a 64-bit pointer per piece.
+template <class Cfg>
+__device__ __forceinline__ uint32_t stage_lane_offset(int64_t ldk, int wave, int lane) {
+  static_assert(Cfg::NWAVES % 2 == 0, "piece parity must be a wave constant");
+  const int r = lane >> 3;
+  const int logical = (lane & 7) ^ (((r >> 1) ^ ((wave & 1) << 2)) & 7);
+  return (uint32_t)(((int64_t)r * ldk + logical * 8) * 2);
+}
+
 template <class Cfg, int C0 = 0, int C1 = Cfg::CHUNKS_PER_WAVE>
 __device__ __forceinline__ void gemm_stage(const half_t* __restrict__ a_rows, const half_t* __restrict__ a_rows2, int a_split,
                                            const half_t* __restrict__ b_rows, int64_t ldk, int kt, char* stage, int wave,
-                                           int lane) {
+                                           uint32_t lane_off) {
 #pragma unroll
   for (int c = C0; c < C1; ++c) {
-    const int chunk = wave + c * Cfg::NWAVES;
-    const int row = chunk * 8 + (lane >> 3);
-    const int logical = (lane & 7) ^ ((row >> 1) & 7);
-    const half_t* src;
-    if (row < Cfg::BM) src = (row < a_split) ? a_rows + (int64_t)row * ldk : a_rows2 + (int64_t)(row - a_split) * ldk;
-    else src = b_rows + (int64_t)(row - Cfg::BM) * ldk;
-    src += (int64_t)kt * 64 + logical * 8;
+    const int chunk = wave + c * Cfg::NWAVES;              // wave-uniform
+    const int row0 = chunk * 8;
+    const half_t* base;
+    if (row0 < Cfg::BM) base = (row0 < a_split) ? a_rows + (int64_t)row0 * ldk : a_rows2 + (int64_t)(row0 - a_split) * ldk;
+    else base = b_rows + (int64_t)(row0 - Cfg::BM) * ldk;
+    const char* src = reinterpret_cast<const char*>(base + (int64_t)kt * 64) + lane_off;
     __builtin_amdgcn_global_load_lds(GLOBAL_PTR(src), LDS_PTR(stage + chunk * 1024), 16, 0, 0);
   }
 }
@@ -76,7 +90,7 @@ __device__ __forceinline__ void wait_vmcnt(int n) {
 // wave's older LDS-DMA groups must have landed), ONE raw s_barrier (publishes step kt to every
 // wave and proves every wave is done reading buffer (kt-1) % NS), then the refill of that buffer
 // is issued before the MFMAs of step kt.  acc must be initialised by the caller.
-template <class Cfg, int NS = 2, bool SPREAD = false>
+template <class Cfg, int NS = 2, bool SPREAD = false, int ABLATE = 0, bool PIPE = false, bool PRIO = false>
 __device__ __forceinline__ void gemm_mainloop(const half_t* __restrict__ a_rows, const half_t* __restrict__ b_rows,
                                               int64_t ldk, int ktiles, char* smem, f32x16 (&acc)[Cfg::WM][Cfg::WN],
                                               const half_t* __restrict__ a_rows2 = nullptr, int a_split = Cfg::BM) {
@@ -84,40 +98,87 @@ __device__ __forceinline__ void gemm_mainloop(const half_t* __restrict__ a_rows,
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   const int wm = wave / Cfg::WGN, wn = wave % Cfg::WGN;
+  const uint32_t lane_off = stage_lane_offset<Cfg>(ldk, wave, lane);
   const int a_row0 = wm * Cfg::WM * 32 + (lane & 31);
   const int b_row0 = Cfg::BM + wn * Cfg::WN * 32 + (lane & 31);
 
 #pragma unroll
   for (int st = 0; st < NS - 1; ++st)
-    if (st < ktiles) gemm_stage<Cfg>(a_rows, a_rows2, a_split, b_rows, ldk, st, smem + st * Cfg::STAGE_BYTES, wave, lane);
+    if (st < ktiles) gemm_stage<Cfg>(a_rows, a_rows2, a_split, b_rows, ldk, st, smem + st * Cfg::STAGE_BYTES, wave, lane_off);
   for (int kt = 0; kt < ktiles; ++kt) {
     const int ahead = ktiles - 1 - kt;                                   // groups issued after step kt's
     wait_vmcnt(Cfg::CHUNKS_PER_WAVE * (ahead < NS - 2 ? ahead : NS - 2));
     __builtin_amdgcn_s_barrier();
     const char* cur = smem + (kt % NS) * Cfg::STAGE_BYTES;
-    const bool refill = kt + NS - 1 < ktiles;
+    const bool refill = (ABLATE != 1) && (kt + NS - 1 < ktiles);      // ABLATE 1: timing-only build without refills
     char* nxt = smem + ((kt + NS - 1) % NS) * Cfg::STAGE_BYTES;
-    if (!SPREAD && refill) gemm_stage<Cfg>(a_rows, a_rows2, a_split, b_rows, ldk, kt + NS - 1, nxt, wave, lane);
+    if (!SPREAD && refill) gemm_stage<Cfg>(a_rows, a_rows2, a_split, b_rows, ldk, kt + NS - 1, nxt, wave, lane_off);
+    if constexpr (PIPE && Cfg::WM == 2 && Cfg::WN >= 4) {
+      // Software-pipelined 16-deep steps.  Step kk runs the four MFMAs on (a0,a1) x (b0,b1) first;
+      // b0,b1 are then dead and are refilled with step kk+1's values together with a second pair
+      // of A registers, under the remaining 2*(WN-2) MFMAs.  Step kk+1 therefore starts with its
+      // first four MFMAs ready and only has to fetch b2.. -- one exposed LDS latency per K step
+      // (at kk = 0) instead of four.  Costs 8 extra VGPRs.
+      half8 a_cur[2], a_nxt[2], b01[2], brest[Cfg::WN - 2];
+      a_cur[0] = lds_frag(cur, a_row0, 0, lane);
+      a_cur[1] = lds_frag(cur, a_row0 + 32, 0, lane);
+      b01[0] = lds_frag(cur, b_row0, 0, lane);
+      b01[1] = lds_frag(cur, b_row0 + 32, 0, lane);
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      half8 af[Cfg::WM], bf[Cfg::WN];
+      for (int kk = 0; kk < 4; ++kk) {
 #pragma unroll
-      for (int a = 0; a < Cfg::WM; ++a) af[a] = lds_frag(cur, a_row0 + a * 32, kk, lane);
+        for (int n = 2; n < Cfg::WN; ++n) brest[n - 2] = lds_frag(cur, b_row0 + n * 32, kk, lane);
+        if (SPREAD && refill) {
+          constexpr int CPW = Cfg::CHUNKS_PER_WAVE;
+          if (kk == 0) gemm_stage<Cfg, 0, (CPW + 3) / 4>(a_rows, a_rows2, a_split, b_rows, ldk, kt + NS - 1, nxt, wave, lane_off);
+          if (kk == 1) gemm_stage<Cfg, (CPW + 3) / 4, (2 * CPW + 3) / 4>(a_rows, a_rows2, a_split, b_rows, ldk, kt + NS - 1, nxt, wave, lane_off);
+          if (kk == 2) gemm_stage<Cfg, (2 * CPW + 3) / 4, (3 * CPW + 3) / 4>(a_rows, a_rows2, a_split, b_rows, ldk, kt + NS - 1, nxt, wave, lane_off);
+          if (kk == 3) gemm_stage<Cfg, (3 * CPW + 3) / 4, CPW>(a_rows, a_rows2, a_split, b_rows, ldk, kt + NS - 1, nxt, wave, lane_off);
+        }
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_cur[0], b01[0], acc[0][0], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_cur[1], b01[0], acc[1][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_cur[0], b01[1], acc[0][1], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_cur[1], b01[1], acc[1][1], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (kk < 3) {
+          b01[0] = lds_frag(cur, b_row0, kk + 1, lane);
+          b01[1] = lds_frag(cur, b_row0 + 32, kk + 1, lane);
+          a_nxt[0] = lds_frag(cur, a_row0, kk + 1, lane);
+          a_nxt[1] = lds_frag(cur, a_row0 + 32, kk + 1, lane);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-      for (int n = 0; n < Cfg::WN; ++n) bf[n] = lds_frag(cur, b_row0 + n * 32, kk, lane);
-      if (SPREAD && refill) {
-        // a quarter of the refill per MFMA group instead of one burst after the barrier
-        constexpr int CPW = Cfg::CHUNKS_PER_WAVE;
-        if (kk == 0) gemm_stage<Cfg, 0, (CPW + 3) / 4>(a_rows, a_rows2, a_split, b_rows, ldk, kt + NS - 1, nxt, wave, lane);
-        if (kk == 1) gemm_stage<Cfg, (CPW + 3) / 4, (2 * CPW + 3) / 4>(a_rows, a_rows2, a_split, b_rows, ldk, kt + NS - 1, nxt, wave, lane);
-        if (kk == 2) gemm_stage<Cfg, (2 * CPW + 3) / 4, (3 * CPW + 3) / 4>(a_rows, a_rows2, a_split, b_rows, ldk, kt + NS - 1, nxt, wave, lane);
-        if (kk == 3) gemm_stage<Cfg, (3 * CPW + 3) / 4, CPW>(a_rows, a_rows2, a_split, b_rows, ldk, kt + NS - 1, nxt, wave, lane);
+        for (int n = 2; n < Cfg::WN; ++n) {
+          acc[0][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_cur[0], brest[n - 2], acc[0][n], 0, 0, 0);
+          acc[1][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_cur[1], brest[n - 2], acc[1][n], 0, 0, 0);
+        }
+        if (PRIO) __builtin_amdgcn_s_setprio(0);
+        if (kk < 3) { a_cur[0] = a_nxt[0]; a_cur[1] = a_nxt[1]; }
       }
+    } else {
 #pragma unroll
-      for (int a = 0; a < Cfg::WM; ++a)
+      for (int kk = 0; kk < 4; ++kk) {
+        half8 af[Cfg::WM], bf[Cfg::WN];
 #pragma unroll
-        for (int n = 0; n < Cfg::WN; ++n)
-          acc[a][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[a], bf[n], acc[a][n], 0, 0, 0);
+        for (int a = 0; a < Cfg::WM; ++a) af[a] = lds_frag(cur, a_row0 + a * 32, kk, lane);
+#pragma unroll
+        for (int n = 0; n < Cfg::WN; ++n) bf[n] = lds_frag(cur, b_row0 + n * 32, kk, lane);
+        if (SPREAD && refill) {
+          // a quarter of the refill per MFMA group instead of one burst after the barrier
+          constexpr int CPW = Cfg::CHUNKS_PER_WAVE;
+          if (kk == 0) gemm_stage<Cfg, 0, (CPW + 3) / 4>(a_rows, a_rows2, a_split, b_rows, ldk, kt + NS - 1, nxt, wave, lane_off);
+          if (kk == 1) gemm_stage<Cfg, (CPW + 3) / 4, (2 * CPW + 3) / 4>(a_rows, a_rows2, a_split, b_rows, ldk, kt + NS - 1, nxt, wave, lane_off);
+          if (kk == 2) gemm_stage<Cfg, (2 * CPW + 3) / 4, (3 * CPW + 3) / 4>(a_rows, a_rows2, a_split, b_rows, ldk, kt + NS - 1, nxt, wave, lane_off);
+          if (kk == 3) gemm_stage<Cfg, (3 * CPW + 3) / 4, CPW>(a_rows, a_rows2, a_split, b_rows, ldk, kt + NS - 1, nxt, wave, lane_off);
+        }
+#pragma unroll
+        for (int a = 0; a < Cfg::WM; ++a)
+#pragma unroll
+          for (int n = 0; n < Cfg::WN; ++n)
+            if (ABLATE != 2) acc[a][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[a], bf[n], acc[a][n], 0, 0, 0);
+            else { asm volatile("" :: "v"(af[a]), "v"(bf[n])); }      // ABLATE 2: timing-only build without MFMAs
+      }
     }
   }
 }

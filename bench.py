@@ -67,7 +67,7 @@ def kernel_roofline(im, s, il, sl, iters=50):
     flops = B * B * 2 * 32 * (T - 3) * D
     achieved = flops / (ms * 1e-3) / 1e12
     traffic, src = pmc_traffic('align_scores_kernel')
-    return {'bound': 'mfma', 'traffic_source': src, 'kernel': 'align_scores_kernel<4,2,1,3,true,2> (256x384 tile)', 'achieved': round(achieved, 2), 'peak': PEAK_TFLOPS,
+    return {'bound': 'mfma', 'traffic_source': src, 'kernel': 'align_scores_kernel<4,2,1,3,true,2,3> (256x384 tile, pipelined fragments)', 'achieved': round(achieved, 2), 'peak': PEAK_TFLOPS,
             'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_TFLOPS, 4), 'traffic': traffic,
             'kernel_us': round(ms * 1e3, 2), 'flops_per_launch': flops}
 
@@ -85,7 +85,7 @@ def pmc_traffic(kernel_substr):
         except Exception:
             continue
         for name, d in ks.items():
-            if kernel_substr in name and 'ELi2EE' in name.replace(' ', '') + 'ELi2EE' and 'hbm_bytes_corrected' in d:
+            if kernel_substr in name and 'hbm_bytes_corrected' in d:
                 return int(d['hbm_bytes_corrected']), os.path.relpath(f, ROOT)
     return None, None
 
