@@ -344,3 +344,36 @@ def test_config3_full_size_retrieval_ranks():
         assert abs(100.0 * np.mean(r_t2i < K) - 100.0 * np.mean(ref_t2i < K)) <= 0.1
     m = E.compute_recall(img, cap, verbose=False)
     assert 5.0 < m[0] < 95.0                                            # non-degenerate
+
+
+def test_sharded_loss_under_rccl_world1():
+    """aladin_amd.distributed on the real backend ("nccl" == RCCL).  A 1-GPU box only allows
+    world_size 1, which still runs every collective call and the autograd wrappers on device; the
+    result must equal the single-device fused loss bit for bit (world 2 is covered under gloo in
+    tests/test_distributed_cpu.py)."""
+    import os
+    import torch.distributed as dist
+    from aladin_amd import synth
+    from aladin_amd.distributed import sharded_alignment_loss
+    from aladin_amd.loss import AlignmentContrastiveLoss
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29611')
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev())
+        created = True
+    try:
+        im, s, il, sl = synth.alignment_batch(32, 34, 50, 768, seed=77, ragged=True)
+        a1, b1 = T(im).requires_grad_(True), T(s).requires_grad_(True)
+        loss1, S1 = sharded_alignment_loss(a1, b1, il, sl, 0.2, True)
+        loss1.backward()
+        a2, b2 = T(im).requires_grad_(True), T(s).requires_grad_(True)
+        loss2, S2 = AlignmentContrastiveLoss(0.2, 'dot', True, 'MrSw')(a2, b2, il, sl, return_similarity_mat=True)
+        loss2.backward()
+        assert torch.equal(S1.detach(), S2) and torch.equal(loss1.detach(), loss2.detach())
+        np.testing.assert_allclose(a1.grad.cpu().numpy(), a2.grad.cpu().numpy(), rtol=1e-6, atol=1e-9)
+        np.testing.assert_allclose(b1.grad.cpu().numpy(), b2.grad.cpu().numpy(), rtol=1e-6, atol=1e-9)
+    finally:
+        if created:
+            dist.destroy_process_group()
