@@ -27,11 +27,13 @@ def T(x):
     return torch.from_numpy(np.ascontiguousarray(x)).to(dev())
 
 
-def assert_scores_close(S, ref, rtol=RTOL):
+def assert_scores_close(S, ref, rtol=RTOL, atol_rel=5e-4, scale='mean'):
+    """|S - ref| <= rtol*|ref| + atol_rel*scale, scale = mean (or max) |ref|: elements that happen
+    to be near zero are judged against the magnitude of the score matrix."""
     S = np.asarray(S, np.float64)
     ref = np.asarray(ref, np.float64)
-    scale = max(1e-6, np.abs(ref).mean())
-    np.testing.assert_allclose(S, ref, rtol=rtol, atol=5e-4 * scale)
+    mag = np.abs(ref).max() if scale == 'max' else np.abs(ref).mean()
+    np.testing.assert_allclose(S, ref, rtol=rtol, atol=atol_rel * max(1e-6, mag))
 
 
 def test_extension_is_loaded():
@@ -377,3 +379,57 @@ def test_sharded_loss_under_rccl_world1():
     finally:
         if created:
             dist.destroy_process_group()
+
+
+SWEEP = [
+    # Bi, Bc, R,  T,  D    -> tiling class exercised
+    (3, 5, 2, 4, 8),        # one region, one word
+    (9, 4, 17, 9, 40),      # mtiles 1 padded, tp16 1, D not a multiple of 64 nor of 8
+    (7, 7, 33, 20, 64),     # R' = 32 exactly, tp16 2
+    (10, 6, 34, 35, 96),    # 32 + 1 side row, tp16 2
+    (5, 9, 34, 67, 64),     # side row, tp16 4
+    (6, 3, 50, 50, 128),    # mtiles 2 padded, tp16 3
+    (4, 5, 66, 40, 64),     # mtiles 2 + side row (R' = 65), tp16 3
+    (3, 4, 71, 71, 64),     # evaluation shape: mtiles 3, tp16 5 -> 6
+    (2, 2, 97, 99, 32),     # maximum supported regions / tokens
+    (40, 24, 34, 50, 72),   # several workgroup tiles, ragged
+]
+
+
+@pytest.mark.parametrize('shape', SWEEP)
+def test_alignment_scores_shape_sweep(shape):
+    from aladin_amd import ops, synth
+    Bi, Bc, R, Tn, D = shape
+    im, s, il, sl = synth.alignment_batch(Bi, R, Tn, D, seed=1000 + Bi * 7 + R, ragged=True, Bc=Bc)
+    il = [max(2, v) for v in il]
+    sl = [max(4, v) for v in sl]
+    S = ops.alignment_scores(T(im), T(s), il, sl).cpu().numpy()
+    ref = O.alignment_scores(im, s, il, sl)
+    assert S.shape == (Bi, Bc)
+    # tiny D (8..40): few, large vector components, so the fp16 operand rounding (2^-11 relative per
+    # component) is not averaged down as at D=768; still within 1e-3 of the score magnitude
+    assert_scores_close(S, ref, rtol=1e-3, atol_rel=1e-3, scale='max')
+
+
+@pytest.mark.parametrize('shape', [(6, 6, 17, 9, 40), (5, 5, 34, 35, 96), (4, 4, 50, 50, 128), (3, 3, 71, 71, 64),
+                                   (12, 12, 34, 50, 100)])
+@pytest.mark.parametrize('mv', [True, False])
+def test_alignment_backward_shape_sweep(shape, mv):
+    """Autograd through the differentiable scores + hinge for every backward code path (fp16 pair
+    kernel, fp32 fallback for multi-tile / long shapes), against the oracle chained on the HIP S."""
+    from aladin_amd import ops, synth
+    Bi, Bc, R, Tn, D = shape
+    im, s, il, sl = synth.structured_alignment_batch(Bi, R, Tn, D, seed=2000 + R, noise=3.0, ragged=True)
+    il = [max(2, v) for v in il]
+    sl = [max(4, v) for v in sl]
+    a, b = T(im).requires_grad_(True), T(s).requires_grad_(True)
+    S = ops.alignment_scores(a, b, il, sl)
+    loss = ops.hinge_loss(S, 0.2, mv)
+    loss.backward()
+    S_np = S.detach().cpu().numpy()
+    ref_loss, dS = O.hinge_loss(S_np, 0.2, mv, return_grad=True)
+    np.testing.assert_allclose(loss.item(), ref_loss, rtol=1e-5, atol=1e-6)
+    dim, ds = O.alignment_scores_backward(im, s, il, sl, dS)
+    for got, ref in ((a.grad, dim), (b.grad, ds)):
+        scale = max(1e-9, float(np.abs(ref).max()))
+        np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=1e-3, atol=2e-5 * scale)
