@@ -130,7 +130,7 @@ def main():
 
     from aladin_amd import synth
     from aladin_amd.loss import AlignmentContrastiveLoss
-    from aladin_amd.distributed import sharded_alignment_loss
+    from aladin_amd.distributed import sharded_alignment_loss_fast
 
     im_np, s_np, il, sl = synth.alignment_batch(B, R, T, D, seed=1234 + 17 * rank, ragged=False)
     im = torch.from_numpy(im_np).to(dev).requires_grad_(True)
@@ -141,7 +141,7 @@ def main():
         im.grad = None
         s.grad = None
         if world > 1:
-            loss, _ = sharded_alignment_loss(im, s, il, sl, 0.2, True)
+            loss, _ = sharded_alignment_loss_fast(im, s, il, sl, 0.2, True)
         else:
             loss = crit(im, s, il, sl)
         loss.backward()

@@ -433,3 +433,71 @@ def test_alignment_backward_shape_sweep(shape, mv):
     for got, ref in ((a.grad, dim), (b.grad, ds)):
         scale = max(1e-9, float(np.abs(ref).max()))
         np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=1e-3, atol=2e-5 * scale)
+
+
+def test_sharded_fast_path_rank_logic_emulated_world2():
+    """The per-rank pieces of aladin_amd.distributed's fast path, driven for rank 0 and rank 1 on
+    ONE GPU with hand-made 'gathered' tensors (concatenation == all-gather, sum == reduce-scatter):
+    global loss, score matrix and both gradients must equal the single-device result on the
+    concatenated batch."""
+    from aladin_amd import distributed as DD, ops, synth
+    from aladin_amd.loss import AlignmentContrastiveLoss
+    W, B, R, Tn, D = 2, 64, 34, 50, 768
+    im, s, il, sl = synth.alignment_batch(W * B, R, Tn, D, seed=4242, ragged=True)
+    d = dev()
+    g_loc, g_glob, ok = DD._local_and_global_geometry(B, W, R, Tn, D)
+    assert ok
+    ims = [T(im[r * B:(r + 1) * B]) for r in range(W)]
+    caps = [T(s[r * B:(r + 1) * B]) for r in range(W)]
+    ilt = [ops.lengths_tensor(il[r * B:(r + 1) * B], d) for r in range(W)]
+    slt = [ops.lengths_tensor(sl[r * B:(r + 1) * B], d) for r in range(W)]
+    packs = [ops.pack_images(ims[r], ilt[r], g_loc) for r in range(W)]
+    xm_all = torch.cat([p[0] for p in packs])
+    xe_all = torch.cat([p[1] for p in packs])
+    il_all = torch.cat(ilt)
+    im_all = torch.cat(ims)
+    blocks = [DD.rank_scores_block(xm_all, xe_all, caps[r], slt[r], g_glob) for r in range(W)]
+    S_full = torch.cat([b[0] for b in blocks], dim=1)
+    loss, dS_full, _ = ops._hinge_raw(S_full, 0.2, True, True)
+    d_im_all = torch.zeros_like(im_all)
+    d_caps = []
+    for r in range(W):
+        gi, gs = DD.rank_backward_block(im_all, il_all, caps[r], slt[r], dS_full, r, g_glob, xm_all, xe_all, blocks[r][1])
+        d_im_all += gi
+        d_caps.append(gs)
+    a, b = T(im).requires_grad_(True), T(s).requires_grad_(True)
+    ref_loss, ref_S = AlignmentContrastiveLoss(0.2, 'dot', True, 'MrSw')(a, b, il, sl, return_similarity_mat=True)
+    ref_loss.backward()
+    assert torch.equal(S_full, ref_S) and torch.equal(loss, ref_loss.detach())
+    np.testing.assert_allclose(d_im_all.cpu().numpy(), a.grad.cpu().numpy(), rtol=1e-5, atol=1e-8)
+    np.testing.assert_allclose(torch.cat(d_caps).cpu().numpy(), b.grad.cpu().numpy(), rtol=1e-5, atol=1e-8)
+
+
+def test_sharded_fast_path_under_rccl_world1():
+    import os
+    import torch.distributed as dist
+    from aladin_amd import synth
+    from aladin_amd.distributed import sharded_alignment_loss_fast
+    from aladin_amd.loss import AlignmentContrastiveLoss
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29612')
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev())
+        created = True
+    try:
+        im, s, il, sl = synth.alignment_batch(64, 34, 50, 768, seed=78, ragged=True)
+        a1, b1 = T(im).requires_grad_(True), T(s).requires_grad_(True)
+        loss1, S1 = sharded_alignment_loss_fast(a1, b1, il, sl, 0.2, True)
+        loss1.backward()
+        a2, b2 = T(im).requires_grad_(True), T(s).requires_grad_(True)
+        loss2, S2 = AlignmentContrastiveLoss(0.2, 'dot', True, 'MrSw')(a2, b2, il, sl, return_similarity_mat=True)
+        loss2.backward()
+        assert torch.equal(S1, S2) and torch.equal(loss1.detach(), loss2.detach())
+        assert torch.equal(a1.grad, a2.grad) and torch.equal(b1.grad, b2.grad)
+        with pytest.raises(ValueError):
+            sharded_alignment_loss_fast(T(im[:10]), T(s[:10]), il[:10], sl[:10])
+    finally:
+        if created:
+            dist.destroy_process_group()
