@@ -307,6 +307,7 @@ __global__ __launch_bounds__(WGM * 128) void align_scores_kernel(const half_t* _
   } else if constexpr (SCHED == 2) gemm_mainloop<Cfg, 2, true, 0, true>(a_rows, b_rows, ldk, ktiles, smem, acc);
   else if constexpr (SCHED == 3) gemm_mainloop<Cfg, 2, true, 0, true, true>(a_rows, b_rows, ldk, ktiles, smem, acc);
   else if constexpr (SCHED == 7) gemm_mainloop<Cfg, 2, true, 1, true>(a_rows, b_rows, ldk, ktiles, smem, acc);
+  else if constexpr (SCHED == 5) gemm_mainloop<Cfg, 2, true, 3, true, true>(a_rows, b_rows, ldk, ktiles, smem, acc);
   else if constexpr (SCHED == 8) gemm_mainloop<Cfg, 2, true, 1>(a_rows, b_rows, ldk, ktiles, smem, acc);
   else if constexpr (SCHED == 9) gemm_mainloop<Cfg, 2, true, 2>(a_rows, b_rows, ldk, ktiles, smem, acc);
   else if constexpr (SCHED == 1) gemm_mainloop<Cfg, 2, true>(a_rows, b_rows, ldk, ktiles, smem, acc);
@@ -373,7 +374,7 @@ __global__ __launch_bounds__(WGM * 128) void align_scores_kernel(const half_t* _
 
 static int scores_spread() {
   static int v = -1;
-  if (v < 0) { const char* e = getenv("ALADIN_ALIGN_SPREAD"); v = e ? atoi(e) : 3; }
+  if (v < 0) { const char* e = getenv("ALADIN_ALIGN_SPREAD"); v = e ? atoi(e) : 16; }
   return v;
 }
 
@@ -381,6 +382,86 @@ static int scores_wgm() {
   static int v = 0;
   if (!v) { const char* e = getenv("ALADIN_ALIGN_WGM"); v = (e && atoi(e) == 2) ? 2 : 4; }
   return v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// score kernel, v_mfma_f32_16x16x32_f16 body, for the headline tile class: one region tile (R' <= 32,
+// plus the side row), 48-word captions, 256 x 384 workgroup tile (8 waves: 4 x 2; wave = 2 images x
+// 4 captions = 4 x 12 accumulator tiles of 16 x 16).
+//   max over regions : in-lane over 2 row tiles x 4 registers, v_permlane32_swap pairs the wave's two
+//                      images into the two half-waves, one 16-lane exchange finishes the 32 rows
+//   sum over words   : a caption is exactly 3 column tiles -> in-lane adds, then a 16-lane reduction
+// ------------------------------------------------------------------------------------------------
+template <bool HAS_E>
+__global__ __launch_bounds__(512) void align_scores16_kernel(const half_t* __restrict__ xm, const half_t* __restrict__ y,
+                                                             const float* __restrict__ E, int64_t ldE,
+                                                             float* __restrict__ S, int64_t ldS, int Bi, int Bc,
+                                                             int64_t ldk, int ktiles, int n_nblk, int n_blocks) {
+  using Cfg = GemmCfg<4, 2, 2, 6>;
+  constexpr int RT = 4, CT = 12;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int mb, nb;
+  tile_coords(blockIdx.x, n_blocks / n_nblk, n_nblk, 4, mb, nb);
+
+  f32x4 acc[RT][CT];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) acc[rt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  gemm_mainloop16<Cfg, true>(xm + (int64_t)mb * Cfg::BM * ldk, y + (int64_t)nb * Cfg::BN * ldk, ldk, ktiles, smem, acc);
+
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wm = wave / 2, wn = wave % 2;
+  const int half = lane >> 5, l4 = lane & 15;
+  const int img = (mb * 4 + wm) * 2 + half;                        // lanes 0-31: image 0, lanes 32-63: image 1
+  const float* e = HAS_E ? E + (int64_t)img * ldE + (int64_t)nb * Cfg::BN + wn * 192 + l4 : nullptr;
+  float v[4] = {0.f, 0.f, 0.f, 0.f};                               // 4 captions of the strip
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct) {
+    float p0 = fmaxf(fmaxf(acc[0][ct][0], acc[0][ct][1]), fmaxf(acc[0][ct][2], acc[0][ct][3]));
+    p0 = fmaxf(p0, fmaxf(fmaxf(acc[1][ct][0], acc[1][ct][1]), fmaxf(acc[1][ct][2], acc[1][ct][3])));
+    float p1 = fmaxf(fmaxf(acc[2][ct][0], acc[2][ct][1]), fmaxf(acc[2][ct][2], acc[2][ct][3]));
+    p1 = fmaxf(p1, fmaxf(fmaxf(acc[3][ct][0], acc[3][ct][1]), fmaxf(acc[3][ct][2], acc[3][ct][3])));
+    // rows are spread over the four 16-lane quarters; gather image 0 into lanes 0-31, image 1 into 32-63
+    auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(p0), __float_as_uint(p1), false, false);
+    float m = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+    m = fmaxf(m, __shfl_xor(m, 16, 64));
+    if constexpr (HAS_E) m = fmaxf(m, e[ct * 16]);
+    v[ct / 3] += m;
+  }
+  const int cap = (nb * 2 + wn) * 4;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    float t = v[c];
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+    if ((lane & 31) == 0 && img < Bi && cap + c < Bc) S[(int64_t)img * ldS + cap + c] = t;
+  }
+}
+
+template <bool HAS_E>
+static int launch_scores16(const aladin_align_geom* g, const half_t* xm, const half_t* y, const float* E, float* S,
+                           int64_t ldS, hipStream_t stream) {
+  using Cfg = GemmCfg<4, 2, 2, 6>;
+  const int n_mblk = (int)(g->xm_rows / Cfg::BM), n_nblk = (int)(g->y_rows / Cfg::BN);
+  if ((int64_t)n_mblk * Cfg::BM != g->xm_rows || (int64_t)n_nblk * Cfg::BN != g->y_rows) {
+    aladin_set_error("align_scores16: packed rows do not tile");
+    return ALADIN_ERR_ARG;
+  }
+  auto kern = align_scores16_kernel<HAS_E>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES) != hipSuccess) {
+      aladin_set_error("align_scores16: cannot reserve %d B of LDS", Cfg::LDS_BYTES);
+      return ALADIN_ERR_HIP;
+    }
+    attr_done = true;
+  }
+  const int n_blocks = n_mblk * n_nblk;
+  hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(Cfg::THREADS), Cfg::LDS_BYTES, stream, xm, y, E, g->y_rows, S, ldS, g->Bi,
+                     g->Bc, (int64_t)g->Dp, g->Dp / 64, n_nblk, n_blocks);
+  return aladin_check_launch("align_scores16_kernel");
 }
 
 template <int WGM, int WM, int Q, int TP16, bool HAS_E, int SM, int SCHED = 1>
@@ -414,9 +495,11 @@ static int launch_scores(const aladin_align_geom* g, const half_t* xm, const hal
                          int64_t ldS, hipStream_t stream) {
   if constexpr (TP16 == 3 && Q == 1)
     if (scores_strip_mult(TP16, g->mtiles) == 2) {
-      switch (scores_spread()) {                       // schedule knob ALADIN_ALIGN_SPREAD (default 3 = pipelined fragments + setprio)
+      if (scores_spread() == 16) return launch_scores16<HAS_E>(g, xm, y, E, S, ldS, stream);      // 16x16x32 body
+      switch (scores_spread()) {                       // ALADIN_ALIGN_SPREAD: 16 (default) = 16x16x32 body above; 0/1/2/3 = 32x32x16 schedules
         case 0: return launch_scores_w<4, WM, Q, TP16, HAS_E, 2, 0>(g, xm, y, E, S, ldS, stream);
         case 2: return launch_scores_w<4, WM, Q, TP16, HAS_E, 2, 2>(g, xm, y, E, S, ldS, stream);
+        case 5: return launch_scores_w<4, WM, Q, TP16, HAS_E, 2, 5>(g, xm, y, E, S, ldS, stream);
         case 6: return launch_scores_w<4, WM, Q, TP16, HAS_E, 2, 6>(g, xm, y, E, S, ldS, stream);
         case 7: return launch_scores_w<4, WM, Q, TP16, HAS_E, 2, 7>(g, xm, y, E, S, ldS, stream);
         case 8: return launch_scores_w<4, WM, Q, TP16, HAS_E, 2, 8>(g, xm, y, E, S, ldS, stream);

@@ -69,6 +69,22 @@ __device__ __forceinline__ half8 lds_frag(const char* stage, int row, int kk, in
   return *reinterpret_cast<const half8*>(stage + row * 128 + phys * 16);
 }
 
+// MFMA step on one 32x32 accumulator.  SHAPE16 (timing-only ablation): two v_mfma_f32_16x16x32_f16 on
+// two 4-register slices of the same accumulator -- equal flops, meaningless values -- to measure the
+// clock / time the chip holds with that instruction shape before committing to its fragment layout.
+template <bool SHAPE16>
+__device__ __forceinline__ void mfma_step(const half8& a, const half8& b, f32x16& c) {
+  if constexpr (!SHAPE16) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+  } else {
+    f32x4 lo = {c[0], c[1], c[2], c[3]}, hi = {c[4], c[5], c[6], c[7]};
+    lo = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, lo, 0, 0, 0);
+    hi = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, hi, 0, 0, 0);
+    c[0] = lo[0]; c[1] = lo[1]; c[2] = lo[2]; c[3] = lo[3];
+    c[4] = hi[0]; c[5] = hi[1]; c[6] = hi[2]; c[7] = hi[3];
+  }
+}
+
 // s_waitcnt vmcnt(n) with a run-time n <= 32 (the instruction needs an immediate)
 __device__ __forceinline__ void wait_vmcnt(int n) {
   switch (n) {
@@ -135,10 +151,10 @@ __device__ __forceinline__ void gemm_mainloop(const half_t* __restrict__ a_rows,
           if (kk == 2) gemm_stage<Cfg, (2 * CPW + 3) / 4, (3 * CPW + 3) / 4>(a_rows, a_rows2, a_split, b_rows, ldk, kt + NS - 1, nxt, wave, lane_off);
           if (kk == 3) gemm_stage<Cfg, (3 * CPW + 3) / 4, CPW>(a_rows, a_rows2, a_split, b_rows, ldk, kt + NS - 1, nxt, wave, lane_off);
         }
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_cur[0], b01[0], acc[0][0], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_cur[1], b01[0], acc[1][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_cur[0], b01[1], acc[0][1], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_cur[1], b01[1], acc[1][1], 0, 0, 0);
+        mfma_step<ABLATE == 3>(a_cur[0], b01[0], acc[0][0]);
+        mfma_step<ABLATE == 3>(a_cur[1], b01[0], acc[1][0]);
+        mfma_step<ABLATE == 3>(a_cur[0], b01[1], acc[0][1]);
+        mfma_step<ABLATE == 3>(a_cur[1], b01[1], acc[1][1]);
         __builtin_amdgcn_sched_barrier(0);
         if (kk < 3) {
           b01[0] = lds_frag(cur, b_row0, kk + 1, lane);
@@ -150,8 +166,8 @@ __device__ __forceinline__ void gemm_mainloop(const half_t* __restrict__ a_rows,
         if (PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int n = 2; n < Cfg::WN; ++n) {
-          acc[0][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_cur[0], brest[n - 2], acc[0][n], 0, 0, 0);
-          acc[1][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_cur[1], brest[n - 2], acc[1][n], 0, 0, 0);
+          mfma_step<ABLATE == 3>(a_cur[0], brest[n - 2], acc[0][n]);
+          mfma_step<ABLATE == 3>(a_cur[1], brest[n - 2], acc[1][n]);
         }
         if (PRIO) __builtin_amdgcn_s_setprio(0);
         if (kk < 3) { a_cur[0] = a_nxt[0]; a_cur[1] = a_nxt[1]; }
@@ -178,6 +194,118 @@ __device__ __forceinline__ void gemm_mainloop(const half_t* __restrict__ a_rows,
           for (int n = 0; n < Cfg::WN; ++n)
             if (ABLATE != 2) acc[a][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[a], bf[n], acc[a][n], 0, 0, 0);
             else { asm volatile("" :: "v"(af[a]), "v"(bf[n])); }      // ABLATE 2: timing-only build without MFMAs
+      }
+    }
+  }
+}
+
+// ================================================================================================
+// v_mfma_f32_16x16x32_f16 body (same LDS image, same staging, same barrier structure).
+// The chip holds a higher clock on this MFMA shape than on 32x32x16 (measured here: the identical
+// loop with the instruction swapped ran 121 vs 139 us), so the headline tile class uses it.
+//   A/B fragment: lane l holds row (l&15), k = 8*(l>>4) + j of a 32-deep step (one ds_read_b128)
+//   C/D (16x16) : col = lane&15, row = 4*(lane>>4) + reg, reg = 0..3
+// A wave owns RT x CT accumulator tiles (RT = 2*WM row tiles, CT = 2*WN column tiles).  Per 32-deep
+// step the RT A-fragments stay in registers while the B-fragments stream through a 3-deep ring in
+// groups of two column tiles (8 MFMAs = 128 cycles per group); the next step's A-fragments are
+// fetched one per group.  Only the first fragments after each barrier expose an LDS latency.
+// ================================================================================================
+__device__ __forceinline__ half8 lds_frag16(const char* stage, int row, int k32, int lane) {
+  const int logical = k32 * 4 + (lane >> 4);
+  const int phys = logical ^ ((row >> 1) & 7);
+  return *reinterpret_cast<const half8*>(stage + row * 128 + phys * 16);
+}
+
+template <class Cfg, bool SPREAD = true>
+__device__ __forceinline__ void gemm_mainloop16(const half_t* __restrict__ a_rows, const half_t* __restrict__ b_rows,
+                                                int64_t ldk, int ktiles, char* smem,
+                                                f32x4 (&acc)[2 * Cfg::WM][2 * Cfg::WN]) {
+  constexpr int RT = 2 * Cfg::WM, CT = 2 * Cfg::WN;
+  static_assert(RT == 4, "written for a 64-row wave tile");
+  constexpr int CPW = Cfg::CHUNKS_PER_WAVE;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  const int wm = wave / Cfg::WGN, wn = wave % Cfg::WGN;
+  const uint32_t lane_off = stage_lane_offset<Cfg>(ldk, wave, lane);
+  const int a_row0 = wm * Cfg::WM * 32 + (lane & 15);
+  const int b_row0 = Cfg::BM + wn * Cfg::WN * 32 + (lane & 15);
+
+  gemm_stage<Cfg>(a_rows, nullptr, Cfg::BM, b_rows, ldk, 0, smem, wave, lane_off);
+  for (int kt = 0; kt < ktiles; ++kt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    const char* cur = smem + (kt & 1) * Cfg::STAGE_BYTES;
+    const bool refill = kt + 1 < ktiles;
+    char* nxt = smem + ((kt + 1) & 1) * Cfg::STAGE_BYTES;
+    if (!SPREAD && refill) gemm_stage<Cfg>(a_rows, nullptr, Cfg::BM, b_rows, ldk, kt + 1, nxt, wave, lane_off);
+
+    // Three clusters of 16 MFMAs (RT row tiles x 4 column tiles = 256 pipe cycles) per 32-deep step.
+    // B fragments alternate between two register groups of four; the next group's reads are issued
+    // ahead of the current cluster's MFMAs.  The last cluster of a step runs row-tile-major so that
+    // each A fragment dies early and its register takes the next step's fragment.
+    static_assert(CT == 12, "three clusters of four column tiles");
+    half8 a[RT], bA[4], bB[4];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) a[rt] = lds_frag16(cur, a_row0 + rt * 16, 0, lane);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bA[j] = lds_frag16(cur, b_row0 + j * 16, 0, lane);
+#pragma unroll
+    for (int k32 = 0; k32 < 2; ++k32) {
+      // ---- cluster 0: column tiles 0..3 (bA); fetch 4..7 into bB
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bB[j] = lds_frag16(cur, b_row0 + (4 + j) * 16, k32, lane);
+      if (SPREAD && refill) {
+        if (k32 == 0) gemm_stage<Cfg, 0, (CPW + 5) / 6>(a_rows, nullptr, Cfg::BM, b_rows, ldk, kt + 1, nxt, wave, lane_off);
+        else gemm_stage<Cfg, (3 * CPW + 5) / 6, (4 * CPW + 5) / 6>(a_rows, nullptr, Cfg::BM, b_rows, ldk, kt + 1, nxt, wave, lane_off);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+          acc[rt][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[rt], bA[j], acc[rt][j], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- cluster 1: column tiles 4..7 (bB); fetch 8..11 into bA
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bA[j] = lds_frag16(cur, b_row0 + (8 + j) * 16, k32, lane);
+      if (SPREAD && refill) {
+        if (k32 == 0) gemm_stage<Cfg, (CPW + 5) / 6, (2 * CPW + 5) / 6>(a_rows, nullptr, Cfg::BM, b_rows, ldk, kt + 1, nxt, wave, lane_off);
+        else gemm_stage<Cfg, (4 * CPW + 5) / 6, (5 * CPW + 5) / 6>(a_rows, nullptr, Cfg::BM, b_rows, ldk, kt + 1, nxt, wave, lane_off);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+          acc[rt][4 + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[rt], bB[j], acc[rt][4 + j], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- cluster 2: column tiles 8..11 (bA), row-tile-major; fetch the next step's first fragments
+      if (k32 == 0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bB[j] = lds_frag16(cur, b_row0 + j * 16, 1, lane);
+      }
+      if (SPREAD && refill) {
+        if (k32 == 0) gemm_stage<Cfg, (2 * CPW + 5) / 6, (3 * CPW + 5) / 6>(a_rows, nullptr, Cfg::BM, b_rows, ldk, kt + 1, nxt, wave, lane_off);
+        else gemm_stage<Cfg, (5 * CPW + 5) / 6, CPW>(a_rows, nullptr, Cfg::BM, b_rows, ldk, kt + 1, nxt, wave, lane_off);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[rt][8 + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[rt], bA[j], acc[rt][8 + j], 0, 0, 0);
+        if (k32 == 0) a[rt] = lds_frag16(cur, a_row0 + rt * 16, 1, lane);      // a[rt] is dead: reuse its register
+      }
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (k32 == 0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bA[j] = bB[j];
       }
     }
   }

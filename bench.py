@@ -66,8 +66,8 @@ def kernel_roofline(im, s, il, sl, iters=50):
     ms = e0.elapsed_time(e1) / iters
     flops = B * B * 2 * 32 * (T - 3) * D
     achieved = flops / (ms * 1e-3) / 1e12
-    traffic, src = pmc_traffic('align_scores_kernel')
-    return {'bound': 'mfma', 'traffic_source': src, 'kernel': 'align_scores_kernel<4,2,1,3,true,2,3> (256x384 tile, pipelined fragments)', 'achieved': round(achieved, 2), 'peak': PEAK_TFLOPS,
+    traffic, src = pmc_traffic('align_scores16_kernel')
+    return {'bound': 'mfma', 'traffic_source': src, 'kernel': 'align_scores16_kernel<true> (256x384 tile, v_mfma_f32_16x16x32_f16)', 'achieved': round(achieved, 2), 'peak': PEAK_TFLOPS,
             'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_TFLOPS, 4), 'traffic': traffic,
             'kernel_us': round(ms * 1e3, 2), 'flops_per_launch': flops}
 
