@@ -86,7 +86,15 @@ def compute_sim_matrix(img, cap, img_len=None, cap_len=None, mode='matching'):
         if mode == 'alignment':
             if img_len is None or cap_len is None:
                 raise ValueError("compute_sim_matrix(mode='alignment') needs img_len and cap_len")
-            return ops.alignment_scores(img, cap, img_len, cap_len)
+            # encode_data pads every set to 71 positions (alad/evaluation.py:98-99,120-125).  Positions
+            # at or beyond the longest real length are masked out by alad/loss.py:103-116 whatever
+            # they hold, and the "[1:-2]" slice never reaches a real word of the longest caption
+            # (its last scored word sits at index len-3), so trimming both sets to the maximum
+            # length -- what the training path does, alad_model.py:174-175 -- changes no score while
+            # shrinking the padded 70 x 68 block per pair to the real one.
+            r_eff = min(img.shape[1], max(2, max(int(v) for v in img_len)))
+            t_eff = min(cap.shape[1], max(4, max(int(v) for v in cap_len)))
+            return ops.alignment_scores(img[:, :r_eff], cap[:, :t_eff], img_len, cap_len)
     raise ValueError("mode must be 'matching' or 'alignment'")
 
 

@@ -11,7 +11,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
 
-from aladin_amd import ops, synth
+from aladin_amd import evaluation as E, ops, synth
 
 
 def timed(fn, iters=10, warm=2):
@@ -44,10 +44,12 @@ def main():
     ia = torch.from_numpy(images[0::5]).to(dev)
     ca = torch.from_numpy(captions).to(dev)
     ilen = il[0::5]
-    ms_align = timed(lambda: ops.alignment_scores(ia, ca, ilen, cl), iters=5)
+    ms_align = timed(lambda: E.compute_sim_matrix(ia, ca, ilen, cl, mode='alignment'), iters=5)
+    ms_align_padded = timed(lambda: ops.alignment_scores(ia, ca, ilen, cl), iters=3)
     pairs = n * 5 * n
-    print(json.dumps({'workload': 'alignment-head grid 1000x5000 at L=71 (70x68 after slicing)', 'ms': round(ms_align, 3),
-                      'pairs_per_s': round(pairs / ms_align * 1e3, 1)}))
+    print(json.dumps({'workload': 'alignment-head grid 1000x5000, sets padded to L=71, trimmed to the longest real length',
+                      'ms': round(ms_align, 3), 'pairs_per_s': round(pairs / ms_align * 1e3, 1),
+                      'ms_untrimmed_70x68': round(ms_align_padded, 3)}))
 
 
 if __name__ == '__main__':
