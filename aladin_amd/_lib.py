@@ -9,25 +9,26 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'lib', 'libaladin_hip.so')
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 # every symbol include/aladin_hip.h declares (tests check that the library exports all of them)
 SYMBOLS = [
-    'aladin_version', 'aladin_last_error', 'aladin_align_geometry', 'aladin_align_pack_images',
+    'aladin_version', 'aladin_last_error', 'aladin_align_geometry', 'aladin_align_geometry_ex',
+    'aladin_align_pack_images',
     'aladin_align_pack_captions', 'aladin_align_pack_both', 'aladin_align_scores', 'aladin_align_scores_ex',
     'aladin_align_bwd_workspace_bytes',
     'aladin_align_bwd', 'aladin_align_bwd_packed', 'aladin_hinge_workspace_bytes', 'aladin_hinge_fwd_bwd',
     'aladin_hinge_fused',
     'aladin_listnet_workspace_bytes', 'aladin_listnet_fwd_bwd', 'aladin_sgemm_strided',
     'aladin_sim_workspace_bytes', 'aladin_sim_matrix', 'aladin_recall_workspace_bytes',
-    'aladin_recall_ranks',
+    'aladin_recall_ranks', 'aladin_normsum_fwd', 'aladin_normsum_bwd',
 ]
 
 
 class AlignGeom(C.Structure):
     """struct aladin_align_geom."""
     _fields_ = [(n, C.c_int32) for n in ('Bi', 'Bc', 'R', 'T', 'D', 'Rq', 'Tq', 'mtiles', 'rem', 'tp16', 'Dp',
-                                         'img_unit', 'cap_unit', 'Bi_pad', 'Bc_pad')] + \
+                                         'img_unit', 'cap_unit', 'Bi_pad', 'Bc_pad', 'x_tail', 'y_tail', 'reserved_')] + \
                [(n, C.c_int64) for n in ('xm_rows', 'xe_rows', 'y_rows', 'xm_bytes', 'xe_bytes', 'y_bytes',
                                          'e_bytes')]
 
@@ -42,6 +43,7 @@ def _declare(lib):
         'aladin_version': (C.c_int, []),
         'aladin_last_error': (C.c_char_p, []),
         'aladin_align_geometry': (C.c_int, [i32, i32, i32, i32, i32, G]),
+        'aladin_align_geometry_ex': (C.c_int, [i32, i32, i32, i32, i32, i32, i32, G]),
         'aladin_align_pack_images': (C.c_int, [p, i64, i64, p, G, p, p, p]),
         'aladin_align_pack_captions': (C.c_int, [p, i64, i64, p, G, p, p]),
         'aladin_align_pack_both': (C.c_int, [p, i64, i64, p, p, i64, i64, p, G, p, p, p, p]),
@@ -58,6 +60,8 @@ def _declare(lib):
         'aladin_sgemm_strided': (C.c_int, [i32, i32, i32, p, i64, i64, p, i64, i64, p, i64, p]),
         'aladin_sim_workspace_bytes': (sz, [i32, i32, i32]),
         'aladin_sim_matrix': (C.c_int, [p, i64, p, i64, i32, i32, i32, p, i64, p, p]),
+        'aladin_normsum_fwd': (C.c_int, [p, i64, i64, p, i32, i32, i32, i32, p, p]),
+        'aladin_normsum_bwd': (C.c_int, [p, i64, i64, p, i32, i32, i32, i32, p, p, p]),
         'aladin_recall_workspace_bytes': (sz, [i32]),
         'aladin_recall_ranks': (C.c_int, [p, i64, i32, i32, i32, p, p, p, p, p, p]),
     }

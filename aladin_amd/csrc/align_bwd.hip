@@ -45,8 +45,8 @@ static size_t bwd_ws_layout(int Bi, int Bc, int Tq, char* base, BwdWs* ws) {
 
 extern "C" size_t aladin_align_bwd_workspace_bytes(int Bi, int Bc, int R, int T, int D) {
   (void)R; (void)D;
-  if (Bi < 1 || Bc < 1 || T < 4) return 0;
-  return bwd_ws_layout(Bi, Bc, T - 3, nullptr, nullptr);
+  if (Bi < 1 || Bc < 1 || T < 2) return 0;
+  return bwd_ws_layout(Bi, Bc, T - 1, nullptr, nullptr);      // sized for the longest possible word axis (tail 0)
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -76,7 +76,8 @@ __global__ __launch_bounds__(256) void bwd_compact_kernel(const float* __restric
 __global__ __launch_bounds__(256) void bwd_pair_argmax_kernel(
     const float* __restrict__ im, int64_t im_sb, int64_t im_sr, const int32_t* __restrict__ im_len,
     const float* __restrict__ s, int64_t s_sb, int64_t s_st, const int32_t* __restrict__ s_len, int Bc, int Rq, int Tq,
-    int D, const int* __restrict__ counter, const int* __restrict__ pairs, uint8_t* __restrict__ table, int tstride) {
+    int D, const int* __restrict__ counter, const int* __restrict__ pairs, uint8_t* __restrict__ table, int tstride,
+    int x_tail, int y_tail) {
   __shared__ float blk[PA_MAXR][PA_MAXT + 1];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int h = lane >> 5, l5 = lane & 31;
@@ -85,8 +86,8 @@ __global__ __launch_bounds__(256) void bwd_pair_argmax_kernel(
                    (((uintptr_t)im & 15) == 0) && (((uintptr_t)s & 15) == 0);
   for (int p = blockIdx.x; p < count; p += gridDim.x) {
     const int i = pairs[p] / Bc, j = pairs[p] % Bc;
-    int Li = im_len[i] - 1; Li = Li < 0 ? 0 : (Li > Rq ? Rq : Li);
-    int Lj = s_len[j] - 3; Lj = Lj < 0 ? 0 : (Lj > Tq ? Tq : Lj);
+    int Li = im_len[i] - 1 - x_tail; Li = Li < 0 ? 0 : (Li > Rq ? Rq : Li);
+    int Lj = s_len[j] - 1 - y_tail; Lj = Lj < 0 ? 0 : (Lj > Tq ? Tq : Lj);
     const int ntm = (Li + 31) / 32, ntn = (Lj + 31) / 32;
     __syncthreads();                                   // previous pair's readers are done with blk
     for (int tile = wave; tile < ntm * ntn; tile += 4) {
@@ -162,7 +163,8 @@ __global__ __launch_bounds__(256) void bwd_pair_argmax16_kernel(
     int tpad, int xe_rows, int y_rows, const float* __restrict__ im, int64_t im_sb, int64_t im_sr,
     const int32_t* __restrict__ im_len, const float* __restrict__ s, int64_t s_sb, int64_t s_st,
     const int32_t* __restrict__ s_len, int Bc, int Rq, int Tq, int D, const int* __restrict__ counter,
-    const int* __restrict__ pairs, uint8_t* __restrict__ table, int tstride, int blk_rows, int blk_ld) {
+    const int* __restrict__ pairs, uint8_t* __restrict__ table, int tstride, int blk_rows, int blk_ld, int x_tail,
+    int y_tail) {
   // dynamic LDS: the operand ring of the MFMA phase, re-used afterwards as the score block
   // blk[(blk_rows + 2) x blk_ld] (the two extra rows carry per-word scratch).
   extern __shared__ __attribute__((aligned(16))) char pair_smem[];
@@ -177,8 +179,8 @@ __global__ __launch_bounds__(256) void bwd_pair_argmax16_kernel(
   const int count = *counter;
   for (int p = blockIdx.x; p < count; p += gridDim.x) {
     const int i = pairs[p] / Bc, j = pairs[p] % Bc;
-    int Li = im_len[i] - 1; Li = Li < 0 ? 0 : (Li > Rq ? Rq : Li);
-    int Lj = s_len[j] - 3; Lj = Lj < 0 ? 0 : (Lj > Tq ? Tq : Lj);
+    int Li = im_len[i] - 1 - x_tail; Li = Li < 0 ? 0 : (Li > Rq ? Rq : Li);
+    int Lj = s_len[j] - 1 - y_tail; Lj = Lj < 0 ? 0 : (Lj > Tq ? Tq : Lj);
     __syncthreads();                                   // everyone is done with the previous pair's blk
     if (threadIdx.x == 0) ncand = 0;
     // operand panels: rows [0,32) = the image's 32 main regions, rows [32,64) = 32 consecutive rows
@@ -349,7 +351,8 @@ __global__ __launch_bounds__(256) void bwd_rows_kernel(
     const float* __restrict__ im, int64_t im_sb, int64_t im_sr, const int32_t* __restrict__ im_len,
     const float* __restrict__ s, int64_t s_sb, int64_t s_st, const int32_t* __restrict__ s_len, int Bi, int Bc, int R,
     int T, int D, const float* __restrict__ dS, int64_t ld, const float* __restrict__ gscale,
-    const uint8_t* __restrict__ table, int tstride, float* __restrict__ d_im, float* __restrict__ d_s) {
+    const uint8_t* __restrict__ table, int tstride, float* __restrict__ d_im, float* __restrict__ d_s, int x_tail,
+    int y_tail) {
   __shared__ int lst_p[4][ROWS_LIST];
   __shared__ float lst_g[4][ROWS_LIST];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -357,7 +360,7 @@ __global__ __launch_bounds__(256) void bwd_rows_kernel(
   const int64_t n_im_rows = (int64_t)Bi * R;
   if (row >= n_im_rows + (int64_t)Bc * T) return;
   const bool is_img = row < n_im_rows;
-  const int Rq = R - 1, Tq = T - 3;
+  const int Rq = R - 1 - x_tail, Tq = T - 1 - y_tail;
 
   int own_b, own_p;           // owner sample and position inside it
   float* out;
@@ -366,8 +369,8 @@ __global__ __launch_bounds__(256) void bwd_rows_kernel(
   else { const int64_t q = row - n_im_rows; own_b = (int)(q / T); own_p = (int)(q % T); out = d_s + q * D; xrow = s + own_b * s_sb + (int64_t)own_p * s_st; }
   const int idx = own_p - 1;  // region / word index inside the alignment
   int L;
-  if (is_img) { L = im_len[own_b] - 1; L = L < 0 ? 0 : (L > Rq ? Rq : L); }
-  else { L = s_len[own_b] - 3; L = L < 0 ? 0 : (L > Tq ? Tq : L); }
+  if (is_img) { L = im_len[own_b] - 1 - x_tail; L = L < 0 ? 0 : (L > Rq ? Rq : L); }
+  else { L = s_len[own_b] - 1 - y_tail; L = L < 0 ? 0 : (L > Tq ? Tq : L); }
 
   RowAcc<NCH> acc;
   acc.zero();
@@ -514,10 +517,11 @@ static int align_bwd_impl(const float* im, int64_t im_sb, int64_t im_sr, const i
                           int64_t s_sb, int64_t s_st, const int32_t* s_len, int Bi, int Bc, int R, int T, int D,
                           const float* dS, int64_t ld_dS, const float* gscale, const void* xm, const void* xe,
                           const void* y, const aladin_align_geom* g, const int32_t* pairs_in, const int32_t* count_in,
-                          float* d_im, float* d_s, void* workspace, void* stream) {
+                          float* d_im, float* d_s, void* workspace, void* stream, int x_tail = 0, int y_tail = 2) {
   if (!im || !s || !im_len || !s_len || !dS || !d_im || !d_s || !workspace) { aladin_set_error("align_bwd: null argument"); return ALADIN_ERR_ARG; }
-  if (Bi < 1 || Bc < 1 || R < 2 || T < 4 || D < 1 || ld_dS < Bc) { aladin_set_error("align_bwd: bad sizes"); return ALADIN_ERR_ARG; }
-  if (R - 1 > PA_MAXR - 2 || R - 1 >= NO_GRAD || T - 3 > PA_MAXT) { aladin_set_error("align_bwd: at most %d regions / %d words", PA_MAXR - 2, PA_MAXT); return ALADIN_ERR_UNSUPPORTED; }
+  if (Bi < 1 || Bc < 1 || R < 2 + x_tail || T < 2 + y_tail || D < 1 || ld_dS < Bc) { aladin_set_error("align_bwd: bad sizes"); return ALADIN_ERR_ARG; }
+  const int Rq = R - 1 - x_tail;
+  if (Rq > PA_MAXR - 2 || Rq >= NO_GRAD || T - 1 - y_tail > PA_MAXT) { aladin_set_error("align_bwd: at most %d regions / %d words", PA_MAXR - 2, PA_MAXT); return ALADIN_ERR_UNSUPPORTED; }
   if (D % 4 != 0 || D > 1024 || im_sb % 4 || im_sr % 4 || s_sb % 4 || s_st % 4 || ((uintptr_t)im & 15) || ((uintptr_t)s & 15)) {
     aladin_set_error("align_bwd: needs D %% 4 == 0, D <= 1024 and 16-byte aligned rows (D=%d)", D);
     return ALADIN_ERR_UNSUPPORTED;
@@ -529,7 +533,7 @@ static int align_bwd_impl(const float* im, int64_t im_sb, int64_t im_sr, const i
   }
   hipStream_t st = (hipStream_t)stream;
   BwdWs ws;
-  const int Tq = T - 3, tstride = table_stride(Tq);
+  const int Tq = T - 1 - y_tail, tstride = table_stride(Tq);
   bwd_ws_layout(Bi, Bc, Tq, (char*)workspace, &ws);
   const int64_t n = (int64_t)Bi * Bc;
   int rc = ALADIN_OK;
@@ -551,12 +555,12 @@ static int align_bwd_impl(const float* im, int64_t im_sb, int64_t im_sr, const i
     if (lds < (size_t)PAIR_STAGES * PairCfg::STAGE_BYTES) lds = (size_t)PAIR_STAGES * PairCfg::STAGE_BYTES;
     hipLaunchKernelGGL(bwd_pair_argmax16_kernel, dim3(pgrid), dim3(256), lds, st, (const half_t*)xm, (const half_t*)xe,
                        (const half_t*)y, g->Dp, g->rem, 16 * g->tp16, (int)g->xe_rows, (int)g->y_rows, im, im_sb, im_sr,
-                       im_len, s, s_sb, s_st, s_len, Bc, R - 1, Tq, D, ws.counter, ws.pairs, ws.table, tstride, blk_rows,
-                       blk_ld);
+                       im_len, s, s_sb, s_st, s_len, Bc, Rq, Tq, D, ws.counter, ws.pairs, ws.table, tstride, blk_rows,
+                       blk_ld, x_tail, y_tail);
     rc = aladin_check_launch("bwd_pair_argmax16_kernel");
   } else {
     hipLaunchKernelGGL(bwd_pair_argmax_kernel, dim3(pgrid), dim3(256), 0, st, im, im_sb, im_sr, im_len, s, s_sb, s_st,
-                       s_len, Bc, R - 1, Tq, D, ws.counter, ws.pairs, ws.table, tstride);
+                       s_len, Bc, Rq, Tq, D, ws.counter, ws.pairs, ws.table, tstride, x_tail, y_tail);
     rc = aladin_check_launch("bwd_pair_argmax_kernel");
   }
   if (rc) return rc;
@@ -565,7 +569,7 @@ static int align_bwd_impl(const float* im, int64_t im_sb, int64_t im_sr, const i
   const int nch = (D + 255) / 256;
 #define LAUNCH_ROWS(N)                                                                                                  \
   hipLaunchKernelGGL(bwd_rows_kernel<N>, dim3(rgrid), dim3(256), 0, st, im, im_sb, im_sr, im_len, s, s_sb, s_st, s_len, \
-                     Bi, Bc, R, T, D, dS, ld_dS, gscale, ws.table, tstride, d_im, d_s)
+                     Bi, Bc, R, T, D, dS, ld_dS, gscale, ws.table, tstride, d_im, d_s, x_tail, y_tail)
   switch (nch) {
     case 1: LAUNCH_ROWS(1); break;
     case 2: LAUNCH_ROWS(2); break;
@@ -591,5 +595,6 @@ extern "C" int aladin_align_bwd_packed(const float* im, int64_t im_sb, int64_t i
                                        float* d_im, float* d_s, void* workspace, void* stream) {
   if (!geom) { aladin_set_error("align_bwd_packed: null geometry"); return ALADIN_ERR_ARG; }
   return align_bwd_impl(im, im_sb, im_sr, im_len, s, s_sb, s_st, s_len, geom->Bi, geom->Bc, geom->R, geom->T, geom->D, dS,
-                        ld_dS, gscale, xm, xe, y, geom, pairs, pair_count, d_im, d_s, workspace, stream);
+                        ld_dS, gscale, xm, xe, y, geom, pairs, pair_count, d_im, d_s, workspace, stream, geom->x_tail,
+                        geom->y_tail);
 }

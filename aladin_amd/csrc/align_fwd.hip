@@ -37,11 +37,17 @@ static int scores_strip_mult(int tp16, int mtiles) {
 }
 
 extern "C" int aladin_align_geometry(int Bi, int Bc, int R, int T, int D, aladin_align_geom* g) {
+  return aladin_align_geometry_ex(Bi, Bc, R, T, D, 0, 2, g);       // images: drop region 0; captions: token 0 and the last two
+}
+
+extern "C" int aladin_align_geometry_ex(int Bi, int Bc, int R, int T, int D, int x_tail, int y_tail, aladin_align_geom* g) {
   if (!g || Bi < 1 || Bc < 1 || D < 1) { aladin_set_error("align_geometry: bad sizes Bi=%d Bc=%d D=%d", Bi, Bc, D); return ALADIN_ERR_ARG; }
-  if (R < 2 || T < 4) { aladin_set_error("align_geometry: need R >= 2 and T >= 4 (got R=%d T=%d): region 0, token 0 and the last two tokens are dropped", R, T); return ALADIN_ERR_ARG; }
+  if (x_tail < 0 || y_tail < 0 || x_tail > 8 || y_tail > 8) { aladin_set_error("align_geometry: bad tails %d %d", x_tail, y_tail); return ALADIN_ERR_ARG; }
+  if (R < 2 + x_tail || T < 2 + y_tail) { aladin_set_error("align_geometry: sets too short (R=%d T=%d): position 0 and the last %d / %d positions are dropped", R, T, x_tail, y_tail); return ALADIN_ERR_ARG; }
   memset(g, 0, sizeof(*g));
   g->Bi = Bi; g->Bc = Bc; g->R = R; g->T = T; g->D = D;
-  g->Rq = R - 1; g->Tq = T - 3;
+  g->x_tail = x_tail; g->y_tail = y_tail;
+  g->Rq = R - 1 - x_tail; g->Tq = T - 1 - y_tail;
   if (g->Rq > 96 || g->Tq > 96) { aladin_set_error("align_geometry: at most 97 regions / 99 tokens supported (got R=%d T=%d)", R, T); return ALADIN_ERR_UNSUPPORTED; }
   if (g->Rq > 32 && g->Rq % 32 == 1 && g->Rq < 96) { g->mtiles = g->Rq / 32; g->rem = 1; }
   else { g->mtiles = cdiv(g->Rq, 32); g->rem = 0; }
@@ -99,7 +105,7 @@ __device__ __forceinline__ void pack_row(const float* __restrict__ src, half_t* 
 }
 
 __global__ __launch_bounds__(256) void pack_images_kernel(const float* __restrict__ im, int64_t sb, int64_t sr,
-                                                          const int32_t* __restrict__ im_len, int Bi, int Rq, int D,
+                                                          const int32_t* __restrict__ im_len, int Bi, int Rq, int x_tail, int D,
                                                           int Dp, int mtiles, int rem, int64_t xm_rows,
                                                           int64_t total_rows, half_t* __restrict__ xm,
                                                           half_t* __restrict__ xe, int vec4) {
@@ -121,7 +127,7 @@ __global__ __launch_bounds__(256) void pack_images_kernel(const float* __restric
   }
   const float* src = nullptr;
   if (i < Bi) {
-    int Li = im_len[i] - 1;                       // alad/loss.py:89
+    int Li = im_len[i] - 1 - x_tail;              // alad/loss.py:89
     Li = Li < 0 ? 0 : (Li > Rq ? Rq : Li);
     if (rho < Li) src = im + i * sb + (int64_t)(rho + 1) * sr;     // region 0 dropped (alad/loss.py:87)
   }
@@ -129,7 +135,7 @@ __global__ __launch_bounds__(256) void pack_images_kernel(const float* __restric
 }
 
 __global__ __launch_bounds__(256) void pack_captions_kernel(const float* __restrict__ s, int64_t sb, int64_t st,
-                                                            const int32_t* __restrict__ s_len, int Bc, int Tq, int D,
+                                                            const int32_t* __restrict__ s_len, int Bc, int Tq, int y_tail, int D,
                                                             int Dp, int tpad, int64_t total_rows,
                                                             half_t* __restrict__ y, int vec4) {
   const int lane = threadIdx.x & 63;
@@ -138,7 +144,7 @@ __global__ __launch_bounds__(256) void pack_captions_kernel(const float* __restr
   const int j = (int)(d / tpad), w = (int)(d % tpad);
   const float* src = nullptr;
   if (j < Bc) {
-    int Lj = s_len[j] - 3;                        // alad/loss.py:90
+    int Lj = s_len[j] - 1 - y_tail;               // alad/loss.py:90
     Lj = Lj < 0 ? 0 : (Lj > Tq ? Tq : Lj);
     if (w < Lj) src = s + j * sb + (int64_t)(w + 1) * st;          // token 0 dropped (alad/loss.py:88)
   }
@@ -149,7 +155,7 @@ __global__ __launch_bounds__(256) void pack_captions_kernel(const float* __restr
 __global__ __launch_bounds__(256) void pack_both_kernel(const float* __restrict__ im, int64_t isb, int64_t isr,
                                                         const int32_t* __restrict__ im_len, const float* __restrict__ s,
                                                         int64_t ssb, int64_t sst, const int32_t* __restrict__ s_len, int Bi,
-                                                        int Bc, int Rq, int Tq, int D, int Dp, int mtiles, int64_t xm_rows,
+                                                        int Bc, int Rq, int Tq, int x_tail, int y_tail, int D, int Dp, int mtiles, int64_t xm_rows,
                                                         int64_t img_rows, int64_t total_rows, int tpad,
                                                         half_t* __restrict__ xm, half_t* __restrict__ xe,
                                                         half_t* __restrict__ y, int vec_i, int vec_s) {
@@ -173,7 +179,7 @@ __global__ __launch_bounds__(256) void pack_both_kernel(const float* __restrict_
       dst = xe + (d - xm_rows) * Dp;
     }
     if (i < Bi) {
-      int Li = im_len[i] - 1;
+      int Li = im_len[i] - 1 - x_tail;
       Li = Li < 0 ? 0 : (Li > Rq ? Rq : Li);
       if (rho < Li) src = im + i * isb + (int64_t)(rho + 1) * isr;
     }
@@ -182,7 +188,7 @@ __global__ __launch_bounds__(256) void pack_both_kernel(const float* __restrict_
     const int64_t q = d - img_rows;
     const int j = (int)(q / tpad), w = (int)(q % tpad);
     if (j < Bc) {
-      int Lj = s_len[j] - 3;
+      int Lj = s_len[j] - 1 - y_tail;
       Lj = Lj < 0 ? 0 : (Lj > Tq ? Tq : Lj);
       if (w < Lj) src = s + j * ssb + (int64_t)(w + 1) * sst;
     }
@@ -202,7 +208,7 @@ extern "C" int aladin_align_pack_images(const float* im, int64_t stride_b, int64
   const int64_t total = g->xm_rows + g->xe_rows;
   const unsigned grid = (unsigned)((total + 3) / 4);
   hipLaunchKernelGGL(pack_images_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, im, stride_b, stride_r, im_len,
-                     g->Bi, g->Rq, g->D, g->Dp, g->mtiles, g->rem, g->xm_rows, total, (half_t*)xm, (half_t*)xe,
+                     g->Bi, g->Rq, g->x_tail, g->D, g->Dp, g->mtiles, g->rem, g->xm_rows, total, (half_t*)xm, (half_t*)xe,
                      is_vec4_ok(im, stride_b, stride_r, g->D));
   return aladin_check_launch("pack_images_kernel");
 }
@@ -212,7 +218,7 @@ extern "C" int aladin_align_pack_captions(const float* s, int64_t stride_b, int6
   if (!s || !s_len || !g || !y) { aladin_set_error("align_pack_captions: null argument"); return ALADIN_ERR_ARG; }
   const unsigned grid = (unsigned)((g->y_rows + 3) / 4);
   hipLaunchKernelGGL(pack_captions_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, s, stride_b, stride_t, s_len,
-                     g->Bc, g->Tq, g->D, g->Dp, 16 * g->tp16, g->y_rows, (half_t*)y,
+                     g->Bc, g->Tq, g->y_tail, g->D, g->Dp, 16 * g->tp16, g->y_rows, (half_t*)y,
                      is_vec4_ok(s, stride_b, stride_t, g->D));
   return aladin_check_launch("pack_captions_kernel");
 }
@@ -223,7 +229,7 @@ extern "C" int aladin_align_pack_both(const float* im, int64_t im_stride_b, int6
   if (!im || !im_len || !s || !s_len || !g || !xm || !y || (g->rem && !xe)) { aladin_set_error("align_pack_both: null argument"); return ALADIN_ERR_ARG; }
   const int64_t img_rows = g->xm_rows + g->xe_rows, total = img_rows + g->y_rows;
   hipLaunchKernelGGL(pack_both_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, (hipStream_t)stream, im, im_stride_b,
-                     im_stride_r, im_len, s, s_stride_b, s_stride_t, s_len, g->Bi, g->Bc, g->Rq, g->Tq, g->D, g->Dp, g->mtiles,
+                     im_stride_r, im_len, s, s_stride_b, s_stride_t, s_len, g->Bi, g->Bc, g->Rq, g->Tq, g->x_tail, g->y_tail, g->D, g->Dp, g->mtiles,
                      g->xm_rows, img_rows, total, 16 * g->tp16, (half_t*)xm, (half_t*)xe, (half_t*)y,
                      is_vec4_ok(im, im_stride_b, im_stride_r, g->D), is_vec4_ok(s, s_stride_b, s_stride_t, g->D));
   return aladin_check_launch("pack_both_kernel");

@@ -53,23 +53,30 @@ class Contrastive(nn.Module):
 
 
 class AlignmentContrastiveLoss(Contrastive):
-    """reference alad/loss.py:70-159.  aggregation: 'MrSw' (all shipped configs) and 'MrAVGw'
-    (= MrSw divided by the caption length, :126-129)."""
+    """reference alad/loss.py:70-159.  aggregation: 'MrSw' (all shipped configs), 'MrAVGw' (= MrSw
+    divided by the caption length, :126-129), 'MwSr' / 'symm' (the MrSw kernels with the sets'
+    roles swapped, :130-135), 'sum' / 'mean' (:120-123: the double sum of cosines factorises into
+    one dot product of the summed unit vectors).  'scan-sentences' is not provided."""
 
     def __init__(self, margin=0, measure=False, max_violation=False, aggregation='sum-max-sentences'):
         super().__init__(margin, measure, max_violation)
         self.aggregation = aggregation
 
     def forward(self, im_set, s_seq, im_len, s_len, return_loss=True, return_similarity_mat=False):
-        if self.aggregation not in ('MrSw', 'MrAVGw'):
-            raise NotImplementedError("aladin_amd: alignment aggregation %r is not implemented in HIP yet "
-                                      "(supported: 'MrSw', 'MrAVGw')" % (self.aggregation,))
+        if self.aggregation not in ('MrSw', 'MrAVGw', 'MwSr', 'symm', 'sum', 'mean'):
+            raise NotImplementedError("aladin_amd: alignment aggregation %r is not implemented in HIP "
+                                      "(supported: 'MrSw', 'MrAVGw', 'MwSr', 'symm', 'sum', 'mean')" % (self.aggregation,))
         if return_loss and self.aggregation == 'MrSw':
             # fused scores + hinge node; the returned matrix is detached (see ops.alignment_triplet_loss)
             loss, aggr_similarity = ops.alignment_triplet_loss(im_set, s_seq, im_len, s_len, self.margin,
                                                                self.max_violation)
             return (loss, aggr_similarity) if return_similarity_mat else loss
-        aggr_similarity = ops.alignment_scores(im_set, s_seq, im_len, s_len)
+        if self.aggregation in ('sum', 'mean'):
+            aggr_similarity = ops.alignment_sum_scores(im_set, s_seq, im_len, s_len, mean=(self.aggregation == 'mean'))
+        elif self.aggregation in ('MwSr', 'symm'):
+            aggr_similarity = ops.alignment_scores(im_set, s_seq, im_len, s_len, self.aggregation)
+        else:
+            aggr_similarity = ops.alignment_scores(im_set, s_seq, im_len, s_len)
         if self.aggregation == 'MrAVGw':
             lens = ops.lengths_tensor(s_len, aggr_similarity.device).to(torch.float32) - 3.0
             aggr_similarity = aggr_similarity / lens.unsqueeze(0)

@@ -66,12 +66,14 @@ def _workspace(nbytes, device):
 _GEOM_CACHE = {}
 
 
-def align_geometry(Bi, Bc, R, T, D):
-    key = (Bi, Bc, R, T, D)
+def align_geometry(Bi, Bc, R, T, D, x_tail=0, y_tail=2):
+    """Packed layout for a (max-side set Bi x R) x (sum-side set Bc x T) problem; the tails are the
+    trailing positions each set drops (images 0, captions 2 -- reference alad/loss.py:87-90)."""
+    key = (Bi, Bc, R, T, D, x_tail, y_tail)
     g = _GEOM_CACHE.get(key)
     if g is None:
         g = _lib.AlignGeom()
-        _lib.check(_lib.load().aladin_align_geometry(Bi, Bc, R, T, D, C.byref(g)), 'align_geometry')
+        _lib.check(_lib.load().aladin_align_geometry_ex(Bi, Bc, R, T, D, x_tail, y_tail, C.byref(g)), 'align_geometry')
         if len(_GEOM_CACHE) < 1024:
             _GEOM_CACHE[key] = g
     return g
@@ -106,13 +108,14 @@ def scores_from_packed(xm, xe, y, geom, out=None, e_scratch=None, reuse_side=Fal
     return S
 
 
-def _align_forward(im, s, im_len_t, s_len_t):
-    """-> (S, packed) where packed = (geom, xm, xe, y) is kept for the backward pass."""
+def _align_forward(im, s, im_len_t, s_len_t, x_tail=0, y_tail=2):
+    """-> (S, packed) where packed = (geom, xm, xe, y) is kept for the backward pass.
+    `im` is the max-side set, `s` the sum-side set (images / captions for 'MrSw')."""
     Bi, R, D = im.shape
     Bc, T, D2 = s.shape
     if D != D2:
         raise ValueError('aladin_amd: feature sizes differ (%d vs %d)' % (D, D2))
-    geom = align_geometry(Bi, Bc, R, T, D)
+    geom = align_geometry(Bi, Bc, R, T, D, x_tail, y_tail)
     im = _rows_inner_contig(im)
     s = _rows_inner_contig(s)
     xm = torch.empty(geom.xm_bytes // 2, dtype=torch.float16, device=im.device)
@@ -124,7 +127,7 @@ def _align_forward(im, s, im_len_t, s_len_t):
     return scores_from_packed(xm, xe, y, geom), (geom, xm, xe, y)
 
 
-def _align_backward(im, s, im_len_t, s_len_t, dS, gscale=None, packed=None, pairs=None):
+def _align_backward(im, s, im_len_t, s_len_t, dS, gscale=None, packed=None, pairs=None, x_tails=(0, 2)):
     lib = _lib.load()
     im = _rows_inner_contig(im)
     s = _rows_inner_contig(s)
@@ -134,6 +137,9 @@ def _align_backward(im, s, im_len_t, s_len_t, dS, gscale=None, packed=None, pair
     d_im = torch.empty((Bi, R, D), dtype=torch.float32, device=im.device)
     d_s = torch.empty((Bc, T, D), dtype=torch.float32, device=im.device)
     ws = _workspace(lib.aladin_align_bwd_workspace_bytes(Bi, Bc, R, T, D), im.device)
+    if packed is None:
+        if x_tails != (0, 2):
+            raise NotImplementedError('aladin_amd: the stand-alone backward entry point is the image/caption form')
     if packed is not None:
         geom, xm, xe, y = packed
         _lib.check(lib.aladin_align_bwd_packed(_ptr(im), im.stride(0), im.stride(1), _ptr(im_len_t),
@@ -153,8 +159,8 @@ def _align_backward(im, s, im_len_t, s_len_t, dS, gscale=None, packed=None, pair
 
 class _AlignScores(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, im, s, im_len_t, s_len_t):
-        S, packed = _align_forward(im, s, im_len_t, s_len_t)
+    def forward(ctx, im, s, im_len_t, s_len_t, x_tail, y_tail):
+        S, packed = _align_forward(im, s, im_len_t, s_len_t, x_tail, y_tail)
         if any(ctx.needs_input_grad[:2]):
             ctx.save_for_backward(im, s, im_len_t, s_len_t, packed[1], packed[2], packed[3])
             ctx.geom = packed[0]
@@ -164,7 +170,7 @@ class _AlignScores(torch.autograd.Function):
     def backward(ctx, dS):
         im, s, im_len_t, s_len_t, xm, xe, y = ctx.saved_tensors
         d_im, d_s = _align_backward(im, s, im_len_t, s_len_t, dS, packed=(ctx.geom, xm, xe, y))
-        return d_im, d_s, None, None
+        return d_im, d_s, None, None, None, None
 
 
 def _hinge_raw(scores, margin, max_violation, want_grad, want_pairs=False):
@@ -234,11 +240,56 @@ def alignment_triplet_loss(im_set, s_seq, im_len, s_len, margin, max_violation):
     return _AlignTriplet.apply(im_set, s_seq, im_len_t, s_len_t, margin, max_violation)
 
 
-def alignment_scores(im_set, s_seq, im_len, s_len):
-    """S (Bi, Bc) = sum over words of max over regions of the cosine ('MrSw'), differentiable.
-    Replaces reference alad/loss.py:80-125."""
+def alignment_scores(im_set, s_seq, im_len, s_len, aggregation='MrSw'):
+    """Differentiable S (Bi, Bc); replaces reference alad/loss.py:80-135.
+      'MrSw'  sum over words of the max over regions                       (:124-125)
+      'MwSr'  sum over regions of the max over words: the same kernels with the two sets swapped --
+              captions on the max side (tail 2), images on the sum side (tail 0) -- transposed (:134-135)
+      'symm'  MrSw + MwSr                                                  (:130-133)"""
     im_len_t, s_len_t = _check_sets(im_set, s_seq, im_len, s_len)
-    return _AlignScores.apply(im_set, s_seq, im_len_t, s_len_t)
+    if aggregation == 'MrSw':
+        return _AlignScores.apply(im_set, s_seq, im_len_t, s_len_t, 0, 2)
+    if aggregation == 'MwSr':
+        return _AlignScores.apply(s_seq, im_set, s_len_t, im_len_t, 2, 0).t()
+    if aggregation == 'symm':
+        return _AlignScores.apply(im_set, s_seq, im_len_t, s_len_t, 0, 2) + \
+            _AlignScores.apply(s_seq, im_set, s_len_t, im_len_t, 2, 0).t()
+    raise NotImplementedError('aladin_amd: aggregation %r' % (aggregation,))
+
+
+class _NormSum(torch.autograd.Function):
+    """(B,N,D) set -> (B,D) sum of its L2-normalised rows 1 .. len-1-tail."""
+
+    @staticmethod
+    def forward(ctx, x, len_t, tail):
+        x = _rows_inner_contig(x)
+        B, N, D = x.shape
+        out = torch.empty((B, D), dtype=torch.float32, device=x.device)
+        _lib.check(_lib.load().aladin_normsum_fwd(_ptr(x), x.stride(0), x.stride(1), _ptr(len_t), B, N, D, tail, _ptr(out),
+                                                  _stream()), 'normsum_fwd')
+        ctx.save_for_backward(x, len_t)
+        ctx.tail = tail
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, len_t = ctx.saved_tensors
+        B, N, D = x.shape
+        g = g.contiguous()
+        d_x = torch.empty((B, N, D), dtype=torch.float32, device=x.device)
+        _lib.check(_lib.load().aladin_normsum_bwd(_ptr(x), x.stride(0), x.stride(1), _ptr(len_t), B, N, D, ctx.tail,
+                                                  _ptr(g), _ptr(d_x), _stream()), 'normsum_bwd')
+        return d_x, None, None
+
+
+def alignment_sum_scores(im_set, s_seq, im_len, s_len, mean=False):
+    """'sum' / 'mean' pooling (reference alad/loss.py:120-123): the double sum of masked cosines equals
+    the dot product of the summed unit vectors, so no region x word tensor is formed."""
+    im_len_t, s_len_t = _check_sets(im_set, s_seq, im_len, s_len)
+    S = _DotScores.apply(_NormSum.apply(im_set, im_len_t, 0), _NormSum.apply(s_seq, s_len_t, 2))
+    if mean:
+        S = S / float((im_set.shape[1] - 1) * (s_seq.shape[1] - 3))
+    return S
 
 
 # ------------------------------------------------------------------------------------------------

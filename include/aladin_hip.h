@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define ALADIN_ABI_VERSION 1
+#define ALADIN_ABI_VERSION 2
 
 int aladin_version(void);
 const char* aladin_last_error(void);
@@ -51,13 +51,22 @@ typedef struct aladin_align_geom {
   int32_t Dp;                   /* D rounded up to 64 (zero filled)                             */
   int32_t img_unit, cap_unit;   /* images / captions per workgroup tile                         */
   int32_t Bi_pad, Bc_pad;       /* batch sizes rounded up to the units (zero rows)              */
+  int32_t x_tail, y_tail;       /* positions dropped at the END of the max-side / sum-side sets: the
+                                   set uses positions 1 .. N-1-tail and length len-1-tail.  Images 0
+                                   (alad/loss.py:87,89), captions 2 (:88,90)                      */
+  int32_t reserved_;            /* keeps the 64-bit fields aligned                              */
   int64_t xm_rows, xe_rows, y_rows;            /* rows of the packed fp16 operands              */
   int64_t xm_bytes, xe_bytes, y_bytes;         /* their sizes                                   */
   int64_t e_bytes;              /* fp32 scratch for the side GEMM, xe_rows x y_rows (0 if !rem) */
 } aladin_align_geom;
 
-/* Host-only: derive the packed layout for a problem. */
+/* Host-only: derive the packed layout for a problem ('MrSw': images on the max side). */
 int aladin_align_geometry(int Bi, int Bc, int R, int T, int D, aladin_align_geom* out);
+/* General form: the set on the MAX side (Bi x R) and the set on the SUM side (Bc x T) each state how
+ * many trailing positions they drop.  'MrSw' = (images, tail 0) x (captions, tail 2); 'MwSr'
+ * (alad/loss.py:134-135, max over words, sum over regions) = (captions, tail 2) x (images, tail 0),
+ * result transposed.  Every "image"/"caption" argument below means max-side / sum-side set. */
+int aladin_align_geometry_ex(int Bi, int Bc, int R, int T, int D, int x_tail, int y_tail, aladin_align_geom* out);
 
 /* L2-normalise (eps 1e-12, F.normalize), slice, length-mask and convert the image sets to the
  * packed fp16 MFMA operand.  im[(b*stride_b + r*stride_r) + d], innermost stride 1 (the reference
@@ -106,6 +115,17 @@ int aladin_align_bwd_packed(const float* im, int64_t im_stride_b, int64_t im_str
                             const void* xm, const void* xe, const void* y, const aladin_align_geom* geom,
                             const int32_t* pairs, const int32_t* pair_count,
                             float* d_im, float* d_s, void* workspace, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * 'sum' / 'mean' pooling (alad/loss.py:120-123): sum_r sum_w <im^,s^> = <sum_r im^, sum_w s^>.
+ * normsum: out[b][:] = sum over positions 1 .. len[b]-1-tail of the L2-normalised rows of x (B,N,D);
+ * the scores are then aladin_sgemm_strided(out_img, out_cap^T).  bwd: d_x (B,N,D contiguous, fully
+ * written) from d_out (B,D).
+ * ------------------------------------------------------------------------------------------- */
+int aladin_normsum_fwd(const float* x, int64_t stride_b, int64_t stride_r, const int32_t* len, int B, int N, int D,
+                       int tail, float* out, void* stream);
+int aladin_normsum_bwd(const float* x, int64_t stride_b, int64_t stride_r, const int32_t* len, int B, int N, int D,
+                       int tail, const float* d_out, float* d_x, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * VSE++ hinge loss on a square score matrix -- Contrastive.compute_contrastive_loss,

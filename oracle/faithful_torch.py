@@ -13,8 +13,8 @@ import torch
 import torch.nn.functional as F
 
 
-def alignment_scores_faithful(im_set, s_seq, im_len, s_len):
-    """(Bi, Bc) MrSw scores via the reference's dataflow (alad/loss.py:80-125)."""
+def alignment_scores_faithful(im_set, s_seq, im_len, s_len, aggregation='MrSw'):
+    """(Bi, Bc) scores via the reference's dataflow (alad/loss.py:80-135), differentiable."""
     a = F.normalize(im_set, p=2, dim=2)[:, 1:, :]                  # :80,87
     b = F.normalize(s_seq, p=2, dim=2)[:, 1:-2, :]                 # :81,88
     Bi, Rp = a.shape[0], a.shape[1]
@@ -25,8 +25,20 @@ def alignment_scores_faithful(im_set, s_seq, im_len, s_len):
     rvalid = torch.arange(Rp).unsqueeze(0) < (torch.as_tensor(im_len) - 1).unsqueeze(1)
     wvalid = torch.arange(Tp).unsqueeze(0) < (torch.as_tensor(s_len) - 3).unsqueeze(1)
     dead = ~(rvalid[:, None, :, None] & wvalid[None, :, None, :])  # :103-115
-    al.masked_fill_(dead, 0.0)                                     # :116
-    return al.max(2)[0].sum(2)                                     # :124-125
+    al = al.masked_fill(dead, 0.0)                                 # :116
+    if aggregation == 'MrSw':
+        return al.max(2)[0].sum(2)                                 # :124-125
+    if aggregation == 'MrAVGw':
+        return al.max(2)[0].sum(2) / (torch.as_tensor(s_len, dtype=al.dtype) - 3).unsqueeze(0)   # :126-129
+    if aggregation == 'MwSr':
+        return al.max(3)[0].sum(2)                                 # :134-135
+    if aggregation == 'symm':
+        return al.max(2)[0].sum(2) + al.max(3)[0].sum(2)           # :130-133
+    if aggregation == 'sum':
+        return al.sum(dim=(2, 3))                                  # :120-121
+    if aggregation == 'mean':
+        return al.mean(dim=(2, 3))                                 # :122-123
+    raise ValueError(aggregation)
 
 
 def hinge_faithful(scores, margin, max_violation):

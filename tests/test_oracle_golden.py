@@ -64,6 +64,17 @@ def test_faithful_torch_matches_reference(name):
         close(ds.numpy()[:, :, ::st], g['ds_' + tag], rtol=1e-4, atol=1e-6)
 
 
+@pytest.mark.parametrize('name', ['align_b5_d64', 'align_rect', 'align_r33'])
+@pytest.mark.parametrize('mode', ['MrSw', 'MrAVGw', 'MwSr', 'symm', 'sum', 'mean'])
+def test_faithful_torch_all_modes(name, mode):
+    import torch
+    import faithful_torch as FT
+    g = load_golden(name)
+    im, s, il, sl = golden_alignment_inputs(g)
+    S = FT.alignment_scores_faithful(torch.from_numpy(im), torch.from_numpy(s), il, sl, mode)
+    close(S.numpy(), g['S_' + mode])
+
+
 @pytest.mark.parametrize('name', ['match_b16_d768', 'match_b7_d64'])
 def test_matching(name):
     g = load_golden(name)
