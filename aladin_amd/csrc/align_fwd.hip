@@ -238,29 +238,33 @@ extern "C" int aladin_align_pack_both(const float* im, int64_t im_stride_b, int6
 // ------------------------------------------------------------------------------------------------
 // side GEMM: E[i][col] = <last region of image i, word col>   (fp32, xe_rows x y_rows)
 // ------------------------------------------------------------------------------------------------
-#define SIDE_STAGES 4
-template <int NT>
+#define SIDE_STAGES 3
+template <int NT, int SWM>
 __global__ __launch_bounds__(256) void align_side_gemm_kernel(const half_t* __restrict__ xe, const half_t* __restrict__ y,
                                                               float* __restrict__ E, int64_t ldE, int64_t ldk,
                                                               int ktiles, int n_nblk) {
-  using Cfg = GemmCfg<2, 2, 1, NT>;
+  using Cfg = GemmCfg<2, 2, SWM, NT>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int mb = blockIdx.x / n_nblk, nb = blockIdx.x % n_nblk;
-  f32x16 acc[1][NT];
+  f32x16 acc[SWM][NT];
 #pragma unroll
-  for (int n = 0; n < NT; ++n)
+  for (int m = 0; m < SWM; ++m)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[0][n][r] = 0.f;
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
   gemm_mainloop<Cfg, SIDE_STAGES>(xe + (int64_t)mb * Cfg::BM * ldk, y + (int64_t)nb * Cfg::BN * ldk, ldk, ktiles, smem, acc);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int wm = wave / 2, wn = wave % 2;
-  const int64_t row0 = (int64_t)mb * Cfg::BM + wm * 32 + 4 * (lane >> 5);
+  const int64_t row0 = (int64_t)mb * Cfg::BM + wm * SWM * 32 + 4 * (lane >> 5);
   const int64_t col0 = (int64_t)nb * Cfg::BN + wn * NT * 32 + (lane & 31);
 #pragma unroll
-  for (int n = 0; n < NT; ++n)
+  for (int m = 0; m < SWM; ++m)
 #pragma unroll
-    for (int r = 0; r < 16; ++r)
-      E[(row0 + (r & 3) + 8 * (r >> 2)) * ldE + col0 + n * 32] = acc[0][n][r];
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        E[(row0 + m * 32 + (r & 3) + 8 * (r >> 2)) * ldE + col0 + n * 32] = acc[m][n][r];
 }
 
 // Diagnostic only (SCHED == 6 instantiation, never on the product path): per-workgroup shader-clock
@@ -518,11 +522,11 @@ static int launch_scores(const aladin_align_geom* g, const half_t* xm, const hal
   return launch_scores_w<2, WM, Q, TP16, HAS_E, 1>(g, xm, y, E, S, ldS, stream);
 }
 
-template <int NT>
-static int launch_side(const aladin_align_geom* g, const half_t* xe, const half_t* y, float* E, hipStream_t stream) {
-  using Cfg = GemmCfg<2, 2, 1, NT>;
+template <int NT, int SWM>
+static int launch_side_w(const aladin_align_geom* g, const half_t* xe, const half_t* y, float* E, hipStream_t stream) {
+  using Cfg = GemmCfg<2, 2, SWM, NT>;
   const int n_mblk = (int)(g->xe_rows / Cfg::BM), n_nblk = (int)(g->y_rows / Cfg::BN);
-  auto kern = align_side_gemm_kernel<NT>;
+  auto kern = align_side_gemm_kernel<NT, SWM>;
   constexpr int lds_bytes = SIDE_STAGES * Cfg::STAGE_BYTES;
   static bool attr_done = false;
   if (!attr_done) {
@@ -535,6 +539,15 @@ static int launch_side(const aladin_align_geom* g, const half_t* xe, const half_
   hipLaunchKernelGGL(kern, dim3(n_mblk * n_nblk), dim3(Cfg::THREADS), lds_bytes, stream, xe, y, E, g->y_rows,
                      (int64_t)g->Dp, g->Dp / 64, n_nblk);
   return aladin_check_launch("align_side_gemm_kernel");
+}
+
+template <int NT>
+static int launch_side(const aladin_align_geom* g, const half_t* xe, const half_t* y, float* E, hipStream_t stream) {
+  static int big = -1;
+  if (big < 0) { const char* e = getenv("ALADIN_SIDE_BIG"); big = e ? atoi(e) : 0; }
+  // 128-row tiles halve the LDS-DMA traffic of this fill-bound kernel when there are enough images
+  if (big && g->xe_rows % 128 == 0 && g->xe_rows >= 256) return launch_side_w<NT, 2>(g, xe, y, E, stream);
+  return launch_side_w<NT, 1>(g, xe, y, E, stream);
 }
 
 template <int TP16>
