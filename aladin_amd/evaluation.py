@@ -65,6 +65,48 @@ class LogCollector(object):
             tb_logger.add_scalar(prefix + k, v.val, global_step=step)
 
 
+def encode_data(model, data_loader, log_step=10, logging=print, max_len=71):
+    """reference alad/evaluation.py:80-155 with the embedding store kept ON THE DEVICE.
+
+    Same protocol (model.forward_emb per batch under no_grad, sets zero-padded to `max_len` positions,
+    slot 0 overwritten with the global matching-head embedding, length lists) and same return
+    signature, but `img_embs` / `cap_embs` are float32 CUDA tensors: the reference's per-batch
+    device->host copy (:124-128) and the per-query host->device copies of i2t / t2i
+    (:179,202,267,291) disappear, and compute_sim_matrix() consumes the buffers in place."""
+    import time
+    batch_time = AverageMeter()
+    val_logger = LogCollector()
+    model.eval()
+    end = time.time()
+    img_embs = cap_embs = None
+    img_lengths, cap_lengths = [], []
+    ids_pointer = 0
+    n_total = len(data_loader.dataset)
+    for i, (example_imgs, example_txts) in enumerate(data_loader):
+        model.logger = val_logger
+        with torch.no_grad():
+            img_glob, cap_glob, img_emb, cap_emb, img_length, cap_length, _ = model.forward_emb(example_imgs, example_txts)
+            bs = img_glob.shape[0]
+            if img_embs is None:
+                dev = img_emb.device
+                img_embs = torch.zeros((n_total, max_len, img_emb.size(2)), dtype=torch.float32, device=dev)
+                cap_embs = torch.zeros((n_total, max_len, cap_emb.size(2)), dtype=torch.float32, device=dev)
+            sl = slice(ids_pointer, ids_pointer + bs)
+            img_embs[sl, :img_emb.size(0), :] = img_emb.permute(1, 0, 2)          # (S,B,D) -> (B,S,D)
+            cap_embs[sl, :cap_emb.size(0), :] = cap_emb.permute(1, 0, 2)
+            img_embs[sl, 0, :] = img_glob                                         # I-CLS / T-CLS slots (:127-128)
+            cap_embs[sl, 0, :] = cap_glob
+            img_lengths.extend(img_length)
+            cap_lengths.extend(cap_length)
+            ids_pointer += bs
+        batch_time.update(time.time() - end)
+        end = time.time()
+        if logging is not None and i % log_step == 0:
+            logging('Test: [{0}/{1}]\t{e_log}\tTime {bt.val:.3f} ({bt.avg:.3f})\t'.format(
+                i, len(data_loader), bt=batch_time, e_log=str(model.logger)))
+    return img_embs, cap_embs, img_lengths, cap_lengths
+
+
 def _device():
     if not torch.cuda.is_available():
         raise RuntimeError('aladin_amd: retrieval scoring runs in HIP kernels on an MI355X only (no GPU visible)')

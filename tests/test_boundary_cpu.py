@@ -150,3 +150,43 @@ def test_synth_is_deterministic():
     b = synth.normal((4, 5), 7)
     assert np.array_equal(a, b) and a.dtype == np.float32
     assert abs(float(synth.normal((200000,), 3).std()) - 1.0) < 0.01
+
+
+def test_encode_data_store_layout():
+    """encode_data mirror: (N, 71, D) zero-padded store, slot 0 = global embedding, lengths in order
+    (reference alad/evaluation.py:119-130).  Runs on CPU tensors: it is pure tensor plumbing."""
+    from aladin_amd.evaluation import encode_data
+
+    class FakeModel:
+        logger = None
+
+        def eval(self):
+            return self
+
+        def forward_emb(self, imgs, txts):
+            feats, lens = imgs
+            toks, tl = txts
+            B = feats.shape[0]
+            R, Tn = max(lens), max(tl)
+            return (feats[:, 0, :8] * 0 + 7.0, toks[:, 0, :8] * 0 - 7.0, feats[:, :R, :8].permute(1, 0, 2),
+                    toks[:, :Tn, :8].permute(1, 0, 2), list(lens), list(tl), 0)
+
+    class DS(list):
+        pass
+
+    batches = []
+    rng = np.random.RandomState(0)
+    for b in range(3):
+        lens, tl = [5, 9], [4, 6]
+        batches.append(((torch.from_numpy(rng.randn(2, 12, 8).astype(np.float32)), lens),
+                        (torch.from_numpy(rng.randn(2, 10, 8).astype(np.float32)), tl)))
+
+    class Loader(list):
+        dataset = list(range(6))
+
+    img, cap, il, cl = encode_data(FakeModel(), Loader(batches), logging=None)
+    assert img.shape == (6, 71, 8) and cap.shape == (6, 71, 8)
+    assert il == [5, 9] * 3 and cl == [4, 6] * 3
+    assert torch.all(img[:, 0, :] == 7.0) and torch.all(cap[:, 0, :] == -7.0)
+    assert torch.equal(img[2:4, 1:9, :], batches[1][0][0][:, 1:9, :8]) and torch.all(img[:, 9:, :] == 0)
+    assert torch.equal(cap[4:6, 1:6, :], batches[2][1][0][:, 1:6, :8]) and torch.all(cap[:, 6:, :] == 0)
