@@ -140,6 +140,8 @@ def alignment_scores_backward(im_set, s_seq, im_len, s_len, dS, dtype=np.float64
             if g == 0:
                 continue
             Lj = s_len[j] - 3
+            if Li <= 0 or Lj <= 0:                                 # everything masked: no gradient
+                continue
             A = ih[i, 1:1 + Li] @ sh[j, 1:1 + Lj].T            # (Li, Lj)
             rstar = A.argmax(0)
             for w in range(Lj):

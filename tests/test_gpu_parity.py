@@ -535,3 +535,51 @@ def test_sharded_fast_path_under_rccl_world1():
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def test_degenerate_lengths_and_zero_vectors():
+    """Edge cases the reference's masks define (alad/loss.py:89-116): a caption with s_len = 3 has no
+    scored word (its column of S is exactly 0), s_len = 4 one word, im_len = 2 one region, im_len = 1
+    none (row of S exactly 0); all-zero vectors inside the valid range normalise to 0 (eps 1e-12),
+    not NaN; gradients stay finite and vanish on the dropped positions."""
+    from aladin_amd import ops, synth
+    B, R, Tn, D = 8, 34, 50, 64
+    im, s, il, sl = synth.alignment_batch(B, R, Tn, D, seed=606, ragged=True)
+    sl[0], sl[1], sl[2] = 3, 4, 50
+    il[0], il[1], il[2] = 1, 2, 34
+    im[3, 5] = 0.0                      # a zero region inside the valid range
+    s[4, 3] = 0.0                       # a zero word inside the valid range
+    a, b = T(im).requires_grad_(True), T(s).requires_grad_(True)
+    S = ops.alignment_scores(a, b, il, sl)
+    ref = O.alignment_scores(im, s, il, sl)
+    S_np = S.detach().cpu().numpy()
+    assert np.isfinite(S_np).all()
+    assert np.all(S_np[:, 0] == 0) and np.all(S_np[0, :] == 0)
+    assert_scores_close(S_np, ref, atol_rel=1e-3, scale='max')
+    loss = ops.hinge_loss(S, 0.2, True)
+    loss.backward()
+    ga, gb = a.grad.cpu().numpy(), b.grad.cpu().numpy()
+    assert np.isfinite(ga).all() and np.isfinite(gb).all()
+    assert np.all(ga[0] == 0) and np.all(gb[0] == 0)          # nothing of sample 0 takes part
+    assert np.all(ga[1, 2:] == 0) and np.all(gb[1, 2:] == 0)  # one region / one word
+    assert np.all(ga[3, 5] == 0) and np.all(gb[4, 3] == 0)    # zero vectors: normalise backward gives 0
+    _, dS = O.hinge_loss(S_np, 0.2, True, return_grad=True)
+    dim, ds = O.alignment_scores_backward(im, s, il, sl, dS)
+    for got, want in ((ga, dim), (gb, ds)):
+        scale = max(1e-9, float(np.abs(want).max()))
+        np.testing.assert_allclose(got, want, rtol=1e-3, atol=3e-5 * scale)
+
+
+def test_non_contiguous_and_unaligned_inputs():
+    """Strided views with a contiguous feature axis are consumed in place; anything else is copied by
+    the wrapper (results must not depend on the memory layout)."""
+    from aladin_amd import ops, synth
+    B, R, Tn, D = 6, 20, 25, 96
+    im, s, il, sl = synth.alignment_batch(B, R, Tn, D, seed=707, ragged=True)
+    ref = ops.alignment_scores(T(im), T(s), il, sl)
+    big_i = torch.zeros((B, R, D + 4), device=dev())
+    big_i[:, :, 1:D + 1] = T(im)
+    big_s = torch.zeros((Tn, B, D), device=dev())
+    big_s.copy_(T(s).permute(1, 0, 2))
+    S = ops.alignment_scores(big_i[:, :, 1:D + 1], big_s.permute(1, 0, 2), il, sl)     # misaligned rows + permuted view
+    assert torch.equal(S, ref)
