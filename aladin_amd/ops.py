@@ -56,6 +56,11 @@ def lengths_tensor(lens, device):
     return t
 
 
+def _ld(t):
+    """Leading dimension of a 2-D tensor whose rows are contiguous (stride(0) is arbitrary when there is one row)."""
+    return t.stride(0) if t.shape[0] > 1 else max(t.shape[1], 1)
+
+
 def _workspace(nbytes, device):
     return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
 
@@ -132,6 +137,7 @@ def _align_backward(im, s, im_len_t, s_len_t, dS, gscale=None, packed=None, pair
     im = _rows_inner_contig(im)
     s = _rows_inner_contig(s)
     dS = dS.contiguous()
+    ld_dS = dS.shape[1]            # (not stride(0): a contiguous (1, n) view may report any leading stride)
     Bi, R, D = im.shape
     Bc, T, _ = s.shape
     d_im = torch.empty((Bi, R, D), dtype=torch.float32, device=im.device)
@@ -144,7 +150,7 @@ def _align_backward(im, s, im_len_t, s_len_t, dS, gscale=None, packed=None, pair
         geom, xm, xe, y = packed
         _lib.check(lib.aladin_align_bwd_packed(_ptr(im), im.stride(0), im.stride(1), _ptr(im_len_t),
                                                _ptr(s), s.stride(0), s.stride(1), _ptr(s_len_t),
-                                               _ptr(dS), dS.stride(0), _ptr(gscale), _ptr(xm), _ptr(xe), _ptr(y),
+                                               _ptr(dS), ld_dS, _ptr(gscale), _ptr(xm), _ptr(xe), _ptr(y),
                                                C.byref(geom), _ptr(pairs[0] if pairs else None),
                                                _ptr(pairs[1] if pairs else None), _ptr(d_im), _ptr(d_s), _ptr(ws),
                                                _stream()),
@@ -152,7 +158,7 @@ def _align_backward(im, s, im_len_t, s_len_t, dS, gscale=None, packed=None, pair
     else:
         _lib.check(lib.aladin_align_bwd(_ptr(im), im.stride(0), im.stride(1), _ptr(im_len_t),
                                         _ptr(s), s.stride(0), s.stride(1), _ptr(s_len_t), Bi, Bc, R, T, D,
-                                        _ptr(dS), dS.stride(0), _ptr(gscale), _ptr(d_im), _ptr(d_s), _ptr(ws),
+                                        _ptr(dS), ld_dS, _ptr(gscale), _ptr(d_im), _ptr(d_s), _ptr(ws),
                                         _stream()), 'align_bwd')
     return d_im, d_s
 
@@ -185,7 +191,7 @@ def _hinge_raw(scores, margin, max_violation, want_grad, want_pairs=False):
     pairs = None
     if want_grad and want_pairs:
         pairs = (torch.empty(B * B, dtype=torch.int32, device=dev), torch.empty(1, dtype=torch.int32, device=dev))
-    _lib.check(lib.aladin_hinge_fused(_ptr(sc), sc.stride(0), B, float(margin), int(bool(max_violation)), _ptr(loss),
+    _lib.check(lib.aladin_hinge_fused(_ptr(sc), _ld(sc), B, float(margin), int(bool(max_violation)), _ptr(loss),
                                       _ptr(dS), _ptr(pairs[0] if pairs else None), _ptr(pairs[1] if pairs else None),
                                       _ptr(ws), _stream()), 'hinge_fused')
     return loss, dS, pairs
@@ -325,7 +331,7 @@ class _ListNet(torch.autograd.Function):
         loss = torch.empty((), dtype=torch.float32, device=student.device)
         dM = torch.empty((B, B), dtype=torch.float32, device=student.device) if ctx.needs_input_grad[1] else None
         ws = _workspace(lib.aladin_listnet_workspace_bytes(B), student.device)
-        _lib.check(lib.aladin_listnet_fwd_bwd(_ptr(t), t.stride(0), _ptr(m), m.stride(0), B, float(temperature),
+        _lib.check(lib.aladin_listnet_fwd_bwd(_ptr(t), _ld(t), _ptr(m), _ld(m), B, float(temperature),
                                               float(eps), _ptr(loss), _ptr(dM), _ptr(ws), _stream()), 'listnet_fwd_bwd')
         ctx.dM = dM
         return loss
@@ -395,8 +401,8 @@ def sim_matrix(img, cap):
     n_cap = cap.shape[0]
     sim = torch.empty((n_img, n_cap), dtype=torch.float32, device=img.device)
     ws = _workspace(lib.aladin_sim_workspace_bytes(n_img, n_cap, D), img.device)
-    _lib.check(lib.aladin_sim_matrix(_ptr(img), img.stride(0), _ptr(cap), cap.stride(0), n_img, n_cap, D, _ptr(sim),
-                                     sim.stride(0), _ptr(ws), _stream()), 'sim_matrix')
+    _lib.check(lib.aladin_sim_matrix(_ptr(img), _ld(img), _ptr(cap), _ld(cap), n_img, n_cap, D, _ptr(sim),
+                                     _ld(sim), _ptr(ws), _stream()), 'sim_matrix')
     return sim
 
 
@@ -413,6 +419,6 @@ def recall_ranks(sim, caps_per_img=5):
     r_t2i = torch.empty(n_cap, dtype=torch.int32, device=dev)
     t_t2i = torch.empty(n_cap, dtype=torch.int32, device=dev)
     ws = _workspace(lib.aladin_recall_workspace_bytes(n_cap), dev)
-    _lib.check(lib.aladin_recall_ranks(_ptr(sim), sim.stride(0), n_img, n_cap, caps_per_img, _ptr(r_i2t), _ptr(t_i2t),
+    _lib.check(lib.aladin_recall_ranks(_ptr(sim), _ld(sim), n_img, n_cap, caps_per_img, _ptr(r_i2t), _ptr(t_i2t),
                                        _ptr(r_t2i), _ptr(t_t2i), _ptr(ws), _stream()), 'recall_ranks')
     return r_i2t, t_i2t, r_t2i, t_t2i

@@ -583,3 +583,22 @@ def test_non_contiguous_and_unaligned_inputs():
     big_s.copy_(T(s).permute(1, 0, 2))
     S = ops.alignment_scores(big_i[:, :, 1:D + 1], big_s.permute(1, 0, 2), il, sl)     # misaligned rows + permuted view
     assert torch.equal(S, ref)
+
+
+def test_single_sample_sides_backward():
+    """Regression (found by tools/fuzz_parity.py): with one caption (or one image) the upstream
+    gradient is a one-row / one-column matrix whose reported leading stride is arbitrary."""
+    import faithful_torch as FT
+    from aladin_amd import ops, synth
+    for (Bi, Bc, mode) in ((29, 1, 'MwSr'), (1, 9, 'MrSw'), (1, 1, 'symm'), (7, 1, 'MrSw')):
+        im, s, il, sl = synth.alignment_batch(Bi, 20, 18, 64, seed=900 + Bi + Bc, ragged=True, Bc=Bc)
+        a, b = T(im).requires_grad_(True), T(s).requires_grad_(True)
+        S = ops.alignment_scores(a, b, il, sl, mode)
+        w = T(np.random.RandomState(Bi).randn(Bi, Bc).astype(np.float32))
+        (S * w).sum().backward()
+        ra, rb = torch.from_numpy(im).requires_grad_(True), torch.from_numpy(s).requires_grad_(True)
+        (FT.alignment_scores_faithful(ra, rb, il, sl, mode) * w.cpu()).sum().backward()
+        for got, want in ((a.grad, ra.grad), (b.grad, rb.grad)):
+            want = want.numpy()
+            scale = max(1e-9, float(np.abs(want).max()))
+            np.testing.assert_allclose(got.cpu().numpy(), want, rtol=1e-3, atol=5e-5 * scale)
