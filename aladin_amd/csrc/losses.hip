@@ -96,32 +96,35 @@ __global__ __launch_bounds__(256) void hinge_finish_kernel(const float* __restri
     if (threadIdx.x == 0) *loss = rs + cs;
   }
   if (dS == nullptr && pairs == nullptr) return;
-  const int64_t n = (int64_t)B * B;
+  // rows are dealt to blocks, columns to threads: no integer division per element
   const int lane = threadIdx.x & 63;
-  for (int64_t e0 = (int64_t)blockIdx.x * blockDim.x; e0 < n; e0 += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t e = e0 + threadIdx.x;
-    float g = 0.f;
-    if (e < n) {
-    const int i = (int)(e / B), j = (int)(e % B);
-    if (max_violation) {
-      if (i == j) g = -(float)((val[i] > 0.f) + (val[B + i] > 0.f));
-      else g = (float)((val[i] > 0.f && arg[i] == j) + (val[B + j] > 0.f && arg[B + j] == i));
-    } else {
-      if (i == j) g = -(float)(arg[i] + arg[B + i]);
-      else {
-        const float s = S[(int64_t)i * ld + j];
-        g = (float)((margin + s - S[(int64_t)i * ld + i] > 0.f) + (margin + s - S[(int64_t)j * ld + j] > 0.f));
+  for (int i = blockIdx.x; i < B; i += gridDim.x) {
+    const float rv = val[i], di = S[(int64_t)i * ld + i];
+    const int ra = arg[i];
+    for (int j0 = 0; j0 < B; j0 += blockDim.x) {
+      const int j = j0 + threadIdx.x;
+      float g = 0.f;
+      if (j < B) {
+        if (max_violation) {
+          if (i == j) g = -(float)((rv > 0.f) + (val[B + i] > 0.f));
+          else g = (float)((rv > 0.f && ra == j) + (val[B + j] > 0.f && arg[B + j] == i));
+        } else {
+          if (i == j) g = -(float)(ra + arg[B + i]);
+          else {
+            const float s = S[(int64_t)i * ld + j];
+            g = (float)((margin + s - di > 0.f) + (margin + s - S[(int64_t)j * ld + j] > 0.f));
+          }
+        }
+        if (dS) dS[(int64_t)i * B + j] = g;
       }
-    }
-    if (dS) dS[e] = g;
-    }
-    if (pairs) {                                          // list of non-zero pairs for the alignment backward
-      const unsigned long long mask = __ballot(g != 0.f);
-      if (mask) {
-        int base = 0;
-        if (lane == 0) base = atomicAdd(pair_count, __popcll(mask));
-        base = __shfl(base, 0, 64);
-        if (g != 0.f) pairs[base + __popcll(mask & ((1ull << lane) - 1))] = (int)e;
+      if (pairs) {                                        // list of non-zero pairs for the alignment backward
+        const unsigned long long mask = __ballot(g != 0.f);
+        if (mask) {
+          int base = 0;
+          if (lane == 0) base = atomicAdd(pair_count, __popcll(mask));
+          base = __shfl(base, 0, 64);
+          if (g != 0.f) pairs[base + __popcll(mask & ((1ull << lane) - 1))] = i * B + j;
+        }
       }
     }
   }
@@ -139,8 +142,7 @@ static int hinge_impl(const float* S, int64_t ldS, int B, float margin, int max_
                      pairs ? pair_count : nullptr);
   int rc = aladin_check_launch("hinge_stats_kernel");
   if (rc) return rc;
-  const int64_t n = (int64_t)B * B;
-  const int grid = (dS || pairs) ? (int)((n + 1023) / 1024 < 2048 ? (n + 1023) / 1024 : 2048) : 1;
+  const int grid = (dS || pairs) ? (B < 2048 ? B : 2048) : 1;
   hipLaunchKernelGGL(hinge_finish_kernel, dim3(grid < 1 ? 1 : grid), dim3(256), 0, st, S, ldS, B, margin, max_violation, val,
                      arg, loss, dS, pairs, pair_count);
   return aladin_check_launch("hinge_finish_kernel");
