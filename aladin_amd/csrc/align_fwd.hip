@@ -270,6 +270,13 @@ __global__ __launch_bounds__(256) void align_side_gemm_kernel(const half_t* __re
 // Diagnostic only (SCHED == 6 instantiation, never on the product path): per-workgroup shader-clock
 // and 100 MHz real-time deltas around the main loop -> in-kernel clock = d(memtime)/d(memrealtime) * 100 MHz.
 __device__ unsigned long long g_clock_probe[4 * 4096];
+__device__ unsigned long long g_clock_cycles[2048];
+
+extern "C" int aladin_debug_read_clock_cycles(unsigned long long* host_out, int n_blocks) {
+  if (!host_out || n_blocks < 1 || n_blocks > 2048) { aladin_set_error("debug_read_clock_cycles: bad argument"); return ALADIN_ERR_ARG; }
+  if (hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_clock_cycles), (size_t)n_blocks * 8) != hipSuccess) { aladin_set_error("debug_read_clock_cycles: copy failed"); return ALADIN_ERR_HIP; }
+  return ALADIN_OK;
+}
 
 extern "C" int aladin_debug_read_clock_probe(unsigned long long* host_out, int n_blocks) {
   if (!host_out || n_blocks < 1 || n_blocks > 4096) { aladin_set_error("debug_read_clock_probe: bad argument"); return ALADIN_ERR_ARG; }
@@ -403,24 +410,10 @@ static int scores_wgm() {
 //   sum over words   : a caption is exactly 3 column tiles -> in-lane adds, then a 16-lane reduction
 // ------------------------------------------------------------------------------------------------
 template <bool HAS_E>
-__global__ __launch_bounds__(512) void align_scores16_kernel(const half_t* __restrict__ xm, const half_t* __restrict__ y,
-                                                             const float* __restrict__ E, int64_t ldE,
-                                                             float* __restrict__ S, int64_t ldS, int Bi, int Bc,
-                                                             int64_t ldk, int ktiles, int n_nblk, int n_blocks) {
+__device__ __forceinline__ void scores16_epilogue(f32x4 (&acc)[4][12], int mb, int nb, const float* __restrict__ E,
+                                                  int64_t ldE, float* __restrict__ S, int64_t ldS, int Bi, int Bc) {
   using Cfg = GemmCfg<4, 2, 2, 6>;
-  constexpr int RT = 4, CT = 12;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  int mb, nb;
-  tile_coords(blockIdx.x, n_blocks / n_nblk, n_nblk, 4, mb, nb);
-
-  f32x4 acc[RT][CT];
-#pragma unroll
-  for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-    for (int ct = 0; ct < CT; ++ct) acc[rt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  gemm_mainloop16<Cfg, true>(xm + (int64_t)mb * Cfg::BM * ldk, y + (int64_t)nb * Cfg::BN * ldk, ldk, ktiles, smem, acc);
-
+  constexpr int CT = 12;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int wm = wave / 2, wn = wave % 2;
   const int half = lane >> 5, l4 = lane & 15;
@@ -450,7 +443,42 @@ __global__ __launch_bounds__(512) void align_scores16_kernel(const half_t* __res
   }
 }
 
-template <bool HAS_E>
+template <bool HAS_E, bool PROBE = false>
+__global__ __launch_bounds__(512) void align_scores16_kernel(const half_t* __restrict__ xm, const half_t* __restrict__ y,
+                                                             const float* __restrict__ E, int64_t ldE,
+                                                             float* __restrict__ S, int64_t ldS, int Bi, int Bc,
+                                                             int64_t ldk, int ktiles, int n_nblk, int n_blocks) {
+  using Cfg = GemmCfg<4, 2, 2, 6>;
+  constexpr int RT = 4, CT = 12;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int mb, nb;
+  tile_coords(blockIdx.x, n_blocks / n_nblk, n_nblk, 4, mb, nb);
+
+  f32x4 acc[RT][CT];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) acc[rt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  unsigned long long pt0 = 0, pr0 = 0, pt1 = 0, pr1 = 0;
+  if constexpr (PROBE) { pt0 = __builtin_amdgcn_s_memtime(); pr0 = __builtin_amdgcn_s_memrealtime(); }
+  gemm_mainloop16<Cfg, true>(xm + (int64_t)mb * Cfg::BM * ldk, y + (int64_t)nb * Cfg::BN * ldk, ldk, ktiles, smem, acc);
+  if constexpr (PROBE) { pt1 = __builtin_amdgcn_s_memtime(); pr1 = __builtin_amdgcn_s_memrealtime(); }
+
+  scores16_epilogue<HAS_E>(acc, mb, nb, E, ldE, S, ldS, Bi, Bc);
+  if constexpr (PROBE) {
+    __syncthreads();
+    if (threadIdx.x == 0 && blockIdx.x < 4096) {
+      g_clock_probe[4 * blockIdx.x + 1] = pr1 - pr0;
+      g_clock_probe[4 * blockIdx.x + 2] = pr0;
+      g_clock_probe[4 * blockIdx.x + 3] = pr1;
+      g_clock_probe[4 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
+    }
+    if (threadIdx.x == 64 && blockIdx.x < 2048) g_clock_cycles[blockIdx.x] = pt1 - pt0;
+  }
+}
+
+template <bool HAS_E, bool PROBE = false>
 static int launch_scores16(const aladin_align_geom* g, const half_t* xm, const half_t* y, const float* E, float* S,
                            int64_t ldS, hipStream_t stream) {
   using Cfg = GemmCfg<4, 2, 2, 6>;
@@ -459,7 +487,7 @@ static int launch_scores16(const aladin_align_geom* g, const half_t* xm, const h
     aladin_set_error("align_scores16: packed rows do not tile");
     return ALADIN_ERR_ARG;
   }
-  auto kern = align_scores16_kernel<HAS_E>;
+  auto kern = align_scores16_kernel<HAS_E, PROBE>;
   static bool attr_done = false;
   if (!attr_done) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES) != hipSuccess) {
@@ -506,6 +534,7 @@ static int launch_scores(const aladin_align_geom* g, const half_t* xm, const hal
   if constexpr (TP16 == 3 && Q == 1)
     if (scores_strip_mult(TP16, g->mtiles) == 2) {
       if (scores_spread() == 16) return launch_scores16<HAS_E>(g, xm, y, E, S, ldS, stream);      // 16x16x32 body
+      if (scores_spread() == 26) return launch_scores16<HAS_E, true>(g, xm, y, E, S, ldS, stream); // + clock probe (diagnostic)
       switch (scores_spread()) {                       // ALADIN_ALIGN_SPREAD: 16 (default) = 16x16x32 body above; 0/1/2/3 = 32x32x16 schedules
         case 0: return launch_scores_w<4, WM, Q, TP16, HAS_E, 2, 0>(g, xm, y, E, S, ldS, stream);
         case 2: return launch_scores_w<4, WM, Q, TP16, HAS_E, 2, 2>(g, xm, y, E, S, ldS, stream);

@@ -7,7 +7,7 @@ import os
 import sys
 import time
 
-os.environ['ALADIN_ALIGN_SPREAD'] = '6'
+os.environ['ALADIN_ALIGN_SPREAD'] = os.environ.get('PROBE_SCHED', '26')      # 26: 16x16x32 kernel, 6: 32x32x16 kernel
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
@@ -40,6 +40,14 @@ raw = np.array(buf, dtype=np.uint64).reshape(nb, 4)
 loop_rt = raw[:, 1].astype(np.float64)
 r0, r1, rexit = raw[:, 2].astype(np.float64), raw[:, 3].astype(np.float64), raw[:, 0].astype(np.float64)
 print('per workgroup (100 MHz ticks -> us): main loop %.2f, epilogue (loop end -> exit) %.2f' % (np.median(loop_rt) / 100, np.median(rexit - r1) / 100))
+if os.environ['ALADIN_ALIGN_SPREAD'] == '26':
+    lib.aladin_debug_read_clock_cycles.restype = C.c_int
+    cyc = (C.c_ulonglong * nb)()
+    assert lib.aladin_debug_read_clock_cycles(cyc, nb) == 0
+    cyc = np.array(cyc, dtype=np.float64)
+    clk = cyc / loop_rt * 100e6
+    print('main-loop shader cycles per workgroup: median %.0f -> in-kernel clock %.3f GHz (p10 %.3f, p90 %.3f); MFMA pipe cycles per tile per SIMD 36864 -> pipe busy %.1f %% of the loop'
+          % (np.median(cyc), np.median(clk) / 1e9, np.percentile(clk, 10) / 1e9, np.percentile(clk, 90) / 1e9, 100.0 * 36864 / np.median(cyc)))
 start = r0.min()
 print('kernel span: first loop start -> last exit %.2f us; loop start times per round (us, sorted sample): %s' % ((rexit.max() - start) / 100, np.round(np.sort((r0 - start) / 100)[::128], 1)))
 sys.exit(0)
