@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'lib', 'libaladin_hip.so')
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 # every symbol include/aladin_hip.h declares (tests check that the library exports all of them)
 SYMBOLS = [
@@ -19,7 +19,9 @@ SYMBOLS = [
     'aladin_align_bwd_workspace_bytes',
     'aladin_align_bwd', 'aladin_align_bwd_packed', 'aladin_hinge_workspace_bytes', 'aladin_hinge_fwd_bwd',
     'aladin_hinge_fused',
-    'aladin_listnet_workspace_bytes', 'aladin_listnet_fwd_bwd', 'aladin_sgemm_strided',
+    'aladin_listnet_workspace_bytes', 'aladin_listnet_fwd_bwd',
+    'aladin_distill_workspace_bytes', 'aladin_distill_mse_fwd_bwd', 'aladin_distill_contrastive_fwd_bwd',
+    'aladin_distill_ordinal_fwd_bwd', 'aladin_order_sim_fwd', 'aladin_order_sim_bwd', 'aladin_sgemm_strided',
     'aladin_sim_workspace_bytes', 'aladin_sim_matrix', 'aladin_recall_workspace_bytes',
     'aladin_recall_ranks', 'aladin_normsum_fwd', 'aladin_normsum_bwd',
 ]
@@ -57,6 +59,12 @@ def _declare(lib):
         'aladin_hinge_fused': (C.c_int, [p, i64, i32, f32, i32, p, p, p, p, p, p]),
         'aladin_listnet_workspace_bytes': (sz, [i32]),
         'aladin_listnet_fwd_bwd': (C.c_int, [p, i64, p, i64, i32, f32, f32, p, p, p, p]),
+        'aladin_distill_workspace_bytes': (sz, [i32]),
+        'aladin_distill_mse_fwd_bwd': (C.c_int, [p, i64, p, i64, i32, p, p, p, p, p, p]),
+        'aladin_distill_contrastive_fwd_bwd': (C.c_int, [p, i64, p, i64, i32, f32, p, p, p, p]),
+        'aladin_distill_ordinal_fwd_bwd': (C.c_int, [p, i64, p, i64, i32, f32, f32, i32, p, p, p, p]),
+        'aladin_order_sim_fwd': (C.c_int, [p, i64, p, i64, i32, i32, i32, p, i64, p]),
+        'aladin_order_sim_bwd': (C.c_int, [p, i64, p, i64, i32, i32, i32, p, i64, p, i64, p, i64, p, i64, p]),
         'aladin_sgemm_strided': (C.c_int, [i32, i32, i32, p, i64, i64, p, i64, i64, p, i64, p]),
         'aladin_sim_workspace_bytes': (sz, [i32, i32, i32]),
         'aladin_sim_matrix': (C.c_int, [p, i64, p, i64, i32, i32, i32, p, i64, p, p]),

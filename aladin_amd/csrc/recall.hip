@@ -250,8 +250,10 @@ extern "C" int aladin_recall_ranks(const float* sim, int64_t ld_sim, int n_img, 
   int rc = aladin_check_launch("rank_i2t_kernel");
   if (rc) return rc;
   unsigned long long* packed = (unsigned long long*)workspace;
-  hipMemsetAsync(packed, 0, (size_t)n_cap * 8, st);
-  hipMemsetAsync(rank_t2i, 0, (size_t)n_cap * 4, st);
+  if (hipMemsetAsync(packed, 0, (size_t)n_cap * 8, st) != hipSuccess || hipMemsetAsync(rank_t2i, 0, (size_t)n_cap * 4, st) != hipSuccess) {
+    aladin_set_error("recall_ranks: hipMemsetAsync failed");
+    return ALADIN_ERR_HIP;
+  }
   const int ysplit = n_img >= 2048 ? 16 : (n_img >= 256 ? 4 : 1);
   const int rpb = cdiv(n_img, ysplit);
   hipLaunchKernelGGL(rank_t2i_kernel, dim3(cdiv(n_cap, 256), ysplit), dim3(256), 0, st, sim, ld_sim, n_img, n_cap,

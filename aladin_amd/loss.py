@@ -6,10 +6,10 @@
     DistillationLoss          <- alad/loss.py:359-447
     Contrastive               <- alad/loss.py:29-67 (shared hinge)
 
-None of them holds parameters or buffers (DistillationLoss only in the unsupported 'mse' mode), so
-state dicts saved by the reference load unchanged (checkpoint row).
-Modes outside the shipped configs raise NotImplementedError rather
-than fall back to eager PyTorch.
+None of them holds parameters or buffers, except DistillationLoss(mode='mse') whose learnable pair
+`wb` the reference has too (:366) -- state dicts saved by the reference load unchanged (SURVEY.md
+section 5, checkpoint row).  The one mode not provided (aggregation 'scan-sentences') raises
+NotImplementedError rather than fall back to eager PyTorch.
 """
 import torch
 from torch import nn
@@ -33,6 +33,11 @@ def cosine_sim(im, s):
     return ops.dot_scores(l2norm(im), l2norm(s))
 
 
+def order_sim(im, s):
+    """reference alad/loss.py:20-26."""
+    return ops.order_scores(im, s)
+
+
 class Contrastive(nn.Module):
     """reference alad/loss.py:29-67."""
 
@@ -40,8 +45,7 @@ class Contrastive(nn.Module):
         super().__init__()
         self.margin = margin
         if measure == 'order':
-            raise NotImplementedError("aladin_amd: measure='order' is not on the accelerated path "
-                                      "(no shipped ALADIN config uses it)")
+            self.sim = order_sim
         elif measure == 'cosine':
             self.sim = cosine_sim
         elif measure == 'dot':
@@ -102,17 +106,23 @@ class ContrastiveLoss(Contrastive):
 
 
 class DistillationLoss(nn.Module):
-    """reference alad/loss.py:359-447; mode 'listnet' (every shipped config)."""
+    """reference alad/loss.py:359-447: modes 'mse', 'ordinal', 'contrastive', 'listnet' (the one every
+    shipped config uses)."""
 
     def __init__(self, mode='mse', margin=0.2, threshold=0.1, stride=3):
         super().__init__()
-        if mode != 'listnet':
-            raise NotImplementedError("aladin_amd: distillation mode %r is not implemented in HIP yet "
-                                      "(supported: 'listnet')" % (mode,))
+        if mode not in ('mse', 'ordinal', 'contrastive', 'listnet'):
+            # the reference would leave `loss` unbound and fail at :447
+            raise ValueError('aladin_amd: unknown distillation mode %r' % (mode,))
         self.mode = mode
         self.margin = margin
         self.threshold = threshold
         self.stride = stride
+        if mode == 'mse':
+            self.wb = nn.Parameter(torch.FloatTensor([0.5, 0.5]), requires_grad=True)     # :366
 
     def forward(self, teacher_scores, student_scores):
-        return ops.listnet_loss(teacher_scores, student_scores, temperature=6.0, eps=1e-10)
+        if self.mode == 'listnet':
+            return ops.listnet_loss(teacher_scores, student_scores, temperature=6.0, eps=1e-10)
+        return ops.distillation_loss(teacher_scores, student_scores, self.mode, self.margin, self.threshold,
+                                     self.stride, wb=self.wb if self.mode == 'mse' else None)

@@ -350,6 +350,93 @@ def listnet_loss(teacher_scores, student_scores, temperature=6.0, eps=1e-10):
     return _ListNet.apply(teacher_scores.detach(), student_scores, temperature, eps)
 
 
+class _DistillMode(torch.autograd.Function):
+    """mse / contrastive / ordinal distillation: forward computes loss and d student in one call."""
+
+    @staticmethod
+    def forward(ctx, teacher, student, wb, mode, margin, threshold, stride):
+        lib = _lib.load()
+        B = student.shape[0]
+        t = teacher if teacher.stride(1) == 1 else teacher.contiguous()
+        m = student if student.stride(1) == 1 else student.contiguous()
+        dev = student.device
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        dM = torch.empty((B, B), dtype=torch.float32, device=dev) if ctx.needs_input_grad[1] else None
+        ws = _workspace(lib.aladin_distill_workspace_bytes(B), dev)
+        ctx.dwb = None
+        if mode == 'mse':
+            w = wb.detach().to(torch.float32).contiguous()
+            ctx.dwb = torch.empty(2, dtype=torch.float32, device=dev) if ctx.needs_input_grad[2] else None
+            _lib.check(lib.aladin_distill_mse_fwd_bwd(_ptr(t), _ld(t), _ptr(m), _ld(m), B, _ptr(w), _ptr(loss), _ptr(dM),
+                                                      _ptr(ctx.dwb), _ptr(ws), _stream()), 'distill_mse_fwd_bwd')
+        elif mode == 'contrastive':
+            _lib.check(lib.aladin_distill_contrastive_fwd_bwd(_ptr(t), _ld(t), _ptr(m), _ld(m), B, float(margin), _ptr(loss),
+                                                              _ptr(dM), _ptr(ws), _stream()), 'distill_contrastive_fwd_bwd')
+        else:
+            _lib.check(lib.aladin_distill_ordinal_fwd_bwd(_ptr(t), _ld(t), _ptr(m), _ld(m), B, float(margin),
+                                                          float(threshold), int(stride), _ptr(loss), _ptr(dM), _ptr(ws),
+                                                          _stream()), 'distill_ordinal_fwd_bwd')
+        ctx.dM = dM
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        return (None, ctx.dM * g if ctx.dM is not None else None, ctx.dwb * g if ctx.dwb is not None else None,
+                None, None, None, None)
+
+
+def distillation_loss(teacher_scores, student_scores, mode, margin=0.2, threshold=0.1, stride=3, wb=None):
+    """DistillationLoss modes 'mse' / 'contrastive' / 'ordinal'; replaces reference alad/loss.py:371-425
+    (teacher detached, :370).  ``wb`` is the learnable (2,) pair of the 'mse' mode (:366)."""
+    _require_gpu(teacher_scores, student_scores)
+    if mode not in ('mse', 'contrastive', 'ordinal'):
+        raise ValueError('aladin_amd: unknown distillation mode %r' % (mode,))
+    if teacher_scores.shape != student_scores.shape or student_scores.dim() != 2 \
+            or student_scores.shape[0] != student_scores.shape[1]:
+        raise ValueError('aladin_amd: distillation needs two square score matrices of equal shape')
+    if mode == 'mse':
+        if wb is None or wb.numel() != 2:
+            raise ValueError("aladin_amd: mode 'mse' needs the (2,) parameter wb")
+        _require_gpu(wb)
+    elif mode == 'ordinal' and not 1 <= int(stride) < student_scores.shape[0]:
+        raise ValueError('aladin_amd: ordinal distillation needs 1 <= stride < B')
+    return _DistillMode.apply(teacher_scores.detach(), student_scores, wb, mode, margin, threshold, stride)
+
+
+class _OrderScores(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, im, s):
+        lib = _lib.load()
+        a = im if im.stride(1) == 1 else im.contiguous()
+        b = s if s.stride(1) == 1 else s.contiguous()
+        out = torch.empty((a.shape[0], b.shape[0]), dtype=torch.float32, device=a.device)
+        _lib.check(lib.aladin_order_sim_fwd(_ptr(a), a.stride(0), _ptr(b), b.stride(0), a.shape[0], b.shape[0], a.shape[1],
+                                            _ptr(out), out.stride(0), _stream()), 'order_sim_fwd')
+        ctx.save_for_backward(a, b, out)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        a, b, out = ctx.saved_tensors
+        g = g.contiguous()
+        d_im = torch.empty_like(a) if ctx.needs_input_grad[0] else None
+        d_s = torch.empty_like(b) if ctx.needs_input_grad[1] else None
+        _lib.check(lib.aladin_order_sim_bwd(_ptr(a), a.stride(0), _ptr(b), b.stride(0), a.shape[0], b.shape[0], a.shape[1],
+                                            _ptr(g), _ld(g), _ptr(out), out.stride(0), _ptr(d_im),
+                                            d_im.stride(0) if d_im is not None else 0, _ptr(d_s),
+                                            d_s.stride(0) if d_s is not None else 0, _stream()), 'order_sim_bwd')
+        return d_im, d_s
+
+
+def order_scores(im, s):
+    """-||max(s_j - im_i, 0)||; replaces order_sim, reference alad/loss.py:20-26."""
+    _require_gpu(im, s)
+    if im.dim() != 2 or s.dim() != 2 or im.shape[1] != s.shape[1]:
+        raise ValueError('aladin_amd: (Bi,D) and (Bc,D) embeddings expected')
+    return _OrderScores.apply(im, s)
+
+
 # ------------------------------------------------------------------------------------------------
 # dot-product scores (matching head)
 # ------------------------------------------------------------------------------------------------

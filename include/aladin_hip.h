@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define ALADIN_ABI_VERSION 2
+#define ALADIN_ABI_VERSION 3
 
 int aladin_version(void);
 const char* aladin_last_error(void);
@@ -149,6 +149,34 @@ size_t aladin_listnet_workspace_bytes(int B);
 int aladin_listnet_fwd_bwd(const float* teacher, int64_t ld_t, const float* student, int64_t ld_s, int B,
                            float temperature, float eps, float* loss, float* d_student,
                            void* workspace, void* stream);
+
+/* The other modes of DistillationLoss, reference alad/loss.py:359-425 (teacher detached :370).
+ * One workspace query covers the three of them.  d_student (B x B contiguous) may be NULL.
+ *   mse          :371-373  mean((student*wb[0] + wb[1] - teacher)^2); wb = the module's learnable
+ *                          pair (:366), a DEVICE pointer; d_wb (2 floats, may be NULL) receives its gradient
+ *   contrastive  :401-425  as written: teacher diagonal zeroed, its row argmax selects whole columns
+ *                          of cost_s and its column argmax whole rows of cost_im, diagonals kept
+ *   ordinal      :374-399  per-row and per-column teacher sort, strided hinge on the student in that
+ *                          order where teacher_sorted[p + stride] >= threshold; a side with no selected
+ *                          position makes the loss NaN and contributes a zero gradient (as torch). B <= 8192 */
+size_t aladin_distill_workspace_bytes(int B);
+int aladin_distill_mse_fwd_bwd(const float* teacher, int64_t ld_t, const float* student, int64_t ld_s, int B,
+                               const float* wb, float* loss, float* d_student, float* d_wb, void* workspace,
+                               void* stream);
+int aladin_distill_contrastive_fwd_bwd(const float* teacher, int64_t ld_t, const float* student, int64_t ld_s, int B,
+                                       float margin, float* loss, float* d_student, void* workspace, void* stream);
+int aladin_distill_ordinal_fwd_bwd(const float* teacher, int64_t ld_t, const float* student, int64_t ld_s, int B,
+                                   float margin, float threshold, int stride, float* loss, float* d_student,
+                                   void* workspace, void* stream);
+
+/* Order-embedding similarity -- order_sim, reference alad/loss.py:20-26 (measure='order'):
+ * scores[i][j] = -|| max(s_j - im_i, 0) ||_2, and its backward given d_scores and the forward's scores
+ * (a pair without any violation has 0/0 = NaN gradient, as autograd).  d_im / d_s may be NULL. */
+int aladin_order_sim_fwd(const float* im, int64_t ld_im, const float* s, int64_t ld_s, int Bi, int Bc, int D,
+                         float* scores, int64_t ld_scores, void* stream);
+int aladin_order_sim_bwd(const float* im, int64_t ld_im, const float* s, int64_t ld_s, int Bi, int Bc, int D,
+                         const float* d_scores, int64_t ld_g, const float* scores, int64_t ld_scores,
+                         float* d_im, int64_t ld_dim, float* d_s, int64_t ld_ds, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Dot-product scores  C[m][n] = sum_k A[m*a_rs + k*a_cs] * B[k*b_rs + n*b_cs]   (fp32 in/out,

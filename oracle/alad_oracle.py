@@ -189,6 +189,92 @@ def listnet_loss(teacher, student, return_grad=False, temperature=6.0, eps=1e-10
     return (loss, dM.astype(M.dtype)) if return_grad else loss
 
 
+def distill_mse(teacher, student, wb, return_grad=False):
+    """DistillationLoss(mode='mse'), alad/loss.py:371-373: mean((student*wb[0] + wb[1] - teacher)^2);
+    gradients w.r.t. the student and the learnable pair wb (:366)."""
+    T = np.asarray(teacher, np.float64)
+    M = np.asarray(student, np.float64)
+    w0, w1 = float(wb[0]), float(wb[1])
+    r = M * w0 + w1 - T
+    loss = np.float32(np.mean(r * r))
+    if not return_grad:
+        return loss
+    n = r.size
+    return loss, (2.0 * r * w0 / n).astype(np.float32), np.array([np.sum(2.0 * r * M) / n, np.sum(2.0 * r) / n], np.float32)
+
+
+def distill_contrastive(teacher, student, margin=0.2, return_grad=False):
+    """DistillationLoss(mode='contrastive'), alad/loss.py:401-425, as written: the teacher's diagonal
+    is set to 0 (not -inf, :405), its row / column argmax picks whole COLUMNS of cost_s (:417-418) and
+    whole ROWS of cost_im (:420-421), and neither cost has its diagonal cleared.  So
+        loss = sum_k sum_i relu(m + S[i, a_k] - S[i, i]) + sum_k sum_j relu(m + S[b_k, j] - S[j, j]),
+    a_k = argmax_j T0[k, j], b_k = argmax_i T0[i, k]."""
+    T0 = np.array(teacher, np.float64)
+    M = np.asarray(student, np.float64)
+    B = M.shape[0]
+    T0[np.arange(B), np.arange(B)] = 0.0
+    col_count = np.bincount(np.argmax(T0, axis=1), minlength=B).astype(np.float64)   # c_j
+    row_count = np.bincount(np.argmax(T0, axis=0), minlength=B).astype(np.float64)   # r_i
+    diag = np.diag(M)
+    a = margin + M - diag[:, None]
+    b = margin + M - diag[None, :]
+    loss = np.float32(np.sum(col_count[None, :] * np.maximum(a, 0)) + np.sum(row_count[:, None] * np.maximum(b, 0)))
+    if not return_grad:
+        return loss
+    ga = col_count[None, :] * (a > 0)
+    gb = row_count[:, None] * (b > 0)
+    dM = ga + gb
+    dM[np.arange(B), np.arange(B)] -= ga.sum(axis=1) + gb.sum(axis=0)
+    return loss, dM.astype(np.float32)
+
+
+def distill_ordinal(teacher, student, margin=0.2, threshold=0.1, stride=3, return_grad=False):
+    """DistillationLoss(mode='ordinal'), alad/loss.py:374-399: sort every teacher row (then column)
+    ascending, read the student in that order, and ask student[p] + margin <= student[p + stride]
+    wherever teacher_sorted[p + stride] >= threshold; mean hinge over those positions, rows + columns.
+    An empty selection gives a NaN loss (torch's mean of an empty tensor) and a zero gradient."""
+    T = np.asarray(teacher, np.float64)
+    M = np.asarray(student, np.float64)
+    loss = 0.0
+    dM = np.zeros(M.shape, np.float64)
+    for axis in (1, 0):
+        Tt, Mt = (T, M) if axis == 1 else (T.T, M.T)
+        order = np.argsort(Tt, axis=1, kind='stable')
+        ts = np.take_along_axis(Tt, order, axis=1)
+        so = np.take_along_axis(Mt, order, axis=1)
+        diff = so[:, :-stride] - so[:, stride:]
+        valid = ts[:, stride:] >= threshold
+        n = int(valid.sum())
+        with np.errstate(invalid='ignore', divide='ignore'):
+            loss += np.sum(np.maximum(margin + diff, 0) * valid) / n if n else np.nan
+        if return_grad:
+            act = (valid & (margin + diff > 0)).astype(np.float64) / max(n, 1)   # empty selection: NaN loss, zero gradient
+            g_sorted = np.zeros(Mt.shape, np.float64)
+            g_sorted[:, :-stride] += act
+            g_sorted[:, stride:] -= act
+            g = np.zeros(Mt.shape, np.float64)
+            np.put_along_axis(g, order, g_sorted, axis=1)
+            dM += g if axis == 1 else g.T
+    loss = np.float32(loss)
+    return (loss, dM.astype(np.float32)) if return_grad else loss
+
+
+def order_scores(im, s):
+    """order_sim, alad/loss.py:20-26: score[i, j] = -|| max(s_j - im_i, 0) ||_2."""
+    c = np.maximum(np.asarray(s, np.float64)[None, :, :] - np.asarray(im, np.float64)[:, None, :], 0.0)
+    return (-np.sqrt(np.sum(c * c, axis=2))).astype(np.float32)
+
+
+def order_scores_backward(im, s, G):
+    """(d im, d s) of sum(G * order_scores(im, s)); 0/0 -> NaN where a pair has no violation, as autograd."""
+    c = np.maximum(np.asarray(s, np.float64)[None, :, :] - np.asarray(im, np.float64)[:, None, :], 0.0)
+    nrm = np.sqrt(np.sum(c * c, axis=2))
+    with np.errstate(invalid='ignore', divide='ignore'):
+        W = np.asarray(G, np.float64) / nrm
+        u = W[:, :, None] * c
+    return u.sum(axis=1).astype(np.float32), (-u.sum(axis=0)).astype(np.float32)
+
+
 # ----------------------------------------------------------------------------------------------
 # loss orchestration (alad/alad_model.py:371-454)
 # ----------------------------------------------------------------------------------------------

@@ -157,18 +157,49 @@ def gen_matching():
 
 
 def gen_distill():
-    for name, B, seed in (('distill_b16', 16, 41), ('distill_b5', 5, 42)):
+    # name, B, seed, teacher offset, ctor kwargs (defaults of alad/loss.py:360 when empty)
+    cases = (('distill_b16', 16, 41, 4.0, {}), ('distill_b5', 5, 42, 4.0, {}),
+             ('distill_b24_thr', 24, 43, 0.0, dict(margin=0.15, threshold=0.3, stride=2)),
+             ('distill_b40_neg', 40, 44, -2.5, dict(margin=0.25, threshold=-1.0, stride=5)))
+    for name, B, seed, offset, kw in cases:
         img, cap = synth.global_embeddings(B, 64, seed, 1.0)
-        teacher = (synth.normal((B, B), seed + 7) * 0.8 + 3.0 * np.eye(B, dtype=np.float32) + 4.0).astype(np.float32)
+        teacher = (synth.normal((B, B), seed + 7) * 0.8 + 3.0 * np.eye(B, dtype=np.float32) + offset).astype(np.float32)
         student = (img @ cap.T).astype(np.float32)
-        out = dict(B=B, seed=seed, teacher=teacher, student=student)
+        out = dict(B=B, seed=seed, teacher=teacher, student=student, margin=kw.get('margin', 0.2),
+                   threshold=kw.get('threshold', 0.1), stride=kw.get('stride', 3))
         for mode in ('listnet', 'mse', 'ordinal', 'contrastive'):
-            crit = ref_loss.DistillationLoss(mode=mode)
+            crit = ref_loss.DistillationLoss(mode=mode, **kw)
+            if mode == 'mse' and kw:
+                with torch.no_grad():
+                    crit.wb.copy_(torch.tensor([0.8, -0.3]))
             st = t(student).requires_grad_(True)
             loss = crit(t(teacher.copy()), st)
             loss.backward()
             out['loss_' + mode] = loss.item()
             out['dstudent_' + mode] = st.grad.numpy()
+            if mode == 'mse':
+                out['wb_mse'] = crit.wb.detach().numpy().copy()
+                out['dwb_mse'] = crit.wb.grad.numpy().copy()
+        save(name, **out)
+
+
+def gen_order_sim():
+    for name, Bi, Bc, D, seed in (('order_b12', 12, 12, 64, 51), ('order_rect', 5, 9, 40, 52)):
+        im = synth.normal((Bi, D), seed)
+        s = synth.normal((Bc, D), seed + 1)
+        a = t(im).requires_grad_(True)
+        b = t(s).requires_grad_(True)
+        scores = ref_loss.order_sim(a, b)
+        w = synth.normal((Bi, Bc), seed + 2)
+        (scores * t(w)).sum().backward()
+        out = dict(Bi=Bi, Bc=Bc, D=D, seed=seed, scores=scores.detach().numpy(), w=w, dim=a.grad.numpy(), ds=b.grad.numpy())
+        if Bi == Bc:
+            crit = ref_loss.ContrastiveLoss(margin=0.2, measure='order', max_violation=True)
+            a2 = t(im).requires_grad_(True)
+            b2 = t(s).requires_grad_(True)
+            loss = crit(a2, b2)
+            loss.backward()
+            out.update(loss_mv=loss.item(), dim_mv=a2.grad.numpy(), ds_mv=b2.grad.numpy())
         save(name, **out)
 
 
@@ -254,5 +285,6 @@ if __name__ == '__main__':
     gen_eval()
     gen_matching()
     gen_distill()
+    gen_order_sim()
     gen_model()
     gen_recall()

@@ -63,13 +63,19 @@ def test_cpu_tensors_are_rejected_not_silently_computed():
         DistillationLoss('listnet')(torch.randn(3, 3), torch.randn(3, 3))
 
 
-def test_unsupported_modes_raise():
-    from aladin_amd.loss import Contrastive, DistillationLoss
-    with pytest.raises(NotImplementedError):
-        Contrastive(measure='order')
-    for mode in ('mse', 'ordinal', 'contrastive'):
-        with pytest.raises(NotImplementedError):
-            DistillationLoss(mode=mode)
+def test_every_distillation_mode_and_measure_constructs_and_refuses_cpu():
+    from aladin_amd.loss import Contrastive, ContrastiveLoss, DistillationLoss, order_sim
+    assert Contrastive(measure='order').sim is order_sim
+    for mode in ('mse', 'ordinal', 'contrastive', 'listnet'):
+        crit = DistillationLoss(mode=mode)
+        # the reference's 'mse' mode owns a learnable pair (alad/loss.py:366); the others nothing
+        assert sorted(crit.state_dict()) == (['wb'] if mode == 'mse' else [])
+        with pytest.raises(RuntimeError, match='no CPU fallback'):
+            crit(torch.randn(4, 4), torch.randn(4, 4))
+    with pytest.raises(ValueError):
+        DistillationLoss(mode='nope')
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        ContrastiveLoss(0.2, 'order', True)(torch.randn(3, 8), torch.randn(3, 8))
 
 
 def test_loss_modules_hold_no_state():

@@ -203,8 +203,109 @@ def test_listnet(name):
     loss.backward()
     np.testing.assert_allclose(loss.item(), float(g['loss_listnet']), rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(st.grad.cpu().numpy(), g['dstudent_listnet'], rtol=1e-4, atol=1e-7)
-    with pytest.raises(NotImplementedError):
-        DistillationLoss(mode='mse')
+
+
+DISTILL_CASES = ['distill_b16', 'distill_b5', 'distill_b24_thr', 'distill_b40_neg']
+
+
+@pytest.mark.parametrize('mode', ['mse', 'ordinal', 'contrastive'])
+@pytest.mark.parametrize('name', DISTILL_CASES)
+def test_distillation_modes_match_reference(name, mode):
+    """DistillationLoss 'mse' / 'ordinal' / 'contrastive' (alad/loss.py:371-425) vs the reference's
+    loss and autograd gradients; the integer-valued gradients of the two hinge modes must be exact."""
+    from aladin_amd.loss import DistillationLoss
+    g = load_golden(name)
+    crit = DistillationLoss(mode=mode, margin=float(g['margin']), threshold=float(g['threshold']),
+                            stride=int(g["stride"])).to(dev())
+    if mode == 'mse':
+        with torch.no_grad():
+            crit.wb.copy_(T(g['wb_mse']))
+    st = T(g['student']).requires_grad_(True)
+    loss = crit(T(g['teacher']), st)
+    loss.backward()
+    np.testing.assert_allclose(loss.item(), float(g['loss_' + mode]), rtol=2e-6, atol=1e-6)
+    np.testing.assert_allclose(st.grad.cpu().numpy(), g['dstudent_' + mode], rtol=1e-5, atol=1e-8)
+    if mode == 'mse':
+        np.testing.assert_allclose(crit.wb.grad.cpu().numpy(), g['dwb_mse'], rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize('B', [3, 64, 257, 1000])
+def test_distillation_modes_vs_oracle_random(B):
+    """Sizes the goldens do not reach (non power-of-two sort lengths, multi-pass lines), incl. upstream
+    gradient scaling and strided (non-contiguous) inputs."""
+    from aladin_amd import ops
+    rng = np.random.default_rng(B)
+    teacher = rng.standard_normal((B, B)).astype(np.float32)
+    student = rng.standard_normal((B, 2 * B)).astype(np.float32)
+    st_full = T(student).requires_grad_(True)
+    st = st_full[:, ::2]                                            # stride(1) == 2
+    wb = T(np.array([0.7, -0.2], np.float32)).requires_grad_(True)
+    stride = 1 if B < 8 else 3
+    for mode, ref in (('mse', lambda: O.distill_mse(teacher, student[:, ::2], [0.7, -0.2], True)),
+                      ('contrastive', lambda: O.distill_contrastive(teacher, student[:, ::2], 0.2, True)),
+                      ('ordinal', lambda: O.distill_ordinal(teacher, student[:, ::2], 0.2, 0.1, stride, True))):
+        st_full.grad = None
+        wb.grad = None
+        loss = ops.distillation_loss(T(teacher), st, mode, 0.2, 0.1, stride, wb=wb if mode == 'mse' else None)
+        (2.5 * loss).backward()
+        out = ref()
+        np.testing.assert_allclose(loss.item(), out[0], rtol=5e-6, atol=1e-6)
+        got = st_full.grad.cpu().numpy()
+        np.testing.assert_array_equal(got[:, 1::2], 0)
+        np.testing.assert_allclose(got[:, ::2], 2.5 * out[1], rtol=1e-5, atol=1e-9)
+        if mode == 'mse':
+            np.testing.assert_allclose(wb.grad.cpu().numpy(), 2.5 * out[2], rtol=1e-5, atol=1e-6)
+
+
+def test_ordinal_empty_selection_is_nan_loss_zero_grad():
+    from aladin_amd import ops
+    B = 12
+    teacher = T(np.full((B, B), -5.0, np.float32) + np.arange(B * B, dtype=np.float32).reshape(B, B) * 1e-3)
+    st = T(np.random.default_rng(0).standard_normal((B, B)).astype(np.float32)).requires_grad_(True)
+    loss = ops.distillation_loss(teacher, st, 'ordinal', 0.2, 0.1, 3)      # no teacher score reaches 0.1
+    loss.backward()
+    assert np.isnan(loss.item())
+    np.testing.assert_array_equal(st.grad.cpu().numpy(), 0)
+
+
+@pytest.mark.parametrize('name', ['order_b12', 'order_rect'])
+def test_order_sim_matches_reference(name):
+    """order_sim (alad/loss.py:20-26) and ContrastiveLoss(measure='order') vs the reference."""
+    from aladin_amd import synth
+    from aladin_amd.loss import ContrastiveLoss, order_sim
+    g = load_golden(name)
+    im = synth.normal((int(g['Bi']), int(g['D'])), int(g['seed']))
+    s = synth.normal((int(g['Bc']), int(g['D'])), int(g['seed']) + 1)
+    a, b = T(im).requires_grad_(True), T(s).requires_grad_(True)
+    scores = order_sim(a, b)
+    (scores * T(g['w'])).sum().backward()
+    np.testing.assert_allclose(scores.detach().cpu().numpy(), g['scores'], rtol=2e-6, atol=1e-6)
+    np.testing.assert_allclose(a.grad.cpu().numpy(), g['dim'], rtol=1e-4, atol=2e-6)
+    np.testing.assert_allclose(b.grad.cpu().numpy(), g['ds'], rtol=1e-4, atol=2e-6)
+    if 'loss_mv' in g:
+        a2, b2 = T(im).requires_grad_(True), T(s).requires_grad_(True)
+        loss = ContrastiveLoss(margin=0.2, measure='order', max_violation=True)(a2, b2)
+        loss.backward()
+        np.testing.assert_allclose(loss.item(), float(g['loss_mv']), rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(a2.grad.cpu().numpy(), g['dim_mv'], rtol=1e-4, atol=2e-6)
+        np.testing.assert_allclose(b2.grad.cpu().numpy(), g['ds_mv'], rtol=1e-4, atol=2e-6)
+
+
+def test_order_sim_vs_oracle_odd_shapes():
+    from aladin_amd import ops
+    rng = np.random.default_rng(5)
+    for Bi, Bc, D in ((1, 1, 1), (33, 70, 100), (300, 65, 768)):
+        im = rng.standard_normal((Bi, D)).astype(np.float32)
+        s = rng.standard_normal((Bc, D)).astype(np.float32) + 0.5
+        G = rng.standard_normal((Bi, Bc)).astype(np.float32)
+        a, b = T(im).requires_grad_(True), T(s).requires_grad_(True)
+        sc = ops.order_scores(a, b)
+        (sc * T(G)).sum().backward()
+        np.testing.assert_allclose(sc.detach().cpu().numpy(), O.order_scores(im, s), rtol=3e-6, atol=1e-6)
+        di, ds = O.order_scores_backward(im, s, G)
+        scale = max(1.0, float(np.abs(di).max()))
+        np.testing.assert_allclose(a.grad.cpu().numpy(), di, rtol=1e-4, atol=2e-5 * scale, equal_nan=True)
+        np.testing.assert_allclose(b.grad.cpu().numpy(), ds, rtol=1e-4, atol=2e-5 * scale, equal_nan=True)
 
 
 def test_model_forward_matches_reference_configs():

@@ -97,6 +97,43 @@ def test_listnet(name):
     close(dM, g['dstudent_listnet'], rtol=1e-4, atol=1e-7)
 
 
+@pytest.mark.parametrize('name', ['distill_b16', 'distill_b5', 'distill_b24_thr', 'distill_b40_neg'])
+def test_other_distillation_modes(name):
+    """mse / contrastive / ordinal closed forms (alad/loss.py:371-425) vs the reference's autograd."""
+    g = load_golden(name)
+    Tm, M = g['teacher'], g['student']
+    m, th, st = float(g['margin']), float(g['threshold']), int(g['stride'])
+    loss, dM, dwb = O.distill_mse(Tm, M, g['wb_mse'], return_grad=True)
+    close(loss, g['loss_mse'], rtol=2e-6, atol=1e-6)
+    close(dM, g['dstudent_mse'], rtol=1e-5, atol=1e-8)
+    close(dwb, g['dwb_mse'], rtol=1e-5, atol=1e-6)
+    loss, dM = O.distill_contrastive(Tm, M, m, return_grad=True)
+    close(loss, g['loss_contrastive'], rtol=2e-6, atol=1e-6)
+    np.testing.assert_array_equal(dM, g['dstudent_contrastive'])
+    loss, dM = O.distill_ordinal(Tm, M, m, th, st, return_grad=True)
+    close(loss, g['loss_ordinal'], rtol=2e-6, atol=1e-6)
+    close(dM, g['dstudent_ordinal'], rtol=1e-6, atol=1e-9)
+
+
+@pytest.mark.parametrize('name', ['order_b12', 'order_rect'])
+def test_order_sim(name):
+    from aladin_amd import synth
+    g = load_golden(name)
+    im = synth.normal((int(g['Bi']), int(g['D'])), int(g['seed']))
+    s = synth.normal((int(g['Bc']), int(g['D'])), int(g['seed']) + 1)
+    close(O.order_scores(im, s), g['scores'], rtol=2e-6, atol=1e-6)
+    di, ds = O.order_scores_backward(im, s, g['w'])
+    close(di, g['dim'], rtol=1e-5, atol=1e-6)
+    close(ds, g['ds'], rtol=1e-5, atol=1e-6)
+    if 'loss_mv' in g:
+        S = O.order_scores(im, s)
+        loss, dS = O.hinge_loss(S, 0.2, True, return_grad=True)
+        close(loss, g['loss_mv'], rtol=1e-5, atol=1e-6)
+        di, ds = O.order_scores_backward(im, s, dS)
+        close(di, g['dim_mv'], rtol=1e-5, atol=1e-6)
+        close(ds, g['ds_mv'], rtol=1e-5, atol=1e-6)
+
+
 def test_model_forward_dicts():
     g = load_golden('model_forward')
     from aladin_amd import synth
