@@ -9,8 +9,10 @@ on the concatenated global batch.  S[i][j] depends only on image i and caption j
     2. S[:, block r] = HIP alignment scores (all images x own captions)
     3. all-gather the (W*B x B) score blocks -> full S on every rank (2 MB per rank at B=256)
     4. hinge on the full S (replicated, identical bits on every rank)
-    5. backward: each rank differentiates its own column block; d(image sets) from all ranks are
-       summed with a reduce-scatter, d(captions) is local.
+    5. backward: each rank differentiates its own column block; d(captions) is local.  d(image sets):
+       dense dS (sum of violations) -> reduce-scatter of the (W*B, R, D) contributions; sparse dS
+       (max_violation: <= 3 non-zeros per row/column) -> SparseImageExchange: only the image sets a
+       caption block actually pairs with travel (fp32, all-to-all), and only their gradients return.
 
 `scores_fn` / `hinge_fn` default to the HIP ops; CPU tests (gloo, world_size 2) inject the torch
 restatement from oracle/ to exercise the collectives without a GPU.
@@ -122,9 +124,60 @@ def rank_backward_block(im_all, il_all_t, s_local, s_len_t, dS_full, rank, g_glo
                                packed=(g_glob, xm_all, xe_all, y))
 
 
+class SparseImageExchange:
+    """Pair-driven exchange of image sets for the backward of a SPARSE dS (max_violation hinge).
+
+    dS_full is replicated (the hinge runs on the gathered score matrix on every rank), so every rank
+    derives the whole send/receive plan from it without talking: caption block b needs image i iff
+    dS_full[i, block b] has a non-zero.  One device->host copy (the W x W count matrix, needed for the
+    all-to-all split sizes) is the only synchronisation.
+
+        fetch(im_local)        -> (n_need, R, D) fp32 sets of the images this rank's captions pair with,
+                                  in ascending global index order (self.need_idx)
+        give_back(d_im_need)   -> (B, R, D) gradient of the local image sets, summed over the ranks
+                                  that used them in a fixed rank order (deterministic)
+
+    At B=256, W=8 a rank needs ~600 of the 2048 image sets (diagonal + one row- and one column-maximum
+    per sample), so ~45 MB travel each way instead of the 214 MB all-gather + 214 MB reduce-scatter of
+    the dense form.  Pure torch + torch.distributed: runs under gloo on CPU for the tests."""
+
+    def __init__(self, dS_full, B, group=None):
+        self.group = group
+        W, r = _world(group)
+        self.W, self.r, self.B = W, r, B
+        nz = (dS_full.view(W * B, W, B) != 0).any(dim=2).t().contiguous()          # nz[b, i]
+        counts = nz.view(W, W, B).sum(dim=2).cpu().tolist()                        # counts[b][a]; the one sync
+        self.recv_splits = [int(counts[r][a]) for a in range(W)]
+        self.send_splits = [int(counts[b][r]) for b in range(W)]
+        n_recv, n_send = sum(self.recv_splits), sum(self.send_splits)
+        # ascending indices of the True entries without another sync: stable sort of the negated mask
+        self.need_idx = torch.argsort((~nz[r]).to(torch.uint8), stable=True)[:n_recv]
+        mine = nz[:, r * B:(r + 1) * B].reshape(-1)                                # dest-major, local image minor
+        self.send_rows = torch.argsort((~mine).to(torch.uint8), stable=True)[:n_send] % B
+
+    def _all_to_all(self, send, out_splits, in_splits):
+        out = torch.empty((sum(out_splits),) + tuple(send.shape[1:]), dtype=send.dtype, device=send.device)
+        dist.all_to_all_single(out, send.contiguous(), output_split_sizes=out_splits, input_split_sizes=in_splits,
+                               group=self.group)
+        return out
+
+    def fetch(self, im_local):
+        return self._all_to_all(im_local.index_select(0, self.send_rows), self.recv_splits, self.send_splits)
+
+    def give_back(self, d_im_need, shape):
+        back = self._all_to_all(d_im_need, self.send_splits, self.recv_splits)
+        d_im = torch.zeros(shape, dtype=d_im_need.dtype, device=d_im_need.device)
+        off = 0
+        for n in self.send_splits:                     # one source rank at a time: indices unique per call
+            if n:
+                d_im.index_add_(0, self.send_rows[off:off + n], back[off:off + n])
+            off += n
+        return d_im
+
+
 class _ShardedTriplet(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, im, s, im_len_t, s_len_t, margin, max_violation, group):
+    def forward(ctx, im, s, im_len_t, s_len_t, margin, max_violation, group, exchange='auto'):
         from . import ops
         W, r = _world(group)
         B, R, D = im.shape
@@ -142,8 +195,12 @@ class _ShardedTriplet(torch.autograd.Function):
         dist.all_gather_into_tensor(xe_all, xe, group=group)
         dist.all_gather_into_tensor(il_all, im_len_t.contiguous(), group=group)
         need = any(ctx.needs_input_grad[:2])
+        # <= 3 non-zeros of dS per row/column under max_violation: pair-driven exchange
+        # (its fixed cost -- one host sync for the split sizes -- pays off once the dense form would move
+        # >= 4 ranks' worth of fp32 sets; bench.py times both)
+        sparse = (bool(max_violation) and W >= 4) if exchange == 'auto' else (exchange == 'sparse')
         im_all, work = None, None
-        if need:                                   # raw fp32 sets: only the exact backward reads them
+        if need and not sparse:                    # raw fp32 sets: only the exact backward reads them
             im_all = torch.empty((W * B, R, D), dtype=im.dtype, device=im.device)
             work = dist.all_gather_into_tensor(im_all, im_c, group=group, async_op=True)
         S_blk, y = rank_scores_block(xm_all, xe_all, s, s_len_t, g_glob)
@@ -151,7 +208,14 @@ class _ShardedTriplet(torch.autograd.Function):
         dist.all_gather_into_tensor(parts, S_blk, group=group)
         S_full = parts.view(W, W * B, B).permute(1, 0, 2).reshape(W * B, W * B)
         loss, dS_full, _ = ops._hinge_raw(S_full, margin, max_violation, need)
-        if need:
+        ctx.exchange = None
+        if need and sparse:
+            ex = SparseImageExchange(dS_full, B, group)
+            im_need = ex.fetch(im_c)
+            dS_need = dS_full.index_select(0, ex.need_idx)[:, r * B:(r + 1) * B].contiguous()
+            ctx.save_for_backward(im_need, il_all.index_select(0, ex.need_idx), s, s_len_t, dS_need)
+            ctx.exchange, ctx.im_shape = ex, tuple(im.shape)
+        elif need:
             ctx.save_for_backward(im_all, il_all, s, s_len_t, dS_full, xm_all, xe_all, y)
             ctx.work, ctx.g_glob, ctx.group = work, g_glob, group
         ctx.mark_non_differentiable(S_full)
@@ -161,7 +225,16 @@ class _ShardedTriplet(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_loss, _g_scores):
         if g_loss is None:
-            return (None,) * 7
+            return (None,) * 8
+        if ctx.exchange is not None:
+            from . import ops
+            im_need, il_need, s, s_len_t, dS_need = ctx.saved_tensors
+            gscale = g_loss.to(torch.float32).contiguous()
+            if im_need.shape[0]:
+                d_im_need, d_s = ops._align_backward(im_need, s, il_need, s_len_t, dS_need, gscale=gscale)
+            else:                                  # no violation anywhere in this caption block
+                d_im_need, d_s = torch.zeros_like(im_need), torch.zeros_like(s)
+            return ctx.exchange.give_back(d_im_need, ctx.im_shape), d_s, None, None, None, None, None, None
         im_all, il_all, s, s_len_t, dS_full, xm_all, xe_all, y = ctx.saved_tensors
         W, r = _world(ctx.group)
         if ctx.work is not None:
@@ -171,13 +244,18 @@ class _ShardedTriplet(torch.autograd.Function):
         B = s.shape[0]
         d_im = torch.empty((B,) + tuple(d_im_all.shape[1:]), dtype=d_im_all.dtype, device=d_im_all.device)
         dist.reduce_scatter_tensor(d_im, d_im_all, group=ctx.group)
-        return d_im, d_s, None, None, None, None, None
+        return d_im, d_s, None, None, None, None, None, None
 
 
-def sharded_alignment_loss_fast(im_set, s_seq, im_len, s_len, margin=0.2, max_violation=True, group=None):
+def sharded_alignment_loss_fast(im_set, s_seq, im_len, s_len, margin=0.2, max_violation=True, group=None,
+                                exchange='auto'):
     """Same result as sharded_alignment_loss on GPUs over RCCL, with the forward exchange in packed
-    fp16 (13 MB per rank at B=256 instead of 27 MB), the raw all-gather overlapped with scoring and
-    one fused autograd node.  Returns (loss, S_full.detach())."""
+    fp16 (13 MB per rank at B=256 instead of 27 MB), one fused autograd node, and for the backward
+    either the pair-driven SparseImageExchange (max_violation) or the raw all-gather overlapped with
+    scoring + reduce-scatter (dense dS); ``exchange`` = 'auto' | 'sparse' | 'dense' overrides the choice.
+    Returns (loss, S_full.detach())."""
+    if exchange not in ('auto', 'sparse', 'dense'):
+        raise ValueError("aladin_amd.distributed: exchange must be 'auto', 'sparse' or 'dense'")
     from . import ops
     im_len_t, s_len_t = ops._check_sets(im_set, s_seq, im_len, s_len)
-    return _ShardedTriplet.apply(im_set, s_seq, im_len_t, s_len_t, margin, max_violation, group)
+    return _ShardedTriplet.apply(im_set, s_seq, im_len_t, s_len_t, margin, max_violation, group, exchange)

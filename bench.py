@@ -37,6 +37,11 @@ def parse():
     ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--eager', action='store_true', help='do not capture the step in a HIP graph')
+    ap.add_argument('--force-sharded', action='store_true',
+                    help='self-test: run the multi-GPU (sharded, RCCL) step even with one rank')
+    ap.add_argument('--exchange', default='tune', choices=['tune', 'dense', 'sparse'],
+                    help='multi-GPU backward exchange of d(image sets): dense reduce-scatter, pair-driven sparse '
+                         'all-to-all, or time both during warm-up and keep the faster (default)')
     ap.add_argument('--cpu-batch', type=int, default=96, help='batch of the bounded CPU-baseline sample')
     return ap.parse_args()
 
@@ -124,9 +129,15 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-    if world > 1:
+    sharded = world > 1 or args.force_sharded
+    if sharded:
         import torch.distributed as dist
-        dist.init_process_group('nccl', device_id=dev)
+        if world == 1:
+            os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+            os.environ.setdefault('MASTER_PORT', '29671')
+            dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
+        else:
+            dist.init_process_group('nccl', device_id=dev)
 
     from aladin_amd import synth
     from aladin_amd.loss import AlignmentContrastiveLoss
@@ -137,18 +148,21 @@ def main():
     s = torch.from_numpy(s_np).to(dev).requires_grad_(True)
     crit = AlignmentContrastiveLoss(margin=0.2, measure='dot', max_violation=True, aggregation='MrSw')
 
+    exchange = ['dense' if args.exchange == 'tune' else args.exchange]
+    tuned = {}
+
     def step():
         im.grad = None
         s.grad = None
-        if world > 1:
-            loss, _ = sharded_alignment_loss_fast(im, s, il, sl, 0.2, True)
+        if sharded:
+            loss, _ = sharded_alignment_loss_fast(im, s, il, sl, 0.2, True, exchange=exchange[0])
         else:
             loss = crit(im, s, il, sl)
         loss.backward()
         return loss
 
     def fence():
-        if world > 1:
+        if sharded:
             import torch.distributed as dist
             dist.barrier()
         torch.cuda.synchronize()
@@ -159,7 +173,7 @@ def main():
     # (collectives).
     launch = 'eager'
     run = step
-    if world == 1 and not args.eager:
+    if not sharded and not args.eager:
         try:
             for _ in range(3):
                 step()
@@ -178,6 +192,23 @@ def main():
         except Exception as exc:            # capture unsupported: fall back to eager, say so
             print('bench: graph capture failed (%s), running eager' % exc, file=sys.stderr)
             run = step
+    if sharded and args.exchange == 'tune':
+        # Both exchanges give the same gradients (tests/); which is faster depends on the world size and
+        # the fabric.  Time a few untimed steps of each, agree on the MAX over ranks, keep the winner.
+        import torch.distributed as dist
+        for mode in ('dense', 'sparse'):
+            exchange[0] = mode
+            for _ in range(3):
+                step()
+            fence()
+            t0 = time.perf_counter()
+            for _ in range(8):
+                step()
+            fence()
+            tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            tuned[mode] = float(tt.item()) / 8 * 1e3
+        exchange[0] = min(tuned, key=tuned.get)
     for _ in range(args.warmup):
         run()
     fence()
@@ -186,7 +217,7 @@ def main():
         loss = run()
     fence()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if sharded:
         import torch.distributed as dist
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -195,6 +226,11 @@ def main():
     pairs = (B * world) ** 2
     value = pairs / (ms * 1e-3)
 
+    if sharded:
+        # RCCL prints a version banner through C stdio when the communicator comes up; on a pipe it would
+        # surface at exit, AFTER the JSON line.  Push it out now so the JSON line is the last line of stdout.
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
     if rank == 0:
         roof = kernel_roofline(im.detach(), s.detach(), il, sl)
         out = {
@@ -207,13 +243,15 @@ def main():
                                    ('' if world == 1 else '; configs[3]: global %dx%d matrix, images all-gathered '
                                     'over RCCL, caption-block sharding' % (B * world, B * world)),
                        'global_pairs_per_step': pairs, 'loss': float(loss.detach()), 'launch': launch,
+                       **({} if not sharded else {'bwd_exchange': exchange[0],
+                                                  'bwd_exchange_tuning_ms': {k: round(v, 4) for k, v in tuned.items()}}),
                        'step_tflops_algorithmic': round(value * FLOPS_PER_PAIR / 1e12, 2)},
             'roofline': roof,
         }
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args.cpu_batch)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if sharded:
         import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()

@@ -608,6 +608,40 @@ def test_sharded_fast_path_rank_logic_emulated_world2():
     np.testing.assert_allclose(torch.cat(d_caps).cpu().numpy(), b.grad.cpu().numpy(), rtol=1e-5, atol=1e-8)
 
 
+@pytest.mark.parametrize('W,mv', [(4, True), (2, False)])
+def test_sharded_sparse_exchange_compact_backward_emulated(W, mv):
+    """What each rank does under SparseImageExchange, emulated on one GPU: differentiate its caption
+    block against ONLY the image sets its dS block touches (compact problem), scatter the result
+    back by global index.  Summed over ranks it must equal the single-device gradients."""
+    from aladin_amd import ops, synth
+    from aladin_amd.loss import AlignmentContrastiveLoss
+    B, R, Tn, D = 16, 34, 50, 256
+    im, s, il, sl = synth.alignment_batch(W * B, R, Tn, D, seed=9090 + W, ragged=True)
+    d = dev()
+    a, b = T(im).requires_grad_(True), T(s).requires_grad_(True)
+    ref_loss, S = AlignmentContrastiveLoss(0.2, 'dot', mv, 'MrSw')(a, b, il, sl, return_similarity_mat=True)
+    ref_loss.backward()
+    _, dS_full, _ = ops._hinge_raw(S, 0.2, mv, True)
+    il_all, sl_all = ops.lengths_tensor(il, d), ops.lengths_tensor(sl, d)
+    im_all, s_all = T(im), T(s)
+    d_im_all = torch.zeros_like(im_all)
+    d_caps = []
+    touched = 0
+    for r in range(W):
+        blk = dS_full[:, r * B:(r + 1) * B]
+        need = torch.nonzero((blk != 0).any(dim=1)).flatten()
+        touched += need.numel()
+        gi, gs = ops._align_backward(im_all.index_select(0, need), s_all[r * B:(r + 1) * B], il_all.index_select(0, need),
+                                     sl_all[r * B:(r + 1) * B].contiguous(), blk.index_select(0, need).contiguous())
+        d_im_all.index_add_(0, need, gi)
+        d_caps.append(gs)
+    if mv:
+        assert touched < W * W * B * 0.8            # the exchange really is sparse
+    scale = float(a.grad.abs().max())
+    np.testing.assert_allclose(d_im_all.cpu().numpy(), a.grad.cpu().numpy(), rtol=1e-5, atol=1e-6 * scale)
+    np.testing.assert_allclose(torch.cat(d_caps).cpu().numpy(), b.grad.cpu().numpy(), rtol=1e-5, atol=1e-6 * scale)
+
+
 def test_sharded_fast_path_under_rccl_world1():
     import os
     import torch.distributed as dist
@@ -631,6 +665,14 @@ def test_sharded_fast_path_under_rccl_world1():
         loss2.backward()
         assert torch.equal(S1, S2) and torch.equal(loss1.detach(), loss2.detach())
         assert torch.equal(a1.grad, a2.grad) and torch.equal(b1.grad, b2.grad)
+        # the pair-driven exchange (what world > 1 runs under max_violation), forced: RCCL all-to-all + compact backward
+        a3, b3 = T(im).requires_grad_(True), T(s).requires_grad_(True)
+        loss3, S3 = sharded_alignment_loss_fast(a3, b3, il, sl, 0.2, True, exchange='sparse')
+        loss3.backward()
+        assert torch.equal(S3, S2) and torch.equal(loss3.detach(), loss2.detach())
+        scale = float(a2.grad.abs().max())
+        np.testing.assert_allclose(a3.grad.cpu().numpy(), a2.grad.cpu().numpy(), rtol=1e-5, atol=1e-6 * scale)
+        np.testing.assert_allclose(b3.grad.cpu().numpy(), b2.grad.cpu().numpy(), rtol=1e-5, atol=1e-6 * scale)
         with pytest.raises(ValueError):
             sharded_alignment_loss_fast(T(im[:10]), T(s[:10]), il[:10], sl[:10])
     finally:
