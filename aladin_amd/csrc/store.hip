@@ -1,0 +1,153 @@
+// Device-resident embedding store for evaluation (replaces the
+// (N, 71, D) fp32 host buffers of reference alad/evaluation.py:119-130).
+//
+// A store keeps, per sample, ONLY the positions the alignment head reads -- [1, len - tail) of its
+// set (alad/loss.py:87-90) -- L2-normalised exactly as the pack kernels do (fp32 sum of squares, eps
+// 1e-12, one rounding to fp16), contiguous by true length:
+//     rows   : (total_rows, Dp) fp16, sample k at rows [offset[k], offset[k] + count[k])
+// so a 25 000-caption set of ~12 scored words is 0.46 GB instead of 5.4 GB, and building the MFMA
+// operands of any sub-grid is a pure 16-byte row copy (no normalisation, half the bytes read).
+// Scores from a store are bit-identical to scores from the fp32 sets.
+#include "common.hpp"
+#include "../../include/aladin_hip.h"
+
+namespace {
+
+// one wave per destination row; src fp32 row (or none -> nothing written)
+__global__ __launch_bounds__(256) void store_append_kernel(const float* __restrict__ src, int64_t sb, int64_t sr,
+                                                           const int32_t* __restrict__ lens, int B, int L, int D, int Dp,
+                                                           int tail, const int64_t* __restrict__ offsets,
+                                                           half_t* __restrict__ rows, int vec4) {
+  const int lane = threadIdx.x & 63;
+  const int64_t d = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);        // (sample, position) over B x (L - 1)
+  if (d >= (int64_t)B * (L - 1)) return;
+  const int k = (int)(d / (L - 1)), p = (int)(d % (L - 1));               // position p + 1 of the set
+  int cnt = lens[k] - 1 - tail;
+  cnt = cnt < 0 ? 0 : (cnt > L - 1 ? L - 1 : cnt);
+  if (p >= cnt) return;
+  const float* x = src + k * sb + (int64_t)(p + 1) * sr;
+  half_t* dst = rows + (offsets[k] + p) * Dp;
+  float ss = 0.f;
+  if (vec4) {
+    for (int c = lane * 4; c < D; c += 256) {
+      const float4 v = *reinterpret_cast<const float4*>(x + c);
+      ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    }
+  } else {
+    for (int c = lane; c < D; c += 64) ss += x[c] * x[c];
+  }
+  ss = wave_sum(ss);
+  const float inv = 1.0f / fmaxf(sqrtf(ss), 1e-12f);                     // same arithmetic as pack_row (align_fwd.hip)
+  if (vec4) {
+    for (int c = lane * 4; c < Dp; c += 256) {
+      half4 h = {0, 0, 0, 0};
+      if (c < D) {
+        const float4 v = *reinterpret_cast<const float4*>(x + c);
+        h = half4{(half_t)(v.x * inv), (half_t)(v.y * inv), (half_t)(v.z * inv), (half_t)(v.w * inv)};
+      }
+      *reinterpret_cast<half4*>(dst + c) = h;
+    }
+  } else {
+    for (int c = lane; c < Dp; c += 64) dst[c] = (c < D) ? (half_t)(x[c] * inv) : (half_t)0;
+  }
+}
+
+__device__ __forceinline__ void copy_row(const half_t* __restrict__ src, half_t* __restrict__ dst, int Dp, int lane) {
+  if (src == nullptr) {
+    for (int c = lane * 8; c < Dp; c += 512) *reinterpret_cast<half8*>(dst + c) = half8{0, 0, 0, 0, 0, 0, 0, 0};
+  } else {
+    for (int c = lane * 8; c < Dp; c += 512) *reinterpret_cast<half8*>(dst + c) = *reinterpret_cast<const half8*>(src + c);
+  }
+}
+
+// max-side operand (xm / xe) from a store: same row map as pack_images_kernel
+__global__ __launch_bounds__(256) void store_pack_x_kernel(const half_t* __restrict__ rows, const int64_t* __restrict__ offsets,
+                                                           const int32_t* __restrict__ counts,
+                                                           const int32_t* __restrict__ ids, int Bi, int Rq, int Dp, int mtiles,
+                                                           int64_t xm_rows, int64_t total_rows, half_t* __restrict__ xm,
+                                                           half_t* __restrict__ xe) {
+  const int lane = threadIdx.x & 63;
+  const int64_t d = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (d >= total_rows) return;
+  int i, rho;
+  half_t* dst;
+  if (d < xm_rows) {
+    const int rows_per_img = 32 * mtiles;
+    i = (int)(d / rows_per_img);
+    rho = (int)(d % rows_per_img);
+    if (rho >= Rq) rho = 0;
+    dst = xm + d * Dp;
+  } else {
+    i = (int)(d - xm_rows);
+    rho = 32 * mtiles;
+    dst = xe + (d - xm_rows) * Dp;
+  }
+  const half_t* src = nullptr;
+  if (i < Bi) {
+    const int k = ids ? ids[i] : i;
+    int Li = counts[k];
+    Li = Li > Rq ? Rq : Li;
+    if (rho < Li) src = rows + (offsets[k] + rho) * Dp;
+  }
+  copy_row(src, dst, Dp, lane);
+}
+
+// sum-side operand (y): same row map as pack_captions_kernel
+__global__ __launch_bounds__(256) void store_pack_y_kernel(const half_t* __restrict__ rows, const int64_t* __restrict__ offsets,
+                                                           const int32_t* __restrict__ counts,
+                                                           const int32_t* __restrict__ ids, int Bc, int Tq, int Dp, int tpad,
+                                                           int64_t total_rows, half_t* __restrict__ y) {
+  const int lane = threadIdx.x & 63;
+  const int64_t d = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (d >= total_rows) return;
+  const int j = (int)(d / tpad), w = (int)(d % tpad);
+  const half_t* src = nullptr;
+  if (j < Bc) {
+    const int k = ids ? ids[j] : j;
+    int Lj = counts[k];
+    Lj = Lj > Tq ? Tq : Lj;
+    if (w < Lj) src = rows + (offsets[k] + w) * Dp;
+  }
+  copy_row(src, y + d * Dp, Dp, lane);
+}
+
+}  // namespace
+
+extern "C" int aladin_store_row_width(int D) {
+  aladin_align_geom g;
+  if (aladin_align_geometry(1, 1, 2, 4, D, &g) != ALADIN_OK) return -1;
+  return g.Dp;
+}
+
+extern "C" int aladin_store_append(const float* sets, int64_t stride_b, int64_t stride_r, const int32_t* lens, int B, int L,
+                                   int D, int tail, const int64_t* offsets, void* rows, void* stream) {
+  if (!sets || !lens || !offsets || !rows || B < 1 || L < 2 || D < 1 || tail < 0) {
+    aladin_set_error("store_append: bad argument (B=%d L=%d D=%d tail=%d)", B, L, D, tail);
+    return ALADIN_ERR_ARG;
+  }
+  const int Dp = aladin_store_row_width(D);
+  if (Dp < D) return ALADIN_ERR_ARG;
+  const int64_t total = (int64_t)B * (L - 1);
+  const int vec4 = (D % 4 == 0) && (stride_b % 4 == 0) && (stride_r % 4 == 0) && (((uintptr_t)sets & 15) == 0);
+  hipLaunchKernelGGL(store_append_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, (hipStream_t)stream, sets, stride_b,
+                     stride_r, lens, B, L, D, Dp, tail, offsets, (half_t*)rows, vec4);
+  return aladin_check_launch("store_append_kernel");
+}
+
+extern "C" int aladin_align_pack_store_x(const void* rows, const int64_t* offsets, const int32_t* counts, const int32_t* ids,
+                                         const aladin_align_geom* g, void* xm, void* xe, void* stream) {
+  if (!rows || !offsets || !counts || !g || !xm || (g->rem && !xe)) { aladin_set_error("align_pack_store_x: null argument"); return ALADIN_ERR_ARG; }
+  const int64_t total = g->xm_rows + g->xe_rows;
+  hipLaunchKernelGGL(store_pack_x_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                     (const half_t*)rows, offsets, counts, ids, g->Bi, g->Rq, g->Dp, g->mtiles, g->xm_rows, total, (half_t*)xm,
+                     (half_t*)xe);
+  return aladin_check_launch("store_pack_x_kernel");
+}
+
+extern "C" int aladin_align_pack_store_y(const void* rows, const int64_t* offsets, const int32_t* counts, const int32_t* ids,
+                                         const aladin_align_geom* g, void* y, void* stream) {
+  if (!rows || !offsets || !counts || !g || !y) { aladin_set_error("align_pack_store_y: null argument"); return ALADIN_ERR_ARG; }
+  hipLaunchKernelGGL(store_pack_y_kernel, dim3((unsigned)((g->y_rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                     (const half_t*)rows, offsets, counts, ids, g->Bc, g->Tq, g->Dp, 16 * g->tp16, g->y_rows, (half_t*)y);
+  return aladin_check_launch("store_pack_y_kernel");
+}

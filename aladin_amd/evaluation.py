@@ -107,6 +107,40 @@ def encode_data(model, data_loader, log_step=10, logging=print, max_len=71):
     return img_embs, cap_embs, img_lengths, cap_lengths
 
 
+def encode_data_packed(model, data_loader, log_step=10, logging=print):
+    """encode_data with the embedding store kept on the device in packed 16-bit form (SURVEY.md
+    section 8(f) row 2): returns (img_store, cap_store, img_lengths, cap_lengths) where the stores are
+    aladin_amd.store.PackedSetStore objects that compute_sim_matrix / i2t / t2i accept in place of the
+    (N, 71, D) tensors -- same protocol as alad/evaluation.py:80-155 otherwise."""
+    import time
+    from .store import PackedSetStore
+    batch_time = AverageMeter()
+    val_logger = LogCollector()
+    model.eval()
+    end = time.time()
+    img_store = cap_store = None
+    for i, (example_imgs, example_txts) in enumerate(data_loader):
+        model.logger = val_logger
+        with torch.no_grad():
+            img_glob, cap_glob, img_emb, cap_emb, img_length, cap_length, _ = model.forward_emb(example_imgs, example_txts)
+            if img_store is None:
+                img_store = PackedSetStore(img_emb.size(2), 0, img_emb.device)
+                cap_store = PackedSetStore(cap_emb.size(2), 2, cap_emb.device)
+            img_store.append(img_emb.permute(1, 0, 2), img_length, img_glob)      # (S,B,D) -> (B,S,D) view
+            cap_store.append(cap_emb.permute(1, 0, 2), cap_length, cap_glob)
+        batch_time.update(time.time() - end)
+        end = time.time()
+        if logging is not None and i % log_step == 0:
+            logging('Test: [{0}/{1}]\t{e_log}\tTime {bt.val:.3f} ({bt.avg:.3f})\t'.format(
+                i, len(data_loader), bt=batch_time, e_log=str(model.logger)))
+    return img_store, cap_store, list(img_store.lengths), list(cap_store.lengths)
+
+
+def _is_store(x):
+    from .store import PackedSetStore, StoreView
+    return isinstance(x, (PackedSetStore, StoreView))
+
+
 def _device():
     if not torch.cuda.is_available():
         raise RuntimeError('aladin_amd: retrieval scoring runs in HIP kernels on an MI355X only (no GPU visible)')
@@ -118,8 +152,19 @@ def compute_sim_matrix(img, cap, img_len=None, cap_len=None, mode='matching'):
 
     mode='matching'  : img (N_img, D), cap (N_cap, D) global embeddings -> img @ cap.T
     mode='alignment' : img (N_img, R, D), cap (N_cap, T, D) sets with length lists -> MrSw scores
+    Both arguments may instead be PackedSetStore / StoreView objects (encode_data_packed).
     """
     dev = _device()
+    if _is_store(img) != _is_store(cap):
+        raise ValueError('compute_sim_matrix: pass two stores or two tensors')
+    if _is_store(img):                            # packed 16-bit stores (encode_data_packed): lengths travel with them
+        from .store import alignment_scores_from_stores
+        with torch.no_grad():
+            if mode == 'matching':
+                return ops.sim_matrix(img.glob, cap.glob)
+            if mode == 'alignment':
+                return alignment_scores_from_stores(img, cap)
+        raise ValueError("mode must be 'matching' or 'alignment'")
     img = torch.as_tensor(img).to(dev, torch.float32)
     cap = torch.as_tensor(cap).to(dev, torch.float32)
     with torch.no_grad():
@@ -200,6 +245,13 @@ def recall_1k_5fold_test(img_embs, cap_embs, tot_lengths=None, model=None):
 def _eval_scores(images, captions, img_lenghts, cap_lenghts, measure, sim_function):
     if measure == 'order':
         raise NotImplementedError("aladin_amd: measure='order' is not on the accelerated path")
+    if _is_store(images):
+        ims = images.view(slice(0, None, CAPS_PER_IMG))
+        if sim_function is None:
+            return compute_sim_matrix(ims, captions)
+        if sim_function == 'alignment':
+            return compute_sim_matrix(ims, captions, mode='alignment')
+        raise ValueError("aladin_amd: with packed stores sim_function must be None or 'alignment'")
     images = torch.as_tensor(images)
     captions = torch.as_tensor(captions)
     ims = images[0::CAPS_PER_IMG]

@@ -1,0 +1,159 @@
+"""Device-resident, length-packed fp16 embedding store for evaluation.
+
+The reference's encode_data (alad/evaluation.py:80-155) copies every batch to the host into
+(N, 71, D) fp32 buffers and i2t / t2i copy slices back per query.  A PackedSetStore keeps what the
+two retrieval heads read and nothing else:
+
+    rows   fp16 (total_rows, Dp)  the positions [1, len - tail) of every set, L2-normalised exactly
+                                  as the alignment pack kernels do, contiguous by TRUE length
+    glob   fp32 (N, D)            the slot-0 global embedding (matching head, alad/evaluation.py:127-128)
+    lengths                       the raw length list the reference returns
+
+COCO-5k captions (25 000 x ~12 scored words x 768) take 0.46 GB instead of 5.4 GB; alignment scores
+computed from a store are bit-identical to those computed from the fp32 sets (same fp16 operands).
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib, ops
+
+
+class PackedSetStore:
+    def __init__(self, feat_dim, tail, device, capacity_rows=4096):
+        """tail = trailing positions the alignment head drops: 0 for image sets, 2 for captions
+        (reference alad/loss.py:87-90)."""
+        lib = _lib.load()
+        self.D = int(feat_dim)
+        self.Dp = int(lib.aladin_store_row_width(self.D))
+        if self.Dp < self.D:
+            raise ValueError('aladin_amd: bad feature size %r' % (feat_dim,))
+        self.tail = int(tail)
+        self.device = torch.device(device)
+        self.rows = torch.empty((max(int(capacity_rows), 1), self.Dp), dtype=torch.float16, device=self.device)
+        self.n_rows = 0
+        self.lengths = []                     # raw lengths, as the reference's encode_data returns them
+        self._counts = []                     # usable positions per sample (host copy)
+        self._glob, self._offsets_t, self._counts_t = [], None, None
+
+    # ------------------------------------------------------------------------------------------ filling
+    def _reserve(self, extra):
+        need = self.n_rows + extra
+        if need > self.rows.shape[0]:
+            grown = torch.empty((max(need, 2 * self.rows.shape[0]), self.Dp), dtype=torch.float16, device=self.device)
+            grown[:self.n_rows] = self.rows[:self.n_rows]
+            self.rows = grown
+
+    def append(self, sets, lengths, glob=None):
+        """sets: (B, L, D) fp32 on the device (any strides with a unit inner stride); lengths: B ints;
+        glob: (B, D) global embeddings for the matching head (defaults to slot 0 of the sets)."""
+        ops._require_gpu(sets)
+        B, L, D = sets.shape
+        if D != self.D or len(lengths) != B:
+            raise ValueError('aladin_amd: store.append got a (%d,%d,%d) batch with %d lengths (store D=%d)'
+                             % (B, L, D, len(lengths), self.D))
+        lengths = [int(v) for v in lengths]
+        counts = [min(max(v - 1 - self.tail, 0), L - 1) for v in lengths]
+        offs, run = [], self.n_rows
+        for c in counts:
+            offs.append(run)
+            run += c
+        self._reserve(run - self.n_rows)
+        sets = ops._rows_inner_contig(sets)
+        lens_t = torch.tensor(lengths, dtype=torch.int32, device=self.device)
+        offs_t = torch.tensor(offs, dtype=torch.int64, device=self.device)
+        if L >= 2:
+            _lib.check(_lib.load().aladin_store_append(ops._ptr(sets), sets.stride(0), sets.stride(1), ops._ptr(lens_t), B, L, D,
+                                                       self.tail, ops._ptr(offs_t), ops._ptr(self.rows), ops._stream()),
+                       'store_append')
+        self._glob.append((sets[:, 0, :] if glob is None else glob).to(torch.float32).clone())
+        self.n_rows = run
+        self.lengths.extend(lengths)
+        self._counts.extend(counts)
+        self._offsets_t = self._counts_t = None
+
+    # ------------------------------------------------------------------------------------------ reading
+    def __len__(self):
+        return len(self.lengths)
+
+    @property
+    def glob(self):
+        if len(self._glob) != 1:
+            self._glob = [torch.cat(self._glob)] if self._glob else [torch.empty((0, self.D), device=self.device)]
+        return self._glob[0]
+
+    def nbytes(self):
+        return self.n_rows * self.Dp * 2 + len(self) * (self.D * 4 + 12)
+
+    def _tables(self):
+        if self._offsets_t is None:
+            offs, run = [], 0
+            for c in self._counts:
+                offs.append(run)
+                run += c
+            self._offsets_t = torch.tensor(offs, dtype=torch.int64, device=self.device)
+            self._counts_t = torch.tensor(self._counts, dtype=torch.int32, device=self.device)
+        return self._offsets_t, self._counts_t
+
+    def view(self, index):
+        """A selection (slice or index list) sharing this store's rows, e.g. store.view(slice(0, None, 5))
+        for the de-duplicated images of alad/evaluation.py:171."""
+        ids = list(range(len(self)))[index] if isinstance(index, slice) else [int(v) for v in index]
+        return StoreView(self, ids)
+
+    def max_count(self, ids=None):
+        cs = self._counts if ids is None else [self._counts[k] for k in ids]
+        return max(cs) if cs else 0
+
+
+class StoreView:
+    def __init__(self, store, ids):
+        self.store, self.ids = store, ids
+        self._ids_t = None
+
+    def __len__(self):
+        return len(self.ids)
+
+    @property
+    def lengths(self):
+        return [self.store.lengths[k] for k in self.ids]
+
+    @property
+    def glob(self):
+        return self.store.glob.index_select(0, self.ids_t.to(torch.int64))
+
+    @property
+    def ids_t(self):
+        if self._ids_t is None:
+            self._ids_t = torch.tensor(self.ids, dtype=torch.int32, device=self.store.device)
+        return self._ids_t
+
+
+def _unwrap(x):
+    return (x.store, x.ids, x.ids_t) if isinstance(x, StoreView) else (x, None, None)
+
+
+def alignment_scores_from_stores(img, cap):
+    """(N_img, N_cap) 'MrSw' scores (reference alad/loss.py:80-125) between two stores / views:
+    operands are row copies of the stores (no fp32 read, no normalisation), one score launch."""
+    si, ids_i, idt_i = _unwrap(img)
+    sc, ids_c, idt_c = _unwrap(cap)
+    if si.D != sc.D:
+        raise ValueError('aladin_amd: feature sizes differ (%d vs %d)' % (si.D, sc.D))
+    Bi, Bc = len(img), len(cap)
+    if Bi < 1 or Bc < 1:
+        raise ValueError('aladin_amd: empty store')
+    Rq, Tq = max(si.max_count(ids_i), 1), max(sc.max_count(ids_c), 1)
+    geom = ops.align_geometry(Bi, Bc, Rq + 1 + si.tail, Tq + 1 + sc.tail, si.D, si.tail, sc.tail)
+    lib = _lib.load()
+    dev = si.device
+    xm = torch.empty(geom.xm_bytes // 2, dtype=torch.float16, device=dev)
+    xe = torch.empty(max(geom.xe_bytes // 2, 8), dtype=torch.float16, device=dev)
+    y = torch.empty(geom.y_bytes // 2, dtype=torch.float16, device=dev)
+    oi, ci = si._tables()
+    oc, cc = sc._tables()
+    _lib.check(lib.aladin_align_pack_store_x(ops._ptr(si.rows), ops._ptr(oi), ops._ptr(ci), ops._ptr(idt_i), C.byref(geom),
+                                             ops._ptr(xm), ops._ptr(xe), ops._stream()), 'align_pack_store_x')
+    _lib.check(lib.aladin_align_pack_store_y(ops._ptr(sc.rows), ops._ptr(oc), ops._ptr(cc), ops._ptr(idt_c), C.byref(geom),
+                                             ops._ptr(y), ops._stream()), 'align_pack_store_y')
+    return ops.scores_from_packed(xm, xe, y, geom)

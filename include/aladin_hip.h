@@ -150,6 +150,27 @@ int aladin_listnet_fwd_bwd(const float* teacher, int64_t ld_t, const float* stud
                            float temperature, float eps, float* loss, float* d_student,
                            void* workspace, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Device-resident evaluation store (replaces the (N, 71, D) fp32 host buffers that encode_data fills,
+ * reference alad/evaluation.py:119-130, and the per-query H2D copies of i2t / t2i :179,202,267,291).
+ * A store holds, per sample, only positions [1, len - tail) of its set, L2-normalised like the pack
+ * kernels and rounded once to fp16, contiguous by true length:
+ *   rows (total_rows x aladin_store_row_width(D)) fp16; sample k = rows [offsets[k], offsets[k]+counts[k]).
+ * aladin_store_append normalises one encoder batch (B, L, D; strides in elements) into rows at the
+ * given per-sample offsets (int64, device); counts are max(0, lens[k] - 1 - tail) clipped to L - 1.
+ * aladin_align_pack_store_x / _y build the max-side (xm, xe) / sum-side (y) operands of
+ * aladin_align_scores for the samples ids[0..Bi) / ids[0..Bc) (ids NULL = 0, 1, 2, ...) under a
+ * geometry whose Rq / Tq bound the counts; the operands -- hence the scores -- are bit-identical to
+ * aladin_align_pack_images / _captions on the fp32 sets.
+ * ------------------------------------------------------------------------------------------- */
+int aladin_store_row_width(int D);
+int aladin_store_append(const float* sets, int64_t stride_b, int64_t stride_r, const int32_t* lens, int B, int L,
+                        int D, int tail, const int64_t* offsets, void* rows, void* stream);
+int aladin_align_pack_store_x(const void* rows, const int64_t* offsets, const int32_t* counts, const int32_t* ids,
+                              const aladin_align_geom* g, void* xm, void* xe, void* stream);
+int aladin_align_pack_store_y(const void* rows, const int64_t* offsets, const int32_t* counts, const int32_t* ids,
+                              const aladin_align_geom* g, void* y, void* stream);
+
 /* The other modes of DistillationLoss, reference alad/loss.py:359-425 (teacher detached :370).
  * One workspace query covers the three of them.  d_student (B x B contiguous) may be NULL.
  *   mse          :371-373  mean((student*wb[0] + wb[1] - teacher)^2); wb = the module's learnable

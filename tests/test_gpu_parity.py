@@ -383,6 +383,96 @@ def test_eval_i2t_t2i_vs_reference():
         np.testing.assert_allclose(m[:3], g['t2i_align_metrics'][:3], atol=0.81)
 
 
+def _fill_stores(images, captions, il, cl, batch=37):
+    """Feed (N, 71, D) eval sets to PackedSetStores the way encode_data_packed does: batch by batch,
+    each batch trimmed to ITS longest sample (the encoder's output length varies per batch)."""
+    from aladin_amd.store import PackedSetStore
+    D = images.shape[2]
+    si, sc = PackedSetStore(D, 0, dev(), capacity_rows=64), PackedSetStore(D, 2, dev(), capacity_rows=64)
+    for k0 in range(0, images.shape[0], batch):
+        k1 = min(images.shape[0], k0 + batch)
+        Li, Lc = max(il[k0:k1]), max(cl[k0:k1])
+        # (S, B, D) -> (B, S, D) permuted views, as forward_emb hands them over
+        si.append(T(np.ascontiguousarray(images[k0:k1, :Li].transpose(1, 0, 2))).permute(1, 0, 2), il[k0:k1])
+        sc.append(T(np.ascontiguousarray(captions[k0:k1, :Lc].transpose(1, 0, 2))).permute(1, 0, 2), cl[k0:k1])
+    return si, sc
+
+
+def test_packed_store_scores_are_bit_identical_and_smaller():
+    """the 16-bit length-packed store gives the SAME bits as the fp32 (N, 71, D)
+    buffers for both heads, for whole stores and strided views, at a fraction of the memory."""
+    from aladin_amd import evaluation as E, synth
+    from aladin_amd.store import alignment_scores_from_stores
+    g = load_golden('eval_sets')
+    images, captions, il, cl = synth.eval_sets(int(g['n_img']), int(g['D']), int(g['seed']))
+    cl = list(cl)
+    cl[3], cl[4] = 3, 4                                   # a caption with no scored word, one with a single word
+    captions[3, 3:] = 0
+    captions[4, 4:] = 0
+    si, sc = _fill_stores(images, captions, il, cl)
+    assert len(si) == images.shape[0] and si.lengths == list(il) and sc.lengths == cl
+    dense_bytes = images.nbytes + captions.nbytes
+    assert si.nbytes() + sc.nbytes() < 0.25 * dense_bytes
+    S_dense = E.compute_sim_matrix(images[0::5], captions, il[0::5], cl, mode='alignment')
+    S_store = E.compute_sim_matrix(si.view(slice(0, None, 5)), sc, mode='alignment')
+    assert torch.equal(S_dense, S_store)
+    assert torch.equal(S_store[:, 3], torch.zeros_like(S_store[:, 3]))        # no scored word -> exact 0 column
+    # arbitrary sub-grids through index views
+    N = images.shape[0]
+    pick_i, pick_c = [N - 5, 0, 15, 5], [7, 3, N - 1, 4, N // 2]
+    sub = alignment_scores_from_stores(si.view(pick_i), sc.view(pick_c))
+    ref = E.compute_sim_matrix(images[pick_i], captions[pick_c], [il[k] for k in pick_i], [cl[k] for k in pick_c],
+                               mode='alignment')
+    assert torch.equal(sub, ref)
+    # matching head reads the fp32 globals
+    M_dense = E.compute_sim_matrix(images[0::5, 0, :], captions[:, 0, :])
+    M_store = E.compute_sim_matrix(si.view(slice(0, None, 5)), sc)
+    assert torch.equal(M_dense, M_store)
+    # retrieval drivers accept the stores in place of the tensors
+    for fn in (None, 'alignment'):
+        for drv in (E.i2t, E.t2i):
+            m1, (r1, t1) = drv(images, captions, il, cl, return_ranks=True, sim_function=fn)
+            m2, (r2, t2) = drv(si, sc, si.lengths, sc.lengths, return_ranks=True, sim_function=fn)
+            assert m1 == m2
+            np.testing.assert_array_equal(r1, r2)
+            np.testing.assert_array_equal(t1, t2)
+
+
+def test_encode_data_packed_matches_encode_data():
+    """The two embedding stores, filled by the same stand-in encoder, score identically."""
+    from aladin_amd import evaluation as E
+    from aladin_amd.alad_model import StandInEncoder
+
+    class _Model(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.enc = StandInEncoder(feat_dim=48, embed=64, vocab=500).to(dev())
+
+        def forward_emb(self, imgs, txts):
+            return self.enc(imgs, txts)
+
+    class _Loader(list):
+        dataset = list(range(30))
+
+    rng = np.random.default_rng(3)
+    batches = _Loader()
+    for k in range(3):
+        n = 10
+        il = [int(v) for v in rng.integers(5, 20, n)]
+        cl = [int(v) for v in rng.integers(4, 16, n)]
+        imgs = (T(rng.standard_normal((n, max(il), 48)).astype(np.float32)), il)
+        txts = (T(rng.integers(0, 500, (n, max(cl))).astype(np.int64)), cl)
+        batches.append((imgs, txts))
+    model = _Model()
+    dense = E.encode_data(model, batches, logging=None)
+    si, sc, il2, cl2 = E.encode_data_packed(model, batches, logging=None)
+    assert il2 == list(dense[2]) and cl2 == list(dense[3])
+    S1 = E.compute_sim_matrix(dense[0], dense[1], dense[2], dense[3], mode='alignment')
+    S2 = E.compute_sim_matrix(si, sc, mode='alignment')
+    assert torch.equal(S1, S2)
+    assert torch.equal(E.compute_sim_matrix(dense[0][:, 0], dense[1][:, 0]), E.compute_sim_matrix(si, sc))
+
+
 # ------------------------------------------------------------------ BASELINE-size property tests
 def test_b256_scores_vs_oracle_and_properties():
     from aladin_amd import ops, synth

@@ -50,6 +50,19 @@ def main():
     print(json.dumps({'workload': 'alignment-head grid 1000x5000, sets padded to L=71, trimmed to the longest real length',
                       'ms': round(ms_align, 3), 'pairs_per_s': round(pairs / ms_align * 1e3, 1),
                       'ms_untrimmed_70x68': round(ms_align_padded, 3)}))
+    # the same grid from the packed 16-bit stores (aladin_amd/store.py): operands are row copies
+    from aladin_amd.store import PackedSetStore
+    si, sc = PackedSetStore(768, 0, dev), PackedSetStore(768, 2, dev)
+    for k0 in range(0, images.shape[0], 500):
+        si.append(torch.from_numpy(images[k0:k0 + 500]).to(dev), il[k0:k0 + 500])
+        sc.append(ca[k0:k0 + 500], cl[k0:k0 + 500])
+    view = si.view(slice(0, None, 5))
+    assert torch.equal(E.compute_sim_matrix(view, sc, mode='alignment'), E.compute_sim_matrix(ia, ca, ilen, cl, mode='alignment'))
+    ms_store = timed(lambda: E.compute_sim_matrix(view, sc, mode='alignment'), iters=5)
+    print(json.dumps({'workload': 'alignment-head grid 1000x5000 from PackedSetStore (fp16, packed by true length), bit-identical scores',
+                      'ms': round(ms_store, 3), 'pairs_per_s': round(pairs / ms_store * 1e3, 1),
+                      'store_MB': round((si.nbytes() + sc.nbytes()) / 2 ** 20, 1),
+                      'dense_fp32_MB': round((images.nbytes + captions.nbytes) / 2 ** 20, 1)}))
 
 
 if __name__ == '__main__':
