@@ -45,6 +45,49 @@ while time.time() - t0 < budget:
         ref, dM = O.listnet_loss(teacher, student, return_grad=True)
         assert abs(loss.item() - float(ref)) <= 2e-5 * max(1.0, abs(float(ref))), ('listnet', B, loss.item(), float(ref))
         np.testing.assert_allclose(st.grad.cpu().numpy(), dM, rtol=2e-3, atol=2e-6)
+    if B >= 2:
+        # the other distillation modes: teacher offsets move the ordinal threshold through the data
+        teacher = (rng.randn(B, B) * float(rng.choice([0.3, 2.0])) + float(rng.choice([-3.0, 0.0, 3.0]))).astype(np.float32)
+        student = (rng.randn(B, B) * float(rng.choice([0.2, 1.5]))).astype(np.float32)
+        dm = float(rng.choice([0.0, 0.2, 0.7]))
+        thr = float(rng.choice([-1.0, 0.1, 2.5]))
+        stride = int(rng.randint(1, min(B, 6)))
+        wbv = rng.randn(2).astype(np.float32)
+        wb = T(wbv).requires_grad_(True)
+        for mode, ref_fn in (('mse', lambda: O.distill_mse(teacher, student, wbv, True)),
+                             ('contrastive', lambda: O.distill_contrastive(teacher, student, dm, True)),
+                             ('ordinal', lambda: O.distill_ordinal(teacher, student, dm, thr, stride, True))):
+            st = T(student).requires_grad_(True)
+            loss = ops.distillation_loss(T(teacher), st, mode, dm, thr, stride, wb=wb if mode == 'mse' else None)
+            loss.backward()
+            out = ref_fn()
+            if np.isnan(out[0]):
+                assert np.isnan(loss.item()), (mode, B)
+            else:
+                assert abs(loss.item() - float(out[0])) <= 3e-5 * max(1.0, abs(float(out[0]))), (mode, B, loss.item(), float(out[0]))
+            got = st.grad.cpu().numpy()
+            if mode == 'mse':
+                np.testing.assert_allclose(got, out[1], rtol=1e-4, atol=1e-7)
+                np.testing.assert_allclose(wb.grad.cpu().numpy(), out[2], rtol=2e-4, atol=1e-5)
+                wb.grad = None
+            else:
+                # integer-valued (contrastive) / count-normalised (ordinal) gradients; a hinge sitting on
+                # the fp32 rounding edge may flip, which moves single entries only
+                bad = np.abs(got - out[1]) > 1e-5 * max(1.0, np.abs(out[1]).max())
+                assert bad.sum() <= max(2, B // 64), (mode, B, int(bad.sum()))
+        Bi2, Bc2, D2 = int(rng.randint(1, 90)), int(rng.randint(1, 90)), int(rng.choice([1, 5, 64, 100, 768]))
+        im_o = rng.randn(Bi2, D2).astype(np.float32)
+        s_o = (rng.randn(Bc2, D2) + 0.3).astype(np.float32)
+        a_o, b_o = T(im_o).requires_grad_(True), T(s_o).requires_grad_(True)
+        sc = ops.order_scores(a_o, b_o)
+        G = rng.randn(Bi2, Bc2).astype(np.float32)
+        (sc * T(G)).sum().backward()
+        np.testing.assert_allclose(sc.detach().cpu().numpy(), O.order_scores(im_o, s_o), rtol=5e-6, atol=1e-6)
+        di, ds = O.order_scores_backward(im_o, s_o, G)
+        if np.isfinite(di).all():
+            tol = 3e-5 * max(1.0, float(np.abs(di).max()), float(np.abs(ds).max()))
+            np.testing.assert_allclose(a_o.grad.cpu().numpy(), di, rtol=1e-4, atol=tol)
+            np.testing.assert_allclose(b_o.grad.cpu().numpy(), ds, rtol=1e-4, atol=tol)
     M, N, K = int(rng.randint(1, 200)), int(rng.randint(1, 200)), int(rng.choice([1, 7, 64, 100, 768]))
     A = rng.randn(M, K).astype(np.float32)
     Bm = rng.randn(N, K).astype(np.float32)
