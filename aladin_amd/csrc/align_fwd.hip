@@ -33,7 +33,7 @@
 static int scores_strip_mult(int tp16, int mtiles) {
   static int env = -1;
   if (env < 0) { const char* e = getenv("ALADIN_ALIGN_STRIP"); env = e ? atoi(e) : 2; }
-  return (env == 2 && tp16 == 3 && mtiles == 1) ? 2 : 1;
+  return (env == 2 && mtiles == 1 && tp16 <= 6) ? 2 : 1;       // tp16 in {1,2,3,4,6}: 24 / tp16 captions per 384-row tile
 }
 
 extern "C" int aladin_align_geometry(int Bi, int Bc, int R, int T, int D, aladin_align_geom* g) {
@@ -56,7 +56,7 @@ extern "C" int aladin_align_geometry_ex(int Bi, int Bc, int R, int T, int D, int
   g->Dp = round_up(D, 64);
   const int imgs_per_wave = (g->mtiles == 1) ? 2 : 1;
   g->img_unit = 4 * imgs_per_wave;
-  g->cap_unit = 2 * ((g->tp16 & 1) ? 2 : 1) * scores_strip_mult(g->tp16, g->mtiles);
+  g->cap_unit = (scores_strip_mult(g->tp16, g->mtiles) == 2) ? 24 / g->tp16 : 2 * ((g->tp16 & 1) ? 2 : 1);
   g->Bi_pad = round_up(Bi, g->img_unit);
   g->Bc_pad = round_up(Bc, g->cap_unit);
   g->xm_rows = (int64_t)g->Bi_pad * 32 * g->mtiles;
@@ -402,14 +402,15 @@ static int scores_wgm() {
 }
 
 // ------------------------------------------------------------------------------------------------
-// score kernel, v_mfma_f32_16x16x32_f16 body, for the headline tile class: one region tile (R' <= 32,
-// plus the side row), 48-word captions, 256 x 384 workgroup tile (8 waves: 4 x 2; wave = 2 images x
-// 4 captions = 4 x 12 accumulator tiles of 16 x 16).
+// score kernel, v_mfma_f32_16x16x32_f16 body, for every class with one region tile (R' <= 32, plus the
+// side row) and captions of TP16 = 1, 2, 3, 4 or 6 sixteen-word tiles (headline: 3 = 48 words):
+// 256 x 384 workgroup tile (8 waves: 4 x 2; wave = 2 images x 12/TP16 captions = 4 x 12 accumulator
+// tiles of 16 x 16).
 //   max over regions : in-lane over 2 row tiles x 4 registers, v_permlane32_swap pairs the wave's two
 //                      images into the two half-waves, one 16-lane exchange finishes the 32 rows
-//   sum over words   : a caption is exactly 3 column tiles -> in-lane adds, then a 16-lane reduction
+//   sum over words   : a caption is exactly TP16 column tiles -> in-lane adds, then a 16-lane reduction
 // ------------------------------------------------------------------------------------------------
-template <bool HAS_E>
+template <bool HAS_E, int TP16>
 __device__ __forceinline__ void scores16_epilogue(f32x4 (&acc)[4][12], int mb, int nb, const float* __restrict__ E,
                                                   int64_t ldE, float* __restrict__ S, int64_t ldS, int Bi, int Bc) {
   using Cfg = GemmCfg<4, 2, 2, 6>;
@@ -419,7 +420,11 @@ __device__ __forceinline__ void scores16_epilogue(f32x4 (&acc)[4][12], int mb, i
   const int half = lane >> 5, l4 = lane & 15;
   const int img = (mb * 4 + wm) * 2 + half;                        // lanes 0-31: image 0, lanes 32-63: image 1
   const float* e = HAS_E ? E + (int64_t)img * ldE + (int64_t)nb * Cfg::BN + wn * 192 + l4 : nullptr;
-  float v[4] = {0.f, 0.f, 0.f, 0.f};                               // 4 captions of the strip
+  constexpr int NC = 12 / TP16;                                    // captions of the wave's 192-row strip
+  static_assert(12 % TP16 == 0, "a caption must be a whole number of 16-word column tiles of the strip");
+  float v[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) v[c] = 0.f;
 #pragma unroll
   for (int ct = 0; ct < CT; ++ct) {
     float p0 = fmaxf(fmaxf(acc[0][ct][0], acc[0][ct][1]), fmaxf(acc[0][ct][2], acc[0][ct][3]));
@@ -431,11 +436,11 @@ __device__ __forceinline__ void scores16_epilogue(f32x4 (&acc)[4][12], int mb, i
     float m = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
     m = fmaxf(m, __shfl_xor(m, 16, 64));
     if constexpr (HAS_E) m = fmaxf(m, e[ct * 16]);
-    v[ct / 3] += m;
+    v[ct / TP16] += m;
   }
-  const int cap = (nb * 2 + wn) * 4;
+  const int cap = (nb * 2 + wn) * NC;
 #pragma unroll
-  for (int c = 0; c < 4; ++c) {
+  for (int c = 0; c < NC; ++c) {
     float t = v[c];
 #pragma unroll
     for (int o = 8; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
@@ -443,7 +448,7 @@ __device__ __forceinline__ void scores16_epilogue(f32x4 (&acc)[4][12], int mb, i
   }
 }
 
-template <bool HAS_E, bool PROBE = false>
+template <bool HAS_E, int TP16 = 3, bool PROBE = false>
 __global__ __launch_bounds__(512) void align_scores16_kernel(const half_t* __restrict__ xm, const half_t* __restrict__ y,
                                                              const float* __restrict__ E, int64_t ldE,
                                                              float* __restrict__ S, int64_t ldS, int Bi, int Bc,
@@ -465,7 +470,7 @@ __global__ __launch_bounds__(512) void align_scores16_kernel(const half_t* __res
   gemm_mainloop16<Cfg, true>(xm + (int64_t)mb * Cfg::BM * ldk, y + (int64_t)nb * Cfg::BN * ldk, ldk, ktiles, smem, acc);
   if constexpr (PROBE) { pt1 = __builtin_amdgcn_s_memtime(); pr1 = __builtin_amdgcn_s_memrealtime(); }
 
-  scores16_epilogue<HAS_E>(acc, mb, nb, E, ldE, S, ldS, Bi, Bc);
+  scores16_epilogue<HAS_E, TP16>(acc, mb, nb, E, ldE, S, ldS, Bi, Bc);
   if constexpr (PROBE) {
     __syncthreads();
     if (threadIdx.x == 0 && blockIdx.x < 4096) {
@@ -478,7 +483,7 @@ __global__ __launch_bounds__(512) void align_scores16_kernel(const half_t* __res
   }
 }
 
-template <bool HAS_E, bool PROBE = false>
+template <bool HAS_E, int TP16 = 3, bool PROBE = false>
 static int launch_scores16(const aladin_align_geom* g, const half_t* xm, const half_t* y, const float* E, float* S,
                            int64_t ldS, hipStream_t stream) {
   using Cfg = GemmCfg<4, 2, 2, 6>;
@@ -487,7 +492,7 @@ static int launch_scores16(const aladin_align_geom* g, const half_t* xm, const h
     aladin_set_error("align_scores16: packed rows do not tile");
     return ALADIN_ERR_ARG;
   }
-  auto kern = align_scores16_kernel<HAS_E, PROBE>;
+  auto kern = align_scores16_kernel<HAS_E, TP16, PROBE>;
   static bool attr_done = false;
   if (!attr_done) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES) != hipSuccess) {
@@ -531,21 +536,16 @@ static int launch_scores_w(const aladin_align_geom* g, const half_t* xm, const h
 template <int WM, int Q, int TP16, bool HAS_E>
 static int launch_scores(const aladin_align_geom* g, const half_t* xm, const half_t* y, const float* E, float* S,
                          int64_t ldS, hipStream_t stream) {
-  if constexpr (TP16 == 3 && Q == 1)
+  if constexpr (Q == 1 && TP16 <= 6)
     if (scores_strip_mult(TP16, g->mtiles) == 2) {
-      if (scores_spread() == 16) return launch_scores16<HAS_E>(g, xm, y, E, S, ldS, stream);      // 16x16x32 body
-      if (scores_spread() == 26) return launch_scores16<HAS_E, true>(g, xm, y, E, S, ldS, stream); // + clock probe (diagnostic)
-      switch (scores_spread()) {                       // ALADIN_ALIGN_SPREAD: 16 (default) = 16x16x32 body above; 0/1/2/3 = 32x32x16 schedules
-        case 0: return launch_scores_w<4, WM, Q, TP16, HAS_E, 2, 0>(g, xm, y, E, S, ldS, stream);
-        case 2: return launch_scores_w<4, WM, Q, TP16, HAS_E, 2, 2>(g, xm, y, E, S, ldS, stream);
-        case 5: return launch_scores_w<4, WM, Q, TP16, HAS_E, 2, 5>(g, xm, y, E, S, ldS, stream);
-        case 6: return launch_scores_w<4, WM, Q, TP16, HAS_E, 2, 6>(g, xm, y, E, S, ldS, stream);
-        case 7: return launch_scores_w<4, WM, Q, TP16, HAS_E, 2, 7>(g, xm, y, E, S, ldS, stream);
-        case 8: return launch_scores_w<4, WM, Q, TP16, HAS_E, 2, 8>(g, xm, y, E, S, ldS, stream);
-        case 9: return launch_scores_w<4, WM, Q, TP16, HAS_E, 2, 9>(g, xm, y, E, S, ldS, stream);
-        case 1: return launch_scores_w<4, WM, Q, TP16, HAS_E, 2, 1>(g, xm, y, E, S, ldS, stream);
-        default: return launch_scores_w<4, WM, Q, TP16, HAS_E, 2, 3>(g, xm, y, E, S, ldS, stream);
+      // ALADIN_ALIGN_SPREAD: 16 (default) = v_mfma_f32_16x16x32_f16 body; 26 = the same + clock probe
+      // (diagnostic); 3 / 6 = the earlier 32x32x16 body and its clock probe (headline class only)
+      if constexpr (TP16 == 3) {
+        if (scores_spread() == 26) return launch_scores16<HAS_E, 3, true>(g, xm, y, E, S, ldS, stream);
+        if (scores_spread() == 3) return launch_scores_w<4, WM, Q, TP16, HAS_E, 2, 3>(g, xm, y, E, S, ldS, stream);
+        if (scores_spread() == 6) return launch_scores_w<4, WM, Q, TP16, HAS_E, 2, 6>(g, xm, y, E, S, ldS, stream);
       }
+      return launch_scores16<HAS_E, TP16>(g, xm, y, E, S, ldS, stream);
     }
   if (scores_wgm() == 4) return launch_scores_w<4, WM, Q, TP16, HAS_E, 1>(g, xm, y, E, S, ldS, stream);
   return launch_scores_w<2, WM, Q, TP16, HAS_E, 1>(g, xm, y, E, S, ldS, stream);

@@ -12,7 +12,7 @@
 #include "../../include/aladin_hip.h"
 #include "gemm_core.hpp"
 
-using SimCfg = GemmCfg<4, 2, 2, 4>;       // 256 x 256 tile, 8 waves, 128 accumulator VGPRs per lane
+using SimCfg = GemmCfg<4, 2, 2, 6>;       // 256 x 384 tile, 8 waves x (64 x 192), v_mfma_f32_16x16x32_f16 body (gemm_core.hpp)
 
 struct SimWs {
   float* scale;      // [0] = 2^ea, [1] = 2^eb, [2] = absmax(img), [3] = absmax(cap)  (256 B block)
@@ -44,13 +44,26 @@ extern "C" size_t aladin_sim_workspace_bytes(int n_img, int n_cap, int D) {
 __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, int64_t rs, int rows, int D,
                                                      unsigned* __restrict__ out) {
   float m = 0.f;
-  const int64_t n = (int64_t)rows * D;
-  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
-    const float v = fabsf(x[(e / D) * rs + (e % D)]);
-    if (v > m) m = v;                                   // NaN never wins
+  const int lane = threadIdx.x & 63;
+  const bool vec4 = (D % 4 == 0) && (rs % 4 == 0) && (((uintptr_t)x & 15) == 0);
+  // one wave per row, rows dealt round-robin over all waves of the grid
+  for (int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); r < rows; r += (int64_t)gridDim.x * 4) {
+    const float* row = x + r * rs;
+    if (vec4) {
+      for (int c = lane * 4; c < D; c += 256) {
+        const float4 v = *reinterpret_cast<const float4*>(row + c);
+        const float a = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));   // fmaxf drops NaN
+        if (a > m) m = a;
+      }
+    } else {
+      for (int c = lane; c < D; c += 64) {
+        const float a = fabsf(row[c]);
+        if (a > m) m = a;                                 // NaN never wins
+      }
+    }
   }
   m = wave_max(m);
-  if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));
+  if (lane == 0) atomicMax(out, __float_as_uint(m));
 }
 
 __global__ void sim_scale_kernel(float* __restrict__ sc) {
@@ -77,6 +90,21 @@ __global__ __launch_bounds__(256) void sim_pack_kernel(const float* __restrict__
   const float sc = scale[kind];
   half_t* d = dst + r * 3 * Dp;
   const int lo_slot = kind == 0 ? 1 : 2, hi2_slot = kind == 0 ? 2 : 1;
+  const bool vec4 = (D % 4 == 0) && (rs % 4 == 0) && (((uintptr_t)x & 15) == 0);      // Dp is a multiple of 64
+  if (vec4) {
+    for (int c = lane * 4; c < Dp; c += 256) {
+      float4 v = {0.f, 0.f, 0.f, 0.f};
+      if (r < rows && c < D) v = *reinterpret_cast<const float4*>(x + r * rs + c);
+      const float w[4] = {v.x * sc, v.y * sc, v.z * sc, v.w * sc};
+      half4 hi, lo;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { hi[k] = (half_t)w[k]; lo[k] = (half_t)(w[k] - (float)hi[k]); }
+      *reinterpret_cast<half4*>(d + c) = hi;
+      *reinterpret_cast<half4*>(d + lo_slot * Dp + c) = lo;
+      *reinterpret_cast<half4*>(d + hi2_slot * Dp + c) = hi;
+    }
+    return;
+  }
   for (int c = lane; c < Dp; c += 64) {
     float v = 0.f;
     if (r < rows && c < D) v = x[r * rs + c] * sc;
@@ -96,26 +124,29 @@ __global__ __launch_bounds__(512) void sim_gemm_kernel(const half_t* __restrict_
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int mb, nb;
   tile_coords(blockIdx.x, n_blocks / n_nblk, n_nblk, 4, mb, nb);
-  f32x16 acc[Cfg::WM][Cfg::WN];
+  f32x4 acc[4][12];
 #pragma unroll
-  for (int m = 0; m < Cfg::WM; ++m)
+  for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
-    for (int n = 0; n < Cfg::WN; ++n)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
-  gemm_mainloop<Cfg>(a + (int64_t)mb * Cfg::BM * ldk, b + (int64_t)nb * Cfg::BN * ldk, ldk, ktiles, smem, acc);
+    for (int ct = 0; ct < 12; ++ct) acc[rt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+  gemm_mainloop16<Cfg>(a + (int64_t)mb * Cfg::BM * ldk, b + (int64_t)nb * Cfg::BN * ldk, ldk, ktiles, smem, acc);
   const float unscale = 1.0f / (scale[0] * scale[1]);   // exact: powers of two
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int wm = wave / Cfg::WGN, wn = wave % Cfg::WGN;
+  // 16x16 C tile: col = lane & 15, row = 4 * (lane >> 4) + reg
+  const int row0 = mb * Cfg::BM + wm * 64 + 4 * (lane >> 4);
+  const int col0 = nb * Cfg::BN + wn * 192 + (lane & 15);
 #pragma unroll
-  for (int m = 0; m < Cfg::WM; ++m)
+  for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
-    for (int n = 0; n < Cfg::WN; ++n) {
-      const int col = nb * Cfg::BN + (wn * Cfg::WN + n) * 32 + (lane & 31);
+    for (int reg = 0; reg < 4; ++reg) {
+      const int row = row0 + rt * 16 + reg;
+      if (row >= n_img) continue;
+      float* out = sim + (int64_t)row * ld;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = mb * Cfg::BM + (wm * Cfg::WM + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (row < n_img && col < n_cap) sim[(int64_t)row * ld + col] = acc[m][n][r] * unscale;
+      for (int ct = 0; ct < 12; ++ct) {
+        const int col = col0 + ct * 16;
+        if (col < n_cap) out[col] = acc[rt][ct][reg] * unscale;
       }
     }
 }
