@@ -8,8 +8,8 @@
 
 None of them holds parameters or buffers, except DistillationLoss(mode='mse') whose learnable pair
 `wb` the reference has too (:366) -- state dicts saved by the reference load unchanged (SURVEY.md
-section 5, checkpoint row).  The one mode not provided (aggregation 'scan-sentences') raises
-NotImplementedError rather than fall back to eager PyTorch.
+section 5, checkpoint row).  Every aggregation / distillation mode / measure of the reference is
+computed by HIP kernels; nothing falls back to eager PyTorch.
 """
 import torch
 from torch import nn
@@ -60,22 +60,25 @@ class AlignmentContrastiveLoss(Contrastive):
     """reference alad/loss.py:70-159.  aggregation: 'MrSw' (all shipped configs), 'MrAVGw' (= MrSw
     divided by the caption length, :126-129), 'MwSr' / 'symm' (the MrSw kernels with the sets'
     roles swapped, :130-135), 'sum' / 'mean' (:120-123: the double sum of cosines factorises into
-    one dot product of the summed unit vectors).  'scan-sentences' is not provided."""
+    one dot product of the summed unit vectors), 'scan-sentences' (:136-149, fp32 throughout)."""
 
     def __init__(self, margin=0, measure=False, max_violation=False, aggregation='sum-max-sentences'):
         super().__init__(margin, measure, max_violation)
         self.aggregation = aggregation
 
     def forward(self, im_set, s_seq, im_len, s_len, return_loss=True, return_similarity_mat=False):
-        if self.aggregation not in ('MrSw', 'MrAVGw', 'MwSr', 'symm', 'sum', 'mean'):
-            raise NotImplementedError("aladin_amd: alignment aggregation %r is not implemented in HIP "
-                                      "(supported: 'MrSw', 'MrAVGw', 'MwSr', 'symm', 'sum', 'mean')" % (self.aggregation,))
+        if self.aggregation not in ('MrSw', 'MrAVGw', 'MwSr', 'symm', 'sum', 'mean', 'scan-sentences'):
+            # the reference leaves aggr_similarity unbound and dies with a NameError (:151-159)
+            raise ValueError("aladin_amd: unknown alignment aggregation %r (supported: 'MrSw', 'MrAVGw', 'MwSr', "
+                             "'symm', 'sum', 'mean', 'scan-sentences')" % (self.aggregation,))
         if return_loss and self.aggregation == 'MrSw':
             # fused scores + hinge node; the returned matrix is detached (see ops.alignment_triplet_loss)
             loss, aggr_similarity = ops.alignment_triplet_loss(im_set, s_seq, im_len, s_len, self.margin,
                                                                self.max_violation)
             return (loss, aggr_similarity) if return_similarity_mat else loss
-        if self.aggregation in ('sum', 'mean'):
+        if self.aggregation == 'scan-sentences':
+            aggr_similarity = ops.alignment_scan_scores(im_set, s_seq, im_len, s_len)
+        elif self.aggregation in ('sum', 'mean'):
             aggr_similarity = ops.alignment_sum_scores(im_set, s_seq, im_len, s_len, mean=(self.aggregation == 'mean'))
         elif self.aggregation in ('MwSr', 'symm'):
             aggr_similarity = ops.alignment_scores(im_set, s_seq, im_len, s_len, self.aggregation)

@@ -263,6 +263,47 @@ def alignment_scores(im_set, s_seq, im_len, s_len, aggregation='MrSw'):
     raise NotImplementedError('aladin_amd: aggregation %r' % (aggregation,))
 
 
+class _ScanScores(torch.autograd.Function):
+    """aggregation='scan-sentences' (reference alad/loss.py:136-149)."""
+
+    @staticmethod
+    def forward(ctx, im, s, im_len_t, s_len_t):
+        lib = _lib.load()
+        im = _rows_inner_contig(im)
+        s = _rows_inner_contig(s)
+        Bi, R, D = im.shape
+        Bc, T, _ = s.shape
+        S = torch.empty((Bi, Bc), dtype=torch.float32, device=im.device)
+        ws = _workspace(lib.aladin_scan_workspace_bytes(Bi, Bc, R, T, D, 0), im.device)
+        _lib.check(lib.aladin_scan_fwd(_ptr(im), im.stride(0), im.stride(1), _ptr(im_len_t), _ptr(s), s.stride(0), s.stride(1),
+                                       _ptr(s_len_t), Bi, Bc, R, T, D, _ptr(S), S.stride(0), _ptr(ws), _stream()), 'scan_fwd')
+        ctx.save_for_backward(im, s, im_len_t, s_len_t)
+        return S
+
+    @staticmethod
+    def backward(ctx, dS):
+        lib = _lib.load()
+        im, s, im_len_t, s_len_t = ctx.saved_tensors
+        Bi, R, D = im.shape
+        Bc, T, _ = s.shape
+        dS = dS.contiguous()
+        d_im = torch.empty((Bi, R, D), dtype=torch.float32, device=im.device)
+        d_s = torch.empty((Bc, T, D), dtype=torch.float32, device=im.device)
+        ws = _workspace(lib.aladin_scan_workspace_bytes(Bi, Bc, R, T, D, 1), im.device)
+        _lib.check(lib.aladin_scan_bwd(_ptr(im), im.stride(0), im.stride(1), _ptr(im_len_t), _ptr(s), s.stride(0), s.stride(1),
+                                       _ptr(s_len_t), Bi, Bc, R, T, D, _ptr(dS), dS.shape[1], _ptr(None), _ptr(d_im), _ptr(d_s),
+                                       _ptr(ws), _stream()), 'scan_bwd')
+        return d_im, d_s, None, None
+
+
+def alignment_scan_scores(im_set, s_seq, im_len, s_len):
+    """(Bi, Bc) 'scan-sentences' scores, differentiable; replaces reference alad/loss.py:136-149 (+ :80-116)."""
+    im_len_t, s_len_t = _check_sets(im_set, s_seq, im_len, s_len)
+    if s_seq.shape[1] < 4:
+        raise ValueError('aladin_amd: captions need at least 4 positions (token 0 and the last two are dropped)')
+    return _ScanScores.apply(im_set, s_seq, im_len_t, s_len_t)
+
+
 class _NormSum(torch.autograd.Function):
     """(B,N,D) set -> (B,D) sum of its L2-normalised rows 1 .. len-1-tail."""
 

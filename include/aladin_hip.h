@@ -171,6 +171,25 @@ int aladin_align_pack_store_x(const void* rows, const int64_t* offsets, const in
 int aladin_align_pack_store_y(const void* rows, const int64_t* offsets, const int32_t* counts, const int32_t* ids,
                               const aladin_align_geom* g, void* y, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * aggregation = 'scan-sentences' -- reference alad/loss.py:136-149 (no shipped config uses it).
+ * Per pair: relu(cosines) L2-normalised over regions, softmax over the caption's valid words for each
+ * valid region, attended sentence vector, S = sum over regions of cos(region, attended vector).
+ * Everything in fp32 (exact-fp32 MFMA GEMMs).  Same set / length / stride conventions as
+ * aladin_align_bwd; R - 1 <= 96, T - 3 <= 96.  A caption without scored words gives NaN like the
+ * reference.  aladin_scan_bwd recomputes the forward state itself and returns the gradient of the
+ * length-masked expression (the reference's autograd is NaN on ragged batches and equal to this on
+ * full-length ones); gscale (device scalar, may be NULL) multiplies dS.
+ * ------------------------------------------------------------------------------------------- */
+size_t aladin_scan_workspace_bytes(int Bi, int Bc, int R, int T, int D, int backward);
+int aladin_scan_fwd(const float* im, int64_t im_stride_b, int64_t im_stride_r, const int32_t* im_len, const float* s,
+                    int64_t s_stride_b, int64_t s_stride_t, const int32_t* s_len, int Bi, int Bc, int R, int T, int D,
+                    float* S, int64_t ldS, void* workspace, void* stream);
+int aladin_scan_bwd(const float* im, int64_t im_stride_b, int64_t im_stride_r, const int32_t* im_len, const float* s,
+                    int64_t s_stride_b, int64_t s_stride_t, const int32_t* s_len, int Bi, int Bc, int R, int T, int D,
+                    const float* dS, int64_t ld_dS, const float* gscale, float* d_im, float* d_s, void* workspace,
+                    void* stream);
+
 /* The other modes of DistillationLoss, reference alad/loss.py:359-425 (teacher detached :370).
  * One workspace query covers the three of them.  d_student (B x B contiguous) may be NULL.
  *   mse          :371-373  mean((student*wb[0] + wb[1] - teacher)^2); wb = the module's learnable

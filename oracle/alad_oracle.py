@@ -189,6 +189,79 @@ def listnet_loss(teacher, student, return_grad=False, temperature=6.0, eps=1e-10
     return (loss, dM.astype(M.dtype)) if return_grad else loss
 
 
+def scan_sentences_scores(im_set, s_seq, im_len, s_len, dS=None):
+    """aggregation='scan-sentences', alad/loss.py:136-149, pair by pair in float64.
+
+    Per pair, with A the masked cosine block (:99-116): N = relu(A) L2-normalised over REGIONS per word
+    (:137-138), W = softmax over the valid WORDS of each valid region row (:139-140), the attended
+    sentence vector att_r = sum_w W[r,w] s_w (:142-145) and S = sum_{r<Li} cos(i_r, att_r) (:146-149),
+    where <i_r, att_r> = sum_w W[r,w] A[r,w] and |att_r|^2 = W_r G W_r^T with G the caption's Gram matrix.
+    A pair whose caption has no scored word is NaN (softmax over an empty row), as in the reference.
+
+    With dS (Bi, Bc) also returns (d im_set, d s_seq) of sum(dS * S): the analytic gradient of the
+    masked expression.  (The reference's own autograd returns NaN as soon as any image is shorter than
+    the batch maximum -- 0 * NaN from its -inf rows -- so it is only comparable on full-length batches.)"""
+    im = np.asarray(im_set, np.float64)
+    s = np.asarray(s_seq, np.float64)
+    Bi, Bc = im.shape[0], s.shape[0]
+    ni = np.sqrt((im * im).sum(-1, keepdims=True))
+    ns = np.sqrt((s * s).sum(-1, keepdims=True))
+    xn = (im / np.maximum(ni, F_EPS))[:, 1:, :]
+    yn = (s / np.maximum(ns, F_EPS))[:, 1:-2, :]
+    S = np.zeros((Bi, Bc), np.float64)
+    dxn = np.zeros_like(xn)
+    dyn = np.zeros_like(yn)
+    for i in range(Bi):
+        Li = max(int(im_len[i]) - 1, 0)
+        for j in range(Bc):
+            Lj = max(int(s_len[j]) - 3, 0)
+            if Li == 0:
+                continue
+            if Lj == 0:
+                S[i, j] = np.nan
+                continue
+            x, y = xn[i, :Li], yn[j, :Lj]
+            A = x @ y.T
+            P = np.maximum(A, 0.0)
+            c = np.maximum(np.sqrt((P * P).sum(0)), 1e-12)
+            N = P / c
+            E = np.exp(N - N.max(1, keepdims=True))
+            W = E / E.sum(1, keepdims=True)
+            G = y @ y.T
+            u = (W * A).sum(1)
+            t = W @ G
+            q = (W * t).sum(1)
+            n = np.sqrt(q)
+            a = np.maximum(np.sqrt((x * x).sum(1)), 1e-8)
+            m = np.maximum(n, 1e-8)
+            cos = u / (a * m)
+            S[i, j] = cos.sum()
+            if dS is None or dS[i, j] == 0:
+                continue
+            g = float(dS[i, j])
+            k = np.where(n > 1e-8, cos / m ** 2, 0.0)              # d cos / d q = -k / 2 (0 when |att| is clamped)
+            dW = g * (A / (a * m)[:, None] - k[:, None] * t)
+            dZ = W * (dW - (W * dW).sum(1, keepdims=True))
+            dot = (N * dZ).sum(0)
+            dP = (dZ - N * dot) / c
+            dA = g * W / (a * m)[:, None] + dP * (A > 0)
+            H = g * (W * k[:, None]).T @ W
+            dxn[i, :Li] += dA @ y
+            dyn[j, :Lj] += dA.T @ x - H @ y
+    S = S.astype(np.float32)
+    if dS is None:
+        return S
+
+    def norm_bwd(vn, dvn, nrm):
+        return (dvn - vn * (vn * dvn).sum(-1, keepdims=True)) / np.maximum(nrm, F_EPS)
+
+    d_im = np.zeros_like(im)
+    d_s = np.zeros_like(s)
+    d_im[:, 1:, :] = norm_bwd(xn, dxn, ni[:, 1:, :])
+    d_s[:, 1:-2, :] = norm_bwd(yn, dyn, ns[:, 1:-2, :])
+    return S, d_im.astype(np.float32), d_s.astype(np.float32)
+
+
 def distill_mse(teacher, student, wb, return_grad=False):
     """DistillationLoss(mode='mse'), alad/loss.py:371-373: mean((student*wb[0] + wb[1] - teacher)^2);
     gradients w.r.t. the student and the learnable pair wb (:366)."""

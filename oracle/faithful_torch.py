@@ -38,6 +38,18 @@ def alignment_scores_faithful(im_set, s_seq, im_len, s_len, aggregation='MrSw'):
         return al.sum(dim=(2, 3))                                  # :120-121
     if aggregation == 'mean':
         return al.mean(dim=(2, 3))                                 # :122-123
+    if aggregation == 'scan-sentences':                            # :136-149
+        nrm = F.normalize(F.relu(al), p=2, dim=2)
+        # The reference fills the dead entries with -inf, so a region row r >= Li is all -inf, its
+        # softmax NaN, and (the row being zeroed only afterwards, :147) autograd returns NaN for every
+        # ragged batch.  Here such rows get finite logits and are zeroed the same way: identical scores,
+        # and the gradient of the masked expression instead of NaN.
+        dead_row = ~rvalid[:, None, :, None].expand_as(dead)
+        logits = nrm.masked_fill(dead & ~dead_row, float('-inf')).masked_fill(dead_row, 0.0)
+        w = torch.softmax(logits, dim=3)
+        att = torch.matmul(w, b4)                                  # (Bi, Bc, R', D)
+        cos = F.cosine_similarity(a4, att, dim=3)
+        return cos.masked_fill(~rvalid[:, None, :].expand_as(cos), 0.0).sum(2)
     raise ValueError(aggregation)
 
 

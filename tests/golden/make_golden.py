@@ -76,6 +76,26 @@ def gen_alignment():
             with torch.no_grad():
                 S = crit(t(im), t(s), im_len, s_len, return_loss=False, return_similarity_mat=True)
             out['S_' + mode] = S.numpy()
+        # 'scan-sentences' (alad/loss.py:136-149): scores for every case; loss + gradients only where the
+        # reference's autograd is finite, i.e. full-length batches (its -inf rows give 0 * NaN otherwise)
+        crit = ref_loss.AlignmentContrastiveLoss(margin=margin, measure='dot', max_violation=False,
+                                                 aggregation='scan-sentences')
+        a = t(im).requires_grad_(True)
+        b = t(s).requires_grad_(True)
+        S = crit(a, b, im_len, s_len, return_loss=False, return_similarity_mat=True)
+        out['S_scan-sentences'] = S.detach().numpy()
+        if not ragged and B == Bc:
+            w = synth.normal((B, Bc), seed + 555)
+            (S * t(w)).sum().backward()
+            assert torch.isfinite(a.grad).all() and torch.isfinite(b.grad).all()
+            sc_stride = 16 if D >= 512 else 1
+            out['scan_w'] = w
+            out['scan_stride'] = sc_stride
+            out['dim_scan'] = a.grad.numpy()[:, :, ::sc_stride]
+            out['ds_scan'] = b.grad.numpy()[:, :, ::sc_stride]
+            a2 = t(im).requires_grad_(True)
+            b2 = t(s).requires_grad_(True)
+            out['loss_scan_sum'] = crit(a2, b2, im_len, s_len).item()
         if B == Bc:
             stride = 16 if D >= 512 else 1
             out['grad_stride'] = stride

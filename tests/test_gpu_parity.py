@@ -63,13 +63,63 @@ def test_alignment_module_modes(name, mode):
     assert_scores_close(S.cpu().numpy(), g['S_' + mode], atol_rel=1e-3, scale='max')
 
 
+@pytest.mark.parametrize('name', ALIGN_GOLDENS)
+def test_scan_sentences_scores_match_reference(name):
+    """aggregation='scan-sentences' (alad/loss.py:136-149), fp32 end to end."""
+    from aladin_amd.loss import AlignmentContrastiveLoss
+    g = load_golden(name)
+    im, s, il, sl = golden_alignment_inputs(g)
+    crit = AlignmentContrastiveLoss(margin=float(g['margin']), measure='dot', max_violation=False, aggregation='scan-sentences')
+    S = crit(T(im), T(s), il, sl, return_loss=False, return_similarity_mat=True)
+    np.testing.assert_allclose(S.cpu().numpy(), g['S_scan-sentences'], rtol=3e-5, atol=5e-6)
+
+
+@pytest.mark.parametrize('name', ['align_tiny', 'align_b16_d768'])
+def test_scan_sentences_loss_and_gradients_match_reference(name):
+    from aladin_amd.loss import AlignmentContrastiveLoss
+    g = load_golden(name)
+    im, s, il, sl = golden_alignment_inputs(g)
+    crit = AlignmentContrastiveLoss(margin=float(g['margin']), measure='dot', max_violation=False, aggregation='scan-sentences')
+    a, b = T(im).requires_grad_(True), T(s).requires_grad_(True)
+    S = crit(a, b, il, sl, return_loss=False, return_similarity_mat=True)
+    (S * T(g['scan_w'])).sum().backward()
+    st = int(g['scan_stride'])
+    scale = max(1.0, float(np.abs(g['dim_scan']).max()))
+    np.testing.assert_allclose(a.grad.cpu().numpy()[:, :, ::st], g['dim_scan'], rtol=2e-4, atol=5e-6 * scale)
+    np.testing.assert_allclose(b.grad.cpu().numpy()[:, :, ::st], g['ds_scan'], rtol=2e-4, atol=5e-6 * scale)
+    a2, b2 = T(im).requires_grad_(True), T(s).requires_grad_(True)
+    loss = crit(a2, b2, il, sl)
+    loss.backward()
+    np.testing.assert_allclose(loss.item(), float(g['loss_scan_sum']), rtol=2e-5)
+    assert torch.isfinite(a2.grad).all() and torch.isfinite(b2.grad).all()
+
+
+@pytest.mark.parametrize('shape', [(4, 6, 20, 24, 32), (7, 3, 34, 50, 100), (3, 3, 71, 71, 64), (2, 5, 2, 4, 8)])
+def test_scan_sentences_ragged_vs_oracle(shape):
+    """Ragged / rectangular / minimum-size batches against the oracle's closed form (whose gradient is
+    pinned to the reference on full-length batches and to the NaN-free torch restatement on ragged ones)."""
+    from aladin_amd import ops, synth
+    Bi, Bc, R, Tn, D = shape
+    im, s, il, sl = synth.alignment_batch(Bi, R, Tn, D, seed=31 + Bi, ragged=True, Bc=Bc)
+    w = synth.normal((Bi, Bc), 77)
+    a, b = T(im).requires_grad_(True), T(s).requires_grad_(True)
+    S = ops.alignment_scan_scores(a, b, il, sl)
+    (S * T(w)).sum().backward()
+    So, d_im, d_s = O.scan_sentences_scores(im, s, il, sl, dS=w)
+    np.testing.assert_allclose(S.detach().cpu().numpy(), So, rtol=3e-5, atol=5e-6)
+    scale = max(1e-3, float(np.abs(d_im).max()), float(np.abs(d_s).max()))
+    np.testing.assert_allclose(a.grad.cpu().numpy(), d_im, rtol=2e-4, atol=1e-5 * scale)
+    np.testing.assert_allclose(b.grad.cpu().numpy(), d_s, rtol=2e-4, atol=1e-5 * scale)
+    assert np.all(a.grad.cpu().numpy()[:, 0] == 0) and np.all(b.grad.cpu().numpy()[:, 0] == 0)
+
+
 def test_unsupported_aggregation_raises():
     from aladin_amd.loss import AlignmentContrastiveLoss
     g = load_golden('align_tiny')
     im, s, il, sl = golden_alignment_inputs(g)
-    with pytest.raises(NotImplementedError):
-        AlignmentContrastiveLoss(aggregation='scan-sentences')(T(im), T(s), il, sl, return_loss=False,
-                                                               return_similarity_mat=True)
+    with pytest.raises(ValueError):                      # the reference dies with a NameError (alad/loss.py:151-159)
+        AlignmentContrastiveLoss(aggregation='sum-max-sentences')(T(im), T(s), il, sl, return_loss=False,
+                                                                  return_similarity_mat=True)
 
 
 @pytest.mark.parametrize('name', ['align_b5_d64', 'align_b12_struct', 'align_r33'])

@@ -6,6 +6,8 @@ import pytest
 
 from conftest import (ALIGN_GOLDENS, SQUARE_ALIGN_GOLDENS, golden_alignment_inputs, load_golden)
 import alad_oracle as O
+import faithful_torch as FT
+import torch
 
 RTOL = 1e-3          # north_star tolerance; the oracle itself lands around 1e-6
 
@@ -178,3 +180,42 @@ def test_eval_i2t_t2i():
         m, (r, t1) = O.t2i(images, captions, il, cl, sim, return_ranks=True)
         close(m, g['t2i_%s_metrics' % tag], rtol=0, atol=1e-9)
         assert np.array_equal(r, g['t2i_%s_ranks' % tag]) and np.array_equal(t1, g['t2i_%s_top1' % tag])
+
+
+@pytest.mark.parametrize('name', ALIGN_GOLDENS)
+def test_scan_sentences_scores(name):
+    """aggregation='scan-sentences' (alad/loss.py:136-149): scores for every case (ragged included)."""
+    g = load_golden(name)
+    im, s, il, sl = golden_alignment_inputs(g)
+    S = O.scan_sentences_scores(im, s, il, sl)
+    close(S, g['S_scan-sentences'], rtol=2e-5, atol=2e-6)
+    Sf = FT.alignment_scores_faithful(torch.from_numpy(im), torch.from_numpy(s), il, sl, 'scan-sentences').numpy()
+    close(Sf, g['S_scan-sentences'], rtol=2e-5, atol=2e-6)
+
+
+@pytest.mark.parametrize('name', ['align_tiny', 'align_b16_d768'])
+def test_scan_sentences_gradients_full_length(name):
+    """The analytic gradient equals the reference's autograd where the latter is finite (full-length batches)."""
+    g = load_golden(name)
+    im, s, il, sl = golden_alignment_inputs(g)
+    st = int(g['scan_stride'])
+    _, d_im, d_s = O.scan_sentences_scores(im, s, il, sl, dS=g['scan_w'])
+    scale = float(np.abs(g['dim_scan']).max())
+    close(d_im[:, :, ::st], g['dim_scan'], rtol=1e-4, atol=2e-6 * max(scale, 1.0))
+    close(d_s[:, :, ::st], g['ds_scan'], rtol=1e-4, atol=2e-6 * max(scale, 1.0))
+
+
+def test_scan_sentences_ragged_gradient_is_that_of_the_masked_expression():
+    """Ragged batches: the reference's autograd is NaN; the oracle's closed form must equal autograd of
+    the NaN-free torch restatement (oracle/faithful_torch.py) in float64."""
+    from aladin_amd import synth
+    im, s, il, sl = synth.alignment_batch(4, 20, 24, 32, seed=808, ragged=True, Bc=6)
+    w = synth.normal((4, 6), 809)
+    a = torch.from_numpy(im).double().requires_grad_(True)
+    b = torch.from_numpy(s).double().requires_grad_(True)
+    S = FT.alignment_scores_faithful(a, b, il, sl, 'scan-sentences')
+    (S * torch.from_numpy(w).double()).sum().backward()
+    So, d_im, d_s = O.scan_sentences_scores(im, s, il, sl, dS=w)
+    close(So, S.detach().numpy(), rtol=1e-6, atol=1e-6)
+    close(d_im, a.grad.numpy(), rtol=1e-5, atol=1e-7)
+    close(d_s, b.grad.numpy(), rtol=1e-5, atol=1e-7)
