@@ -539,11 +539,15 @@ static int launch_scores(const aladin_align_geom* g, const half_t* xm, const hal
   if constexpr (Q == 1 && TP16 <= 6)
     if (scores_strip_mult(TP16, g->mtiles) == 2) {
       // ALADIN_ALIGN_SPREAD: 16 (default) = v_mfma_f32_16x16x32_f16 body; 26 = the same + clock probe
-      // (diagnostic); 3 / 6 = the earlier 32x32x16 body and its clock probe (headline class only)
+      // (diagnostic); 3 / 6 = the earlier 32x32x16 body and its clock probe, 7 / 9 = its ablations
+      // (headline class only)
       if constexpr (TP16 == 3) {
         if (scores_spread() == 26) return launch_scores16<HAS_E, 3, true>(g, xm, y, E, S, ldS, stream);
         if (scores_spread() == 3) return launch_scores_w<4, WM, Q, TP16, HAS_E, 2, 3>(g, xm, y, E, S, ldS, stream);
         if (scores_spread() == 6) return launch_scores_w<4, WM, Q, TP16, HAS_E, 2, 6>(g, xm, y, E, S, ldS, stream);
+        // timing-only ablations of the 32x32x16 body quoted in DESIGN.md (results are wrong by construction)
+        if (scores_spread() == 7) return launch_scores_w<4, WM, Q, TP16, HAS_E, 2, 7>(g, xm, y, E, S, ldS, stream);   // no refill
+        if (scores_spread() == 9) return launch_scores_w<4, WM, Q, TP16, HAS_E, 2, 9>(g, xm, y, E, S, ldS, stream);   // no MFMA
       }
       return launch_scores16<HAS_E, TP16>(g, xm, y, E, S, ldS, stream);
     }
