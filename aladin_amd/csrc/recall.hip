@@ -12,6 +12,7 @@
 #include "../../include/aladin_hip.h"
 #include "gemm_core.hpp"
 
+#define MAX_CPI 8                         // captions per image supported by the rank kernels
 using SimCfg = GemmCfg<4, 2, 2, 6>;       // 256 x 384 tile, 8 waves x (64 x 192), v_mfma_f32_16x16x32_f16 body (gemm_core.hpp)
 
 struct SimWs {
@@ -116,10 +117,35 @@ __global__ __launch_bounds__(256) void sim_pack_kernel(const float* __restrict__
   }
 }
 
+// order-preserving map float -> uint (NaN excluded by the callers)
+__device__ __forceinline__ unsigned float_key(float v) {
+  const unsigned u = __float_as_uint(v);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ unsigned long long pack_best(float v, int idx) {
+  return ((unsigned long long)float_key(v) << 32) | (unsigned)(0x7fffffff - idx);      // ties -> the smaller index wins
+}
+
+// What the similarity GEMM does with its tile:
+//   SIM_STORE  writes the scores                                        (aladin_sim_matrix)
+//   SIM_RANK   never writes S: counts, per image row, the scores beating the best of its cpi ground
+//              truths and, per caption column, the scores beating its ground truth (gt[] comes from
+//              sim_gt_kernel, bit-identical to this kernel's own values); tracks both arg-maxima
+struct SimRankArgs {
+  int cpi;
+  const float* gt;                    // n_cap
+  int32_t* cnt_i2t;                   // n_img: scores beating the row's best ground truth = its i2t rank
+  int32_t* cnt_t2i;                   // n_cap
+  unsigned long long* best_i2t;       // n_img
+  unsigned long long* best_t2i;       // n_cap
+};
+enum { SIM_STORE = 0, SIM_RANK = 2 };
+
+template <int MODE>
 __global__ __launch_bounds__(512) void sim_gemm_kernel(const half_t* __restrict__ a, const half_t* __restrict__ b,
                                                        const float* __restrict__ scale, float* __restrict__ sim,
                                                        int64_t ld, int n_img, int n_cap, int64_t ldk, int ktiles,
-                                                       int n_nblk, int n_blocks) {
+                                                       int n_nblk, int n_blocks, SimRankArgs ra) {
   using Cfg = SimCfg;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int mb, nb;
@@ -136,19 +162,192 @@ __global__ __launch_bounds__(512) void sim_gemm_kernel(const half_t* __restrict_
   // 16x16 C tile: col = lane & 15, row = 4 * (lane >> 4) + reg
   const int row0 = mb * Cfg::BM + wm * 64 + 4 * (lane >> 4);
   const int col0 = nb * Cfg::BN + wn * 192 + (lane & 15);
+  if constexpr (MODE == SIM_STORE) {
 #pragma unroll
-  for (int rt = 0; rt < 4; ++rt)
+    for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
-    for (int reg = 0; reg < 4; ++reg) {
-      const int row = row0 + rt * 16 + reg;
-      if (row >= n_img) continue;
-      float* out = sim + (int64_t)row * ld;
+      for (int reg = 0; reg < 4; ++reg) {
+        const int row = row0 + rt * 16 + reg;
+        if (row >= n_img) continue;
+        float* out = sim + (int64_t)row * ld;
 #pragma unroll
-      for (int ct = 0; ct < 12; ++ct) {
-        const int col = col0 + ct * 16;
-        if (col < n_cap) out[col] = acc[rt][ct][reg] * unscale;
+        for (int ct = 0; ct < 12; ++ct) {
+          const int col = col0 + ct * 16;
+          if (col < n_cap) out[col] = acc[rt][ct][reg] * unscale;
+        }
+      }
+  } else {
+    // Scores are compared in the accumulators' own scale: unscale is a power of two, so
+    // acc * unscale > gt  <=>  acc > gt * (1 / unscale) exactly, and the arg-maxima do not care.
+    const float rescale = scale[0] * scale[1];
+    // The workgroup's partial results meet in LDS (free after the main loop) so that each row / column
+    // of the tile costs ONE global atomic per counter instead of one per wave.
+    // i2t: the reference's rank is the best of the image's cpi captions (recall_auxiliary.py:38-44);
+    // #(v > t) never grows with t, so that minimum is the count against the LARGEST ground truth.
+    __syncthreads();                                                   // every wave is done with the operand stages
+    int* l_row = reinterpret_cast<int*>(smem);                         // [BM] scores beating the row's best ground truth
+    int* l_col = l_row + Cfg::BM;                                      // [BN]
+    unsigned long long* l_brow = reinterpret_cast<unsigned long long*>(l_col + Cfg::BN);    // [BM]
+    unsigned long long* l_bcol = l_brow + Cfg::BM;                     // [BN]
+    float* l_grow = reinterpret_cast<float*>(l_bcol + Cfg::BN);        // [BM] max of the row's ground truths
+    float* l_gcol = l_grow + Cfg::BM;                                  // [BN]
+    for (int e = threadIdx.x; e < Cfg::BM + Cfg::BN; e += Cfg::THREADS) { l_row[e] = 0; l_brow[e] = 0ull; }
+    for (int e = threadIdx.x; e < Cfg::BM; e += Cfg::THREADS) {
+      const int row = mb * Cfg::BM + e;
+      float g = INFINITY;
+      if (row < n_img) {
+        g = -INFINITY;
+        for (int q = 0; q < ra.cpi; ++q) g = fmaxf(g, ra.gt[row * ra.cpi + q]);
+        g *= rescale;
+      }
+      l_grow[e] = g;
+    }
+    for (int e = threadIdx.x; e < Cfg::BN; e += Cfg::THREADS) {
+      const int c = nb * Cfg::BN + e;
+      l_gcol[e] = (c < n_cap) ? ra.gt[c] * rescale : INFINITY;
+    }
+    __syncthreads();
+    const int lrow0 = wm * 64 + 4 * (lane >> 4), lcol0 = wn * 192 + (lane & 15);
+    // ---- rows: lanes with the same lane >> 4 share a row; 12 columns each
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int row = row0 + rt * 16 + reg, lrow = lrow0 + rt * 16 + reg;
+        const float g = l_grow[lrow];
+        int cnt = 0;
+        float best = -INFINITY;
+#pragma unroll
+        for (int ct = 0; ct < 12; ++ct) {
+          const float v = (col0 + ct * 16 < n_cap) ? acc[rt][ct][reg] : -INFINITY;    // pad columns never count, never win
+          cnt += (v > g);
+          best = fmaxf(best, v);
+        }
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) {
+          cnt += __shfl_xor(cnt, o, 64);
+          best = fmaxf(best, __shfl_xor(best, o, 64));
+        }
+        // the maximum's first column: this lane's first hit (columns ascend with ct), then the smallest over the 16 lanes
+        int besti = 0x7fffffff;
+#pragma unroll
+        for (int ct = 11; ct >= 0; --ct)
+          if (col0 + ct * 16 < n_cap && acc[rt][ct][reg] == best) besti = col0 + ct * 16;
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) { const int oi = __shfl_xor(besti, o, 64); besti = oi < besti ? oi : besti; }
+        if (row < n_img && (lane & 15) == 0) {
+          if (cnt) atomicAdd(&l_row[lrow], cnt);
+          if (besti != 0x7fffffff) atomicMax(&l_brow[lrow], pack_best(best, besti));
+        }
+      }
+    // ---- columns: lanes with the same lane & 15 share a column; 16 rows each
+#pragma unroll
+    for (int ct = 0; ct < 12; ++ct) {
+      const int col = col0 + ct * 16, lcol = lcol0 + ct * 16;
+      const float g = l_gcol[lcol];
+      int cnt = 0;
+      float best = -INFINITY;
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          const float v = (row0 + rt * 16 + reg < n_img) ? acc[rt][ct][reg] : -INFINITY;
+          cnt += (v > g);
+          best = fmaxf(best, v);
+        }
+#pragma unroll
+      for (int o = 16; o < 64; o <<= 1) {
+        cnt += __shfl_xor(cnt, o, 64);
+        best = fmaxf(best, __shfl_xor(best, o, 64));
+      }
+      int besti = 0x7fffffff;
+#pragma unroll
+      for (int rt = 3; rt >= 0; --rt)
+#pragma unroll
+        for (int reg = 3; reg >= 0; --reg)
+          if (row0 + rt * 16 + reg < n_img && acc[rt][ct][reg] == best) besti = row0 + rt * 16 + reg;     // rows ascend with (rt, reg)
+#pragma unroll
+      for (int o = 16; o < 64; o <<= 1) { const int oi = __shfl_xor(besti, o, 64); besti = oi < besti ? oi : besti; }
+      if (col < n_cap && lane < 16) {
+        if (cnt) atomicAdd(&l_col[lcol], cnt);
+        if (besti != 0x7fffffff) atomicMax(&l_bcol[lcol], pack_best(best, besti));
       }
     }
+    __syncthreads();
+    // ---- one global atomic per non-zero counter; arg-maxima only when they beat what is already there
+    for (int e = threadIdx.x; e < Cfg::BM; e += Cfg::THREADS) {
+      const int row = mb * Cfg::BM + e;
+      if (row < n_img) {
+        if (l_row[e]) atomicAdd(&ra.cnt_i2t[row], l_row[e]);
+        const unsigned long long p = l_brow[e];
+        if (p > __hip_atomic_load(&ra.best_i2t[row], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&ra.best_i2t[row], p);
+      }
+    }
+    for (int e = threadIdx.x; e < Cfg::BN; e += Cfg::THREADS) {
+      const int col = nb * Cfg::BN + e;
+      if (col < n_cap) {
+        if (l_col[e]) atomicAdd(&ra.cnt_t2i[col], l_col[e]);
+        const unsigned long long p = l_bcol[e];
+        if (p > __hip_atomic_load(&ra.best_t2i[col], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&ra.best_t2i[col], p);
+      }
+    }
+  }
+}
+
+// Ground-truth scores gt[c] = S[c / cpi][c] with the bits the big kernel produces: an output element
+// of v_mfma_f32_16x16x32_f16 depends only on its own row / column operands and on the order of the
+// 32-deep K blocks, which is ascending in both kernels.  For 16 consecutive images the ground truths
+// sit in the 16 x (16 * cpi) block starting at column 16 * cpi * t -- cpi aligned 16 x 16 tiles; one
+// wave per tile, fragments straight from global memory (16 B per lane and K block).
+__global__ __launch_bounds__(256) void sim_gt_kernel(const half_t* __restrict__ a, const half_t* __restrict__ b,
+                                                     const float* __restrict__ scale, int n_img, int n_cap, int cpi,
+                                                     int64_t ldk, int kblocks, float* __restrict__ gt) {
+  const int lane = threadIdx.x & 63;
+  const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int t = tile / cpi, c = tile % cpi;
+  if (t * 16 >= n_img) return;
+  const int row_t = t * 16, col_t = t * 16 * cpi + c * 16;
+  const half_t* ap = a + (int64_t)(row_t + (lane & 15)) * ldk + 8 * (lane >> 4);     // padded rows exist (Mp, Np)
+  const half_t* bp = b + (int64_t)(col_t + (lane & 15)) * ldk + 8 * (lane >> 4);
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int k = 0; k < kblocks; ++k) {
+    const half8 af = *reinterpret_cast<const half8*>(ap + (int64_t)k * 32);
+    const half8 bf = *reinterpret_cast<const half8*>(bp + (int64_t)k * 32);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf, acc, 0, 0, 0);
+  }
+  const float unscale = 1.0f / (scale[0] * scale[1]);
+  const int col = col_t + (lane & 15);
+#pragma unroll
+  for (int reg = 0; reg < 4; ++reg) {
+    const int row = row_t + 4 * (lane >> 4) + reg;
+    if (row < n_img && col < n_cap && col / cpi == row) gt[col] = acc[reg] * unscale;
+  }
+}
+
+// scale search, split-fp16 packing and the LDS reservation shared by the GEMM modes
+template <int MODE>
+static int sim_prepare(const float* img, int64_t img_rs, const float* cap, int64_t cap_rs, int n_img, int n_cap, int D,
+                       void* workspace, SimWs* ws, int* Mp, int* Np, int* Dp, hipStream_t st, bool pack) {
+  sim_ws_layout(n_img, n_cap, D, (char*)workspace, ws, Mp, Np, Dp);
+  if (pack) {
+    if (hipMemsetAsync(ws->scale, 0, 256, st) != hipSuccess) { aladin_set_error("sim: memset failed"); return ALADIN_ERR_HIP; }
+    hipLaunchKernelGGL(absmax_kernel, dim3(512), dim3(256), 0, st, img, img_rs, n_img, D, (unsigned*)(ws->scale + 2));
+    hipLaunchKernelGGL(absmax_kernel, dim3(1024), dim3(256), 0, st, cap, cap_rs, n_cap, D, (unsigned*)(ws->scale + 3));
+    hipLaunchKernelGGL(sim_scale_kernel, dim3(1), dim3(1), 0, st, ws->scale);
+    hipLaunchKernelGGL(sim_pack_kernel, dim3((*Mp + 3) / 4), dim3(256), 0, st, img, img_rs, n_img, D, *Dp, *Mp, ws->scale, 0, ws->a);
+    hipLaunchKernelGGL(sim_pack_kernel, dim3((*Np + 3) / 4), dim3(256), 0, st, cap, cap_rs, n_cap, D, *Dp, *Np, ws->scale, 1, ws->b);
+    const int rc = aladin_check_launch("sim_pack_kernel");
+    if (rc) return rc;
+  }
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute((const void*)sim_gemm_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, SimCfg::LDS_BYTES) != hipSuccess) {
+      aladin_set_error("sim: cannot reserve %d B of LDS", SimCfg::LDS_BYTES);
+      return ALADIN_ERR_HIP;
+    }
+    attr_done = true;
+  }
+  return ALADIN_OK;
 }
 
 extern "C" int aladin_sim_matrix(const float* img, int64_t img_rs, const float* cap, int64_t cap_rs, int n_img, int n_cap,
@@ -160,33 +359,17 @@ extern "C" int aladin_sim_matrix(const float* img, int64_t img_rs, const float* 
   hipStream_t st = (hipStream_t)stream;
   SimWs ws;
   int Mp, Np, Dp;
-  sim_ws_layout(n_img, n_cap, D, (char*)workspace, &ws, &Mp, &Np, &Dp);
-  if (hipMemsetAsync(ws.scale, 0, 256, st) != hipSuccess) { aladin_set_error("sim_matrix: memset failed"); return ALADIN_ERR_HIP; }
-  hipLaunchKernelGGL(absmax_kernel, dim3(512), dim3(256), 0, st, img, img_rs, n_img, D, (unsigned*)(ws.scale + 2));
-  hipLaunchKernelGGL(absmax_kernel, dim3(1024), dim3(256), 0, st, cap, cap_rs, n_cap, D, (unsigned*)(ws.scale + 3));
-  hipLaunchKernelGGL(sim_scale_kernel, dim3(1), dim3(1), 0, st, ws.scale);
-  hipLaunchKernelGGL(sim_pack_kernel, dim3((Mp + 3) / 4), dim3(256), 0, st, img, img_rs, n_img, D, Dp, Mp, ws.scale, 0, ws.a);
-  hipLaunchKernelGGL(sim_pack_kernel, dim3((Np + 3) / 4), dim3(256), 0, st, cap, cap_rs, n_cap, D, Dp, Np, ws.scale, 1, ws.b);
-  int rc = aladin_check_launch("sim_pack_kernel");
+  int rc = sim_prepare<SIM_STORE>(img, img_rs, cap, cap_rs, n_img, n_cap, D, workspace, &ws, &Mp, &Np, &Dp, st, true);
   if (rc) return rc;
-  static bool attr_done = false;
-  if (!attr_done) {
-    if (hipFuncSetAttribute((const void*)sim_gemm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SimCfg::LDS_BYTES) != hipSuccess) {
-      aladin_set_error("sim_matrix: cannot reserve %d B of LDS", SimCfg::LDS_BYTES);
-      return ALADIN_ERR_HIP;
-    }
-    attr_done = true;
-  }
   const int n_mblk = Mp / SimCfg::BM, n_nblk = Np / SimCfg::BN;
-  hipLaunchKernelGGL(sim_gemm_kernel, dim3(n_mblk * n_nblk), dim3(SimCfg::THREADS), SimCfg::LDS_BYTES, st, ws.a, ws.b,
-                     ws.scale, sim, ld_sim, n_img, n_cap, (int64_t)3 * Dp, 3 * Dp / 64, n_nblk, n_mblk * n_nblk);
+  hipLaunchKernelGGL(sim_gemm_kernel<SIM_STORE>, dim3(n_mblk * n_nblk), dim3(SimCfg::THREADS), SimCfg::LDS_BYTES, st, ws.a, ws.b,
+                     ws.scale, sim, ld_sim, n_img, n_cap, (int64_t)3 * Dp, 3 * Dp / 64, n_nblk, n_mblk * n_nblk, SimRankArgs{});
   return aladin_check_launch("sim_gemm_kernel");
 }
 
 // ------------------------------------------------------------------------------------------------
 // ranks.  rank = number of strictly larger scores (argsort position unless scores tie exactly).
 // ------------------------------------------------------------------------------------------------
-#define MAX_CPI 8
 __global__ __launch_bounds__(256) void rank_i2t_kernel(const float* __restrict__ sim, int64_t ld, int n_cap, int cpi,
                                                        int32_t* __restrict__ rank, int32_t* __restrict__ top1) {
   __shared__ int red[4][MAX_CPI];
@@ -291,4 +474,89 @@ extern "C" int aladin_recall_ranks(const float* sim, int64_t ld_sim, int n_img, 
                      caps_per_img, rpb, rank_t2i, packed);
   hipLaunchKernelGGL(unpack_top1_kernel, dim3(cdiv(n_cap, 256)), dim3(256), 0, st, packed, n_cap, top1_t2i);
   return aladin_check_launch("rank_t2i_kernel");
+}
+
+// ------------------------------------------------------------------------------------------------
+// Fused retrieval: ranks and arg-maxima of both directions straight from the embeddings; the
+// (n_img x n_cap) score matrix is never written (500 MB at COCO-5k) nor re-read by rank kernels.
+//   1. ground-truth scores through the GEMM kernel itself on the band of tiles that holds them
+//   2. the full GEMM whose epilogue compares every score with its row's / column's ground truths
+//   3. a small kernel folds the counters into the reference's ranks
+// Integer counters and packed-max atomics only: the result does not depend on the tile order.
+// ------------------------------------------------------------------------------------------------
+struct RetrWs {
+  float* gt;
+  unsigned long long *best_i2t, *best_t2i;
+};
+static size_t retr_layout(int n_img, int n_cap, int D, char* base, RetrWs* w, size_t* counters_off, size_t* counters_bytes) {
+  size_t off = (sim_ws_layout(n_img, n_cap, D, nullptr, nullptr, nullptr, nullptr, nullptr) + 255) / 256 * 256;
+  auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off += (bytes + 255) / 256 * 256; return p; };
+  float* gt = (float*)take((size_t)n_cap * 4);
+  const size_t c0 = off;
+  unsigned long long* bi = (unsigned long long*)take((size_t)n_img * 8);
+  unsigned long long* bt = (unsigned long long*)take((size_t)n_cap * 8);
+  if (w) *w = RetrWs{gt, bi, bt};
+  if (counters_off) *counters_off = c0;
+  if (counters_bytes) *counters_bytes = off - c0;
+  return off;
+}
+
+__global__ __launch_bounds__(256) void retrieval_finish_kernel(const unsigned long long* __restrict__ best_i2t,
+                                                               const unsigned long long* __restrict__ best_t2i, int n_img,
+                                                               int n_cap, int32_t* __restrict__ top1_i2t,
+                                                               int32_t* __restrict__ top1_t2i) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < n_img) top1_i2t[t] = 0x7fffffff - (int)(unsigned)(best_i2t[t] & 0xffffffffull);
+  if (t < n_cap) top1_t2i[t] = 0x7fffffff - (int)(unsigned)(best_t2i[t] & 0xffffffffull);
+}
+
+extern "C" size_t aladin_retrieval_workspace_bytes(int n_img, int n_cap, int D) {
+  if (n_img < 1 || n_cap < 1 || D < 1) return 0;
+  return retr_layout(n_img, n_cap, D, nullptr, nullptr, nullptr, nullptr);
+}
+
+extern "C" int aladin_retrieval_ranks(const float* img, int64_t img_rs, const float* cap, int64_t cap_rs, int n_img, int n_cap,
+                                      int D, int caps_per_img, int32_t* rank_i2t, int32_t* top1_i2t, int32_t* rank_t2i,
+                                      int32_t* top1_t2i, void* workspace, void* stream) {
+  if (!img || !cap || !rank_i2t || !top1_i2t || !rank_t2i || !top1_t2i || !workspace || D < 1 || img_rs < D || cap_rs < D) {
+    aladin_set_error("retrieval_ranks: bad argument");
+    return ALADIN_ERR_ARG;
+  }
+  if (n_img < 1 || caps_per_img < 1 || caps_per_img > MAX_CPI || n_cap != n_img * caps_per_img) {
+    aladin_set_error("retrieval_ranks: need n_cap == n_img * caps_per_img, caps_per_img <= %d (n_img=%d n_cap=%d cpi=%d)", MAX_CPI, n_img, n_cap, caps_per_img);
+    return ALADIN_ERR_ARG;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  SimWs ws;
+  RetrWs rw;
+  size_t c_off, c_bytes;
+  retr_layout(n_img, n_cap, D, (char*)workspace, &rw, &c_off, &c_bytes);
+  int Mp, Np, Dp;
+  int rc = sim_prepare<SIM_RANK>(img, img_rs, cap, cap_rs, n_img, n_cap, D, workspace, &ws, &Mp, &Np, &Dp, st, true);
+  if (rc) return rc;
+  if (hipMemsetAsync((char*)workspace + c_off, 0, c_bytes, st) != hipSuccess || hipMemsetAsync(rank_t2i, 0, (size_t)n_cap * 4, st) != hipSuccess ||
+      hipMemsetAsync(rank_i2t, 0, (size_t)n_img * 4, st) != hipSuccess) {
+    aladin_set_error("retrieval_ranks: memset failed");
+    return ALADIN_ERR_HIP;
+  }
+  const int n_mblk = Mp / SimCfg::BM, n_nblk = Np / SimCfg::BN;
+  SimRankArgs ra{};
+  ra.cpi = caps_per_img;
+  ra.gt = rw.gt;
+  ra.cnt_i2t = rank_i2t;                                 // the row counters ARE the i2t ranks
+  ra.cnt_t2i = rank_t2i;                                 // the column counters ARE the t2i ranks
+  ra.best_i2t = rw.best_i2t;
+  ra.best_t2i = rw.best_t2i;
+  {
+    const int tiles = cdiv(n_img, 16) * caps_per_img;
+    hipLaunchKernelGGL(sim_gt_kernel, dim3(cdiv(tiles, 4)), dim3(256), 0, st, ws.a, ws.b, ws.scale, n_img, n_cap, caps_per_img,
+                       (int64_t)3 * Dp, 3 * Dp / 32, rw.gt);
+  }
+  hipLaunchKernelGGL(sim_gemm_kernel<SIM_RANK>, dim3(n_mblk * n_nblk), dim3(SimCfg::THREADS), SimCfg::LDS_BYTES, st, ws.a, ws.b,
+                     ws.scale, nullptr, 0, n_img, n_cap, (int64_t)3 * Dp, 3 * Dp / 64, n_nblk, n_mblk * n_nblk, ra);
+  rc = aladin_check_launch("sim_gemm_kernel<rank>");
+  if (rc) return rc;
+  hipLaunchKernelGGL(retrieval_finish_kernel, dim3(cdiv(n_cap, 256)), dim3(256), 0, st, rw.best_i2t, rw.best_t2i, n_img, n_cap,
+                     top1_i2t, top1_t2i);
+  return aladin_check_launch("retrieval_finish_kernel");
 }

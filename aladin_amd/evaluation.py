@@ -202,21 +202,32 @@ def _ranks(sim):
     return both[:n_img], both[n_img:2 * n_img], both[2 * n_img:2 * n_img + n_cap], both[2 * n_img + n_cap:]
 
 
+def _fused_ranks(img, cap):
+    """Ranks of both directions straight from the global embeddings (ops.retrieval_ranks: the score
+    matrix is never materialised); same numbers as _ranks(compute_sim_matrix(img, cap))."""
+    dev = _device()
+    img = torch.as_tensor(img).to(dev, torch.float32)
+    cap = torch.as_tensor(cap).to(dev, torch.float32)
+    n_img, n_cap = img.shape[0], cap.shape[0]
+    with torch.no_grad():
+        r_i2t, t_i2t, r_t2i, t_t2i = ops.retrieval_ranks(img, cap, CAPS_PER_IMG)
+    both = torch.cat([r_i2t, t_i2t, r_t2i, t_t2i]).cpu().numpy().astype(np.float64)      # one D2H copy
+    return both[:n_img], both[n_img:2 * n_img], both[2 * n_img:2 * n_img + n_cap], both[2 * n_img + n_cap:]
+
+
 def recall(images, captions, model=None, mode='i2t', lenghts=None, return_ranks=False):
     """reference alad/recall_auxiliary.py:8-69: rows 0::5 of `images` are the distinct images."""
     if mode not in ('i2t', 't2i'):
         raise ValueError('mode not correct')
-    sim = compute_sim_matrix(torch.as_tensor(images)[0::CAPS_PER_IMG], captions)
-    r_i2t, t_i2t, r_t2i, t_t2i = _ranks(sim)
+    r_i2t, t_i2t, r_t2i, t_t2i = _fused_ranks(torch.as_tensor(images)[0::CAPS_PER_IMG], captions)
     ranks, top1 = (r_i2t, t_i2t) if mode == 'i2t' else (r_t2i, t_t2i)
     m = _metrics(ranks)
     return (m, (ranks, top1)) if return_ranks else m
 
 
 def recall_test(img_embs, cap_embs, tot_lengths=None, model=None):
-    """reference alad/recall_auxiliary.py:72-86; both directions from one score matrix."""
-    sim = compute_sim_matrix(torch.as_tensor(img_embs)[0::CAPS_PER_IMG], cap_embs)
-    r_i2t, _, r_t2i, _ = _ranks(sim)
+    """reference alad/recall_auxiliary.py:72-86; both directions from one fused GEMM + rank pass."""
+    r_i2t, _, r_t2i, _ = _fused_ranks(torch.as_tensor(img_embs)[0::CAPS_PER_IMG], cap_embs)
     r1, r5, r10, _, _ = _metrics(r_i2t)
     r1i, r5i, r10i, _, _ = _metrics(r_t2i)
     return r1, r5, r10, r1i, r5i, r10i, r1 + r5 + r10 + r1i + r5i + r10i

@@ -550,3 +550,26 @@ def recall_ranks(sim, caps_per_img=5):
     _lib.check(lib.aladin_recall_ranks(_ptr(sim), _ld(sim), n_img, n_cap, caps_per_img, _ptr(r_i2t), _ptr(t_i2t),
                                        _ptr(r_t2i), _ptr(t_t2i), _ptr(ws), _stream()), 'recall_ranks')
     return r_i2t, t_i2t, r_t2i, t_t2i
+
+
+def retrieval_ranks(img, cap, caps_per_img=5):
+    """(rank_i2t, top1_i2t, rank_t2i, top1_t2i) straight from the (n_img, D) / (n_cap, D) embeddings:
+    sim_matrix + recall_ranks fused, the (n_img, n_cap) score matrix is never written.  Same bits as
+    the two-step path; replaces reference alad/recall_auxiliary.py:30-56 in one pass."""
+    _require_gpu(img, cap)
+    if img.dim() != 2 or cap.dim() != 2 or img.shape[1] != cap.shape[1]:
+        raise ValueError('aladin_amd: (n_img,D) and (n_cap,D) embeddings expected')
+    lib = _lib.load()
+    img = img if img.stride(1) == 1 else img.contiguous()
+    cap = cap if cap.stride(1) == 1 else cap.contiguous()
+    n_img, n_cap, D = img.shape[0], cap.shape[0], img.shape[1]
+    dev = img.device
+    r_i2t = torch.empty(n_img, dtype=torch.int32, device=dev)
+    t_i2t = torch.empty(n_img, dtype=torch.int32, device=dev)
+    r_t2i = torch.empty(n_cap, dtype=torch.int32, device=dev)
+    t_t2i = torch.empty(n_cap, dtype=torch.int32, device=dev)
+    ws = _workspace(lib.aladin_retrieval_workspace_bytes(n_img, n_cap, D), dev)
+    _lib.check(lib.aladin_retrieval_ranks(_ptr(img), img.stride(0), _ptr(cap), cap.stride(0), n_img, n_cap, D, caps_per_img,
+                                          _ptr(r_i2t), _ptr(t_i2t), _ptr(r_t2i), _ptr(t_t2i), _ptr(ws), _stream()),
+               'retrieval_ranks')
+    return r_i2t, t_i2t, r_t2i, t_t2i

@@ -249,6 +249,17 @@ int aladin_recall_ranks(const float* sim, int64_t ld_sim, int n_img, int n_cap, 
                         int32_t* rank_i2t, int32_t* top1_i2t, int32_t* rank_t2i, int32_t* top1_t2i,
                         void* workspace, void* stream);
 
+/* Fused retrieval: the same four outputs as aladin_sim_matrix + aladin_recall_ranks straight from the
+ * embeddings, without ever writing the (n_img x n_cap) score matrix (reference
+ * alad/recall_auxiliary.py:30-56 / alad/evaluation.py:196-223,285-308 in one pass): the ground-truth
+ * scores come from the GEMM kernel itself run on the band of tiles that holds them, and the full GEMM's
+ * epilogue counts, per image row and per caption column, the scores that beat them (integer and
+ * packed-max atomics: independent of the tile order, bit-identical to the two-step path). */
+size_t aladin_retrieval_workspace_bytes(int n_img, int n_cap, int D);
+int aladin_retrieval_ranks(const float* img, int64_t img_row_stride, const float* cap, int64_t cap_row_stride, int n_img,
+                           int n_cap, int D, int caps_per_img, int32_t* rank_i2t, int32_t* top1_i2t, int32_t* rank_t2i,
+                           int32_t* top1_t2i, void* workspace, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -586,6 +586,28 @@ def test_error_behaviour():
         ops.alignment_scores(T(im), T(s), il[:-1], sl)
 
 
+@pytest.mark.parametrize('n_img,cpi,D', [(1, 5, 8), (7, 1, 33), (77, 3, 100), (300, 5, 64), (1000, 5, 768), (257, 8, 50)])
+def test_fused_retrieval_ranks_equal_two_step(n_img, cpi, D):
+    """aladin_retrieval_ranks (ranks inside the GEMM epilogue, no score matrix) must give the very ints of
+    aladin_sim_matrix + aladin_recall_ranks: ragged tile edges, every captions-per-image count, odd D."""
+    from aladin_amd import ops
+    rng = np.random.default_rng(n_img * 31 + cpi)
+    img = rng.standard_normal((n_img, D)).astype(np.float32)
+    cap = (np.repeat(img, cpi, axis=0) + 1.5 * rng.standard_normal((n_img * cpi, D))).astype(np.float32)
+    img /= np.linalg.norm(img, axis=1, keepdims=True)
+    cap /= np.linalg.norm(cap, axis=1, keepdims=True)
+    a, b = T(img), T(cap)
+    two = ops.recall_ranks(ops.sim_matrix(a, b), cpi)
+    one = ops.retrieval_ranks(a, b, cpi)
+    for x, y in zip(one, two):
+        assert torch.equal(x, y)
+    # and against the oracle's argsort-free definition
+    if n_img <= 300:
+        r_i2t, _, r_t2i, _ = O.ranks_from_scores(img.astype(np.float64) @ cap.astype(np.float64).T, cpi)
+        # fp64 vs device near-ties may swap neighbours
+        assert np.mean(one[0].cpu().numpy() == r_i2t) >= 0.99 and np.mean(one[2].cpu().numpy() == r_t2i) >= 0.99
+
+
 def test_config3_full_size_retrieval_ranks():
     """BASELINE configs[2]: 5000 images x 25000 captions, D=768.  Ranks from the HIP split-fp16 sim
     matrix + rank kernels must equal ranks computed on the host in float64 from the same embeddings

@@ -113,5 +113,8 @@ while time.time() - t0 < budget:
     e_i2t, e_top_i, e_t2i, e_top_t = O.ranks_from_scores(sim_h)
     assert np.array_equal(r_i2t, e_i2t) and np.array_equal(r_t2i, e_t2i), ('ranks', n_img, D)
     assert np.array_equal(sim_h[np.arange(n_img), t_i2t], sim_h.max(1)) and np.array_equal(sim_h[t_t2i, np.arange(5 * n_img)], sim_h.max(0))
+    fused = [x.cpu().numpy() for x in ops.retrieval_ranks(T(img), T(cap))]      # no score matrix: same ints
+    for got, want, what in zip(fused, (r_i2t, t_i2t, r_t2i, t_t2i), ('r_i2t', 'top_i2t', 'r_t2i', 'top_t2i')):
+        assert np.array_equal(got, want), ('fused ' + what, n_img, D)
     n += 1
 print('fuzz_losses ok: %d rounds, %.0f s' % (n, time.time() - t0))
