@@ -310,7 +310,8 @@ __global__ __launch_bounds__(256) void sim_gt_kernel(const half_t* __restrict__ 
   const half_t* ap = a + (int64_t)(row_t + (lane & 15)) * ldk + 8 * (lane >> 4);     // padded rows exist (Mp, Np)
   const half_t* bp = b + (int64_t)(col_t + (lane & 15)) * ldk + 8 * (lane >> 4);
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  for (int k = 0; k < kblocks; ++k) {
+#pragma unroll 8
+  for (int k = 0; k < kblocks; ++k) {                                  // loads of later blocks hoisted; the MFMA chain stays in K order
     const half8 af = *reinterpret_cast<const half8*>(ap + (int64_t)k * 32);
     const half8 bf = *reinterpret_cast<const half8*>(bp + (int64_t)k * 32);
     acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf, acc, 0, 0, 0);
@@ -331,6 +332,7 @@ static int sim_prepare(const float* img, int64_t img_rs, const float* cap, int64
   sim_ws_layout(n_img, n_cap, D, (char*)workspace, ws, Mp, Np, Dp);
   if (pack) {
     if (hipMemsetAsync(ws->scale, 0, 256, st) != hipSuccess) { aladin_set_error("sim: memset failed"); return ALADIN_ERR_HIP; }
+    // fixed grids: one same-address atomicMax per wave, so more waves cost more than they stream (measured)
     hipLaunchKernelGGL(absmax_kernel, dim3(512), dim3(256), 0, st, img, img_rs, n_img, D, (unsigned*)(ws->scale + 2));
     hipLaunchKernelGGL(absmax_kernel, dim3(1024), dim3(256), 0, st, cap, cap_rs, n_cap, D, (unsigned*)(ws->scale + 3));
     hipLaunchKernelGGL(sim_scale_kernel, dim3(1), dim3(1), 0, st, ws->scale);
