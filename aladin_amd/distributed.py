@@ -115,6 +115,21 @@ def rank_scores_block(xm_all, xe_all, s_local, s_len_t, g_glob):
     return ops.scores_from_packed(xm_all, xe_all, y, g_glob), y
 
 
+def rank_scores_rows(xm_all, xe_all, y, S_blk, first, count, B, R, T, D):
+    """Fill rows [first*B, (first+count)*B) of this rank's (W*B x B) score block: the images of `count`
+    consecutive ranks against the local captions.  The packed operands of a rank range are contiguous
+    slices of the gathered buffers (the fast path requires xe_rows == B per rank), and a score depends
+    only on its own image / caption rows, so any split into ranges gives the bits of one launch."""
+    from . import ops
+    if count <= 0:
+        return
+    g = ops.align_geometry(count * B, B, R, T, D)
+    per_m = (g.xm_bytes // 2) // count
+    per_e = (g.xe_bytes // 2) // count
+    xe = xe_all[first * per_e:(first + count) * per_e] if per_e else xe_all
+    ops.scores_from_packed(xm_all[first * per_m:(first + count) * per_m], xe, y, g, out=S_blk[first * B:(first + count) * B])
+
+
 def rank_backward_block(im_all, il_all_t, s_local, s_len_t, dS_full, rank, g_glob, xm_all, xe_all, y, gscale=None):
     """This rank's contribution: d(all image sets) restricted to its caption block, and d(its captions)."""
     from . import ops
@@ -191,9 +206,9 @@ class _ShardedTriplet(torch.autograd.Function):
         xm_all = torch.empty(W * xm.numel(), dtype=xm.dtype, device=im.device)
         xe_all = torch.empty(W * xe.numel(), dtype=xe.dtype, device=im.device)
         il_all = torch.empty(W * B, dtype=torch.int32, device=im.device)
-        dist.all_gather_into_tensor(xm_all, xm, group=group)
-        dist.all_gather_into_tensor(xe_all, xe, group=group)
-        dist.all_gather_into_tensor(il_all, im_len_t.contiguous(), group=group)
+        gathers = [dist.all_gather_into_tensor(xm_all, xm, group=group, async_op=True),
+                   dist.all_gather_into_tensor(xe_all, xe, group=group, async_op=True),
+                   dist.all_gather_into_tensor(il_all, im_len_t.contiguous(), group=group, async_op=True)]
         need = any(ctx.needs_input_grad[:2])
         # <= 3 non-zeros of dS per row/column under max_violation: pair-driven exchange
         # (its fixed cost -- one host sync for the split sizes -- pays off once the dense form would move
@@ -203,7 +218,15 @@ class _ShardedTriplet(torch.autograd.Function):
         if need and not sparse:                    # raw fp32 sets: only the exact backward reads them
             im_all = torch.empty((W * B, R, D), dtype=im.dtype, device=im.device)
             work = dist.all_gather_into_tensor(im_all, im_c, group=group, async_op=True)
-        S_blk, y = rank_scores_block(xm_all, xe_all, s, s_len_t, g_glob)
+        # The local images' block does not need the exchange: score it while the gathers are in flight,
+        # then the rank ranges before and after this rank.
+        y = ops.pack_captions(s, s_len_t, g_glob)
+        S_blk = torch.empty((W * B, B), dtype=torch.float32, device=im.device)
+        ops.scores_from_packed(xm, xe, y, g_loc, out=S_blk[r * B:(r + 1) * B])
+        for w_ in gathers:
+            w_.wait()
+        rank_scores_rows(xm_all, xe_all, y, S_blk, 0, r, B, R, T, D)
+        rank_scores_rows(xm_all, xe_all, y, S_blk, r + 1, W - 1 - r, B, R, T, D)
         parts = torch.empty((W * S_blk.shape[0], B), dtype=S_blk.dtype, device=im.device)
         dist.all_gather_into_tensor(parts, S_blk, group=group)
         S_full = parts.view(W, W * B, B).permute(1, 0, 2).reshape(W * B, W * B)

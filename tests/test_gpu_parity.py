@@ -732,14 +732,14 @@ def test_alignment_backward_shape_sweep(shape, mv):
         np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=1e-3, atol=2e-5 * scale)
 
 
-def test_sharded_fast_path_rank_logic_emulated_world2():
+def test_sharded_fast_path_rank_logic_emulated_world3():
     """The per-rank pieces of aladin_amd.distributed's fast path, driven for rank 0 and rank 1 on
-    ONE GPU with hand-made 'gathered' tensors (concatenation == all-gather, sum == reduce-scatter):
+    ONE GPU (three emulated ranks) with hand-made 'gathered' tensors (concatenation == all-gather, sum == reduce-scatter):
     global loss, score matrix and both gradients must equal the single-device result on the
     concatenated batch."""
     from aladin_amd import distributed as DD, ops, synth
     from aladin_amd.loss import AlignmentContrastiveLoss
-    W, B, R, Tn, D = 2, 64, 34, 50, 768
+    W, B, R, Tn, D = 3, 64, 34, 50, 768
     im, s, il, sl = synth.alignment_batch(W * B, R, Tn, D, seed=4242, ragged=True)
     d = dev()
     g_loc, g_glob, ok = DD._local_and_global_geometry(B, W, R, Tn, D)
@@ -754,6 +754,14 @@ def test_sharded_fast_path_rank_logic_emulated_world2():
     il_all = torch.cat(ilt)
     im_all = torch.cat(ims)
     blocks = [DD.rank_scores_block(xm_all, xe_all, caps[r], slt[r], g_glob) for r in range(W)]
+    # the overlapped form (local block first, then the rank ranges before / after) gives the same bits
+    for r in range(W):
+        y = ops.pack_captions(caps[r], slt[r], g_glob)
+        S_blk = torch.full((W * B, B), float('nan'), device=d)
+        ops.scores_from_packed(packs[r][0], packs[r][1], y, g_loc, out=S_blk[r * B:(r + 1) * B])
+        DD.rank_scores_rows(xm_all, xe_all, y, S_blk, 0, r, B, R, Tn, D)
+        DD.rank_scores_rows(xm_all, xe_all, y, S_blk, r + 1, W - 1 - r, B, R, Tn, D)
+        assert torch.equal(S_blk, blocks[r][0])
     S_full = torch.cat([b[0] for b in blocks], dim=1)
     loss, dS_full, _ = ops._hinge_raw(S_full, 0.2, True, True)
     d_im_all = torch.zeros_like(im_all)
