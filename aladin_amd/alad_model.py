@@ -62,8 +62,15 @@ class ALADModel(nn.Module):
         img_emb_set = img_emb_set.permute(1, 0, 2)                    # :377-378  (S,B,D) -> (B,S,D) views
         cap_emb_seq = cap_emb_seq.permute(1, 0, 2)
 
-        matching_loss, matching_mat = self.matching_criterion(img_emb, cap_emb, return_similarity_mat=True)   # :380
-        if 'matching' in self.config['training']['loss-type']:        # :381 (substring test on the string)
+        wants_matching = 'matching' in self.config['training']['loss-type']      # :381 (substring test on the string)
+        sim = getattr(self.matching_criterion, 'sim', None)
+        if wants_matching or sim is None:
+            matching_loss, matching_mat = self.matching_criterion(img_emb, cap_emb, return_similarity_mat=True)   # :380
+        else:
+            # the reference computes the matching hinge here and drops it (:380-381); only the score matrix
+            # is used further down (distillation student, :405), so the two hinge launches are skipped
+            matching_mat = sim(img_emb, cap_emb)
+        if wants_matching:
             losses['matching'] = matching_loss
             logged.append(('matching_loss', matching_loss, img_emb.size(0)))
 

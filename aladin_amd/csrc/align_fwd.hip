@@ -493,14 +493,8 @@ static int launch_scores16(const aladin_align_geom* g, const half_t* xm, const h
     return ALADIN_ERR_ARG;
   }
   auto kern = align_scores16_kernel<HAS_E, TP16, PROBE>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES) != hipSuccess) {
-      aladin_set_error("align_scores16: cannot reserve %d B of LDS", Cfg::LDS_BYTES);
-      return ALADIN_ERR_HIP;
-    }
-    attr_done = true;
-  }
+  static unsigned long long lds_reserved = 0;
+  if (int rc = aladin_reserve_lds((const void*)kern, Cfg::LDS_BYTES, &lds_reserved, "align_scores16")) return rc;
   const int n_blocks = n_mblk * n_nblk;
   hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(Cfg::THREADS), Cfg::LDS_BYTES, stream, xm, y, E, g->y_rows, S, ldS, g->Bi,
                      g->Bc, (int64_t)g->Dp, g->Dp / 64, n_nblk, n_blocks);
@@ -519,14 +513,8 @@ static int launch_scores_w(const aladin_align_geom* g, const half_t* xm, const h
     return ALADIN_ERR_ARG;
   }
   auto kern = align_scores_kernel<WGM, WM, Q, TP16, HAS_E, SM, SCHED>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES) != hipSuccess) {
-      aladin_set_error("align_scores: cannot reserve %d B of LDS", Cfg::LDS_BYTES);
-      return ALADIN_ERR_HIP;
-    }
-    attr_done = true;
-  }
+  static unsigned long long lds_reserved = 0;
+  if (int rc = aladin_reserve_lds((const void*)kern, Cfg::LDS_BYTES, &lds_reserved, "align_scores")) return rc;
   const int n_blocks = n_mblk * n_nblk;
   hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(Cfg::THREADS), Cfg::LDS_BYTES, stream, xm, y, E, g->y_rows, S, ldS, g->Bi,
                      g->Bc, (int64_t)g->Dp, g->Dp / 64, n_nblk, n_blocks);
@@ -561,14 +549,8 @@ static int launch_side_w(const aladin_align_geom* g, const half_t* xe, const hal
   const int n_mblk = (int)(g->xe_rows / Cfg::BM), n_nblk = (int)(g->y_rows / Cfg::BN);
   auto kern = align_side_gemm_kernel<NT, SWM>;
   constexpr int lds_bytes = SIDE_STAGES * Cfg::STAGE_BYTES;
-  static bool attr_done = false;
-  if (!attr_done) {
-    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess) {
-      aladin_set_error("align_side_gemm: cannot reserve %d B of LDS", lds_bytes);
-      return ALADIN_ERR_HIP;
-    }
-    attr_done = true;
-  }
+  static unsigned long long lds_reserved = 0;
+  if (int rc = aladin_reserve_lds((const void*)kern, lds_bytes, &lds_reserved, "align_side_gemm")) return rc;
   hipLaunchKernelGGL(kern, dim3(n_mblk * n_nblk), dim3(Cfg::THREADS), lds_bytes, stream, xe, y, E, g->y_rows,
                      (int64_t)g->Dp, g->Dp / 64, n_nblk);
   return aladin_check_launch("align_side_gemm_kernel");

@@ -20,6 +20,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 void aladin_set_error(const char* fmt, ...);
 int aladin_check_launch(const char* what);
+// Raise a kernel's dynamic-LDS limit once per DEVICE (the attribute is per device; `done` is a per-call-site
+// bit mask indexed by the current device, thread-safe).  Returns ALADIN_OK or ALADIN_ERR_HIP.
+int aladin_reserve_lds(const void* kernel, int bytes, unsigned long long* done, const char* what);
 
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 #define GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void*)(p))

@@ -359,14 +359,8 @@ extern "C" int aladin_distill_ordinal_fwd_bwd(const float* teacher, int64_t ld_t
     aladin_set_error("distill_ordinal: B=%d exceeds the in-LDS sort (max 8192)", B);
     return ALADIN_ERR_UNSUPPORTED;
   }
-  static bool attr_done = false;
-  if (!attr_done) {
-    if (hipFuncSetAttribute((const void*)ordinal_line_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess) {
-      aladin_set_error("distill_ordinal: cannot reserve LDS");
-      return ALADIN_ERR_HIP;
-    }
-    attr_done = true;
-  }
+  static unsigned long long lds_reserved = 0;
+  if (int rc = aladin_reserve_lds((const void*)ordinal_line_kernel, 150 * 1024, &lds_reserved, "distill_ordinal")) return rc;
   float* G = (float*)workspace;
   double* part = (double*)(G + 2 * (size_t)B * B);
   hipStream_t st = (hipStream_t)stream;

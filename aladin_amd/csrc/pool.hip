@@ -58,11 +58,8 @@ extern "C" int aladin_normsum_fwd(const float* x, int64_t stride_b, int64_t stri
                                   int D, int tail, float* out, void* stream) {
   if (!x || !len || !out || B < 1 || N < 2 + tail || D < 1 || tail < 0) { aladin_set_error("normsum_fwd: bad argument"); return ALADIN_ERR_ARG; }
   if ((size_t)D * 16 > 160 * 1024) { aladin_set_error("normsum_fwd: D too large (%d)", D); return ALADIN_ERR_UNSUPPORTED; }
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)normsum_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_done = true;
-  }
+  static unsigned long long lds_reserved = 0;
+  if (int rc = aladin_reserve_lds((const void*)normsum_fwd_kernel, 160 * 1024, &lds_reserved, "normsum_fwd")) return rc;
   hipLaunchKernelGGL(normsum_fwd_kernel, dim3(B), dim3(256), (size_t)D * 16, (hipStream_t)stream, x, stride_b, stride_r, len, N,
                      D, tail, out);
   return aladin_check_launch("normsum_fwd_kernel");

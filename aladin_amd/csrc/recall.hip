@@ -12,7 +12,6 @@
 #include "../../include/aladin_hip.h"
 #include "gemm_core.hpp"
 
-#define MAX_CPI 8                         // captions per image supported by the rank kernels
 using SimCfg = GemmCfg<4, 2, 2, 6>;       // 256 x 384 tile, 8 waves x (64 x 192), v_mfma_f32_16x16x32_f16 body (gemm_core.hpp)
 
 struct SimWs {
@@ -310,8 +309,7 @@ __global__ __launch_bounds__(256) void sim_gt_kernel(const half_t* __restrict__ 
   const half_t* ap = a + (int64_t)(row_t + (lane & 15)) * ldk + 8 * (lane >> 4);     // padded rows exist (Mp, Np)
   const half_t* bp = b + (int64_t)(col_t + (lane & 15)) * ldk + 8 * (lane >> 4);
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 8
-  for (int k = 0; k < kblocks; ++k) {                                  // loads of later blocks hoisted; the MFMA chain stays in K order
+  for (int k = 0; k < kblocks; ++k) {                                  // the MFMA chain stays in K order
     const half8 af = *reinterpret_cast<const half8*>(ap + (int64_t)k * 32);
     const half8 bf = *reinterpret_cast<const half8*>(bp + (int64_t)k * 32);
     acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf, acc, 0, 0, 0);
@@ -341,14 +339,8 @@ static int sim_prepare(const float* img, int64_t img_rs, const float* cap, int64
     const int rc = aladin_check_launch("sim_pack_kernel");
     if (rc) return rc;
   }
-  static bool attr_done = false;
-  if (!attr_done) {
-    if (hipFuncSetAttribute((const void*)sim_gemm_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, SimCfg::LDS_BYTES) != hipSuccess) {
-      aladin_set_error("sim: cannot reserve %d B of LDS", SimCfg::LDS_BYTES);
-      return ALADIN_ERR_HIP;
-    }
-    attr_done = true;
-  }
+  static unsigned long long lds_reserved = 0;
+  if (int rc = aladin_reserve_lds((const void*)sim_gemm_kernel<MODE>, SimCfg::LDS_BYTES, &lds_reserved, "sim_gemm")) return rc;
   return ALADIN_OK;
 }
 
@@ -374,46 +366,35 @@ extern "C" int aladin_sim_matrix(const float* img, int64_t img_rs, const float* 
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void rank_i2t_kernel(const float* __restrict__ sim, int64_t ld, int n_cap, int cpi,
                                                        int32_t* __restrict__ rank, int32_t* __restrict__ top1) {
-  __shared__ int red[4][MAX_CPI];
+  __shared__ int red[4];
   __shared__ float redv[4];
   __shared__ int redi[4];
   const int i = blockIdx.x;
   const float* row = sim + (int64_t)i * ld;
-  float gt[MAX_CPI];
-  int cnt[MAX_CPI];
-#pragma unroll
-  for (int g = 0; g < MAX_CPI; ++g) { gt[g] = (g < cpi) ? row[(int64_t)i * cpi + g] : INFINITY; cnt[g] = 0; }
+  // best of the image's captions (recall_auxiliary.py:38-44): #(v > t) never grows with t, so the minimum
+  // over the cpi ground truths is the count against the largest of them
+  float gt = -INFINITY;
+  for (int g = 0; g < cpi; ++g) gt = fmaxf(gt, row[(int64_t)i * cpi + g]);
+  int cnt = 0;
   float best = -INFINITY;
   int besti = 0x7fffffff;
   for (int c = threadIdx.x; c < n_cap; c += blockDim.x) {
     const float v = row[c];
-#pragma unroll
-    for (int g = 0; g < MAX_CPI; ++g) cnt[g] += (v > gt[g]);
+    cnt += (v > gt);
     if (v > best) { best = v; besti = c; }
   }
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #pragma unroll
-  for (int g = 0; g < MAX_CPI; ++g) {
-    int c = cnt[g];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
-    if (lane == 0) red[wave][g] = c;
-  }
-#pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
+    cnt += __shfl_xor(cnt, o, 64);
     const float ov = __shfl_xor(best, o, 64);
     const int oi = __shfl_xor(besti, o, 64);
     if (ov > best || (ov == best && oi < besti)) { best = ov; besti = oi; }
   }
-  if (lane == 0) { redv[wave] = best; redi[wave] = besti; }
+  if (lane == 0) { red[wave] = cnt; redv[wave] = best; redi[wave] = besti; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    int r = 0x7fffffff;
-    for (int g = 0; g < cpi; ++g) {
-      const int c = red[0][g] + red[1][g] + red[2][g] + red[3][g];
-      r = c < r ? c : r;
-    }
-    rank[i] = r;                                         // best of the image's captions (recall_auxiliary.py:38-44)
+    rank[i] = red[0] + red[1] + red[2] + red[3];
     for (int w = 1; w < 4; ++w)
       if (redv[w] > best || (redv[w] == best && redi[w] < besti)) { best = redv[w]; besti = redi[w]; }
     top1[i] = besti;
@@ -457,8 +438,8 @@ extern "C" int aladin_recall_ranks(const float* sim, int64_t ld_sim, int n_img, 
                                    int32_t* rank_i2t, int32_t* top1_i2t, int32_t* rank_t2i, int32_t* top1_t2i,
                                    void* workspace, void* stream) {
   if (!sim || !rank_i2t || !top1_i2t || !rank_t2i || !top1_t2i || !workspace) { aladin_set_error("recall_ranks: null argument"); return ALADIN_ERR_ARG; }
-  if (n_img < 1 || caps_per_img < 1 || caps_per_img > MAX_CPI || n_cap != n_img * caps_per_img || ld_sim < n_cap) {
-    aladin_set_error("recall_ranks: need n_cap == n_img * caps_per_img, caps_per_img <= %d (n_img=%d n_cap=%d cpi=%d)", MAX_CPI, n_img, n_cap, caps_per_img);
+  if (n_img < 1 || caps_per_img < 1 || n_cap != n_img * caps_per_img || ld_sim < n_cap) {
+    aladin_set_error("recall_ranks: need n_cap == n_img * caps_per_img (n_img=%d n_cap=%d cpi=%d)", n_img, n_cap, caps_per_img);
     return ALADIN_ERR_ARG;
   }
   hipStream_t st = (hipStream_t)stream;
@@ -524,8 +505,8 @@ extern "C" int aladin_retrieval_ranks(const float* img, int64_t img_rs, const fl
     aladin_set_error("retrieval_ranks: bad argument");
     return ALADIN_ERR_ARG;
   }
-  if (n_img < 1 || caps_per_img < 1 || caps_per_img > MAX_CPI || n_cap != n_img * caps_per_img) {
-    aladin_set_error("retrieval_ranks: need n_cap == n_img * caps_per_img, caps_per_img <= %d (n_img=%d n_cap=%d cpi=%d)", MAX_CPI, n_img, n_cap, caps_per_img);
+  if (n_img < 1 || caps_per_img < 1 || n_cap != n_img * caps_per_img) {
+    aladin_set_error("retrieval_ranks: need n_cap == n_img * caps_per_img (n_img=%d n_cap=%d cpi=%d)", n_img, n_cap, caps_per_img);
     return ALADIN_ERR_ARG;
   }
   hipStream_t st = (hipStream_t)stream;

@@ -586,7 +586,7 @@ def test_error_behaviour():
         ops.alignment_scores(T(im), T(s), il[:-1], sl)
 
 
-@pytest.mark.parametrize('n_img,cpi,D', [(1, 5, 8), (7, 1, 33), (77, 3, 100), (300, 5, 64), (1000, 5, 768), (257, 8, 50)])
+@pytest.mark.parametrize('n_img,cpi,D', [(1, 5, 8), (7, 1, 33), (77, 3, 100), (300, 5, 64), (1000, 5, 768), (257, 8, 50), (40, 13, 24)])
 def test_fused_retrieval_ranks_equal_two_step(n_img, cpi, D):
     """aladin_retrieval_ranks (ranks inside the GEMM epilogue, no score matrix) must give the very ints of
     aladin_sim_matrix + aladin_recall_ranks: ragged tile edges, every captions-per-image count, odd D."""
