@@ -22,47 +22,44 @@ from . import ops
 CAPS_PER_IMG = 5
 
 
-class AverageMeter(object):
-    """reference alad/evaluation.py:22-47."""
+class AverageMeter:
+    """Last value and running weighted mean of one logged quantity (same fields and printing as the
+    meter of reference alad/evaluation.py:22-47: val, avg, sum, count; weight 0 records without averaging)."""
+
+    __slots__ = ('val', 'avg', 'sum', 'count')
 
     def __init__(self):
         self.reset()
 
     def reset(self):
-        self.val = 0
-        self.avg = 0
-        self.sum = 0
-        self.count = 0
+        self.val = self.avg = self.sum = self.count = 0
 
     def update(self, val, n=0):
         self.val = val
-        self.sum += val * n
         self.count += n
-        self.avg = self.sum / (.0001 + self.count)
+        self.sum += n * val
+        self.avg = self.sum / (self.count + 1e-4)          # the reference's guard against an empty meter
 
     def __str__(self):
-        if self.count == 0:
-            return str(self.val)
-        return '%.4f (%.4f)' % (self.val, self.avg)
+        return str(self.val) if not self.count else '{:.4f} ({:.4f})'.format(self.val, self.avg)
 
 
-class LogCollector(object):
-    """reference alad/evaluation.py:50-77."""
+class LogCollector:
+    """Named AverageMeters in insertion order (reference alad/evaluation.py:50-77), incl. the
+    TensorBoard hook `tb_log` the training driver calls."""
 
     def __init__(self):
         self.meters = OrderedDict()
 
     def update(self, k, v, n=0):
-        if k not in self.meters:
-            self.meters[k] = AverageMeter()
-        self.meters[k].update(v, n)
+        self.meters.setdefault(k, AverageMeter()).update(v, n)
 
     def __str__(self):
-        return '  '.join(k + ' ' + str(v) for k, v in self.meters.items())
+        return '  '.join('%s %s' % (name, meter) for name, meter in self.meters.items())
 
     def tb_log(self, tb_logger, prefix='', step=None):
-        for k, v in self.meters.items():
-            tb_logger.add_scalar(prefix + k, v.val, global_step=step)
+        for name, meter in self.meters.items():
+            tb_logger.add_scalar(prefix + name, meter.val, global_step=step)
 
 
 def encode_data(model, data_loader, log_step=10, logging=print, max_len=71):
