@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
 """Randomised parity fuzz (GPU) for the B x B loss kernels and the retrieval kernels against the
-oracle.  usage: tools/fuzz_losses.py [seconds] [seed]"""
+oracle.  usage: tests/fuzz/fuzz_losses.py [seconds] [seed]"""
 import os
 import sys
 import time
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'oracle'))
 import numpy as np

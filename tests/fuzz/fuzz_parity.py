@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
 """Randomised parity fuzz (GPU): random shapes, lengths and pooling modes; HIP scores vs the oracle and
-HIP gradients vs the oracle chained on the HIP scores.  usage: tools/fuzz_parity.py [seconds] [seed]"""
+HIP gradients vs the oracle chained on the HIP scores.  usage: tests/fuzz/fuzz_parity.py [seconds] [seed]"""
 import os
 import sys
 import time
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'oracle'))
 import numpy as np
