@@ -572,6 +572,22 @@ def test_b256_triplet_step_gradient_sparsity():
     assert dots.max() <= 1e-3 * max(1e-6, np.abs(ga).sum(-1).max() * np.abs(im).max())
 
 
+def test_large_batch_equals_its_blocks():
+    """A score depends only on its own image and caption, not on where its tile sits: the 1024 x 768 matrix
+    must equal, bit for bit, the 256 x 256 blocks scored one by one (64-bit indexing, tile order, XCD remap,
+    side-GEMM strides at sizes beyond the headline batch)."""
+    from aladin_amd import ops, synth
+    Bi, Bc, blk = 1024, 768, 256
+    im, s, il, sl = synth.alignment_batch(Bi, 34, 50, 256, seed=515, ragged=True, Bc=Bc)
+    il[0], sl[0] = 34, 50                                  # keep the batch maxima at R'=33, T'=47 in every block
+    a, b = T(im), T(s)
+    S = ops.alignment_scores(a, b, il, sl)
+    for i0 in range(0, Bi, blk):
+        for j0 in range(0, Bc, blk):
+            part = ops.alignment_scores(a[i0:i0 + blk], b[j0:j0 + blk], il[i0:i0 + blk], sl[j0:j0 + blk])
+            assert torch.equal(S[i0:i0 + blk, j0:j0 + blk], part), (i0, j0)
+
+
 def test_error_behaviour():
     from aladin_amd import ops
     from aladin_amd.loss import AlignmentContrastiveLoss
