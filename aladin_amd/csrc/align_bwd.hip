@@ -177,7 +177,13 @@ __global__ __launch_bounds__(256) void bwd_pair_argmax16_kernel(
   const int h = lane >> 5, l5 = lane & 31;
   const int wm = wave >> 1, wn = wave & 1;
   const int count = *counter;
-  for (int p = blockIdx.x; p < count; p += gridDim.x) {
+  // The pair list groups the pairs of one image (hinge_finish / bwd_compact emit row chunks), and blocks
+  // are dealt round-robin over the 8 XCDs: give each XCD a CONTIGUOUS eighth of the list so that pairs
+  // sharing an image panel meet in the same L2.
+  const int per_xcd = (count + 7) >> 3;
+  for (int b = blockIdx.x; b < 8 * per_xcd; b += gridDim.x) {
+    const int p = (b & 7) * per_xcd + (b >> 3);
+    if (p >= count) continue;                          // uniform per workgroup
     const int i = pairs[p] / Bc, j = pairs[p] % Bc;
     int Li = im_len[i] - 1 - x_tail; Li = Li < 0 ? 0 : (Li > Rq ? Rq : Li);
     int Lj = s_len[j] - 1 - y_tail; Lj = Lj < 0 ? 0 : (Lj > Tq ? Tq : Lj);
