@@ -198,14 +198,19 @@ def main():
         import torch.distributed as dist
         for mode in ('dense', 'sparse'):
             exchange[0] = mode
-            for _ in range(3):
-                step()
-            fence()
-            t0 = time.perf_counter()
-            for _ in range(8):
-                step()
-            fence()
-            tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+            try:
+                for _ in range(3):
+                    step()
+                fence()
+                t0 = time.perf_counter()
+                for _ in range(8):
+                    step()
+                fence()
+                elapsed = time.perf_counter() - t0
+            except Exception as exc:                  # same code on every rank: they fail (or not) together
+                print('bench: exchange %r failed on rank %d (%s); not used' % (mode, rank, exc), file=sys.stderr)
+                elapsed = float('inf')
+            tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             tuned[mode] = float(tt.item()) / 8 * 1e3
         exchange[0] = min(tuned, key=tuned.get)
@@ -244,7 +249,8 @@ def main():
                                     'over RCCL, caption-block sharding' % (B * world, B * world)),
                        'global_pairs_per_step': pairs, 'loss': float(loss.detach()), 'launch': launch,
                        **({} if not sharded else {'bwd_exchange': exchange[0],
-                                                  'bwd_exchange_tuning_ms': {k: round(v, 4) for k, v in tuned.items()}}),
+                                                  'bwd_exchange_tuning_ms': {k: (round(v, 4) if v != float('inf') else None)
+                                                                             for k, v in tuned.items()}}),
                        'step_tflops_algorithmic': round(value * FLOPS_PER_PAIR / 1e12, 2)},
             'roofline': roof,
         }
