@@ -33,7 +33,7 @@
 static int scores_strip_mult(int tp16, int mtiles) {
   static int env = -1;
   if (env < 0) { const char* e = getenv("ALADIN_ALIGN_STRIP"); env = e ? atoi(e) : 2; }
-  return (env == 2 && mtiles == 1 && tp16 <= 6) ? 2 : 1;       // tp16 in {1,2,3,4,6}: 24 / tp16 captions per 384-row tile
+  return (env == 2 && mtiles <= 2 && tp16 <= 6) ? 2 : 1;       // tp16 in {1,2,3,4,6}: 24 / tp16 captions per 384-row tile
 }
 
 extern "C" int aladin_align_geometry(int Bi, int Bc, int R, int T, int D, aladin_align_geom* g) {
@@ -402,15 +402,15 @@ static int scores_wgm() {
 }
 
 // ------------------------------------------------------------------------------------------------
-// score kernel, v_mfma_f32_16x16x32_f16 body, for every class with one region tile (R' <= 32, plus the
-// side row) and captions of TP16 = 1, 2, 3, 4 or 6 sixteen-word tiles (headline: 3 = 48 words):
+// score kernel, v_mfma_f32_16x16x32_f16 body, for every class with one or two 32-row region tiles per image
+// (R' <= 64, plus the side row: Q = 1 -> a wave's 64 rows are two images, Q = 2 -> one) and captions of TP16 = 1, 2, 3, 4 or 6 sixteen-word tiles (headline: 3 = 48 words):
 // 256 x 384 workgroup tile (8 waves: 4 x 2; wave = 2 images x 12/TP16 captions = 4 x 12 accumulator
 // tiles of 16 x 16).
 //   max over regions : in-lane over 2 row tiles x 4 registers, v_permlane32_swap pairs the wave's two
 //                      images into the two half-waves, one 16-lane exchange finishes the 32 rows
 //   sum over words   : a caption is exactly TP16 column tiles -> in-lane adds, then a 16-lane reduction
 // ------------------------------------------------------------------------------------------------
-template <bool HAS_E, int TP16>
+template <bool HAS_E, int TP16, int Q>
 __device__ __forceinline__ void scores16_epilogue(f32x4 (&acc)[4][12], int mb, int nb, const float* __restrict__ E,
                                                   int64_t ldE, float* __restrict__ S, int64_t ldS, int Bi, int Bc) {
   using Cfg = GemmCfg<4, 2, 2, 6>;
@@ -418,7 +418,10 @@ __device__ __forceinline__ void scores16_epilogue(f32x4 (&acc)[4][12], int mb, i
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int wm = wave / 2, wn = wave % 2;
   const int half = lane >> 5, l4 = lane & 15;
-  const int img = (mb * 4 + wm) * 2 + half;                        // lanes 0-31: image 0, lanes 32-63: image 1
+  static_assert(Q == 1 || Q == 2, "one or two 32-row region tiles per image");
+  // Q == 1: the wave's 64 rows are two images (lanes 0-31 finish image 0, lanes 32-63 image 1);
+  // Q == 2: they are ONE image (R' in 34..64, or 65 with the side row)
+  const int img = (Q == 1) ? (mb * 4 + wm) * 2 + half : mb * 4 + wm;
   const float* e = HAS_E ? E + (int64_t)img * ldE + (int64_t)nb * Cfg::BN + wn * 192 + l4 : nullptr;
   constexpr int NC = 12 / TP16;                                    // captions of the wave's 192-row strip
   static_assert(12 % TP16 == 0, "a caption must be a whole number of 16-word column tiles of the strip");
@@ -431,10 +434,17 @@ __device__ __forceinline__ void scores16_epilogue(f32x4 (&acc)[4][12], int mb, i
     p0 = fmaxf(p0, fmaxf(fmaxf(acc[1][ct][0], acc[1][ct][1]), fmaxf(acc[1][ct][2], acc[1][ct][3])));
     float p1 = fmaxf(fmaxf(acc[2][ct][0], acc[2][ct][1]), fmaxf(acc[2][ct][2], acc[2][ct][3]));
     p1 = fmaxf(p1, fmaxf(fmaxf(acc[3][ct][0], acc[3][ct][1]), fmaxf(acc[3][ct][2], acc[3][ct][3])));
-    // rows are spread over the four 16-lane quarters; gather image 0 into lanes 0-31, image 1 into 32-63
-    auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(p0), __float_as_uint(p1), false, false);
-    float m = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
-    m = fmaxf(m, __shfl_xor(m, 16, 64));
+    float m;
+    if constexpr (Q == 1) {
+      // rows are spread over the four 16-lane quarters; gather image 0 into lanes 0-31, image 1 into 32-63
+      auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(p0), __float_as_uint(p1), false, false);
+      m = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+      m = fmaxf(m, __shfl_xor(m, 16, 64));
+    } else {
+      m = fmaxf(p0, p1);                                           // all 64 rows belong to the image
+      m = fmaxf(m, __shfl_xor(m, 16, 64));
+      m = fmaxf(m, __shfl_xor(m, 32, 64));
+    }
     if constexpr (HAS_E) m = fmaxf(m, e[ct * 16]);
     v[ct / TP16] += m;
   }
@@ -444,11 +454,11 @@ __device__ __forceinline__ void scores16_epilogue(f32x4 (&acc)[4][12], int mb, i
     float t = v[c];
 #pragma unroll
     for (int o = 8; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
-    if ((lane & 31) == 0 && img < Bi && cap + c < Bc) S[(int64_t)img * ldS + cap + c] = t;
+    if ((lane & (Q == 1 ? 31 : 63)) == 0 && img < Bi && cap + c < Bc) S[(int64_t)img * ldS + cap + c] = t;
   }
 }
 
-template <bool HAS_E, int TP16 = 3, bool PROBE = false>
+template <bool HAS_E, int TP16 = 3, bool PROBE = false, int Q = 1>
 __global__ __launch_bounds__(512) void align_scores16_kernel(const half_t* __restrict__ xm, const half_t* __restrict__ y,
                                                              const float* __restrict__ E, int64_t ldE,
                                                              float* __restrict__ S, int64_t ldS, int Bi, int Bc,
@@ -470,7 +480,7 @@ __global__ __launch_bounds__(512) void align_scores16_kernel(const half_t* __res
   gemm_mainloop16<Cfg, true>(xm + (int64_t)mb * Cfg::BM * ldk, y + (int64_t)nb * Cfg::BN * ldk, ldk, ktiles, smem, acc);
   if constexpr (PROBE) { pt1 = __builtin_amdgcn_s_memtime(); pr1 = __builtin_amdgcn_s_memrealtime(); }
 
-  scores16_epilogue<HAS_E, TP16>(acc, mb, nb, E, ldE, S, ldS, Bi, Bc);
+  scores16_epilogue<HAS_E, TP16, Q>(acc, mb, nb, E, ldE, S, ldS, Bi, Bc);
   if constexpr (PROBE) {
     __syncthreads();
     if (threadIdx.x == 0 && blockIdx.x < 4096) {
@@ -483,7 +493,7 @@ __global__ __launch_bounds__(512) void align_scores16_kernel(const half_t* __res
   }
 }
 
-template <bool HAS_E, int TP16 = 3, bool PROBE = false>
+template <bool HAS_E, int TP16 = 3, bool PROBE = false, int Q = 1>
 static int launch_scores16(const aladin_align_geom* g, const half_t* xm, const half_t* y, const float* E, float* S,
                            int64_t ldS, hipStream_t stream) {
   using Cfg = GemmCfg<4, 2, 2, 6>;
@@ -492,7 +502,7 @@ static int launch_scores16(const aladin_align_geom* g, const half_t* xm, const h
     aladin_set_error("align_scores16: packed rows do not tile");
     return ALADIN_ERR_ARG;
   }
-  auto kern = align_scores16_kernel<HAS_E, TP16, PROBE>;
+  auto kern = align_scores16_kernel<HAS_E, TP16, PROBE, Q>;
   static unsigned long long lds_reserved = 0;
   if (int rc = aladin_reserve_lds((const void*)kern, Cfg::LDS_BYTES, &lds_reserved, "align_scores16")) return rc;
   const int n_blocks = n_mblk * n_nblk;
@@ -524,12 +534,12 @@ static int launch_scores_w(const aladin_align_geom* g, const half_t* xm, const h
 template <int WM, int Q, int TP16, bool HAS_E>
 static int launch_scores(const aladin_align_geom* g, const half_t* xm, const half_t* y, const float* E, float* S,
                          int64_t ldS, hipStream_t stream) {
-  if constexpr (Q == 1 && TP16 <= 6)
+  if constexpr (Q <= 2 && TP16 <= 6)
     if (scores_strip_mult(TP16, g->mtiles) == 2) {
       // ALADIN_ALIGN_SPREAD: 16 (default) = v_mfma_f32_16x16x32_f16 body; 26 = the same + clock probe
       // (diagnostic); 3 / 6 = the earlier 32x32x16 body and its clock probe, 7 / 9 = its ablations
       // (headline class only)
-      if constexpr (TP16 == 3) {
+      if constexpr (TP16 == 3 && Q == 1) {
         if (scores_spread() == 26) return launch_scores16<HAS_E, 3, true>(g, xm, y, E, S, ldS, stream);
         if (scores_spread() == 3) return launch_scores_w<4, WM, Q, TP16, HAS_E, 2, 3>(g, xm, y, E, S, ldS, stream);
         if (scores_spread() == 6) return launch_scores_w<4, WM, Q, TP16, HAS_E, 2, 6>(g, xm, y, E, S, ldS, stream);
@@ -537,7 +547,7 @@ static int launch_scores(const aladin_align_geom* g, const half_t* xm, const hal
         if (scores_spread() == 7) return launch_scores_w<4, WM, Q, TP16, HAS_E, 2, 7>(g, xm, y, E, S, ldS, stream);   // no refill
         if (scores_spread() == 9) return launch_scores_w<4, WM, Q, TP16, HAS_E, 2, 9>(g, xm, y, E, S, ldS, stream);   // no MFMA
       }
-      return launch_scores16<HAS_E, TP16>(g, xm, y, E, S, ldS, stream);
+      return launch_scores16<HAS_E, TP16, false, Q>(g, xm, y, E, S, ldS, stream);
     }
   if (scores_wgm() == 4) return launch_scores_w<4, WM, Q, TP16, HAS_E, 1>(g, xm, y, E, S, ldS, stream);
   return launch_scores_w<2, WM, Q, TP16, HAS_E, 1>(g, xm, y, E, S, ldS, stream);
