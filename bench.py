@@ -33,8 +33,8 @@ PEAK_TFLOPS = 2500.0                                 # dense 16-bit MFMA, MI355X
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=50)
-    ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--steps', type=int, default=2000)
+    ap.add_argument('--warmup', type=int, default=200)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--eager', action='store_true', help='do not capture the step in a HIP graph')
     ap.add_argument('--force-sharded', action='store_true',
