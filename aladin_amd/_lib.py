@@ -24,6 +24,7 @@ SYMBOLS = [
     'aladin_distill_ordinal_fwd_bwd', 'aladin_order_sim_fwd', 'aladin_order_sim_bwd', 'aladin_sgemm_strided',
     'aladin_sim_workspace_bytes', 'aladin_sim_matrix', 'aladin_recall_workspace_bytes',
     'aladin_recall_ranks', 'aladin_normsum_fwd', 'aladin_normsum_bwd',
+    'aladin_l2norm_fwd', 'aladin_l2norm_bwd',
     'aladin_retrieval_workspace_bytes', 'aladin_retrieval_ranks',
     'aladin_scan_workspace_bytes', 'aladin_scan_fwd', 'aladin_scan_bwd',
     'aladin_store_row_width', 'aladin_store_append', 'aladin_align_pack_store_x', 'aladin_align_pack_store_y',
@@ -73,6 +74,8 @@ def _declare(lib):
         'aladin_sim_matrix': (C.c_int, [p, i64, p, i64, i32, i32, i32, p, i64, p, p]),
         'aladin_normsum_fwd': (C.c_int, [p, i64, i64, p, i32, i32, i32, i32, p, p]),
         'aladin_normsum_bwd': (C.c_int, [p, i64, i64, p, i32, i32, i32, i32, p, p, p]),
+        'aladin_l2norm_fwd': (C.c_int, [p, i64, i32, i32, p, p]),
+        'aladin_l2norm_bwd': (C.c_int, [p, i64, p, i64, i32, i32, p, p]),
         'aladin_retrieval_workspace_bytes': (sz, [i32, i32, i32]),
         'aladin_retrieval_ranks': (C.c_int, [p, i64, p, i64, i32, i32, i32, i32, p, p, p, p, p, p]),
         'aladin_scan_workspace_bytes': (sz, [i32, i32, i32, i32, i32, i32]),

@@ -73,3 +73,49 @@ extern "C" int aladin_normsum_bwd(const float* x, int64_t stride_b, int64_t stri
                      stride_r, len, B, N, D, tail, d_out, d_x);
   return aladin_check_launch("normsum_bwd_kernel");
 }
+
+// ------------------------------------------------------------------------------------------------
+// l2norm (reference alad/utils.py:134-139): X / sqrt(sum_dim1 X^2), NO eps -- a zero row is 0/0 = NaN,
+// as in the reference (unlike F.normalize).  One wave per row; backward = (g - n <n, g>) / ||x||.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void l2norm_fwd_kernel(const float* __restrict__ x, int64_t rs, int rows, int D,
+                                                         float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  const float* xr = x + r * rs;
+  float ss = 0.f;
+  for (int c = lane; c < D; c += 64) ss += xr[c] * xr[c];
+  const float nrm = sqrtf(wave_sum(ss));
+  for (int c = lane; c < D; c += 64) out[r * D + c] = xr[c] / nrm;
+}
+
+__global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float* __restrict__ x, int64_t rs, const float* __restrict__ g,
+                                                         int64_t gs, int rows, int D, float* __restrict__ dx) {
+  const int lane = threadIdx.x & 63;
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  const float* xr = x + r * rs;
+  const float* gr = g + r * gs;
+  float ss = 0.f, dot = 0.f;
+  for (int c = lane; c < D; c += 64) { ss += xr[c] * xr[c]; dot += xr[c] * gr[c]; }
+  ss = wave_sum(ss);
+  dot = wave_sum(dot);
+  const float nrm = sqrtf(ss);
+  const float proj = dot / ss;                                     // <n, g> / ||x||
+  for (int c = lane; c < D; c += 64) dx[r * D + c] = (gr[c] - xr[c] * proj) / nrm;
+}
+
+extern "C" int aladin_l2norm_fwd(const float* x, int64_t row_stride, int rows, int D, float* out, void* stream) {
+  if (!x || !out || rows < 1 || D < 1 || row_stride < D) { aladin_set_error("l2norm_fwd: bad argument (rows=%d D=%d)", rows, D); return ALADIN_ERR_ARG; }
+  hipLaunchKernelGGL(l2norm_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, row_stride, rows, D, out);
+  return aladin_check_launch("l2norm_fwd_kernel");
+}
+
+extern "C" int aladin_l2norm_bwd(const float* x, int64_t row_stride, const float* d_out, int64_t d_out_stride, int rows, int D,
+                                 float* d_x, void* stream) {
+  if (!x || !d_out || !d_x || rows < 1 || D < 1 || row_stride < D || d_out_stride < D) { aladin_set_error("l2norm_bwd: bad argument (rows=%d D=%d)", rows, D); return ALADIN_ERR_ARG; }
+  hipLaunchKernelGGL(l2norm_bwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, row_stride, d_out, d_out_stride,
+                     rows, D, d_x);
+  return aladin_check_launch("l2norm_bwd_kernel");
+}

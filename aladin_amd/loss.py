@@ -18,9 +18,8 @@ from . import ops
 
 
 def l2norm(X):
-    """X / sqrt(sum_dim1 X^2), no eps -- reference alad/utils.py:134-139 (zero rows give NaN)."""
-    norm = torch.pow(X, 2).sum(dim=1, keepdim=True).sqrt()
-    return torch.div(X, norm)
+    """X / sqrt(sum_dim1 X^2), no eps -- reference alad/utils.py:134-139 (zero rows give NaN), HIP kernel."""
+    return ops.l2norm_rows(X)
 
 
 def dot_sim(im, s):

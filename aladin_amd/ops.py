@@ -580,3 +580,30 @@ def retrieval_ranks(img, cap, caps_per_img=5):
                                           _ptr(r_i2t), _ptr(t_i2t), _ptr(r_t2i), _ptr(t_t2i), _ptr(ws), _stream()),
                'retrieval_ranks')
     return r_i2t, t_i2t, r_t2i, t_t2i
+
+
+class _L2Norm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = x if x.stride(1) == 1 else x.contiguous()
+        out = torch.empty((x.shape[0], x.shape[1]), dtype=torch.float32, device=x.device)
+        _lib.check(_lib.load().aladin_l2norm_fwd(_ptr(x), x.stride(0), x.shape[0], x.shape[1], _ptr(out), _stream()), 'l2norm_fwd')
+        ctx.save_for_backward(x)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        g = g if g.stride(1) == 1 else g.contiguous()
+        dx = torch.empty((x.shape[0], x.shape[1]), dtype=torch.float32, device=x.device)
+        _lib.check(_lib.load().aladin_l2norm_bwd(_ptr(x), x.stride(0), _ptr(g), _ld(g), x.shape[0], x.shape[1], _ptr(dx), _stream()),
+                   'l2norm_bwd')
+        return dx
+
+
+def l2norm_rows(x):
+    """X / sqrt(sum_dim1 X^2) without eps; replaces l2norm, reference alad/utils.py:134-139 (zero rows -> NaN)."""
+    _require_gpu(x)
+    if x.dim() != 2 or x.shape[0] < 1 or x.shape[1] < 1:
+        raise ValueError('aladin_amd: l2norm expects a non-empty (rows, D) matrix')
+    return _L2Norm.apply(x)

@@ -171,6 +171,12 @@ int aladin_align_pack_store_x(const void* rows, const int64_t* offsets, const in
 int aladin_align_pack_store_y(const void* rows, const int64_t* offsets, const int32_t* counts, const int32_t* ids,
                               const aladin_align_geom* g, void* y, void* stream);
 
+/* l2norm -- reference alad/utils.py:134-139: out = X / sqrt(sum_dim1 X^2) on (rows, D), NO eps (a zero row
+ * gives NaN, as the reference; F.normalize would give 0), and its backward.  out / d_x are contiguous. */
+int aladin_l2norm_fwd(const float* x, int64_t row_stride, int rows, int D, float* out, void* stream);
+int aladin_l2norm_bwd(const float* x, int64_t row_stride, const float* d_out, int64_t d_out_stride, int rows, int D,
+                      float* d_x, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * aggregation = 'scan-sentences' -- reference alad/loss.py:136-149 (no shipped config uses it).
  * Per pair: relu(cosines) L2-normalised over regions, softmax over the caption's valid words for each

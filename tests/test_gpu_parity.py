@@ -588,6 +588,35 @@ def test_large_batch_equals_its_blocks():
             assert torch.equal(S[i0:i0 + blk, j0:j0 + blk], part), (i0, j0)
 
 
+def test_l2norm_and_cosine_measure():
+    """l2norm (alad/utils.py:134-139: no eps, zero row -> NaN) forward / backward, and measure='cosine'."""
+    from aladin_amd.loss import ContrastiveLoss, l2norm
+    rng = np.random.default_rng(12)
+    x = rng.standard_normal((37, 200)).astype(np.float32)
+    xt = T(x).requires_grad_(True)
+    xr = torch.from_numpy(x).requires_grad_(True)
+    w = rng.standard_normal((37, 100)).astype(np.float32)
+    out = l2norm(xt[:, ::2])                                           # strided view: made contiguous inside
+    (out * T(w)).sum().backward()
+    ref = xr[:, ::2] / torch.pow(xr[:, ::2], 2).sum(dim=1, keepdim=True).sqrt()
+    (ref * torch.from_numpy(w)).sum().backward()
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().numpy(), rtol=2e-6, atol=1e-7)
+    np.testing.assert_allclose(xt.grad.cpu().numpy(), xr.grad.numpy(), rtol=1e-4, atol=1e-6)
+    z = T(np.zeros((2, 8), np.float32))
+    assert torch.isnan(l2norm(z)).all()
+    a, b = rng.standard_normal((9, 64)).astype(np.float32) * 3, rng.standard_normal((9, 64)).astype(np.float32) * 0.2
+    at, bt = T(a).requires_grad_(True), T(b).requires_grad_(True)
+    loss = ContrastiveLoss(0.2, 'cosine', True)(at, bt)
+    loss.backward()
+    ar, br = torch.from_numpy(a).requires_grad_(True), torch.from_numpy(b).requires_grad_(True)
+    sc = torch.nn.functional.normalize(ar, dim=1) @ torch.nn.functional.normalize(br, dim=1).t()
+    ref_loss, dS = O.hinge_loss(sc.detach().numpy(), 0.2, True, return_grad=True)
+    (sc * torch.from_numpy(dS)).sum().backward()
+    np.testing.assert_allclose(loss.item(), ref_loss, rtol=1e-5)
+    np.testing.assert_allclose(at.grad.cpu().numpy(), ar.grad.numpy(), rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(bt.grad.cpu().numpy(), br.grad.numpy(), rtol=1e-4, atol=1e-6)
+
+
 def test_error_behaviour():
     from aladin_amd import ops
     from aladin_amd.loss import AlignmentContrastiveLoss
