@@ -2,6 +2,8 @@
 #include <stdarg.h>
 #include <stdio.h>
 
+#include <mutex>
+
 #include "../../include/aladin_hip.h"
 #include "common.hpp"
 
@@ -23,8 +25,6 @@ int aladin_check_launch(const char* what) {
 
 extern "C" int aladin_version(void) { return ALADIN_ABI_VERSION; }
 extern "C" const char* aladin_last_error(void) { return g_err; }
-
-#include <mutex>
 
 int aladin_reserve_lds(const void* kernel, int bytes, unsigned long long* done, const char* what) {
   static std::mutex mu;
