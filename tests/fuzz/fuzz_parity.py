@@ -20,7 +20,7 @@ seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 rng = np.random.RandomState(seed)
 dev = torch.device('cuda:0')
 t0 = time.time()
-n = nbwd = 0
+n = nbwd = ties = 0
 worst = 0.0
 while time.time() - t0 < budget:
     Bi = int(rng.randint(1, 40))
@@ -73,9 +73,18 @@ while time.time() - t0 < budget:
             got = got.cpu().numpy()
             scale = max(1e-9, float(np.abs(want).max()))
             bad = np.abs(got - want) > 1e-3 * np.abs(want) + 5e-5 * scale
-            # a flipped argmax between exactly tied fp32 candidates would move whole rows: allow none
-            assert not bad.any(), '%s: %s mismatch in %d elements (max abs %.3e, scale %.3e)' % (
-                tag, nm, int(bad.sum()), float(np.abs(got - want).max()), scale)
+            if bad.any():
+                # Whole rows move when an argmax flips.  The fp32 torch reference and the kernel's exact
+                # fp32 re-decision sum in different orders, so two candidates closer than fp32 rounding may
+                # legitimately be ranked differently: accept the case iff the float64 restatement sides
+                # with the kernel (anything else is a real error).
+                r64a, r64b = torch.from_numpy(im).double().requires_grad_(True), torch.from_numpy(s).double().requires_grad_(True)
+                (FT.alignment_scores_faithful(r64a, r64b, il, sl, mode) * w.cpu().double()).sum().backward()
+                want64 = (r64a.grad if nm == 'd_im' else r64b.grad).numpy()
+                bad64 = np.abs(got - want64) > 1e-3 * np.abs(want64) + 5e-5 * scale
+                assert not bad64.any(), '%s: %s mismatch in %d elements vs fp32 AND %d vs fp64 reference (max abs %.3e, scale %.3e)' % (
+                    tag, nm, int(bad.sum()), int(bad64.sum()), float(np.abs(got - want64).max()), scale)
+                ties += 1
         nbwd += 1
-print('fuzz ok: %d forward cases (%d with backward), worst score error %.2e of the score magnitude, %.0f s'
-      % (n, nbwd, worst, time.time() - t0))
+print('fuzz ok: %d forward cases (%d with backward, %d fp32-reference near-ties resolved by float64), worst score error '
+      '%.2e of the score magnitude, %.0f s' % (n, nbwd, ties, worst, time.time() - t0))
