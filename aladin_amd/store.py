@@ -133,9 +133,14 @@ def _unwrap(x):
     return (x.store, x.ids, x.ids_t) if isinstance(x, StoreView) else (x, None, None)
 
 
+E_SCRATCH_LIMIT = 2 << 30        # bytes of side-GEMM scratch per launch before the caption side is chunked
+
+
 def alignment_scores_from_stores(img, cap):
     """(N_img, N_cap) 'MrSw' scores (reference alad/loss.py:80-125) between two stores / views:
-    operands are row copies of the stores (no fp32 read, no normalisation), one score launch."""
+    operands are row copies of the stores (no fp32 read, no normalisation).  One score launch, or one
+    per caption chunk when the side-row scratch (N_img x 16*tp16*N_cap floats when R' = 33) would pass
+    E_SCRATCH_LIMIT -- 16 GB for a 5000 x 25000 grid otherwise; a score does not depend on the chunking."""
     si, ids_i, idt_i = _unwrap(img)
     sc, ids_c, idt_c = _unwrap(cap)
     if si.D != sc.D:
@@ -144,16 +149,31 @@ def alignment_scores_from_stores(img, cap):
     if Bi < 1 or Bc < 1:
         raise ValueError('aladin_amd: empty store')
     Rq, Tq = max(si.max_count(ids_i), 1), max(sc.max_count(ids_c), 1)
-    geom = ops.align_geometry(Bi, Bc, Rq + 1 + si.tail, Tq + 1 + sc.tail, si.D, si.tail, sc.tail)
     lib = _lib.load()
     dev = si.device
-    xm = torch.empty(geom.xm_bytes // 2, dtype=torch.float16, device=dev)
-    xe = torch.empty(max(geom.xe_bytes // 2, 8), dtype=torch.float16, device=dev)
-    y = torch.empty(geom.y_bytes // 2, dtype=torch.float16, device=dev)
     oi, ci = si._tables()
     oc, cc = sc._tables()
+    geom = ops.align_geometry(Bi, Bc, Rq + 1 + si.tail, Tq + 1 + sc.tail, si.D, si.tail, sc.tail)
+    chunk = Bc
+    if geom.e_bytes > E_SCRATCH_LIMIT:
+        chunk = max(geom.cap_unit, int(Bc * E_SCRATCH_LIMIT // geom.e_bytes) // geom.cap_unit * geom.cap_unit)
+    xm = torch.empty(geom.xm_bytes // 2, dtype=torch.float16, device=dev)
+    xe = torch.empty(max(geom.xe_bytes // 2, 8), dtype=torch.float16, device=dev)
     _lib.check(lib.aladin_align_pack_store_x(ops._ptr(si.rows), ops._ptr(oi), ops._ptr(ci), ops._ptr(idt_i), C.byref(geom),
                                              ops._ptr(xm), ops._ptr(xe), ops._stream()), 'align_pack_store_x')
-    _lib.check(lib.aladin_align_pack_store_y(ops._ptr(sc.rows), ops._ptr(oc), ops._ptr(cc), ops._ptr(idt_c), C.byref(geom),
-                                             ops._ptr(y), ops._stream()), 'align_pack_store_y')
-    return ops.scores_from_packed(xm, xe, y, geom)
+    if chunk >= Bc:
+        y = torch.empty(geom.y_bytes // 2, dtype=torch.float16, device=dev)
+        _lib.check(lib.aladin_align_pack_store_y(ops._ptr(sc.rows), ops._ptr(oc), ops._ptr(cc), ops._ptr(idt_c), C.byref(geom),
+                                                 ops._ptr(y), ops._stream()), 'align_pack_store_y')
+        return ops.scores_from_packed(xm, xe, y, geom)
+    S = torch.empty((Bi, Bc), dtype=torch.float32, device=dev)
+    all_ids = idt_c if idt_c is not None else torch.arange(Bc, dtype=torch.int32, device=dev)
+    for j0 in range(0, Bc, chunk):
+        j1 = min(Bc, j0 + chunk)
+        g = ops.align_geometry(Bi, j1 - j0, Rq + 1 + si.tail, Tq + 1 + sc.tail, si.D, si.tail, sc.tail)   # same x layout
+        y = torch.empty(g.y_bytes // 2, dtype=torch.float16, device=dev)
+        ids = all_ids[j0:j1].contiguous()
+        _lib.check(lib.aladin_align_pack_store_y(ops._ptr(sc.rows), ops._ptr(oc), ops._ptr(cc), ops._ptr(ids), C.byref(g),
+                                                 ops._ptr(y), ops._stream()), 'align_pack_store_y')
+        ops.scores_from_packed(xm, xe, y, g, out=S[:, j0:j1])
+    return S
