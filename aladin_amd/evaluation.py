@@ -20,6 +20,7 @@ import torch
 from . import ops
 
 CAPS_PER_IMG = 5
+E_SCRATCH_LIMIT = 2 << 30       # bytes of side-GEMM scratch per score launch before the caption side is chunked
 
 
 class AverageMeter:
@@ -178,7 +179,16 @@ def compute_sim_matrix(img, cap, img_len=None, cap_len=None, mode='matching'):
             # shrinking the padded 70 x 68 block per pair to the real one.
             r_eff = min(img.shape[1], max(2, max(int(v) for v in img_len)))
             t_eff = min(cap.shape[1], max(4, max(int(v) for v in cap_len)))
-            return ops.alignment_scores(img[:, :r_eff], cap[:, :t_eff], img_len, cap_len)
+            img, cap = img[:, :r_eff], cap[:, :t_eff]
+            # big grids: chunk the caption side so the side-row scratch of the score kernel stays bounded
+            # (it is N_img x 16*tp16*N_cap floats when R' = 33: 16 GB at 5000 x 25000); same bits either way
+            geom = ops.align_geometry(img.shape[0], cap.shape[0], r_eff, t_eff, img.shape[2])
+            if geom.e_bytes <= E_SCRATCH_LIMIT:
+                return ops.alignment_scores(img, cap, img_len, cap_len)
+            step = max(geom.cap_unit, int(cap.shape[0] * E_SCRATCH_LIMIT // geom.e_bytes) // geom.cap_unit * geom.cap_unit)
+            cap_len = list(cap_len)
+            return torch.cat([ops.alignment_scores(img, cap[j0:j0 + step], img_len, cap_len[j0:j0 + step])
+                              for j0 in range(0, cap.shape[0], step)], dim=1)
     raise ValueError("mode must be 'matching' or 'alignment'")
 
 

@@ -476,13 +476,14 @@ def test_packed_store_scores_are_bit_identical_and_smaller():
     assert torch.equal(sub, ref)
     # caption-side chunking (bounds the side-row scratch on big grids) does not change a single bit
     from aladin_amd import store as store_mod
-    limit = store_mod.E_SCRATCH_LIMIT
-    store_mod.E_SCRATCH_LIMIT = 1 << 20
+    limit, limit_e = store_mod.E_SCRATCH_LIMIT, E.E_SCRATCH_LIMIT
+    store_mod.E_SCRATCH_LIMIT = E.E_SCRATCH_LIMIT = 1 << 20
     try:
+        assert torch.equal(E.compute_sim_matrix(images[0::5], captions, il[0::5], cl, mode='alignment'), S_dense)
         assert torch.equal(E.compute_sim_matrix(si.view(slice(0, None, 5)), sc, mode='alignment'), S_dense)
         assert torch.equal(alignment_scores_from_stores(si.view(pick_i), sc.view(pick_c)), ref)
     finally:
-        store_mod.E_SCRATCH_LIMIT = limit
+        store_mod.E_SCRATCH_LIMIT, E.E_SCRATCH_LIMIT = limit, limit_e
     # matching head reads the fp32 globals
     M_dense = E.compute_sim_matrix(images[0::5, 0, :], captions[:, 0, :])
     M_store = E.compute_sim_matrix(si.view(slice(0, None, 5)), sc)
