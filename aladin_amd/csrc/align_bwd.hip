@@ -190,10 +190,10 @@ __global__ __launch_bounds__(256) void bwd_pair_argmax16_kernel(
     __syncthreads();                                   // everyone is done with the previous pair's blk
     if (threadIdx.x == 0) ncand = 0;
     // operand panels: rows [0,32) = the image's 32 main regions, rows [32,64) = 32 consecutive rows
-    // of the extra-region operand containing image i's row at offset eo; 64 caption-word rows
+    // of the extra-region operand containing image i's rem rows at offset eo; 64 caption-word rows
     // starting at by (the caption's words sit at column offset co)
-    const int be = rem ? (i < xe_rows - 32 ? i : xe_rows - 32) : 0;
-    const int eo = i - be;
+    const int be = rem ? (i * rem < xe_rows - 32 ? i * rem : xe_rows - 32) : 0;     // image i's side rows: [i*rem, i*rem + rem)
+    const int eo = i * rem - be;
     const int64_t yrow = (int64_t)j * tpad;
     const int64_t by = yrow < (int64_t)y_rows - 64 ? yrow : (int64_t)y_rows - 64;
     const int co = (int)(yrow - by);
@@ -211,7 +211,7 @@ __global__ __launch_bounds__(256) void bwd_pair_argmax16_kernel(
         const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
         if (w >= 0 && w < blk_ld) {
           if (wm == 0) BLK(row, w) = acc[0][0][r];
-          else if (rem && row == eo) BLK(32, w) = acc[0][0][r];
+          else if (row >= eo && row < eo + rem) BLK(32 + row - eo, w) = acc[0][0][r];
         }
       }
     }

@@ -36,6 +36,21 @@ static int scores_strip_mult(int tp16, int mtiles) {
   return (env == 2 && mtiles <= 2 && tp16 <= 6) ? 2 : 1;       // tp16 in {1,2,3,4,6}: 24 / tp16 captions per 384-row tile
 }
 
+// Largest leftover handled as side rows (ALADIN_ALIGN_SIDE_MAX, default and maximum 8; 1 when the 32x32x16
+// kernels are forced by ALADIN_ALIGN_STRIP).  Measured at B=256, T=50, D=768 (forward incl. packing): R'=34
+// 0.183 vs 0.271 ms with a second region tile, R'=36 0.200 vs 0.273, R'=38 0.215 vs 0.277, R'=40 0.236 vs 0.276.
+static int scores_side_max() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("ALADIN_ALIGN_SIDE_MAX");
+    v = e ? atoi(e) : 8;
+    if (v < 1) v = 1;
+    if (v > 8) v = 8;
+    if (scores_strip_mult(3, 1) != 2) v = 1;
+  }
+  return v;
+}
+
 extern "C" int aladin_align_geometry(int Bi, int Bc, int R, int T, int D, aladin_align_geom* g) {
   return aladin_align_geometry_ex(Bi, Bc, R, T, D, 0, 2, g);       // images: drop region 0; captions: token 0 and the last two
 }
@@ -49,7 +64,11 @@ extern "C" int aladin_align_geometry_ex(int Bi, int Bc, int R, int T, int D, int
   g->x_tail = x_tail; g->y_tail = y_tail;
   g->Rq = R - 1 - x_tail; g->Tq = T - 1 - y_tail;
   if (g->Rq > 96 || g->Tq > 96) { aladin_set_error("align_geometry: at most 97 regions / 99 tokens supported (got R=%d T=%d)", R, T); return ALADIN_ERR_UNSUPPORTED; }
-  if (g->Rq > 32 && g->Rq % 32 == 1 && g->Rq < 96) { g->mtiles = g->Rq / 32; g->rem = 1; }
+  // R' = 32*mtiles + rem: `rem` leftover regions per image go through the side GEMM instead of opening
+  // another 32-row MFMA tile.  33..32+SIDE_MAX regions: one tile + rem side rows (the 16x16x32 kernel's
+  // epilogue takes any rem; the older 32x32x16 kernels only rem == 1); 65: two tiles + one side row.
+  if (g->Rq > 32 && g->Rq <= 32 + scores_side_max()) { g->mtiles = 1; g->rem = g->Rq - 32; }
+  else if (g->Rq > 64 && g->Rq % 32 == 1 && g->Rq < 96) { g->mtiles = g->Rq / 32; g->rem = 1; }
   else { g->mtiles = cdiv(g->Rq, 32); g->rem = 0; }
   g->tp16 = cdiv(g->Tq, 16);
   if (g->tp16 == 5) g->tp16 = 6;
@@ -60,7 +79,7 @@ extern "C" int aladin_align_geometry_ex(int Bi, int Bc, int R, int T, int D, int
   g->Bi_pad = round_up(Bi, g->img_unit);
   g->Bc_pad = round_up(Bc, g->cap_unit);
   g->xm_rows = (int64_t)g->Bi_pad * 32 * g->mtiles;
-  g->xe_rows = g->rem ? round_up(g->Bi_pad, 64) : 0;
+  g->xe_rows = g->rem ? round_up(g->Bi_pad * g->rem, 64) : 0;      // image i: rows [i*rem, i*rem + rem)
   g->y_rows = (int64_t)g->Bc_pad * 16 * g->tp16;
   g->xm_bytes = g->xm_rows * g->Dp * 2;
   g->xe_bytes = g->xe_rows * g->Dp * 2;
@@ -121,8 +140,8 @@ __global__ __launch_bounds__(256) void pack_images_kernel(const float* __restric
     if (rho >= Rq) rho = 0;                       // tile-filling copy of the first region
     dst = xm + d * Dp;
   } else {
-    i = (int)(d - xm_rows);
-    rho = 32 * mtiles;                            // the leftover (last) region
+    i = (int)((d - xm_rows) / rem);
+    rho = 32 * mtiles + (int)((d - xm_rows) % rem);   // the leftover region(s)
     dst = xe + (d - xm_rows) * Dp;
   }
   const float* src = nullptr;
@@ -155,7 +174,7 @@ __global__ __launch_bounds__(256) void pack_captions_kernel(const float* __restr
 __global__ __launch_bounds__(256) void pack_both_kernel(const float* __restrict__ im, int64_t isb, int64_t isr,
                                                         const int32_t* __restrict__ im_len, const float* __restrict__ s,
                                                         int64_t ssb, int64_t sst, const int32_t* __restrict__ s_len, int Bi,
-                                                        int Bc, int Rq, int Tq, int x_tail, int y_tail, int D, int Dp, int mtiles, int64_t xm_rows,
+                                                        int Bc, int Rq, int Tq, int x_tail, int y_tail, int D, int Dp, int mtiles, int rem, int64_t xm_rows,
                                                         int64_t img_rows, int64_t total_rows, int tpad,
                                                         half_t* __restrict__ xm, half_t* __restrict__ xe,
                                                         half_t* __restrict__ y, int vec_i, int vec_s) {
@@ -174,8 +193,8 @@ __global__ __launch_bounds__(256) void pack_both_kernel(const float* __restrict_
       if (rho >= Rq) rho = 0;
       dst = xm + d * Dp;
     } else {
-      i = (int)(d - xm_rows);
-      rho = 32 * mtiles;
+      i = (int)((d - xm_rows) / rem);
+      rho = 32 * mtiles + (int)((d - xm_rows) % rem);
       dst = xe + (d - xm_rows) * Dp;
     }
     if (i < Bi) {
@@ -208,7 +227,7 @@ extern "C" int aladin_align_pack_images(const float* im, int64_t stride_b, int64
   const int64_t total = g->xm_rows + g->xe_rows;
   const unsigned grid = (unsigned)((total + 3) / 4);
   hipLaunchKernelGGL(pack_images_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, im, stride_b, stride_r, im_len,
-                     g->Bi, g->Rq, g->x_tail, g->D, g->Dp, g->mtiles, g->rem, g->xm_rows, total, (half_t*)xm, (half_t*)xe,
+                     g->Bi, g->Rq, g->x_tail, g->D, g->Dp, g->mtiles, g->rem > 0 ? g->rem : 1, g->xm_rows, total, (half_t*)xm, (half_t*)xe,
                      is_vec4_ok(im, stride_b, stride_r, g->D));
   return aladin_check_launch("pack_images_kernel");
 }
@@ -230,7 +249,7 @@ extern "C" int aladin_align_pack_both(const float* im, int64_t im_stride_b, int6
   const int64_t img_rows = g->xm_rows + g->xe_rows, total = img_rows + g->y_rows;
   hipLaunchKernelGGL(pack_both_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, (hipStream_t)stream, im, im_stride_b,
                      im_stride_r, im_len, s, s_stride_b, s_stride_t, s_len, g->Bi, g->Bc, g->Rq, g->Tq, g->x_tail, g->y_tail, g->D, g->Dp, g->mtiles,
-                     g->xm_rows, img_rows, total, 16 * g->tp16, (half_t*)xm, (half_t*)xe, (half_t*)y,
+                     g->rem > 0 ? g->rem : 1, g->xm_rows, img_rows, total, 16 * g->tp16, (half_t*)xm, (half_t*)xe, (half_t*)y,
                      is_vec4_ok(im, im_stride_b, im_stride_r, g->D), is_vec4_ok(s, s_stride_b, s_stride_t, g->D));
   return aladin_check_launch("pack_both_kernel");
 }
@@ -410,9 +429,9 @@ static int scores_wgm() {
 //                      images into the two half-waves, one 16-lane exchange finishes the 32 rows
 //   sum over words   : a caption is exactly TP16 column tiles -> in-lane adds, then a 16-lane reduction
 // ------------------------------------------------------------------------------------------------
-template <bool HAS_E, int TP16, int Q>
+template <bool HAS_E, int TP16, int Q, int REMC>
 __device__ __forceinline__ void scores16_epilogue(f32x4 (&acc)[4][12], int mb, int nb, const float* __restrict__ E,
-                                                  int64_t ldE, float* __restrict__ S, int64_t ldS, int Bi, int Bc) {
+                                                  int64_t ldE, int rem, float* __restrict__ S, int64_t ldS, int Bi, int Bc) {
   using Cfg = GemmCfg<4, 2, 2, 6>;
   constexpr int CT = 12;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -422,7 +441,10 @@ __device__ __forceinline__ void scores16_epilogue(f32x4 (&acc)[4][12], int mb, i
   // Q == 1: the wave's 64 rows are two images (lanes 0-31 finish image 0, lanes 32-63 image 1);
   // Q == 2: they are ONE image (R' in 34..64, or 65 with the side row)
   const int img = (Q == 1) ? (mb * 4 + wm) * 2 + half : mb * 4 + wm;
-  const float* e = HAS_E ? E + (int64_t)img * ldE + (int64_t)nb * Cfg::BN + wn * 192 + l4 : nullptr;
+  // REMC == 1: exactly one side row per image, known at compile time (the headline class: a run-time trip
+  // count here costs the whole kernel ~10 %); REMC == 0: `rem` side rows, run-time loop
+  if constexpr (REMC == 1) rem = 1;
+  const float* e = HAS_E ? E + (int64_t)img * rem * ldE + (int64_t)nb * Cfg::BN + wn * 192 + l4 : nullptr;
   constexpr int NC = 12 / TP16;                                    // captions of the wave's 192-row strip
   static_assert(12 % TP16 == 0, "a caption must be a whole number of 16-word column tiles of the strip");
   float v[NC];
@@ -445,7 +467,12 @@ __device__ __forceinline__ void scores16_epilogue(f32x4 (&acc)[4][12], int mb, i
       m = fmaxf(m, __shfl_xor(m, 16, 64));
       m = fmaxf(m, __shfl_xor(m, 32, 64));
     }
-    if constexpr (HAS_E) m = fmaxf(m, e[ct * 16]);
+    if constexpr (HAS_E && REMC == 1) m = fmaxf(m, e[ct * 16]);
+    if constexpr (HAS_E && REMC != 1) {
+      // branch-free: max is idempotent, so rows past the last side row re-read it (k clamped to rem - 1)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) m = fmaxf(m, e[(int64_t)(k < rem ? k : rem - 1) * ldE + ct * 16]);
+    }
     v[ct / TP16] += m;
   }
   const int cap = (nb * 2 + wn) * NC;
@@ -458,11 +485,11 @@ __device__ __forceinline__ void scores16_epilogue(f32x4 (&acc)[4][12], int mb, i
   }
 }
 
-template <bool HAS_E, int TP16 = 3, bool PROBE = false, int Q = 1>
+template <bool HAS_E, int TP16 = 3, bool PROBE = false, int Q = 1, int REMC = 1>
 __global__ __launch_bounds__(512) void align_scores16_kernel(const half_t* __restrict__ xm, const half_t* __restrict__ y,
                                                              const float* __restrict__ E, int64_t ldE,
                                                              float* __restrict__ S, int64_t ldS, int Bi, int Bc,
-                                                             int64_t ldk, int ktiles, int n_nblk, int n_blocks) {
+                                                             int64_t ldk, int ktiles, int n_nblk, int n_blocks, int rem) {
   using Cfg = GemmCfg<4, 2, 2, 6>;
   constexpr int RT = 4, CT = 12;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -480,7 +507,7 @@ __global__ __launch_bounds__(512) void align_scores16_kernel(const half_t* __res
   gemm_mainloop16<Cfg, true>(xm + (int64_t)mb * Cfg::BM * ldk, y + (int64_t)nb * Cfg::BN * ldk, ldk, ktiles, smem, acc);
   if constexpr (PROBE) { pt1 = __builtin_amdgcn_s_memtime(); pr1 = __builtin_amdgcn_s_memrealtime(); }
 
-  scores16_epilogue<HAS_E, TP16, Q>(acc, mb, nb, E, ldE, S, ldS, Bi, Bc);
+  scores16_epilogue<HAS_E, TP16, Q, REMC>(acc, mb, nb, E, ldE, rem, S, ldS, Bi, Bc);
   if constexpr (PROBE) {
     __syncthreads();
     if (threadIdx.x == 0 && blockIdx.x < 4096) {
@@ -493,7 +520,7 @@ __global__ __launch_bounds__(512) void align_scores16_kernel(const half_t* __res
   }
 }
 
-template <bool HAS_E, int TP16 = 3, bool PROBE = false, int Q = 1>
+template <bool HAS_E, int TP16 = 3, bool PROBE = false, int Q = 1, int REMC = 1>
 static int launch_scores16(const aladin_align_geom* g, const half_t* xm, const half_t* y, const float* E, float* S,
                            int64_t ldS, hipStream_t stream) {
   using Cfg = GemmCfg<4, 2, 2, 6>;
@@ -502,12 +529,12 @@ static int launch_scores16(const aladin_align_geom* g, const half_t* xm, const h
     aladin_set_error("align_scores16: packed rows do not tile");
     return ALADIN_ERR_ARG;
   }
-  auto kern = align_scores16_kernel<HAS_E, TP16, PROBE, Q>;
+  auto kern = align_scores16_kernel<HAS_E, TP16, PROBE, Q, REMC>;
   static unsigned long long lds_reserved = 0;
   if (int rc = aladin_reserve_lds((const void*)kern, Cfg::LDS_BYTES, &lds_reserved, "align_scores16")) return rc;
   const int n_blocks = n_mblk * n_nblk;
   hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(Cfg::THREADS), Cfg::LDS_BYTES, stream, xm, y, E, g->y_rows, S, ldS, g->Bi,
-                     g->Bc, (int64_t)g->Dp, g->Dp / 64, n_nblk, n_blocks);
+                     g->Bc, (int64_t)g->Dp, g->Dp / 64, n_nblk, n_blocks, g->rem);
   return aladin_check_launch("align_scores16_kernel");
 }
 
@@ -547,7 +574,9 @@ static int launch_scores(const aladin_align_geom* g, const half_t* xm, const hal
         if (scores_spread() == 7) return launch_scores_w<4, WM, Q, TP16, HAS_E, 2, 7>(g, xm, y, E, S, ldS, stream);   // no refill
         if (scores_spread() == 9) return launch_scores_w<4, WM, Q, TP16, HAS_E, 2, 9>(g, xm, y, E, S, ldS, stream);   // no MFMA
       }
-      return launch_scores16<HAS_E, TP16, false, Q>(g, xm, y, E, S, ldS, stream);
+      if constexpr (HAS_E && Q == 1)
+        if (g->rem > 1) return launch_scores16<HAS_E, TP16, false, Q, 0>(g, xm, y, E, S, ldS, stream);   // several side rows
+      return launch_scores16<HAS_E, TP16, false, Q, 1>(g, xm, y, E, S, ldS, stream);
     }
   if (scores_wgm() == 4) return launch_scores_w<4, WM, Q, TP16, HAS_E, 1>(g, xm, y, E, S, ldS, stream);
   return launch_scores_w<2, WM, Q, TP16, HAS_E, 1>(g, xm, y, E, S, ldS, stream);
@@ -568,9 +597,12 @@ static int launch_side_w(const aladin_align_geom* g, const half_t* xe, const hal
 
 template <int NT>
 static int launch_side(const aladin_align_geom* g, const half_t* xe, const half_t* y, float* E, hipStream_t stream) {
-  static int big = -1;
-  if (big < 0) { const char* e = getenv("ALADIN_SIDE_BIG"); big = e ? atoi(e) : 0; }
-  // 128-row tiles halve the LDS-DMA traffic of this fill-bound kernel when there are enough images
+  static int forced = -2;
+  if (forced == -2) { const char* e = getenv("ALADIN_SIDE_BIG"); forced = e ? atoi(e) : -1; }
+  // 128-row tiles halve the LDS-DMA traffic of this fill-bound kernel; they pay once there are enough rows
+  // for the grid to stay full: from two side rows per image on (measured at B=256: rem=1 0.187 vs 0.191 ms
+  // forward, rem=2 0.209 vs 0.205, rem=6 0.287 vs 0.275).  ALADIN_SIDE_BIG=0/1 forces the choice.
+  const bool big = forced >= 0 ? forced != 0 : g->rem >= 2;
   if (big && g->xe_rows % 128 == 0 && g->xe_rows >= 256) return launch_side_w<NT, 2>(g, xe, y, E, stream);
   return launch_side_w<NT, 1>(g, xe, y, E, stream);
 }

@@ -12,6 +12,7 @@ import torch
 
 from conftest import ALIGN_GOLDENS, SQUARE_ALIGN_GOLDENS, golden_alignment_inputs, load_golden
 import alad_oracle as O
+import faithful_torch as FT
 
 pytestmark = pytest.mark.gpu
 
@@ -761,6 +762,44 @@ def test_alignment_scores_shape_sweep(shape):
     # tiny D (8..40): few, large vector components, so the fp16 operand rounding (2^-11 relative per
     # component) is not averaged down as at D=768; still within 1e-3 of the score magnitude
     assert_scores_close(S, ref, rtol=1e-3, atol_rel=1e-3, scale='max')
+
+
+@pytest.mark.parametrize('R', [35, 36, 37, 38, 39, 40, 41, 66])
+def test_leftover_regions_as_side_rows(R):
+    """R' = 32 + rem (rem = 2..6 side rows per image through the side GEMM), R' = 39 / 40 (second region tile) and
+    R' = 65 (two tiles + one side row): scores vs the oracle, gradients vs the fp32 restatement, ragged lengths
+    that put the longest image exactly at R'."""
+    from aladin_amd import ops, synth
+    Bi, Bc, Tn, D = 24, 18, 40, 256
+    im, s, il, sl = synth.alignment_batch(Bi, R, Tn, D, seed=4000 + R, ragged=True, Bc=Bc)
+    il[0], il[1], il[2] = R, R - 1, 33                     # full length, one short of it, exactly the main tile
+    a, b = T(im).requires_grad_(True), T(s).requires_grad_(True)
+    S = ops.alignment_scores(a, b, il, sl)
+    assert_scores_close(S.detach().cpu().numpy(), O.alignment_scores(im, s, il, sl), scale='max')
+    w = np.random.default_rng(R).standard_normal((Bi, Bc)).astype(np.float32)
+    w *= np.random.default_rng(R + 1).random((Bi, Bc)) < 0.25
+    (S * T(w)).sum().backward()
+    ra, rb = torch.from_numpy(im).double().requires_grad_(True), torch.from_numpy(s).double().requires_grad_(True)
+    (FT.alignment_scores_faithful(ra, rb, il, sl) * torch.from_numpy(w).double()).sum().backward()
+    for got, want in ((a.grad, ra.grad), (b.grad, rb.grad)):
+        want = want.numpy()
+        scale = max(1e-9, float(np.abs(want).max()))
+        np.testing.assert_allclose(got.cpu().numpy(), want, rtol=1e-3, atol=5e-5 * scale)
+    # and through the fused triplet node (packed backward with the pair list)
+    if Bi == Bc:
+        return
+    n = min(Bi, Bc)
+    a2, b2 = T(im[:n]).requires_grad_(True), T(s[:n]).requires_grad_(True)
+    loss, S2 = ops.alignment_triplet_loss(a2, b2, il[:n], sl[:n], 0.2, True)
+    loss.backward()
+    ref_loss, dS = O.hinge_loss(S2.cpu().numpy(), 0.2, True, return_grad=True)
+    np.testing.assert_allclose(loss.item(), ref_loss, rtol=1e-5)
+    ra, rb = torch.from_numpy(im[:n]).double().requires_grad_(True), torch.from_numpy(s[:n]).double().requires_grad_(True)
+    (FT.alignment_scores_faithful(ra, rb, il[:n], sl[:n]) * torch.from_numpy(dS).double()).sum().backward()
+    for got, want in ((a2.grad, ra.grad), (b2.grad, rb.grad)):
+        want = want.numpy()
+        scale = max(1e-9, float(np.abs(want).max()))
+        np.testing.assert_allclose(got.cpu().numpy(), want, rtol=1e-3, atol=5e-5 * scale)
 
 
 @pytest.mark.parametrize('shape', [(6, 6, 17, 9, 40), (5, 5, 34, 35, 96), (4, 4, 50, 50, 128), (3, 3, 71, 71, 64),
