@@ -35,6 +35,10 @@ def _require_gpu(*tensors):
                                'got a %s tensor (no CPU fallback exists)' % t.device)
         if t.dtype != torch.float32:
             raise TypeError('aladin_amd: float32 expected, got %s' % t.dtype)
+        if t.device.index is not None and t.device.index != torch.cuda.current_device():
+            # kernels are enqueued on the CURRENT device's current stream (one process per GPU)
+            raise RuntimeError('aladin_amd: tensor on %s but the current device is cuda:%d; call torch.cuda.set_device() '
+                               '(or use `with torch.cuda.device(...)`) first' % (t.device, torch.cuda.current_device()))
 
 
 def _rows_inner_contig(t):
