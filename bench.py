@@ -234,8 +234,12 @@ def main():
     if sharded:
         # RCCL prints a version banner through C stdio when the communicator comes up; on a pipe it would
         # surface at exit, AFTER the JSON line.  Push it out now so the JSON line is the last line of stdout.
+        # Every rank does it, and rank 0 prints only after all of them have (barrier).
         import ctypes
+        import torch.distributed as dist
+        sys.stdout.flush()
         ctypes.CDLL(None).fflush(None)
+        dist.barrier()
     if rank == 0:
         roof = kernel_roofline(im.detach(), s.detach(), il, sl)
         out = {
