@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'lib', 'libaladin_hip.so')
+# ALADIN_LIB points at an alternative build of the same ABI (kernel A/B runs, tools/ab_bench.py)
+LIB_PATH = os.environ.get('ALADIN_LIB') or os.path.join(_HERE, 'lib', 'libaladin_hip.so')
 
 ABI_VERSION = 3
 
