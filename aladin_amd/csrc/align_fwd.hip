@@ -494,7 +494,7 @@ __global__ __launch_bounds__(512) void align_scores16_kernel(const half_t* __res
   constexpr int RT = 4, CT = 12;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int mb, nb;
-  tile_coords(blockIdx.x, n_blocks / n_nblk, n_nblk, 4, mb, nb);
+  tile_coords(blockIdx.x, n_blocks / n_nblk, n_nblk, 8, mb, nb);     // 8 x 16 patch per XCD: 121.7 / 126.8 us vs 125.4 / 128.1 with 4 x 32 (two boxes)
 
   f32x4 acc[RT][CT];
 #pragma unroll
