@@ -245,18 +245,19 @@ __device__ __forceinline__ void gemm_mainloop16(const half_t* __restrict__ a_row
     // each A fragment dies early and its register takes the next step's fragment.
     static_assert(CT == 12, "three clusters of four column tiles");
     half8 a[RT], bA[4], bB[4];
+    // first MFMA of the step needs a[0] and bA[0]: ask for those two first (LDS returns in order)
+    bA[0] = lds_frag16(cur, b_row0, 0, lane);
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) a[rt] = lds_frag16(cur, a_row0 + rt * 16, 0, lane);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) bA[j] = lds_frag16(cur, b_row0 + j * 16, 0, lane);
+    for (int j = 1; j < 4; ++j) bA[j] = lds_frag16(cur, b_row0 + j * 16, 0, lane);
 #pragma unroll
     for (int k32 = 0; k32 < 2; ++k32) {
       // ---- cluster 0: column tiles 0..3 (bA); fetch 4..7 into bB
 #pragma unroll
       for (int j = 0; j < 4; ++j) bB[j] = lds_frag16(cur, b_row0 + (4 + j) * 16, k32, lane);
       if (SPREAD && refill) {
-        if (k32 == 0) gemm_stage<Cfg, 0, (CPW + 5) / 6>(a_rows, nullptr, Cfg::BM, b_rows, ldk, kt + 1, nxt, wave, lane_off);
-        else gemm_stage<Cfg, (3 * CPW + 5) / 6, (4 * CPW + 5) / 6>(a_rows, nullptr, Cfg::BM, b_rows, ldk, kt + 1, nxt, wave, lane_off);
+        if (k32 == 1) gemm_stage<Cfg, (6 * CPW) / 10, (8 * CPW) / 10>(a_rows, nullptr, Cfg::BM, b_rows, ldk, kt + 1, nxt, wave, lane_off);
       }
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_setprio(1);
@@ -271,8 +272,8 @@ __device__ __forceinline__ void gemm_mainloop16(const half_t* __restrict__ a_row
 #pragma unroll
       for (int j = 0; j < 4; ++j) bA[j] = lds_frag16(cur, b_row0 + (8 + j) * 16, k32, lane);
       if (SPREAD && refill) {
-        if (k32 == 0) gemm_stage<Cfg, (CPW + 5) / 6, (2 * CPW + 5) / 6>(a_rows, nullptr, Cfg::BM, b_rows, ldk, kt + 1, nxt, wave, lane_off);
-        else gemm_stage<Cfg, (4 * CPW + 5) / 6, (5 * CPW + 5) / 6>(a_rows, nullptr, Cfg::BM, b_rows, ldk, kt + 1, nxt, wave, lane_off);
+        if (k32 == 0) gemm_stage<Cfg, 0, (3 * CPW) / 10>(a_rows, nullptr, Cfg::BM, b_rows, ldk, kt + 1, nxt, wave, lane_off);
+        else gemm_stage<Cfg, (8 * CPW) / 10, CPW>(a_rows, nullptr, Cfg::BM, b_rows, ldk, kt + 1, nxt, wave, lane_off);
       }
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_setprio(1);
@@ -289,8 +290,7 @@ __device__ __forceinline__ void gemm_mainloop16(const half_t* __restrict__ a_row
         for (int j = 0; j < 4; ++j) bB[j] = lds_frag16(cur, b_row0 + j * 16, 1, lane);
       }
       if (SPREAD && refill) {
-        if (k32 == 0) gemm_stage<Cfg, (2 * CPW + 5) / 6, (3 * CPW + 5) / 6>(a_rows, nullptr, Cfg::BM, b_rows, ldk, kt + 1, nxt, wave, lane_off);
-        else gemm_stage<Cfg, (5 * CPW + 5) / 6, CPW>(a_rows, nullptr, Cfg::BM, b_rows, ldk, kt + 1, nxt, wave, lane_off);
+        if (k32 == 0) gemm_stage<Cfg, (3 * CPW) / 10, (6 * CPW) / 10>(a_rows, nullptr, Cfg::BM, b_rows, ldk, kt + 1, nxt, wave, lane_off);
       }
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_setprio(1);
