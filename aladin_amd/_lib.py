@@ -10,11 +10,12 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # ALADIN_LIB points at an alternative build of the same ABI (kernel A/B runs, tools/ab_bench.py)
 LIB_PATH = os.environ.get('ALADIN_LIB') or os.path.join(_HERE, 'lib', 'libaladin_hip.so')
 
-ABI_VERSION = 3
+ABI_VERSION = 4
+PRECISION_FP16, PRECISION_SPLIT = 0, 1      # ALADIN_PRECISION_* of include/aladin_hip.h
 
 # every symbol include/aladin_hip.h declares (tests check that the library exports all of them)
 SYMBOLS = [
-    'aladin_version', 'aladin_last_error', 'aladin_align_geometry', 'aladin_align_geometry_ex',
+    'aladin_version', 'aladin_last_error', 'aladin_align_geometry', 'aladin_align_geometry_ex', 'aladin_align_geometry_mode',
     'aladin_align_pack_images',
     'aladin_align_pack_captions', 'aladin_align_pack_both', 'aladin_align_scores', 'aladin_align_scores_ex',
     'aladin_align_bwd_workspace_bytes',
@@ -29,13 +30,14 @@ SYMBOLS = [
     'aladin_retrieval_workspace_bytes', 'aladin_retrieval_ranks',
     'aladin_scan_workspace_bytes', 'aladin_scan_fwd', 'aladin_scan_bwd',
     'aladin_store_row_width', 'aladin_store_append', 'aladin_align_pack_store_x', 'aladin_align_pack_store_y',
+    'aladin_store_row_width_mode', 'aladin_store_append_mode', 'aladin_topk',
 ]
 
 
 class AlignGeom(C.Structure):
     """struct aladin_align_geom."""
     _fields_ = [(n, C.c_int32) for n in ('Bi', 'Bc', 'R', 'T', 'D', 'Rq', 'Tq', 'mtiles', 'rem', 'tp16', 'Dp',
-                                         'img_unit', 'cap_unit', 'Bi_pad', 'Bc_pad', 'x_tail', 'y_tail', 'reserved_')] + \
+                                         'img_unit', 'cap_unit', 'Bi_pad', 'Bc_pad', 'x_tail', 'y_tail', 'split')] + \
                [(n, C.c_int64) for n in ('xm_rows', 'xe_rows', 'y_rows', 'xm_bytes', 'xe_bytes', 'y_bytes',
                                          'e_bytes')]
 
@@ -51,6 +53,7 @@ def _declare(lib):
         'aladin_last_error': (C.c_char_p, []),
         'aladin_align_geometry': (C.c_int, [i32, i32, i32, i32, i32, G]),
         'aladin_align_geometry_ex': (C.c_int, [i32, i32, i32, i32, i32, i32, i32, G]),
+        'aladin_align_geometry_mode': (C.c_int, [i32, i32, i32, i32, i32, i32, i32, i32, G]),
         'aladin_align_pack_images': (C.c_int, [p, i64, i64, p, G, p, p, p]),
         'aladin_align_pack_captions': (C.c_int, [p, i64, i64, p, G, p, p]),
         'aladin_align_pack_both': (C.c_int, [p, i64, i64, p, p, i64, i64, p, G, p, p, p, p]),
@@ -84,6 +87,9 @@ def _declare(lib):
         'aladin_scan_bwd': (C.c_int, [p, i64, i64, p, p, i64, i64, p, i32, i32, i32, i32, i32, p, i64, p, p, p, p, p]),
         'aladin_store_row_width': (C.c_int, [i32]),
         'aladin_store_append': (C.c_int, [p, i64, i64, p, i32, i32, i32, i32, p, p, p]),
+        'aladin_store_row_width_mode': (C.c_int, [i32, i32]),
+        'aladin_store_append_mode': (C.c_int, [p, i64, i64, p, i32, i32, i32, i32, p, p, i32, p]),
+        'aladin_topk': (C.c_int, [p, i64, i64, i32, i32, i32, p, p, p]),
         'aladin_align_pack_store_x': (C.c_int, [p, p, p, p, G, p, p, p]),
         'aladin_align_pack_store_y': (C.c_int, [p, p, p, p, G, p, p]),
         'aladin_recall_workspace_bytes': (sz, [i32]),

@@ -600,6 +600,7 @@ extern "C" int aladin_align_bwd_packed(const float* im, int64_t im_sb, int64_t i
                                        const aladin_align_geom* geom, const int32_t* pairs, const int32_t* pair_count,
                                        float* d_im, float* d_s, void* workspace, void* stream) {
   if (!geom) { aladin_set_error("align_bwd_packed: null geometry"); return ALADIN_ERR_ARG; }
+  if (geom->split) { aladin_set_error("align_bwd_packed: split-precision operands are forward-only (evaluation); pack with ALADIN_PRECISION_FP16"); return ALADIN_ERR_UNSUPPORTED; }
   return align_bwd_impl(im, im_sb, im_sr, im_len, s, s_sb, s_st, s_len, geom->Bi, geom->Bc, geom->R, geom->T, geom->D, dS,
                         ld_dS, gscale, xm, xe, y, geom, pairs, pair_count, d_im, d_s, workspace, stream, geom->x_tail,
                         geom->y_tail);

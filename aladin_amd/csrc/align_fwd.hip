@@ -30,9 +30,16 @@
 // ------------------------------------------------------------------------------------------------
 // Column-strip multiplier of the score kernel: 2 doubles the captions per wave (256 x 384 tile for
 // 48-word captions: 1.43x less LDS-DMA traffic per flop, half the barriers per MFMA).
+// Tuning knobs read from the environment exist ONLY in the diagnostic build (-DALADIN_DIAG ->
+// libaladin_hip_diag.so, used by tools/): the product library has no getenv and no alternative kernels.
+#ifdef ALADIN_DIAG
+static int diag_env(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+#else
+static constexpr int diag_env(const char*, int dflt) { return dflt; }
+#endif
+
 static int scores_strip_mult(int tp16, int mtiles) {
-  static int env = -1;
-  if (env < 0) { const char* e = getenv("ALADIN_ALIGN_STRIP"); env = e ? atoi(e) : 2; }
+  static const int env = diag_env("ALADIN_ALIGN_STRIP", 2);
   return (env == 2 && mtiles <= 2 && tp16 <= 6) ? 2 : 1;       // tp16 in {1,2,3,4,6}: 24 / tp16 captions per 384-row tile
 }
 
@@ -42,8 +49,7 @@ static int scores_strip_mult(int tp16, int mtiles) {
 static int scores_side_max() {
   static int v = -1;
   if (v < 0) {
-    const char* e = getenv("ALADIN_ALIGN_SIDE_MAX");
-    v = e ? atoi(e) : 8;
+    v = diag_env("ALADIN_ALIGN_SIDE_MAX", 8);
     if (v < 1) v = 1;
     if (v > 8) v = 8;
     if (scores_strip_mult(3, 1) != 2) v = 1;
@@ -56,12 +62,19 @@ extern "C" int aladin_align_geometry(int Bi, int Bc, int R, int T, int D, aladin
 }
 
 extern "C" int aladin_align_geometry_ex(int Bi, int Bc, int R, int T, int D, int x_tail, int y_tail, aladin_align_geom* g) {
+  return aladin_align_geometry_mode(Bi, Bc, R, T, D, x_tail, y_tail, ALADIN_PRECISION_FP16, g);
+}
+
+extern "C" int aladin_align_geometry_mode(int Bi, int Bc, int R, int T, int D, int x_tail, int y_tail, int precision,
+                                          aladin_align_geom* g) {
+  if (precision != ALADIN_PRECISION_FP16 && precision != ALADIN_PRECISION_SPLIT) { aladin_set_error("align_geometry: unknown precision %d", precision); return ALADIN_ERR_ARG; }
   if (!g || Bi < 1 || Bc < 1 || D < 1) { aladin_set_error("align_geometry: bad sizes Bi=%d Bc=%d D=%d", Bi, Bc, D); return ALADIN_ERR_ARG; }
   if (x_tail < 0 || y_tail < 0 || x_tail > 8 || y_tail > 8) { aladin_set_error("align_geometry: bad tails %d %d", x_tail, y_tail); return ALADIN_ERR_ARG; }
   if (R < 2 + x_tail || T < 2 + y_tail) { aladin_set_error("align_geometry: sets too short (R=%d T=%d): position 0 and the last %d / %d positions are dropped", R, T, x_tail, y_tail); return ALADIN_ERR_ARG; }
   memset(g, 0, sizeof(*g));
   g->Bi = Bi; g->Bc = Bc; g->R = R; g->T = T; g->D = D;
   g->x_tail = x_tail; g->y_tail = y_tail;
+  g->split = precision == ALADIN_PRECISION_SPLIT;
   g->Rq = R - 1 - x_tail; g->Tq = T - 1 - y_tail;
   if (g->Rq > 96 || g->Tq > 96) { aladin_set_error("align_geometry: at most 97 regions / 99 tokens supported (got R=%d T=%d)", R, T); return ALADIN_ERR_UNSUPPORTED; }
   // R' = 32*mtiles + rem: `rem` leftover regions per image go through the side GEMM instead of opening
@@ -72,7 +85,9 @@ extern "C" int aladin_align_geometry_ex(int Bi, int Bc, int R, int T, int D, int
   else { g->mtiles = cdiv(g->Rq, 32); g->rem = 0; }
   g->tp16 = cdiv(g->Tq, 16);
   if (g->tp16 == 5) g->tp16 = 6;
-  g->Dp = round_up(D, 64);
+  // split precision: every packed row is three K segments of round_up(D, 64) halfs -- [hi | lo | hi] on the max
+  // side, [hi | hi | lo] on the sum side -- so the unchanged main loops contract hi.hi + lo.hi + hi.lo
+  g->Dp = round_up(D, 64) * (g->split ? 3 : 1);
   const int imgs_per_wave = (g->mtiles == 1) ? 2 : 1;
   g->img_unit = 4 * imgs_per_wave;
   g->cap_unit = (scores_strip_mult(g->tp16, g->mtiles) == 2) ? 24 / g->tp16 : 2 * ((g->tp16 & 1) ? 2 : 1);
@@ -91,11 +106,19 @@ extern "C" int aladin_align_geometry_ex(int Bi, int Bc, int R, int T, int D, int
 // ------------------------------------------------------------------------------------------------
 // pack: one wave per destination row
 // ------------------------------------------------------------------------------------------------
+// seg: 0 = one fp16 rounding of the unit vector (Dp halfs per row);
+//      1 / 2 = split precision, max-side / sum-side row (3 * Dp0 halfs, Dp = Dp0): x^ * 2^14 = hi + lo, both fp16.
+//      The scale keeps lo out of the fp16 subnormals for every component above 2^-14 * 2^-3; what is lost
+//      below that is < 2^-39 absolute per component.  The scores come out scaled by 2^28 (a power of two:
+//      max and sum commute with it exactly) and are scaled back after the score kernel.
+#define ALADIN_SPLIT_SCALE 16384.0f
+#define ALADIN_SPLIT_UNSCALE (1.0f / (16384.0f * 16384.0f))
 __device__ __forceinline__ void pack_row(const float* __restrict__ src, half_t* __restrict__ dst, int D, int Dp,
-                                         int lane, bool vec4) {
+                                         int lane, bool vec4, int seg = 0) {
+  const int width = seg ? 3 * Dp : Dp;
   // src == nullptr -> zero row
   if (src == nullptr) {
-    for (int c = lane * 8; c < Dp; c += 64 * 8) *reinterpret_cast<half8*>(dst + c) = half8{0, 0, 0, 0, 0, 0, 0, 0};
+    for (int c = lane * 8; c < width; c += 64 * 8) *reinterpret_cast<half8*>(dst + c) = half8{0, 0, 0, 0, 0, 0, 0, 0};
     return;
   }
   float ss = 0.f;
@@ -109,6 +132,20 @@ __device__ __forceinline__ void pack_row(const float* __restrict__ src, half_t* 
   }
   ss = wave_sum(ss);
   const float inv = 1.0f / fmaxf(sqrtf(ss), 1e-12f);        // F.normalize eps (alad/loss.py:80-81)
+  if (seg) {
+    half_t* d_lo = dst + (seg == 1 ? Dp : 2 * Dp);          // [hi | lo | hi]  or  [hi | hi | lo]
+    half_t* d_hi2 = dst + (seg == 1 ? 2 * Dp : Dp);
+    for (int c = lane; c < Dp; c += 64) {
+      half_t hi = (half_t)0, lo = (half_t)0;
+      if (c < D) {
+        const float v = src[c] * inv * ALADIN_SPLIT_SCALE;
+        hi = (half_t)v;
+        lo = (half_t)(v - (float)hi);
+      }
+      dst[c] = hi; d_hi2[c] = hi; d_lo[c] = lo;
+    }
+    return;
+  }
   if (vec4) {
     for (int c = lane * 4; c < Dp; c += 256) {
       half4 h = {0, 0, 0, 0};
@@ -127,7 +164,7 @@ __global__ __launch_bounds__(256) void pack_images_kernel(const float* __restric
                                                           const int32_t* __restrict__ im_len, int Bi, int Rq, int x_tail, int D,
                                                           int Dp, int mtiles, int rem, int64_t xm_rows,
                                                           int64_t total_rows, half_t* __restrict__ xm,
-                                                          half_t* __restrict__ xe, int vec4) {
+                                                          half_t* __restrict__ xe, int vec4, int split) {
   const int lane = threadIdx.x & 63;
   const int64_t d = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (d >= total_rows) return;
@@ -150,13 +187,13 @@ __global__ __launch_bounds__(256) void pack_images_kernel(const float* __restric
     Li = Li < 0 ? 0 : (Li > Rq ? Rq : Li);
     if (rho < Li) src = im + i * sb + (int64_t)(rho + 1) * sr;     // region 0 dropped (alad/loss.py:87)
   }
-  pack_row(src, dst, D, Dp, lane, vec4 != 0);
+  pack_row(src, dst, D, split ? Dp / 3 : Dp, lane, vec4 != 0, split ? 1 : 0);
 }
 
 __global__ __launch_bounds__(256) void pack_captions_kernel(const float* __restrict__ s, int64_t sb, int64_t st,
                                                             const int32_t* __restrict__ s_len, int Bc, int Tq, int y_tail, int D,
                                                             int Dp, int tpad, int64_t total_rows,
-                                                            half_t* __restrict__ y, int vec4) {
+                                                            half_t* __restrict__ y, int vec4, int split) {
   const int lane = threadIdx.x & 63;
   const int64_t d = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (d >= total_rows) return;
@@ -167,7 +204,7 @@ __global__ __launch_bounds__(256) void pack_captions_kernel(const float* __restr
     Lj = Lj < 0 ? 0 : (Lj > Tq ? Tq : Lj);
     if (w < Lj) src = s + j * sb + (int64_t)(w + 1) * st;          // token 0 dropped (alad/loss.py:88)
   }
-  pack_row(src, y + d * Dp, D, Dp, lane, vec4 != 0);
+  pack_row(src, y + d * Dp, D, split ? Dp / 3 : Dp, lane, vec4 != 0, split ? 2 : 0);
 }
 
 // both operand sets in one launch (rows [0, img_rows) -> images, the rest -> captions)
@@ -177,14 +214,16 @@ __global__ __launch_bounds__(256) void pack_both_kernel(const float* __restrict_
                                                         int Bc, int Rq, int Tq, int x_tail, int y_tail, int D, int Dp, int mtiles, int rem, int64_t xm_rows,
                                                         int64_t img_rows, int64_t total_rows, int tpad,
                                                         half_t* __restrict__ xm, half_t* __restrict__ xe,
-                                                        half_t* __restrict__ y, int vec_i, int vec_s) {
+                                                        half_t* __restrict__ y, int vec_i, int vec_s, int split) {
   const int lane = threadIdx.x & 63;
   const int64_t d = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (d >= total_rows) return;
   const float* src = nullptr;
   half_t* dst;
   bool vec;
+  int seg = 0;
   if (d < img_rows) {
+    seg = split ? 1 : 0;
     int i, rho;
     if (d < xm_rows) {
       const int rows_per_img = 32 * mtiles;
@@ -213,8 +252,9 @@ __global__ __launch_bounds__(256) void pack_both_kernel(const float* __restrict_
     }
     dst = y + q * Dp;
     vec = vec_s != 0;
+    seg = split ? 2 : 0;
   }
-  pack_row(src, dst, D, Dp, lane, vec);
+  pack_row(src, dst, D, split ? Dp / 3 : Dp, lane, vec, seg);
 }
 
 static int is_vec4_ok(const void* p, int64_t s0, int64_t s1, int D) {
@@ -228,7 +268,7 @@ extern "C" int aladin_align_pack_images(const float* im, int64_t stride_b, int64
   const unsigned grid = (unsigned)((total + 3) / 4);
   hipLaunchKernelGGL(pack_images_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, im, stride_b, stride_r, im_len,
                      g->Bi, g->Rq, g->x_tail, g->D, g->Dp, g->mtiles, g->rem > 0 ? g->rem : 1, g->xm_rows, total, (half_t*)xm, (half_t*)xe,
-                     is_vec4_ok(im, stride_b, stride_r, g->D));
+                     is_vec4_ok(im, stride_b, stride_r, g->D), g->split);
   return aladin_check_launch("pack_images_kernel");
 }
 
@@ -238,7 +278,7 @@ extern "C" int aladin_align_pack_captions(const float* s, int64_t stride_b, int6
   const unsigned grid = (unsigned)((g->y_rows + 3) / 4);
   hipLaunchKernelGGL(pack_captions_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, s, stride_b, stride_t, s_len,
                      g->Bc, g->Tq, g->y_tail, g->D, g->Dp, 16 * g->tp16, g->y_rows, (half_t*)y,
-                     is_vec4_ok(s, stride_b, stride_t, g->D));
+                     is_vec4_ok(s, stride_b, stride_t, g->D), g->split);
   return aladin_check_launch("pack_captions_kernel");
 }
 
@@ -250,7 +290,7 @@ extern "C" int aladin_align_pack_both(const float* im, int64_t im_stride_b, int6
   hipLaunchKernelGGL(pack_both_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, (hipStream_t)stream, im, im_stride_b,
                      im_stride_r, im_len, s, s_stride_b, s_stride_t, s_len, g->Bi, g->Bc, g->Rq, g->Tq, g->x_tail, g->y_tail, g->D, g->Dp, g->mtiles,
                      g->rem > 0 ? g->rem : 1, g->xm_rows, img_rows, total, 16 * g->tp16, (half_t*)xm, (half_t*)xe, (half_t*)y,
-                     is_vec4_ok(im, im_stride_b, im_stride_r, g->D), is_vec4_ok(s, s_stride_b, s_stride_t, g->D));
+                     is_vec4_ok(im, im_stride_b, im_stride_r, g->D), is_vec4_ok(s, s_stride_b, s_stride_t, g->D), g->split);
   return aladin_check_launch("pack_both_kernel");
 }
 
@@ -286,22 +326,25 @@ __global__ __launch_bounds__(256) void align_side_gemm_kernel(const half_t* __re
         E[(row0 + m * 32 + (r & 3) + 8 * (r >> 2)) * ldE + col0 + n * 32] = acc[m][n][r];
 }
 
-// Diagnostic only (SCHED == 6 instantiation, never on the product path): per-workgroup shader-clock
-// and 100 MHz real-time deltas around the main loop -> in-kernel clock = d(memtime)/d(memrealtime) * 100 MHz.
+// Diagnostic build only (SCHED == 6 / PROBE instantiations): per-workgroup shader-clock and 100 MHz real-time
+// deltas around the main loop -> in-kernel clock = d(memtime)/d(memrealtime) * 100 MHz.
+#ifdef ALADIN_DIAG
 __device__ unsigned long long g_clock_probe[4 * 4096];
 __device__ unsigned long long g_clock_cycles[2048];
+#define ALADIN_DIAG_API extern "C" __attribute__((visibility("default")))
 
-extern "C" int aladin_debug_read_clock_cycles(unsigned long long* host_out, int n_blocks) {
+ALADIN_DIAG_API int aladin_debug_read_clock_cycles(unsigned long long* host_out, int n_blocks) {
   if (!host_out || n_blocks < 1 || n_blocks > 2048) { aladin_set_error("debug_read_clock_cycles: bad argument"); return ALADIN_ERR_ARG; }
   if (hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_clock_cycles), (size_t)n_blocks * 8) != hipSuccess) { aladin_set_error("debug_read_clock_cycles: copy failed"); return ALADIN_ERR_HIP; }
   return ALADIN_OK;
 }
 
-extern "C" int aladin_debug_read_clock_probe(unsigned long long* host_out, int n_blocks) {
+ALADIN_DIAG_API int aladin_debug_read_clock_probe(unsigned long long* host_out, int n_blocks) {
   if (!host_out || n_blocks < 1 || n_blocks > 4096) { aladin_set_error("debug_read_clock_probe: bad argument"); return ALADIN_ERR_ARG; }
   if (hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_clock_probe), (size_t)n_blocks * 32) != hipSuccess) { aladin_set_error("debug_read_clock_probe: copy failed"); return ALADIN_ERR_HIP; }
   return ALADIN_OK;
 }
+#endif  // ALADIN_DIAG
 
 // ------------------------------------------------------------------------------------------------
 // score kernel
@@ -335,12 +378,15 @@ __global__ __launch_bounds__(WGM * 128) void align_scores_kernel(const half_t* _
   const half_t* a_rows = xm + (int64_t)mb * Cfg::BM * ldk;
   const half_t* b_rows = y + (int64_t)nb * Cfg::BN * ldk;
   // SCHED: 0 = refill burst right after the barrier, 1 = refill spread over the four MFMA groups
+#ifdef ALADIN_DIAG
   if constexpr (SCHED == 6) {
     const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
     gemm_mainloop<Cfg, 2, true, 0, true>(a_rows, b_rows, ldk, ktiles, smem, acc);
     const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
     if (threadIdx.x == 0 && blockIdx.x < 4096) { g_clock_probe[4 * blockIdx.x] = t1 - t0; g_clock_probe[4 * blockIdx.x + 1] = r1 - r0; g_clock_probe[4 * blockIdx.x + 2] = r0; g_clock_probe[4 * blockIdx.x + 3] = r1; }
-  } else if constexpr (SCHED == 2) gemm_mainloop<Cfg, 2, true, 0, true>(a_rows, b_rows, ldk, ktiles, smem, acc);
+  } else
+#endif
+  if constexpr (SCHED == 2) gemm_mainloop<Cfg, 2, true, 0, true>(a_rows, b_rows, ldk, ktiles, smem, acc);
   else if constexpr (SCHED == 3) gemm_mainloop<Cfg, 2, true, 0, true, true>(a_rows, b_rows, ldk, ktiles, smem, acc);
   else if constexpr (SCHED == 7) gemm_mainloop<Cfg, 2, true, 1, true>(a_rows, b_rows, ldk, ktiles, smem, acc);
   else if constexpr (SCHED == 5) gemm_mainloop<Cfg, 2, true, 3, true, true>(a_rows, b_rows, ldk, ktiles, smem, acc);
@@ -402,21 +448,21 @@ __global__ __launch_bounds__(WGM * 128) void align_scores_kernel(const half_t* _
     if (l5 == 0 && (IPW >= 2 || half == 0) && img < Bi && cap + c < Bc) S[(int64_t)img * ldS + cap + c] = t;
   }
   }
+#ifdef ALADIN_DIAG
   if constexpr (SCHED == 6) {
     __syncthreads();
     if (threadIdx.x == 0 && blockIdx.x < 4096) g_clock_probe[4 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();   // overwrite slot 0 with the exit stamp
   }
+#endif
 }
 
 static int scores_spread() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("ALADIN_ALIGN_SPREAD"); v = e ? atoi(e) : 16; }
+  static const int v = diag_env("ALADIN_ALIGN_SPREAD", 16);
   return v;
 }
 
 static int scores_wgm() {
-  static int v = 0;
-  if (!v) { const char* e = getenv("ALADIN_ALIGN_WGM"); v = (e && atoi(e) == 2) ? 2 : 4; }
+  static const int v = diag_env("ALADIN_ALIGN_WGM", 4) == 2 ? 2 : 4;
   return v;
 }
 
@@ -508,6 +554,7 @@ __global__ __launch_bounds__(512) void align_scores16_kernel(const half_t* __res
   if constexpr (PROBE) { pt1 = __builtin_amdgcn_s_memtime(); pr1 = __builtin_amdgcn_s_memrealtime(); }
 
   scores16_epilogue<HAS_E, TP16, Q, REMC>(acc, mb, nb, E, ldE, rem, S, ldS, Bi, Bc);
+#ifdef ALADIN_DIAG
   if constexpr (PROBE) {
     __syncthreads();
     if (threadIdx.x == 0 && blockIdx.x < 4096) {
@@ -518,6 +565,9 @@ __global__ __launch_bounds__(512) void align_scores16_kernel(const half_t* __res
     }
     if (threadIdx.x == 64 && blockIdx.x < 2048) g_clock_cycles[blockIdx.x] = pt1 - pt0;
   }
+#else
+  (void)pt0; (void)pr0; (void)pt1; (void)pr1;
+#endif
 }
 
 template <bool HAS_E, int TP16 = 3, bool PROBE = false, int Q = 1, int REMC = 1>
@@ -566,6 +616,7 @@ static int launch_scores(const aladin_align_geom* g, const half_t* xm, const hal
       // ALADIN_ALIGN_SPREAD: 16 (default) = v_mfma_f32_16x16x32_f16 body; 26 = the same + clock probe
       // (diagnostic); 3 / 6 = the earlier 32x32x16 body and its clock probe, 7 / 9 = its ablations
       // (headline class only)
+#ifdef ALADIN_DIAG
       if constexpr (TP16 == 3 && Q == 1) {
         if (scores_spread() == 26) return launch_scores16<HAS_E, 3, true>(g, xm, y, E, S, ldS, stream);
         if (scores_spread() == 3) return launch_scores_w<4, WM, Q, TP16, HAS_E, 2, 3>(g, xm, y, E, S, ldS, stream);
@@ -574,12 +625,15 @@ static int launch_scores(const aladin_align_geom* g, const half_t* xm, const hal
         if (scores_spread() == 7) return launch_scores_w<4, WM, Q, TP16, HAS_E, 2, 7>(g, xm, y, E, S, ldS, stream);   // no refill
         if (scores_spread() == 9) return launch_scores_w<4, WM, Q, TP16, HAS_E, 2, 9>(g, xm, y, E, S, ldS, stream);   // no MFMA
       }
+#endif
       if constexpr (HAS_E && Q == 1)
         if (g->rem > 1) return launch_scores16<HAS_E, TP16, false, Q, 0>(g, xm, y, E, S, ldS, stream);   // several side rows
       return launch_scores16<HAS_E, TP16, false, Q, 1>(g, xm, y, E, S, ldS, stream);
     }
-  if (scores_wgm() == 4) return launch_scores_w<4, WM, Q, TP16, HAS_E, 1>(g, xm, y, E, S, ldS, stream);
-  return launch_scores_w<2, WM, Q, TP16, HAS_E, 1>(g, xm, y, E, S, ldS, stream);
+#ifdef ALADIN_DIAG
+  if (scores_wgm() != 4) return launch_scores_w<2, WM, Q, TP16, HAS_E, 1>(g, xm, y, E, S, ldS, stream);
+#endif
+  return launch_scores_w<4, WM, Q, TP16, HAS_E, 1>(g, xm, y, E, S, ldS, stream);
 }
 
 template <int NT, int SWM>
@@ -597,8 +651,7 @@ static int launch_side_w(const aladin_align_geom* g, const half_t* xe, const hal
 
 template <int NT>
 static int launch_side(const aladin_align_geom* g, const half_t* xe, const half_t* y, float* E, hipStream_t stream) {
-  static int forced = -2;
-  if (forced == -2) { const char* e = getenv("ALADIN_SIDE_BIG"); forced = e ? atoi(e) : -1; }
+  static const int forced = diag_env("ALADIN_SIDE_BIG", -1);
   // 128-row tiles halve the LDS-DMA traffic of this fill-bound kernel; they pay once there are enough rows
   // for the grid to stay full: from two side rows per image on (measured at B=256: rem=1 0.187 vs 0.191 ms
   // forward, rem=2 0.209 vs 0.205, rem=6 0.287 vs 0.275).  ALADIN_SIDE_BIG=0/1 forces the choice.
@@ -627,6 +680,13 @@ static int dispatch_tp(const aladin_align_geom* g, const half_t* xm, const half_
   return ALADIN_ERR_UNSUPPORTED;
 }
 
+// split precision: the operands carry 2^14 each, so S comes out times 2^28 -- scale back (exact)
+__global__ __launch_bounds__(256) void scores_unscale_kernel(float* __restrict__ S, int64_t ldS, int Bi, int Bc) {
+  const int64_t n = (int64_t)Bi * Bc;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x)
+    S[(e / Bc) * ldS + (e % Bc)] *= ALADIN_SPLIT_UNSCALE;
+}
+
 extern "C" int aladin_align_scores(const void* xm, const void* xe, const void* y, const aladin_align_geom* g,
                                    void* e_scratch, float* S, int64_t ldS, void* stream) {
   return aladin_align_scores_ex(xm, xe, y, g, e_scratch, S, ldS, 0, stream);
@@ -639,13 +699,20 @@ extern "C" int aladin_align_scores_ex(const void* xm, const void* xe, const void
   hipStream_t st = (hipStream_t)stream;
   const half_t* a = (const half_t*)xm; const half_t* b = (const half_t*)xe; const half_t* c = (const half_t*)y;
   float* E = (float*)e_scratch;
+  int rc;
   switch (g->tp16) {
-    case 1: return dispatch_tp<1>(g, a, b, c, E, S, ldS, flags, st);
-    case 2: return dispatch_tp<2>(g, a, b, c, E, S, ldS, flags, st);
-    case 3: return dispatch_tp<3>(g, a, b, c, E, S, ldS, flags, st);
-    case 4: return dispatch_tp<4>(g, a, b, c, E, S, ldS, flags, st);
-    case 6: return dispatch_tp<6>(g, a, b, c, E, S, ldS, flags, st);
+    case 1: rc = dispatch_tp<1>(g, a, b, c, E, S, ldS, flags, st); break;
+    case 2: rc = dispatch_tp<2>(g, a, b, c, E, S, ldS, flags, st); break;
+    case 3: rc = dispatch_tp<3>(g, a, b, c, E, S, ldS, flags, st); break;
+    case 4: rc = dispatch_tp<4>(g, a, b, c, E, S, ldS, flags, st); break;
+    case 6: rc = dispatch_tp<6>(g, a, b, c, E, S, ldS, flags, st); break;
+    default:
+      aladin_set_error("align_scores: unsupported padded caption length %d", 16 * g->tp16);
+      return ALADIN_ERR_UNSUPPORTED;
   }
-  aladin_set_error("align_scores: unsupported padded caption length %d", 16 * g->tp16);
-  return ALADIN_ERR_UNSUPPORTED;
+  if (rc || !g->split) return rc;
+  const int64_t n = (int64_t)g->Bi * g->Bc;
+  int grid = (int)((n + 255) / 256); if (grid > 2048) grid = 2048;
+  hipLaunchKernelGGL(scores_unscale_kernel, dim3(grid), dim3(256), 0, st, S, ldS, g->Bi, g->Bc);
+  return aladin_check_launch("scores_unscale_kernel");
 }

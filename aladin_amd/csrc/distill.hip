@@ -7,6 +7,7 @@
 // All of it is (B, B) element work far below any roofline (B = 256: 256 KiB per matrix): the kernels
 // are written for determinism (fixed reduction orders, no float atomics) and few launches.
 #include "common.hpp"
+#include "../../include/aladin_hip.h"
 
 namespace {
 

@@ -543,3 +543,75 @@ extern "C" int aladin_retrieval_ranks(const float* img, int64_t img_rs, const fl
                      top1_i2t, top1_t2i);
   return aladin_check_launch("retrieval_finish_kernel");
 }
+
+// ------------------------------------------------------------------------------------------------
+// Top-k lists (the `top50` table of t2i, reference alad/evaluation.py:262,309: inds[i][0:50] of the
+// descending argsort of every query's score row).  One workgroup per query: its n_c scores are staged in
+// LDS, every thread keeps the best of the elements it owns, and k rounds of a workgroup-wide arg-max
+// (larger score first, lower index on ties) each retire one element.  Reads are strided
+// (M[q * q_stride + c * c_stride]) so that the columns of a row-major (n_img x n_cap) matrix serve as
+// queries without a transpose; workgroup ids are XCD-compact, so the queries that share cache lines of
+// such a column sweep run on the same L2.
+// ------------------------------------------------------------------------------------------------
+#define TOPK_MAX_CAND 36864          // 144 KiB of LDS
+__global__ __launch_bounds__(256) void topk_kernel(const float* __restrict__ M, int64_t q_stride, int64_t c_stride, int n_q,
+                                                   int n_c, int k, int32_t* __restrict__ out_idx, float* __restrict__ out_val) {
+  extern __shared__ __attribute__((aligned(16))) char topk_smem[];
+  float* val = reinterpret_cast<float*>(topk_smem);
+  __shared__ float redv[4];
+  __shared__ int redi[4];
+  const int q = xcd_remap(blockIdx.x, n_q);
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const float* row = M + (int64_t)q * q_stride;
+  float best = -INFINITY;
+  int besti = 0x7fffffff;
+  for (int c = tid; c < n_c; c += 256) {
+    float v = row[(int64_t)c * c_stride];
+    if (!(v == v)) v = -INFINITY;                        // NaN sorts last
+    val[c] = v;
+    if (besti == 0x7fffffff || v > best) { best = v; besti = c; }     // ascending c: the first maximum is the lowest index
+  }
+  __syncthreads();
+  for (int r = 0; r < k; ++r) {
+    float bv = best;
+    int bi = besti;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(bv, o, 64);
+      const int oi = __shfl_xor(bi, o, 64);
+      if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    if (lane == 0) { redv[wave] = bv; redi[wave] = bi; }
+    __syncthreads();
+    bv = redv[0]; bi = redi[0];
+#pragma unroll
+    for (int w = 1; w < 4; ++w)
+      if (redv[w] > bv || (redv[w] == bv && redi[w] < bi)) { bv = redv[w]; bi = redi[w]; }
+    const bool live = r < n_c && bi != 0x7fffffff;
+    if (tid == 0) {
+      out_idx[(int64_t)q * k + r] = live ? bi : -1;
+      if (out_val) out_val[(int64_t)q * k + r] = live ? bv : -INFINITY;
+    }
+    if (live && (bi & 255) == tid) {                     // the owner retires the winner and rescans its elements
+      val[bi] = __builtin_nanf("");                      // retired (live scores are never NaN: mapped to -inf on load)
+      best = -INFINITY;
+      besti = 0x7fffffff;
+      for (int c = tid; c < n_c; c += 256) {
+        const float v = val[c];
+        if (v == v && (besti == 0x7fffffff || v > best)) { best = v; besti = c; }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+extern "C" int aladin_topk(const float* M, int64_t q_stride, int64_t c_stride, int n_q, int n_c, int k, int32_t* out_idx,
+                           float* out_val, void* stream) {
+  if (!M || !out_idx || n_q < 1 || n_c < 1 || k < 1) { aladin_set_error("topk: bad argument (n_q=%d n_c=%d k=%d)", n_q, n_c, k); return ALADIN_ERR_ARG; }
+  if (n_c > TOPK_MAX_CAND) { aladin_set_error("topk: at most %d candidates per query (got %d)", TOPK_MAX_CAND, n_c); return ALADIN_ERR_UNSUPPORTED; }
+  const int lds = n_c * 4;
+  static unsigned long long lds_reserved = 0;
+  if (int rc = aladin_reserve_lds((const void*)topk_kernel, TOPK_MAX_CAND * 4, &lds_reserved, "topk")) return rc;
+  hipLaunchKernelGGL(topk_kernel, dim3(n_q), dim3(256), lds, (hipStream_t)stream, M, q_stride, c_stride, n_q, n_c, k, out_idx, out_val);
+  return aladin_check_launch("topk_kernel");
+}

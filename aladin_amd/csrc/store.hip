@@ -17,7 +17,7 @@ namespace {
 __global__ __launch_bounds__(256) void store_append_kernel(const float* __restrict__ src, int64_t sb, int64_t sr,
                                                            const int32_t* __restrict__ lens, int B, int L, int D, int Dp,
                                                            int tail, const int64_t* __restrict__ offsets,
-                                                           half_t* __restrict__ rows, int vec4) {
+                                                           half_t* __restrict__ rows, int vec4, int split) {
   const int lane = threadIdx.x & 63;
   const int64_t d = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);        // (sample, position) over B x (L - 1)
   if (d >= (int64_t)B * (L - 1)) return;
@@ -26,7 +26,7 @@ __global__ __launch_bounds__(256) void store_append_kernel(const float* __restri
   cnt = cnt < 0 ? 0 : (cnt > L - 1 ? L - 1 : cnt);
   if (p >= cnt) return;
   const float* x = src + k * sb + (int64_t)(p + 1) * sr;
-  half_t* dst = rows + (offsets[k] + p) * Dp;
+  half_t* dst = rows + (offsets[k] + p) * (split ? 2 * Dp : Dp);
   float ss = 0.f;
   if (vec4) {
     for (int c = lane * 4; c < D; c += 256) {
@@ -38,6 +38,18 @@ __global__ __launch_bounds__(256) void store_append_kernel(const float* __restri
   }
   ss = wave_sum(ss);
   const float inv = 1.0f / fmaxf(sqrtf(ss), 1e-12f);                     // same arithmetic as pack_row (align_fwd.hip)
+  if (split) {                                                           // [hi | lo] of x^ * 2^14, as pack_row's split branch
+    for (int c = lane; c < Dp; c += 64) {
+      half_t hi = (half_t)0, lo = (half_t)0;
+      if (c < D) {
+        const float v = x[c] * inv * 16384.0f;
+        hi = (half_t)v;
+        lo = (half_t)(v - (float)hi);
+      }
+      dst[c] = hi; dst[Dp + c] = lo;
+    }
+    return;
+  }
   if (vec4) {
     for (int c = lane * 4; c < Dp; c += 256) {
       half4 h = {0, 0, 0, 0};
@@ -60,12 +72,23 @@ __device__ __forceinline__ void copy_row(const half_t* __restrict__ src, half_t*
   }
 }
 
+// split rows: store [hi | lo] (2 * Dp0) -> operand [hi | lo | hi] (seg 1, max side) or [hi | hi | lo] (seg 2, sum side)
+__device__ __forceinline__ void copy_row_split(const half_t* __restrict__ src, half_t* __restrict__ dst, int Dp0, int lane, int seg) {
+  for (int c = lane * 8; c < Dp0; c += 512) {
+    half8 hi = half8{0, 0, 0, 0, 0, 0, 0, 0}, lo = hi;
+    if (src != nullptr) { hi = *reinterpret_cast<const half8*>(src + c); lo = *reinterpret_cast<const half8*>(src + Dp0 + c); }
+    *reinterpret_cast<half8*>(dst + c) = hi;
+    *reinterpret_cast<half8*>(dst + Dp0 + c) = seg == 1 ? lo : hi;
+    *reinterpret_cast<half8*>(dst + 2 * Dp0 + c) = seg == 1 ? hi : lo;
+  }
+}
+
 // max-side operand (xm / xe) from a store: same row map as pack_images_kernel
 __global__ __launch_bounds__(256) void store_pack_x_kernel(const half_t* __restrict__ rows, const int64_t* __restrict__ offsets,
                                                            const int32_t* __restrict__ counts,
                                                            const int32_t* __restrict__ ids, int Bi, int Rq, int Dp, int mtiles, int rem,
                                                            int64_t xm_rows, int64_t total_rows, half_t* __restrict__ xm,
-                                                           half_t* __restrict__ xe) {
+                                                           half_t* __restrict__ xe, int split) {
   const int lane = threadIdx.x & 63;
   const int64_t d = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (d >= total_rows) return;
@@ -87,16 +110,17 @@ __global__ __launch_bounds__(256) void store_pack_x_kernel(const half_t* __restr
     const int k = ids ? ids[i] : i;
     int Li = counts[k];
     Li = Li > Rq ? Rq : Li;
-    if (rho < Li) src = rows + (offsets[k] + rho) * Dp;
+    if (rho < Li) src = rows + (offsets[k] + rho) * (split ? 2 * (Dp / 3) : Dp);
   }
-  copy_row(src, dst, Dp, lane);
+  if (split) copy_row_split(src, dst, Dp / 3, lane, 1);
+  else copy_row(src, dst, Dp, lane);
 }
 
 // sum-side operand (y): same row map as pack_captions_kernel
 __global__ __launch_bounds__(256) void store_pack_y_kernel(const half_t* __restrict__ rows, const int64_t* __restrict__ offsets,
                                                            const int32_t* __restrict__ counts,
                                                            const int32_t* __restrict__ ids, int Bc, int Tq, int Dp, int tpad,
-                                                           int64_t total_rows, half_t* __restrict__ y) {
+                                                           int64_t total_rows, half_t* __restrict__ y, int split) {
   const int lane = threadIdx.x & 63;
   const int64_t d = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (d >= total_rows) return;
@@ -106,9 +130,10 @@ __global__ __launch_bounds__(256) void store_pack_y_kernel(const half_t* __restr
     const int k = ids ? ids[j] : j;
     int Lj = counts[k];
     Lj = Lj > Tq ? Tq : Lj;
-    if (w < Lj) src = rows + (offsets[k] + w) * Dp;
+    if (w < Lj) src = rows + (offsets[k] + w) * (split ? 2 * (Dp / 3) : Dp);
   }
-  copy_row(src, y + d * Dp, Dp, lane);
+  if (split) copy_row_split(src, y + d * Dp, Dp / 3, lane, 2);
+  else copy_row(src, y + d * Dp, Dp, lane);
 }
 
 }  // namespace
@@ -119,8 +144,19 @@ extern "C" int aladin_store_row_width(int D) {
   return g.Dp;
 }
 
+extern "C" int aladin_store_row_width_mode(int D, int precision) {
+  const int w = aladin_store_row_width(D);
+  return (w > 0 && precision == ALADIN_PRECISION_SPLIT) ? 2 * w : w;
+}
+
 extern "C" int aladin_store_append(const float* sets, int64_t stride_b, int64_t stride_r, const int32_t* lens, int B, int L,
                                    int D, int tail, const int64_t* offsets, void* rows, void* stream) {
+  return aladin_store_append_mode(sets, stride_b, stride_r, lens, B, L, D, tail, offsets, rows, ALADIN_PRECISION_FP16, stream);
+}
+
+extern "C" int aladin_store_append_mode(const float* sets, int64_t stride_b, int64_t stride_r, const int32_t* lens, int B, int L,
+                                        int D, int tail, const int64_t* offsets, void* rows, int precision, void* stream) {
+  if (precision != ALADIN_PRECISION_FP16 && precision != ALADIN_PRECISION_SPLIT) { aladin_set_error("store_append: unknown precision %d", precision); return ALADIN_ERR_ARG; }
   if (!sets || !lens || !offsets || !rows || B < 1 || L < 2 || D < 1 || tail < 0) {
     aladin_set_error("store_append: bad argument (B=%d L=%d D=%d tail=%d)", B, L, D, tail);
     return ALADIN_ERR_ARG;
@@ -130,7 +166,7 @@ extern "C" int aladin_store_append(const float* sets, int64_t stride_b, int64_t 
   const int64_t total = (int64_t)B * (L - 1);
   const int vec4 = (D % 4 == 0) && (stride_b % 4 == 0) && (stride_r % 4 == 0) && (((uintptr_t)sets & 15) == 0);
   hipLaunchKernelGGL(store_append_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, (hipStream_t)stream, sets, stride_b,
-                     stride_r, lens, B, L, D, Dp, tail, offsets, (half_t*)rows, vec4);
+                     stride_r, lens, B, L, D, Dp, tail, offsets, (half_t*)rows, vec4, precision == ALADIN_PRECISION_SPLIT);
   return aladin_check_launch("store_append_kernel");
 }
 
@@ -140,7 +176,7 @@ extern "C" int aladin_align_pack_store_x(const void* rows, const int64_t* offset
   const int64_t total = g->xm_rows + g->xe_rows;
   hipLaunchKernelGGL(store_pack_x_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
                      (const half_t*)rows, offsets, counts, ids, g->Bi, g->Rq, g->Dp, g->mtiles, g->rem > 0 ? g->rem : 1, g->xm_rows, total, (half_t*)xm,
-                     (half_t*)xe);
+                     (half_t*)xe, g->split);
   return aladin_check_launch("store_pack_x_kernel");
 }
 
@@ -148,6 +184,6 @@ extern "C" int aladin_align_pack_store_y(const void* rows, const int64_t* offset
                                          const aladin_align_geom* g, void* y, void* stream) {
   if (!rows || !offsets || !counts || !g || !y) { aladin_set_error("align_pack_store_y: null argument"); return ALADIN_ERR_ARG; }
   hipLaunchKernelGGL(store_pack_y_kernel, dim3((unsigned)((g->y_rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
-                     (const half_t*)rows, offsets, counts, ids, g->Bc, g->Tq, g->Dp, 16 * g->tp16, g->y_rows, (half_t*)y);
+                     (const half_t*)rows, offsets, counts, ids, g->Bc, g->Tq, g->Dp, 16 * g->tp16, g->y_rows, (half_t*)y, g->split);
   return aladin_check_launch("store_pack_y_kernel");
 }

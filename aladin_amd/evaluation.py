@@ -20,7 +20,6 @@ import torch
 from . import ops
 
 CAPS_PER_IMG = 5
-E_SCRATCH_LIMIT = 2 << 30       # bytes of side-GEMM scratch per score launch before the caption side is chunked
 
 
 class AverageMeter:
@@ -105,11 +104,12 @@ def encode_data(model, data_loader, log_step=10, logging=print, max_len=71):
     return img_embs, cap_embs, img_lengths, cap_lengths
 
 
-def encode_data_packed(model, data_loader, log_step=10, logging=print):
+def encode_data_packed(model, data_loader, log_step=10, logging=print, precision='split', max_len=71):
     """encode_data with the embedding store kept on the device in packed 16-bit form (SURVEY.md
     section 8(f) row 2): returns (img_store, cap_store, img_lengths, cap_lengths) where the stores are
     aladin_amd.store.PackedSetStore objects that compute_sim_matrix / i2t / t2i accept in place of the
-    (N, 71, D) tensors -- same protocol as alad/evaluation.py:80-155 otherwise."""
+    (N, 71, D) tensors -- same protocol as alad/evaluation.py:80-155 otherwise.  precision 'split' (default:
+    rank-exact alignment retrieval, fp16 hi/lo pair per value) or 'fp16' (half the bytes, ~1e-4 score error)."""
     import time
     from .store import PackedSetStore
     batch_time = AverageMeter()
@@ -122,8 +122,8 @@ def encode_data_packed(model, data_loader, log_step=10, logging=print):
         with torch.no_grad():
             img_glob, cap_glob, img_emb, cap_emb, img_length, cap_length, _ = model.forward_emb(example_imgs, example_txts)
             if img_store is None:
-                img_store = PackedSetStore(img_emb.size(2), 0, img_emb.device)
-                cap_store = PackedSetStore(cap_emb.size(2), 2, cap_emb.device)
+                img_store = PackedSetStore(img_emb.size(2), 0, img_emb.device, precision=precision, padded_len=max_len)
+                cap_store = PackedSetStore(cap_emb.size(2), 2, cap_emb.device, precision=precision, padded_len=max_len)
             img_store.append(img_emb.permute(1, 0, 2), img_length, img_glob)      # (S,B,D) -> (B,S,D) view
             cap_store.append(cap_emb.permute(1, 0, 2), cap_length, cap_glob)
         batch_time.update(time.time() - end)
@@ -145,11 +145,13 @@ def _device():
     return torch.device('cuda', torch.cuda.current_device())
 
 
-def compute_sim_matrix(img, cap, img_len=None, cap_len=None, mode='matching'):
+def compute_sim_matrix(img, cap, img_len=None, cap_len=None, mode='matching', precision=None):
     """(N_img, N_cap) score matrix on the GPU.
 
     mode='matching'  : img (N_img, D), cap (N_cap, D) global embeddings -> img @ cap.T
     mode='alignment' : img (N_img, R, D), cap (N_cap, T, D) sets with length lists -> MrSw scores
+                       (trimmed to the real lengths, chunked, in the evaluation precision: ops._scores_nograd;
+                       precision='fp16' | 'split' overrides ops.set_eval_precision())
     Both arguments may instead be PackedSetStore / StoreView objects (encode_data_packed).
     """
     dev = _device()
@@ -171,24 +173,7 @@ def compute_sim_matrix(img, cap, img_len=None, cap_len=None, mode='matching'):
         if mode == 'alignment':
             if img_len is None or cap_len is None:
                 raise ValueError("compute_sim_matrix(mode='alignment') needs img_len and cap_len")
-            # encode_data pads every set to 71 positions (alad/evaluation.py:98-99,120-125).  Positions
-            # at or beyond the longest real length are masked out by alad/loss.py:103-116 whatever
-            # they hold, and the "[1:-2]" slice never reaches a real word of the longest caption
-            # (its last scored word sits at index len-3), so trimming both sets to the maximum
-            # length -- what the training path does, alad_model.py:174-175 -- changes no score while
-            # shrinking the padded 70 x 68 block per pair to the real one.
-            r_eff = min(img.shape[1], max(2, max(int(v) for v in img_len)))
-            t_eff = min(cap.shape[1], max(4, max(int(v) for v in cap_len)))
-            img, cap = img[:, :r_eff], cap[:, :t_eff]
-            # big grids: chunk the caption side so the side-row scratch of the score kernel stays bounded
-            # (it is N_img x 16*tp16*N_cap floats when R' = 33: 16 GB at 5000 x 25000); same bits either way
-            geom = ops.align_geometry(img.shape[0], cap.shape[0], r_eff, t_eff, img.shape[2])
-            if geom.e_bytes <= E_SCRATCH_LIMIT:
-                return ops.alignment_scores(img, cap, img_len, cap_len)
-            step = max(geom.cap_unit, int(cap.shape[0] * E_SCRATCH_LIMIT // geom.e_bytes) // geom.cap_unit * geom.cap_unit)
-            cap_len = list(cap_len)
-            return torch.cat([ops.alignment_scores(img, cap[j0:j0 + step], img_len, cap_len[j0:j0 + step])
-                              for j0 in range(0, cap.shape[0], step)], dim=1)
+            return ops.alignment_scores(img, cap, list(img_len), list(cap_len), 'MrSw', precision=precision)
     raise ValueError("mode must be 'matching' or 'alignment'")
 
 
@@ -251,20 +236,65 @@ def compute_recall(img_embs, cap_embs, tot_lengths=None, model=None, verbose=Tru
     return r1, r5, r10, r1i, r5i, r10i, rsum
 
 
-def recall_1k_5fold_test(img_embs, cap_embs, tot_lengths=None, model=None):
-    """reference alad/recall_auxiliary.py:90-130: mean over five 5000-row folds."""
+def recall_1k_5fold_test(img_embs, cap_embs, tot_lengths=None, model=None, verbose=True):
+    """reference alad/recall_auxiliary.py:90-130: mean over five 5000-row folds (torch.split(.., 5000))."""
     img_folds = torch.split(torch.as_tensor(img_embs), 5000, dim=0)
     cap_folds = torch.split(torch.as_tensor(cap_embs), 5000, dim=0)
-    res = np.array([recall_test(img_folds[i], cap_folds[i])[:6] for i in range(5)], dtype=np.float64)
-    r1, r5, r10, r1i, r5i, r10i = (float(v) for v in res.mean(0))
-    return r1, r5, r10, r1i, r5i, r10i, r1 + r5 + r10 + r1i + r5i + r10i
+    res = []
+    for i in range(5):
+        if verbose:
+            print('Computing Test recall... chunk %s of 5' % (i + 1))
+        res.append(recall_test(img_folds[i], cap_folds[i])[:6])
+    r1, r5, r10, r1i, r5i, r10i = (float(v) for v in np.mean(np.array(res, dtype=np.float64), axis=0))
+    rsum = r1 + r5 + r10 + r1i + r5i + r10i
+    if verbose:
+        print("Test 1K 5Folds - Recall Image to text: %.2f, %.2f, %.2f" % (r1, r5, r10))
+        print("Test 1K 5Folds - Recall Text to image: %.2f, %.2f, %.2f" % (r1i, r5i, r10i))
+        print('Test 1K 5Folds - Sum score: %.2f' % rsum)
+    return r1, r5, r10, r1i, r5i, r10i, rsum
+
+
+# The score grid of the last i2t / t2i call: validate() / test() call the two back to back on the same
+# embeddings (reference train.py:504-509, test.py:271-276), so the second call re-uses the first one's grid.
+# Keyed on the identity AND version counter of the inputs (an in-place update invalidates it).
+_GRID_MEMO = {'key': None, 'sim': None}
+
+
+def clear_eval_cache():
+    """Drop the memoised score grid (it holds N_img x N_cap floats on the device: 500 MB at COCO-5k)."""
+    _GRID_MEMO['key'] = _GRID_MEMO['sim'] = None
+
+
+def _memo_key(images, captions, img_lenghts, cap_lenghts, measure, sim_function):
+    def ident(x):
+        if isinstance(x, torch.Tensor):
+            return ('t', x.data_ptr(), tuple(x.shape), x._version, str(x.device))
+        if _is_store(x):
+            st = getattr(x, 'store', x)
+            return ('s', id(st), st.n_rows, len(st), tuple(getattr(x, 'ids', ())[:4]), len(x))
+        return ('o', id(x))
+    fn = sim_function if (sim_function is None or isinstance(sim_function, str)) else id(sim_function)
+    return (ident(images), ident(captions), hash(tuple(int(v) for v in img_lenghts)) if img_lenghts is not None else None,
+            hash(tuple(int(v) for v in cap_lenghts)) if cap_lenghts is not None else None, measure, fn, ops._EVAL_PRECISION[0])
 
 
 def _eval_scores(images, captions, img_lenghts, cap_lenghts, measure, sim_function):
-    if measure == 'order':
-        raise NotImplementedError("aladin_amd: measure='order' is not on the accelerated path")
+    """(n_img, n_cap) scores of the de-duplicated images (rows 0::5, alad/evaluation.py:171,252) against every
+    caption -- ONE grid instead of the reference's per-query loops."""
+    key = _memo_key(images, captions, img_lenghts, cap_lenghts, measure, sim_function)
+    if _GRID_MEMO['key'] == key:
+        return _GRID_MEMO['sim']
+    sim = _eval_scores_uncached(images, captions, img_lenghts, cap_lenghts, measure, sim_function)
+    _GRID_MEMO['key'], _GRID_MEMO['sim'] = key, sim
+    return sim
+
+
+def _eval_scores_uncached(images, captions, img_lenghts, cap_lenghts, measure, sim_function):
     if _is_store(images):
         ims = images.view(slice(0, None, CAPS_PER_IMG))
+        if measure == 'order':
+            with torch.no_grad():
+                return ops.order_scores(ims.glob, captions.glob)
         if sim_function is None:
             return compute_sim_matrix(ims, captions)
         if sim_function == 'alignment':
@@ -273,13 +303,33 @@ def _eval_scores(images, captions, img_lenghts, cap_lenghts, measure, sim_functi
     images = torch.as_tensor(images)
     captions = torch.as_tensor(captions)
     ims = images[0::CAPS_PER_IMG]
+    if measure == 'order':
+        # alad/evaluation.py:184-192,272-281 score order embeddings with order_sim (alad/loss.py:20-26) in blocks
+        # of 100 queries.  That branch predates the (N, 71, D) sets -- order_sim's expand() takes (n, D) matrices
+        # and fails on 3-D input -- so here it scores the slot-0 global embeddings, which is what the same call
+        # sites use for 'dot' (:196, :285); 2-D embedding matrices are taken as they are.
+        dev = _device()
+        a = (ims[:, 0, :] if ims.dim() == 3 else ims).to(dev, torch.float32)
+        b = (captions[:, 0, :] if captions.dim() == 3 else captions).to(dev, torch.float32)
+        with torch.no_grad():
+            return ops.order_scores(a, b)
     if sim_function is None:                      # matching head on the slot-0 global embeddings (:196, :285)
         return compute_sim_matrix(ims[:, 0, :], captions[:, 0, :])
     ims_len = list(img_lenghts[0::CAPS_PER_IMG])
     if sim_function == 'alignment':
         return compute_sim_matrix(ims, captions, ims_len, list(cap_lenghts), mode='alignment')
+    # a reference-style closure (train.py:495-498: AlignmentContrastiveLoss(...)(..., return_loss=False) under
+    # no_grad): called ONCE on the whole grid; with aladin_amd's loss module inside, that call lands on the same
+    # trimmed / chunked / split-precision path as sim_function='alignment'
     dev = _device()
-    return sim_function(ims.to(dev), captions.to(dev), ims_len, list(cap_lenghts)).to(torch.float32)
+    with torch.no_grad():
+        return sim_function(ims.to(dev, torch.float32), captions.to(dev, torch.float32), ims_len,
+                            list(cap_lenghts)).to(torch.float32)
+
+
+def _npts(images, npts):
+    n_img = len(images) // CAPS_PER_IMG
+    return n_img if npts is None else min(int(npts), n_img)
 
 
 def i2t(images, captions, img_lenghts, cap_lenghts, npts=None, return_ranks=False, ndcg_scorer=None, fold_index=0,
@@ -287,21 +337,32 @@ def i2t(images, captions, img_lenghts, cap_lenghts, npts=None, return_ranks=Fals
     """reference alad/evaluation.py:158-241.  sim_function may be None (matching head), the string
     'alignment' (HIP alignment scores) or a callable (img, cap, img_len, cap_len) -> scores; it is
     called ONCE on the whole (n_img x n_cap) grid instead of once per query and caption chunk
-    (cap_batches is accepted and ignored)."""
+    (cap_batches is accepted and ignored).  npts: only the first npts images are queries (:164-165); they are
+    still ranked against every caption.  Returns the 7-tuple, plus (ranks, top1) with return_ranks."""
     if ndcg_scorer is not None:
         raise NotImplementedError('aladin_amd: ndcg_scorer is out of scope (None at every reference call site)')
     sim = _eval_scores(images, captions, img_lenghts, cap_lenghts, measure, sim_function)
     ranks, top1, _, _ = _ranks(sim)
+    n = _npts(images, npts)
+    ranks, top1 = ranks[:n], top1[:n]
     m = _metrics(ranks) + (0, 0)
     return (m, (ranks, top1)) if return_ranks else m
 
 
 def t2i(images, captions, img_lenghts, cap_lenghts, npts=None, return_ranks=False, ndcg_scorer=None, fold_index=0,
         measure='dot', sim_function=None, im_batches=1):
-    """reference alad/evaluation.py:244-327 (returns (ranks, top1) instead of the top-50 table)."""
+    """reference alad/evaluation.py:244-327.  With return_ranks the second element is (ranks, top50) as in the
+    reference (:262,309,324-325): top50[c] = the 50 best images of caption c, best first (HIP top-k kernel; -1
+    where there are fewer than 50 images).  npts: only the captions of the first npts images are queries
+    (:250-251), ranked against every image."""
     if ndcg_scorer is not None:
         raise NotImplementedError('aladin_amd: ndcg_scorer is out of scope (None at every reference call site)')
     sim = _eval_scores(images, captions, img_lenghts, cap_lenghts, measure, sim_function)
-    _, _, ranks, top1 = _ranks(sim)
+    _, _, ranks, _ = _ranks(sim)
+    n = CAPS_PER_IMG * _npts(images, npts)
+    ranks = ranks[:n]
     m = _metrics(ranks) + (0, 0)
-    return (m, (ranks, top1)) if return_ranks else m
+    if not return_ranks:
+        return m
+    top50 = ops.topk_indices(sim[:, :n], 50, dim=0).cpu().numpy().astype(np.float64)     # float table like numpy.zeros((5*npts, 50))
+    return m, (ranks, top50)

@@ -81,15 +81,43 @@ def _workspace(nbytes, device):
 # ------------------------------------------------------------------------------------------------
 _GEOM_CACHE = {}
 
+# Operand precision of score matrices computed WITHOUT autograd (evaluation, validation, the reference's
+# alignment_sim_fn closures -- train.py:495-498, test.py:260-263):
+#   'split'  hi/lo fp16 split, three MFMA products per term: scores at the rounding level of the reference's
+#            own fp32 bmm, so Recall@K ranks are the reference's (default);
+#   'fp16'   the training operands (one fp16 rounding, ~1e-4 on a score): 3x faster, near-ties may swap.
+# Differentiable scores always use fp16 operands (north_star's 1e-3 tolerance; the backward re-decides its
+# arg-maxima in exact fp32 anyway).
+_EVAL_PRECISION = ['split']
+E_SCRATCH_LIMIT = 2 << 30       # bytes of side-GEMM scratch per score launch before the sum side is chunked
 
-def align_geometry(Bi, Bc, R, T, D, x_tail=0, y_tail=2):
+
+def set_eval_precision(precision):
+    """'split' (rank-exact, default) or 'fp16' for no-grad alignment scores; returns the previous setting."""
+    if precision not in ('split', 'fp16'):
+        raise ValueError("aladin_amd: eval precision must be 'split' or 'fp16'")
+    old = _EVAL_PRECISION[0]
+    _EVAL_PRECISION[0] = precision
+    return old
+
+
+def _precision_code(precision):
+    if precision in (None, 'fp16', _lib.PRECISION_FP16):
+        return _lib.PRECISION_FP16
+    if precision in ('split', _lib.PRECISION_SPLIT):
+        return _lib.PRECISION_SPLIT
+    raise ValueError("aladin_amd: precision must be 'fp16' or 'split', got %r" % (precision,))
+
+
+def align_geometry(Bi, Bc, R, T, D, x_tail=0, y_tail=2, precision=None):
     """Packed layout for a (max-side set Bi x R) x (sum-side set Bc x T) problem; the tails are the
     trailing positions each set drops (images 0, captions 2 -- reference alad/loss.py:87-90)."""
-    key = (Bi, Bc, R, T, D, x_tail, y_tail)
+    prec = _precision_code(precision)
+    key = (Bi, Bc, R, T, D, x_tail, y_tail, prec)
     g = _GEOM_CACHE.get(key)
     if g is None:
         g = _lib.AlignGeom()
-        _lib.check(_lib.load().aladin_align_geometry_ex(Bi, Bc, R, T, D, x_tail, y_tail, C.byref(g)), 'align_geometry')
+        _lib.check(_lib.load().aladin_align_geometry_mode(Bi, Bc, R, T, D, x_tail, y_tail, prec, C.byref(g)), 'align_geometry')
         if len(_GEOM_CACHE) < 1024:
             _GEOM_CACHE[key] = g
     return g
@@ -124,14 +152,27 @@ def scores_from_packed(xm, xe, y, geom, out=None, e_scratch=None, reuse_side=Fal
     return S
 
 
-def _align_forward(im, s, im_len_t, s_len_t, x_tail=0, y_tail=2):
+def _check_backward_supported(im, s, x_tail, y_tail):
+    """The limits of aladin_align_bwd (align_bwd.hip), checked when the FORWARD of a differentiable score
+    matrix is requested, so that an unsupported shape fails here and not inside loss.backward()."""
+    Bi, R, D = im.shape
+    Bc, T, _ = s.shape
+    if D % 4 != 0 or D > 1024:
+        raise ValueError('aladin_amd: differentiable alignment scores need D %% 4 == 0 and D <= 1024 (got D=%d); '
+                         'score under torch.no_grad() or pad the feature axis' % D)
+    if R - 1 - x_tail > 126 or T - 1 - y_tail > 96:
+        raise ValueError('aladin_amd: differentiable alignment scores support at most 126 scored positions on the '
+                         'max side and 96 on the sum side (got %d, %d)' % (R - 1 - x_tail, T - 1 - y_tail))
+
+
+def _align_forward(im, s, im_len_t, s_len_t, x_tail=0, y_tail=2, precision=None):
     """-> (S, packed) where packed = (geom, xm, xe, y) is kept for the backward pass.
     `im` is the max-side set, `s` the sum-side set (images / captions for 'MrSw')."""
     Bi, R, D = im.shape
     Bc, T, D2 = s.shape
     if D != D2:
         raise ValueError('aladin_amd: feature sizes differ (%d vs %d)' % (D, D2))
-    geom = align_geometry(Bi, Bc, R, T, D, x_tail, y_tail)
+    geom = align_geometry(Bi, Bc, R, T, D, x_tail, y_tail, precision)
     im = _rows_inner_contig(im)
     s = _rows_inner_contig(s)
     xm = torch.empty(geom.xm_bytes // 2, dtype=torch.float16, device=im.device)
@@ -177,6 +218,8 @@ def _align_backward(im, s, im_len_t, s_len_t, dS, gscale=None, packed=None, pair
 class _AlignScores(torch.autograd.Function):
     @staticmethod
     def forward(ctx, im, s, im_len_t, s_len_t, x_tail, y_tail):
+        if any(ctx.needs_input_grad[:2]):
+            _check_backward_supported(im, s, x_tail, y_tail)
         S, packed = _align_forward(im, s, im_len_t, s_len_t, x_tail, y_tail)
         if any(ctx.needs_input_grad[:2]):
             ctx.save_for_backward(im, s, im_len_t, s_len_t, packed[1], packed[2], packed[3])
@@ -215,25 +258,36 @@ class _AlignTriplet(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, im, s, im_len_t, s_len_t, margin, max_violation):
-        S, packed = _align_forward(im, s, im_len_t, s_len_t)
         need = any(ctx.needs_input_grad[:2])
+        if need:
+            _check_backward_supported(im, s, 0, 2)
+        S, packed = _align_forward(im, s, im_len_t, s_len_t)
         loss, dS, pairs = _hinge_raw(S, margin, max_violation, need, want_pairs=True)
         if need:
             ctx.save_for_backward(im, s, im_len_t, s_len_t, packed[1], packed[2], packed[3], dS)
             ctx.geom = packed[0]
             ctx.pairs = pairs
-        ctx.mark_non_differentiable(S)
         ctx.set_materialize_grads(False)
         return loss, S
 
     @staticmethod
-    def backward(ctx, g_loss, _g_scores):
-        if g_loss is None:
+    def backward(ctx, g_loss, g_scores):
+        if g_loss is None and g_scores is None:
             return None, None, None, None, None, None
         im, s, im_len_t, s_len_t, xm, xe, y, dS = ctx.saved_tensors
-        g = g_loss.to(torch.float32).contiguous()
-        d_im, d_s = _align_backward(im, s, im_len_t, s_len_t, dS, gscale=g, packed=(ctx.geom, xm, xe, y),
-                                    pairs=ctx.pairs)
+        packed = (ctx.geom, xm, xe, y)
+        if g_scores is None:
+            # the training path: only the loss is differentiated; dloss/dS (<= 3B non-zeros with the hardest-negative
+            # hinge) never leaves the device and the upstream scalar goes to the kernels as a pointer
+            g = g_loss.to(torch.float32).contiguous()
+            d_im, d_s = _align_backward(im, s, im_len_t, s_len_t, dS, gscale=g, packed=packed, pairs=ctx.pairs)
+        else:
+            # the returned score matrix was used too (the reference's S carries grad, alad/loss.py:151-159):
+            # total dS = g_loss * dloss/dS + g_scores, generally dense
+            total = g_scores.to(torch.float32)
+            if g_loss is not None:
+                total = total + dS * g_loss.to(torch.float32)
+            d_im, d_s = _align_backward(im, s, im_len_t, s_len_t, total.contiguous(), packed=packed)
         return d_im, d_s, None, None, None, None
 
 
@@ -247,9 +301,10 @@ def _check_sets(im_set, s_seq, im_len, s_len):
 
 
 def alignment_triplet_loss(im_set, s_seq, im_len, s_len, margin, max_violation):
-    """(loss, S.detach()) of AlignmentContrastiveLoss(aggregation='MrSw') in one fused node.
-    The returned score matrix carries no gradient (the reference only ever feeds it, detached, to
-    the distillation loss -- alad/loss.py:370); use alignment_scores() for a differentiable S."""
+    """(loss, S) of AlignmentContrastiveLoss(aggregation='MrSw') in one fused autograd node.  Both outputs
+    are differentiable (as in the reference, alad/loss.py:151-159); when only the loss is back-propagated --
+    every shipped config: S is fed, detached, to the distillation loss, alad/loss.py:370 -- the backward
+    stays on the sparse dloss/dS path."""
     im_len_t, s_len_t = _check_sets(im_set, s_seq, im_len, s_len)
     if im_set.shape[0] != s_seq.shape[0]:
         raise ValueError('aladin_amd: the contrastive loss needs a square score matrix, got (%d, %d) '
@@ -257,12 +312,73 @@ def alignment_triplet_loss(im_set, s_seq, im_len, s_len, margin, max_violation):
     return _AlignTriplet.apply(im_set, s_seq, im_len_t, s_len_t, margin, max_violation)
 
 
-def alignment_scores(im_set, s_seq, im_len, s_len, aggregation='MrSw'):
-    """Differentiable S (Bi, Bc); replaces reference alad/loss.py:80-135.
+def _host_lengths(lens):
+    return [int(v) for v in (lens.tolist() if isinstance(lens, torch.Tensor) else lens)]
+
+
+def _scores_nograd(xs, ys, x_len, y_len, x_tail, y_tail, precision):
+    """(Bx, By) scores of a max-side set xs (Bx, N, D) against a sum-side set ys (By, M, D) outside autograd:
+    the evaluation path.  Three things the differentiable path does not do:
+      * operands in the evaluation precision (split fp16 by default: rank-exact Recall);
+      * both sets are trimmed to the positions that can matter.  encode_data pads every set to 71 positions
+        (alad/evaluation.py:98-99); positions past a set's length are masked to 0 by alad/loss.py:103-116
+        whatever they hold.  On the SUM side a masked position adds exactly 0, so the set is cut at the
+        longest length.  On the MAX side the masked positions still take part in the max as zeros
+        (`max(real dots, 0)`, alad/loss.py:116,124) for every sample shorter than the padded set, so ONE
+        masked position is kept: the set is cut at the longest length + 1 (or not at all when some sample
+        fills it).  The 70 x 68 padded block per pair shrinks to the real one and no score changes;
+      * the sum side is chunked so the side-row scratch of the score kernel stays under E_SCRATCH_LIMIT
+        (16 GB at 5000 x 25000 otherwise); a score does not depend on the chunking."""
+    x_len, y_len = _host_lengths(x_len), _host_lengths(y_len)
+    n_eff = min(xs.shape[1], max(2 + x_tail, max(x_len) + 1))
+    m_eff = min(ys.shape[1], max(2 + y_tail, max(y_len)))
+    xs, ys = xs[:, :n_eff], ys[:, :m_eff]
+    dev = xs.device
+    x_len_t, y_len_t = lengths_tensor(x_len, dev), lengths_tensor(y_len, dev)
+    Bx, By, D = xs.shape[0], ys.shape[0], xs.shape[2]
+    geom = align_geometry(Bx, By, n_eff, m_eff, D, x_tail, y_tail, precision)
+    if geom.e_bytes <= E_SCRATCH_LIMIT:
+        return _align_forward(xs, ys, x_len_t, y_len_t, x_tail, y_tail, precision)[0]
+    step = max(geom.cap_unit, int(By * E_SCRATCH_LIMIT // geom.e_bytes) // geom.cap_unit * geom.cap_unit)
+    xm, xe = pack_images(xs, x_len_t, geom)
+    S = torch.empty((Bx, By), dtype=torch.float32, device=dev)
+    for j0 in range(0, By, step):
+        j1 = min(By, j0 + step)
+        g = align_geometry(Bx, j1 - j0, n_eff, m_eff, D, x_tail, y_tail, precision)        # same max-side layout
+        y = pack_captions(ys[j0:j1], y_len_t[j0:j1].contiguous(), g)
+        scores_from_packed(xm, xe, y, g, out=S[:, j0:j1])
+    return S
+
+
+def alignment_scores(im_set, s_seq, im_len, s_len, aggregation='MrSw', precision=None):
+    """S (Bi, Bc); replaces reference alad/loss.py:80-135.  Differentiable when autograd is on and an
+    input requires grad (fp16 operands); otherwise the evaluation path of _scores_nograd in the evaluation
+    precision (`precision` overrides set_eval_precision()).
       'MrSw'  sum over words of the max over regions                       (:124-125)
       'MwSr'  sum over regions of the max over words: the same kernels with the two sets swapped --
               captions on the max side (tail 2), images on the sum side (tail 0) -- transposed (:134-135)
       'symm'  MrSw + MwSr                                                  (:130-133)"""
+    if aggregation not in ('MrSw', 'MwSr', 'symm'):
+        raise NotImplementedError('aladin_amd: aggregation %r' % (aggregation,))
+    if not (torch.is_grad_enabled() and (im_set.requires_grad or s_seq.requires_grad)):
+        _require_gpu(im_set, s_seq)
+        if im_set.dim() != 3 or s_seq.dim() != 3:
+            raise ValueError('aladin_amd: im_set (B,R,D) and s_seq (B,T,D) expected')
+        if len(im_len) != im_set.shape[0] or len(s_len) != s_seq.shape[0]:
+            raise ValueError('aladin_amd: one length per sample expected')
+        if im_set.shape[2] != s_seq.shape[2]:
+            raise ValueError('aladin_amd: feature sizes differ (%d vs %d)' % (im_set.shape[2], s_seq.shape[2]))
+        prec = precision if precision is not None else _EVAL_PRECISION[0]
+        with torch.no_grad():
+            S = None
+            if aggregation in ('MrSw', 'symm'):
+                S = _scores_nograd(im_set, s_seq, im_len, s_len, 0, 2, prec)
+            if aggregation in ('MwSr', 'symm'):
+                St = _scores_nograd(s_seq, im_set, s_len, im_len, 2, 0, prec).t()
+                S = St if S is None else S + St
+        return S
+    if precision not in (None, 'fp16'):
+        raise ValueError('aladin_amd: differentiable alignment scores use fp16 operands (split precision is forward-only)')
     im_len_t, s_len_t = _check_sets(im_set, s_seq, im_len, s_len)
     if aggregation == 'MrSw':
         return _AlignScores.apply(im_set, s_seq, im_len_t, s_len_t, 0, 2)
@@ -271,7 +387,6 @@ def alignment_scores(im_set, s_seq, im_len, s_len, aggregation='MrSw'):
     if aggregation == 'symm':
         return _AlignScores.apply(im_set, s_seq, im_len_t, s_len_t, 0, 2) + \
             _AlignScores.apply(s_seq, im_set, s_len_t, im_len_t, 2, 0).t()
-    raise NotImplementedError('aladin_amd: aggregation %r' % (aggregation,))
 
 
 class _ScanScores(torch.autograd.Function):
@@ -584,6 +699,23 @@ def retrieval_ranks(img, cap, caps_per_img=5):
                                           _ptr(r_i2t), _ptr(t_i2t), _ptr(r_t2i), _ptr(t_t2i), _ptr(ws), _stream()),
                'retrieval_ranks')
     return r_i2t, t_i2t, r_t2i, t_t2i
+
+
+def topk_indices(scores, k, dim=1):
+    """(n_q, k) int32 indices of each query's k best candidates, best first, ties -> lower index; queries are
+    the rows of `scores` (dim=1) or its columns (dim=0, read in place: no transpose).  Replaces the
+    `inds[i][0:50]` slices of the descending argsorts in reference alad/evaluation.py:303-309 (-1 past the
+    number of candidates)."""
+    _require_gpu(scores)
+    if scores.dim() != 2 or dim not in (0, 1):
+        raise ValueError('aladin_amd: topk_indices expects a 2-D score matrix and dim 0 or 1')
+    sc = scores if scores.stride(1) == 1 else scores.contiguous()
+    n_q, n_c = (sc.shape[0], sc.shape[1]) if dim == 1 else (sc.shape[1], sc.shape[0])
+    q_stride, c_stride = (_ld(sc), 1) if dim == 1 else (1, _ld(sc))
+    out = torch.empty((n_q, int(k)), dtype=torch.int32, device=sc.device)
+    _lib.check(_lib.load().aladin_topk(_ptr(sc), q_stride, c_stride, n_q, n_c, int(k), _ptr(out), _ptr(None), _stream()),
+               'topk')
+    return out
 
 
 class _L2Norm(torch.autograd.Function):

@@ -20,12 +20,18 @@ from . import _lib, ops
 
 
 class PackedSetStore:
-    def __init__(self, feat_dim, tail, device, capacity_rows=4096):
+    def __init__(self, feat_dim, tail, device, capacity_rows=4096, precision='split', padded_len=71):
         """tail = trailing positions the alignment head drops: 0 for image sets, 2 for captions
-        (reference alad/loss.py:87-90)."""
+        (reference alad/loss.py:87-90).  precision: 'split' keeps every unit vector as an fp16 hi/lo pair
+        (rows twice as wide) so that alignment scores are rank-exact (ops.set_eval_precision); 'fp16' keeps
+        the single-rounding training operand.  padded_len: the length the reference's encode_data pads every
+        set to (max_len = 71, alad/evaluation.py:98-99): a sample shorter than that competes with the zero
+        fill in the max over regions (alad/loss.py:116,124), one that fills it does not."""
         lib = _lib.load()
         self.D = int(feat_dim)
-        self.Dp = int(lib.aladin_store_row_width(self.D))
+        self.precision = precision
+        self.padded_len = int(padded_len)
+        self.Dp = int(lib.aladin_store_row_width_mode(self.D, ops._precision_code(precision)))
         if self.Dp < self.D:
             raise ValueError('aladin_amd: bad feature size %r' % (feat_dim,))
         self.tail = int(tail)
@@ -53,6 +59,8 @@ class PackedSetStore:
             raise ValueError('aladin_amd: store.append got a (%d,%d,%d) batch with %d lengths (store D=%d)'
                              % (B, L, D, len(lengths), self.D))
         lengths = [int(v) for v in lengths]
+        if L > self.padded_len:
+            raise ValueError('aladin_amd: store.append got sets of %d positions, more than padded_len=%d' % (L, self.padded_len))
         counts = [min(max(v - 1 - self.tail, 0), L - 1) for v in lengths]
         offs, run = [], self.n_rows
         for c in counts:
@@ -63,8 +71,9 @@ class PackedSetStore:
         lens_t = torch.tensor(lengths, dtype=torch.int32, device=self.device)
         offs_t = torch.tensor(offs, dtype=torch.int64, device=self.device)
         if L >= 2:
-            _lib.check(_lib.load().aladin_store_append(ops._ptr(sets), sets.stride(0), sets.stride(1), ops._ptr(lens_t), B, L, D,
-                                                       self.tail, ops._ptr(offs_t), ops._ptr(self.rows), ops._stream()),
+            _lib.check(_lib.load().aladin_store_append_mode(ops._ptr(sets), sets.stride(0), sets.stride(1), ops._ptr(lens_t), B, L,
+                                                            D, self.tail, ops._ptr(offs_t), ops._ptr(self.rows),
+                                                            ops._precision_code(self.precision), ops._stream()),
                        'store_append')
         self._glob.append((sets[:, 0, :] if glob is None else glob).to(torch.float32).clone())
         self.n_rows = run
@@ -83,7 +92,7 @@ class PackedSetStore:
         return self._glob[0]
 
     def nbytes(self):
-        return self.n_rows * self.Dp * 2 + len(self) * (self.D * 4 + 12)
+        return self.n_rows * self.Dp * 2 + len(self) * (self.D * 4 + 12)      # Dp already counts hi and lo for split stores
 
     def _tables(self):
         if self._offsets_t is None:
@@ -133,9 +142,6 @@ def _unwrap(x):
     return (x.store, x.ids, x.ids_t) if isinstance(x, StoreView) else (x, None, None)
 
 
-E_SCRATCH_LIMIT = 2 << 30        # bytes of side-GEMM scratch per launch before the caption side is chunked
-
-
 def alignment_scores_from_stores(img, cap):
     """(N_img, N_cap) 'MrSw' scores (reference alad/loss.py:80-125) between two stores / views:
     operands are row copies of the stores (no fp32 read, no normalisation).  One score launch, or one
@@ -148,15 +154,22 @@ def alignment_scores_from_stores(img, cap):
     Bi, Bc = len(img), len(cap)
     if Bi < 1 or Bc < 1:
         raise ValueError('aladin_amd: empty store')
-    Rq, Tq = max(si.max_count(ids_i), 1), max(sc.max_count(ids_c), 1)
+    if si.precision != sc.precision:
+        raise ValueError('aladin_amd: the two stores hold different precisions (%s vs %s)' % (si.precision, sc.precision))
+    # Max side: every sample shorter than the padded set (encode_data's 71 positions) takes the zero fill into
+    # its max over regions (alad/loss.py:116,124), so the geometry keeps ONE position past the longest count
+    # (a zero row in the operand) unless a sample fills the padded set; the sum side needs none.
+    Rq = min(max(si.max_count(ids_i), 1) + 1, si.padded_len - 1 - si.tail)
+    Tq = max(sc.max_count(ids_c), 1)
+    precision = si.precision
     lib = _lib.load()
     dev = si.device
     oi, ci = si._tables()
     oc, cc = sc._tables()
-    geom = ops.align_geometry(Bi, Bc, Rq + 1 + si.tail, Tq + 1 + sc.tail, si.D, si.tail, sc.tail)
+    geom = ops.align_geometry(Bi, Bc, Rq + 1 + si.tail, Tq + 1 + sc.tail, si.D, si.tail, sc.tail, precision)
     chunk = Bc
-    if geom.e_bytes > E_SCRATCH_LIMIT:
-        chunk = max(geom.cap_unit, int(Bc * E_SCRATCH_LIMIT // geom.e_bytes) // geom.cap_unit * geom.cap_unit)
+    if geom.e_bytes > ops.E_SCRATCH_LIMIT:
+        chunk = max(geom.cap_unit, int(Bc * ops.E_SCRATCH_LIMIT // geom.e_bytes) // geom.cap_unit * geom.cap_unit)
     xm = torch.empty(geom.xm_bytes // 2, dtype=torch.float16, device=dev)
     xe = torch.empty(max(geom.xe_bytes // 2, 8), dtype=torch.float16, device=dev)
     _lib.check(lib.aladin_align_pack_store_x(ops._ptr(si.rows), ops._ptr(oi), ops._ptr(ci), ops._ptr(idt_i), C.byref(geom),
@@ -170,7 +183,7 @@ def alignment_scores_from_stores(img, cap):
     all_ids = idt_c if idt_c is not None else torch.arange(Bc, dtype=torch.int32, device=dev)
     for j0 in range(0, Bc, chunk):
         j1 = min(Bc, j0 + chunk)
-        g = ops.align_geometry(Bi, j1 - j0, Rq + 1 + si.tail, Tq + 1 + sc.tail, si.D, si.tail, sc.tail)   # same x layout
+        g = ops.align_geometry(Bi, j1 - j0, Rq + 1 + si.tail, Tq + 1 + sc.tail, si.D, si.tail, sc.tail, precision)   # same x layout
         y = torch.empty(g.y_bytes // 2, dtype=torch.float16, device=dev)
         ids = all_ids[j0:j1].contiguous()
         _lib.check(lib.aladin_align_pack_store_y(ops._ptr(sc.rows), ops._ptr(oc), ops._ptr(cc), ops._ptr(ids), C.byref(g),

@@ -103,13 +103,18 @@ def retrieval_embeddings(n_img, D=768, seed=2024, sigma=2.0, caps_per_img=5):
     return np.repeat(img, caps_per_img, axis=0).astype(np.float32), cap.astype(np.float32)
 
 
-def eval_sets(n_img, D=64, seed=31, L=71, base_weight=0.25, sigma=3.0):
+def eval_sets(n_img, D=64, seed=31, L=71, base_weight=0.25, sigma=3.0, img_len_range=(12, 34), cap_len_range=(7, 30),
+              n_full=0):
     """(N, 71, D) zero-padded sets as ``encode_data`` lays them out (reference
     alad/evaluation.py:98-99,119-128): N = 5*n_img rows, image rows repeated 5x, slot 0 overwritten
-    with the global (matching-head) embedding.  Returns (images, captions, img_len, cap_len)."""
+    with the global (matching-head) embedding.  Returns (images, captions, img_len, cap_len).
+    ``n_full`` images (spread over the set) are given the full length L: they have NO masked region, so
+    the max over regions of alad/loss.py:124 does not see the zero fill -- the edge the trimmed grid must keep."""
     N = 5 * n_img
-    img_len = integers((n_img,), 12, 34, seed + 1)
-    cap_len = integers((N,), 7, 30, seed + 2)
+    img_len = integers((n_img,), img_len_range[0], img_len_range[1], seed + 1)
+    cap_len = integers((N,), cap_len_range[0], cap_len_range[1], seed + 2)
+    for k in range(n_full):
+        img_len[(k * n_img) // n_full + (seed % max(n_img // n_full, 1))] = L
     base = base_weight * normal((n_img, 1, D), seed + 3)
     reg = normal((n_img, L, D), seed + 4) + base
     tok = normal((N, L, D), seed + 5) + np.repeat(base, 5, axis=0)

@@ -28,10 +28,17 @@
 extern "C" {
 #endif
 
-#define ALADIN_ABI_VERSION 3
+#define ALADIN_ABI_VERSION 4
 
-int aladin_version(void);
-const char* aladin_last_error(void);
+/* The library is built with -fvisibility=hidden: the entry points declared here are its ONLY exports. */
+#if defined(__GNUC__)
+#define ALADIN_API __attribute__((visibility("default")))
+#else
+#define ALADIN_API
+#endif
+
+ALADIN_API int aladin_version(void);
+ALADIN_API const char* aladin_last_error(void);
 
 /* ---------------------------------------------------------------------------------------------
  * Alignment scores  S[i][j] = sum_w max_r <im^[i,r], s^[j,w]>      (aggregation 'MrSw')
@@ -48,48 +55,63 @@ typedef struct aladin_align_geom {
   int32_t mtiles;               /* 32-row MFMA tiles per image in the main operand              */
   int32_t rem;                  /* 1: the last region of every image goes through the side GEMM */
   int32_t tp16;                 /* padded words per caption / 16                                */
-  int32_t Dp;                   /* D rounded up to 64 (zero filled)                             */
+  int32_t Dp;                   /* halfs per packed row: D rounded up to 64 (zero filled), x3 when split */
   int32_t img_unit, cap_unit;   /* images / captions per workgroup tile                         */
   int32_t Bi_pad, Bc_pad;       /* batch sizes rounded up to the units (zero rows)              */
   int32_t x_tail, y_tail;       /* positions dropped at the END of the max-side / sum-side sets: the
                                    set uses positions 1 .. N-1-tail and length len-1-tail.  Images 0
                                    (alad/loss.py:87,89), captions 2 (:88,90)                      */
-  int32_t reserved_;            /* keeps the 64-bit fields aligned                              */
+  int32_t split;                /* 1: split-fp16 operands (ALADIN_PRECISION_SPLIT), Dp = 3 * round_up(D, 64) */
   int64_t xm_rows, xe_rows, y_rows;            /* rows of the packed fp16 operands              */
   int64_t xm_bytes, xe_bytes, y_bytes;         /* their sizes                                   */
   int64_t e_bytes;              /* fp32 scratch for the side GEMM, xe_rows x y_rows (0 if !rem) */
 } aladin_align_geom;
 
 /* Host-only: derive the packed layout for a problem ('MrSw': images on the max side). */
-int aladin_align_geometry(int Bi, int Bc, int R, int T, int D, aladin_align_geom* out);
+ALADIN_API int aladin_align_geometry(int Bi, int Bc, int R, int T, int D, aladin_align_geom* out);
 /* General form: the set on the MAX side (Bi x R) and the set on the SUM side (Bc x T) each state how
  * many trailing positions they drop.  'MrSw' = (images, tail 0) x (captions, tail 2); 'MwSr'
  * (alad/loss.py:134-135, max over words, sum over regions) = (captions, tail 2) x (images, tail 0),
  * result transposed.  Every "image"/"caption" argument below means max-side / sum-side set. */
-int aladin_align_geometry_ex(int Bi, int Bc, int R, int T, int D, int x_tail, int y_tail, aladin_align_geom* out);
+ALADIN_API int aladin_align_geometry_ex(int Bi, int Bc, int R, int T, int D, int x_tail, int y_tail, aladin_align_geom* out);
+
+/* Operand precision of the packed sets.
+ *   ALADIN_PRECISION_FP16   one rounding of every unit vector to fp16: scores within ~1e-4 of the fp32
+ *                           reference (the training path: north_star's 1e-3 tolerance, full MFMA rate).
+ *   ALADIN_PRECISION_SPLIT  x^ * 2^14 = hi + lo (fp16 each); a packed row is three K segments
+ *                           [hi | lo | hi] (max side) / [hi | hi | lo] (sum side), so the SAME pack / score entry
+ *                           points contract hi.hi + lo.hi + hi.lo with fp32 accumulation: ~2^-22 relative operand
+ *                           error, i.e. the rounding level of the reference's own fp32 bmm, at 3x the MFMA work.
+ *                           This is what evaluation uses: Recall needs rank-exact scores (near-ties between
+ *                           thousands of candidates flip at the 1e-4 level; alad/evaluation.py:213-223,303-308).
+ *                           Forward only: aladin_align_bwd_packed rejects split operands. */
+#define ALADIN_PRECISION_FP16 0
+#define ALADIN_PRECISION_SPLIT 1
+ALADIN_API int aladin_align_geometry_mode(int Bi, int Bc, int R, int T, int D, int x_tail, int y_tail, int precision,
+                               aladin_align_geom* out);
 
 /* L2-normalise (eps 1e-12, F.normalize), slice, length-mask and convert the image sets to the
  * packed fp16 MFMA operand.  im[(b*stride_b + r*stride_r) + d], innermost stride 1 (the reference
  * hands a permuted (S,B,D)->(B,S,D) view, alad/alad_model.py:377).  im_len: Bi int32 on device.
  * xm: geom->xm_bytes, xe: geom->xe_bytes (ignored when !rem). */
-int aladin_align_pack_images(const float* im, int64_t stride_b, int64_t stride_r, const int32_t* im_len,
+ALADIN_API int aladin_align_pack_images(const float* im, int64_t stride_b, int64_t stride_r, const int32_t* im_len,
                              const aladin_align_geom* geom, void* xm, void* xe, void* stream);
-int aladin_align_pack_captions(const float* s, int64_t stride_b, int64_t stride_t, const int32_t* s_len,
+ALADIN_API int aladin_align_pack_captions(const float* s, int64_t stride_b, int64_t stride_t, const int32_t* s_len,
                                const aladin_align_geom* geom, void* y, void* stream);
 
 /* Both packs in one launch (single-GPU path). */
-int aladin_align_pack_both(const float* im, int64_t im_stride_b, int64_t im_stride_r, const int32_t* im_len,
+ALADIN_API int aladin_align_pack_both(const float* im, int64_t im_stride_b, int64_t im_stride_r, const int32_t* im_len,
                            const float* s, int64_t s_stride_b, int64_t s_stride_t, const int32_t* s_len,
                            const aladin_align_geom* geom, void* xm, void* xe, void* y, void* stream);
 
 /* S (Bi x Bc, row stride ldS floats) from packed operands.  e_scratch: geom->e_bytes. */
-int aladin_align_scores(const void* xm, const void* xe, const void* y, const aladin_align_geom* geom,
+ALADIN_API int aladin_align_scores(const void* xm, const void* xe, const void* y, const aladin_align_geom* geom,
                         void* e_scratch, float* S, int64_t ldS, void* stream);
 /* Same with flags.  ALADIN_SCORES_REUSE_SIDE: e_scratch already holds the side-GEMM result of a
  * previous call on the same operands, launch the score kernel alone (used by bench.py to time the
  * dominant kernel in isolation). */
 #define ALADIN_SCORES_REUSE_SIDE 1
-int aladin_align_scores_ex(const void* xm, const void* xe, const void* y, const aladin_align_geom* geom,
+ALADIN_API int aladin_align_scores_ex(const void* xm, const void* xe, const void* y, const aladin_align_geom* geom,
                            void* e_scratch, float* S, int64_t ldS, int flags, void* stream);
 
 /* Backward of S w.r.t. the raw sets (autograd of alad/loss.py:80-125).
@@ -97,8 +119,8 @@ int aladin_align_scores_ex(const void* xm, const void* xe, const void* y, const 
  * dS == 0 are skipped, so the max_violation=True hinge (<= 3B non-zeros) costs O(B) pair blocks.
  * The argmax over regions is recomputed in fp32.  d_im (Bi,R,D) and d_s (Bc,T,D) are contiguous
  * and fully written.  workspace: aladin_align_bwd_workspace_bytes(). */
-size_t aladin_align_bwd_workspace_bytes(int Bi, int Bc, int R, int T, int D);
-int aladin_align_bwd(const float* im, int64_t im_stride_b, int64_t im_stride_r, const int32_t* im_len,
+ALADIN_API size_t aladin_align_bwd_workspace_bytes(int Bi, int Bc, int R, int T, int D);
+ALADIN_API int aladin_align_bwd(const float* im, int64_t im_stride_b, int64_t im_stride_r, const int32_t* im_len,
                      const float* s, int64_t s_stride_b, int64_t s_stride_t, const int32_t* s_len,
                      int Bi, int Bc, int R, int T, int D,
                      const float* dS, int64_t ld_dS, const float* gscale,
@@ -109,7 +131,7 @@ int aladin_align_bwd(const float* im, int64_t im_stride_b, int64_t im_stride_r, 
  * the fp16 error bound are re-decided with exact fp32 dot products (same result, cheaper).
  * pairs / pair_count (both or neither; may be NULL): the non-zero (i*Bc + j) list of dS as
  * emitted by aladin_hinge_fused -- skips the in-call compaction. */
-int aladin_align_bwd_packed(const float* im, int64_t im_stride_b, int64_t im_stride_r, const int32_t* im_len,
+ALADIN_API int aladin_align_bwd_packed(const float* im, int64_t im_stride_b, int64_t im_stride_r, const int32_t* im_len,
                             const float* s, int64_t s_stride_b, int64_t s_stride_t, const int32_t* s_len,
                             const float* dS, int64_t ld_dS, const float* gscale,
                             const void* xm, const void* xe, const void* y, const aladin_align_geom* geom,
@@ -122,9 +144,9 @@ int aladin_align_bwd_packed(const float* im, int64_t im_stride_b, int64_t im_str
  * the scores are then aladin_sgemm_strided(out_img, out_cap^T).  bwd: d_x (B,N,D contiguous, fully
  * written) from d_out (B,D).
  * ------------------------------------------------------------------------------------------- */
-int aladin_normsum_fwd(const float* x, int64_t stride_b, int64_t stride_r, const int32_t* len, int B, int N, int D,
+ALADIN_API int aladin_normsum_fwd(const float* x, int64_t stride_b, int64_t stride_r, const int32_t* len, int B, int N, int D,
                        int tail, float* out, void* stream);
-int aladin_normsum_bwd(const float* x, int64_t stride_b, int64_t stride_r, const int32_t* len, int B, int N, int D,
+ALADIN_API int aladin_normsum_bwd(const float* x, int64_t stride_b, int64_t stride_r, const int32_t* len, int B, int N, int D,
                        int tail, const float* d_out, float* d_x, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
@@ -133,20 +155,20 @@ int aladin_normsum_bwd(const float* x, int64_t stride_b, int64_t stride_r, const
  * dloss/dS (max_violation: +-1 at the hardest negatives and the diagonal, <= 3B non-zeros).
  * workspace: aladin_hinge_workspace_bytes(B).
  * ------------------------------------------------------------------------------------------- */
-size_t aladin_hinge_workspace_bytes(int B);
-int aladin_hinge_fwd_bwd(const float* S, int64_t ldS, int B, float margin, int max_violation,
+ALADIN_API size_t aladin_hinge_workspace_bytes(int B);
+ALADIN_API int aladin_hinge_fwd_bwd(const float* S, int64_t ldS, int B, float margin, int max_violation,
                          float* loss, float* dS, void* workspace, void* stream);
 
 /* Same, additionally emitting the list of non-zero pairs of dS (pairs: B*B int32 holding i*B + j in
  * arbitrary order, pair_count: 1 int32) that aladin_align_bwd_packed can consume directly. */
-int aladin_hinge_fused(const float* S, int64_t ldS, int B, float margin, int max_violation, float* loss,
+ALADIN_API int aladin_hinge_fused(const float* S, int64_t ldS, int B, float margin, int max_violation, float* loss,
                        float* dS, int32_t* pairs, int32_t* pair_count, void* workspace, void* stream);
 
 /* ListNet score distillation -- DistillationLoss(mode='listnet'), reference alad/loss.py:427-445
  * (teacher detached :370; temperature 6 on the student only; eps 1e-10 inside the log).
  * d_student (B x B contiguous) may be NULL. */
-size_t aladin_listnet_workspace_bytes(int B);
-int aladin_listnet_fwd_bwd(const float* teacher, int64_t ld_t, const float* student, int64_t ld_s, int B,
+ALADIN_API size_t aladin_listnet_workspace_bytes(int B);
+ALADIN_API int aladin_listnet_fwd_bwd(const float* teacher, int64_t ld_t, const float* student, int64_t ld_s, int B,
                            float temperature, float eps, float* loss, float* d_student,
                            void* workspace, void* stream);
 
@@ -162,19 +184,24 @@ int aladin_listnet_fwd_bwd(const float* teacher, int64_t ld_t, const float* stud
  * aladin_align_scores for the samples ids[0..Bi) / ids[0..Bc) (ids NULL = 0, 1, 2, ...) under a
  * geometry whose Rq / Tq bound the counts; the operands -- hence the scores -- are bit-identical to
  * aladin_align_pack_images / _captions on the fp32 sets.
+ * Split stores (precision ALADIN_PRECISION_SPLIT): a row is [hi | lo], 2 * round_up(D, 64) halfs, written by
+ * aladin_store_append_mode; aladin_align_pack_store_x / _y take such rows when (and only when) geom->split.
  * ------------------------------------------------------------------------------------------- */
-int aladin_store_row_width(int D);
-int aladin_store_append(const float* sets, int64_t stride_b, int64_t stride_r, const int32_t* lens, int B, int L,
+ALADIN_API int aladin_store_row_width(int D);
+ALADIN_API int aladin_store_row_width_mode(int D, int precision);
+ALADIN_API int aladin_store_append_mode(const float* sets, int64_t stride_b, int64_t stride_r, const int32_t* lens, int B, int L,
+                             int D, int tail, const int64_t* offsets, void* rows, int precision, void* stream);
+ALADIN_API int aladin_store_append(const float* sets, int64_t stride_b, int64_t stride_r, const int32_t* lens, int B, int L,
                         int D, int tail, const int64_t* offsets, void* rows, void* stream);
-int aladin_align_pack_store_x(const void* rows, const int64_t* offsets, const int32_t* counts, const int32_t* ids,
+ALADIN_API int aladin_align_pack_store_x(const void* rows, const int64_t* offsets, const int32_t* counts, const int32_t* ids,
                               const aladin_align_geom* g, void* xm, void* xe, void* stream);
-int aladin_align_pack_store_y(const void* rows, const int64_t* offsets, const int32_t* counts, const int32_t* ids,
+ALADIN_API int aladin_align_pack_store_y(const void* rows, const int64_t* offsets, const int32_t* counts, const int32_t* ids,
                               const aladin_align_geom* g, void* y, void* stream);
 
 /* l2norm -- reference alad/utils.py:134-139: out = X / sqrt(sum_dim1 X^2) on (rows, D), NO eps (a zero row
  * gives NaN, as the reference; F.normalize would give 0), and its backward.  out / d_x are contiguous. */
-int aladin_l2norm_fwd(const float* x, int64_t row_stride, int rows, int D, float* out, void* stream);
-int aladin_l2norm_bwd(const float* x, int64_t row_stride, const float* d_out, int64_t d_out_stride, int rows, int D,
+ALADIN_API int aladin_l2norm_fwd(const float* x, int64_t row_stride, int rows, int D, float* out, void* stream);
+ALADIN_API int aladin_l2norm_bwd(const float* x, int64_t row_stride, const float* d_out, int64_t d_out_stride, int rows, int D,
                       float* d_x, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
@@ -187,11 +214,11 @@ int aladin_l2norm_bwd(const float* x, int64_t row_stride, const float* d_out, in
  * length-masked expression (the reference's autograd is NaN on ragged batches and equal to this on
  * full-length ones); gscale (device scalar, may be NULL) multiplies dS.
  * ------------------------------------------------------------------------------------------- */
-size_t aladin_scan_workspace_bytes(int Bi, int Bc, int R, int T, int D, int backward);
-int aladin_scan_fwd(const float* im, int64_t im_stride_b, int64_t im_stride_r, const int32_t* im_len, const float* s,
+ALADIN_API size_t aladin_scan_workspace_bytes(int Bi, int Bc, int R, int T, int D, int backward);
+ALADIN_API int aladin_scan_fwd(const float* im, int64_t im_stride_b, int64_t im_stride_r, const int32_t* im_len, const float* s,
                     int64_t s_stride_b, int64_t s_stride_t, const int32_t* s_len, int Bi, int Bc, int R, int T, int D,
                     float* S, int64_t ldS, void* workspace, void* stream);
-int aladin_scan_bwd(const float* im, int64_t im_stride_b, int64_t im_stride_r, const int32_t* im_len, const float* s,
+ALADIN_API int aladin_scan_bwd(const float* im, int64_t im_stride_b, int64_t im_stride_r, const int32_t* im_len, const float* s,
                     int64_t s_stride_b, int64_t s_stride_t, const int32_t* s_len, int Bi, int Bc, int R, int T, int D,
                     const float* dS, int64_t ld_dS, const float* gscale, float* d_im, float* d_s, void* workspace,
                     void* stream);
@@ -205,22 +232,22 @@ int aladin_scan_bwd(const float* im, int64_t im_stride_b, int64_t im_stride_r, c
  *   ordinal      :374-399  per-row and per-column teacher sort, strided hinge on the student in that
  *                          order where teacher_sorted[p + stride] >= threshold; a side with no selected
  *                          position makes the loss NaN and contributes a zero gradient (as torch). B <= 8192 */
-size_t aladin_distill_workspace_bytes(int B);
-int aladin_distill_mse_fwd_bwd(const float* teacher, int64_t ld_t, const float* student, int64_t ld_s, int B,
+ALADIN_API size_t aladin_distill_workspace_bytes(int B);
+ALADIN_API int aladin_distill_mse_fwd_bwd(const float* teacher, int64_t ld_t, const float* student, int64_t ld_s, int B,
                                const float* wb, float* loss, float* d_student, float* d_wb, void* workspace,
                                void* stream);
-int aladin_distill_contrastive_fwd_bwd(const float* teacher, int64_t ld_t, const float* student, int64_t ld_s, int B,
+ALADIN_API int aladin_distill_contrastive_fwd_bwd(const float* teacher, int64_t ld_t, const float* student, int64_t ld_s, int B,
                                        float margin, float* loss, float* d_student, void* workspace, void* stream);
-int aladin_distill_ordinal_fwd_bwd(const float* teacher, int64_t ld_t, const float* student, int64_t ld_s, int B,
+ALADIN_API int aladin_distill_ordinal_fwd_bwd(const float* teacher, int64_t ld_t, const float* student, int64_t ld_s, int B,
                                    float margin, float threshold, int stride, float* loss, float* d_student,
                                    void* workspace, void* stream);
 
 /* Order-embedding similarity -- order_sim, reference alad/loss.py:20-26 (measure='order'):
  * scores[i][j] = -|| max(s_j - im_i, 0) ||_2, and its backward given d_scores and the forward's scores
  * (a pair without any violation has 0/0 = NaN gradient, as autograd).  d_im / d_s may be NULL. */
-int aladin_order_sim_fwd(const float* im, int64_t ld_im, const float* s, int64_t ld_s, int Bi, int Bc, int D,
+ALADIN_API int aladin_order_sim_fwd(const float* im, int64_t ld_im, const float* s, int64_t ld_s, int Bi, int Bc, int D,
                          float* scores, int64_t ld_scores, void* stream);
-int aladin_order_sim_bwd(const float* im, int64_t ld_im, const float* s, int64_t ld_s, int Bi, int Bc, int D,
+ALADIN_API int aladin_order_sim_bwd(const float* im, int64_t ld_im, const float* s, int64_t ld_s, int Bi, int Bc, int D,
                          const float* d_scores, int64_t ld_g, const float* scores, int64_t ld_scores,
                          float* d_im, int64_t ld_dim, float* d_s, int64_t ld_ds, void* stream);
 
@@ -229,7 +256,7 @@ int aladin_order_sim_bwd(const float* im, int64_t ld_im, const float* s, int64_t
  * exact-fp32 MFMA).  With a_cs = 1, b_rs = 1 it is dot_sim  im.mm(s.t()), reference
  * alad/loss.py:8-11; the strides also give the two backward products.
  * ------------------------------------------------------------------------------------------- */
-int aladin_sgemm_strided(int M, int N, int K, const float* A, int64_t a_rs, int64_t a_cs,
+ALADIN_API int aladin_sgemm_strided(int M, int N, int K, const float* A, int64_t a_rs, int64_t a_cs,
                          const float* B, int64_t b_rs, int64_t b_cs, float* C, int64_t ldc, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
@@ -239,8 +266,8 @@ int aladin_sgemm_strided(int M, int N, int K, const float* A, int64_t a_rs, int6
  * and torch.mm at alad/evaluation.py:196,285.
  * workspace: aladin_sim_workspace_bytes(n_img, n_cap, D).
  * ------------------------------------------------------------------------------------------- */
-size_t aladin_sim_workspace_bytes(int n_img, int n_cap, int D);
-int aladin_sim_matrix(const float* img, int64_t img_rs, const float* cap, int64_t cap_rs,
+ALADIN_API size_t aladin_sim_workspace_bytes(int n_img, int n_cap, int D);
+ALADIN_API int aladin_sim_matrix(const float* img, int64_t img_rs, const float* cap, int64_t cap_rs,
                       int n_img, int n_cap, int D, float* sim, int64_t ld_sim,
                       void* workspace, void* stream);
 
@@ -250,10 +277,17 @@ int aladin_sim_matrix(const float* img, int64_t img_rs, const float* cap, int64_
  * alad/evaluation.py:213-223,303-308, except on exact ties).
  *   rank_i2t[n_img]: best rank among the image's captions;  top1_i2t[n_img]: argmax caption
  *   rank_t2i[n_cap]: rank of the caption's image;           top1_t2i[n_cap]: argmax image */
-size_t aladin_recall_workspace_bytes(int n_cap);
-int aladin_recall_ranks(const float* sim, int64_t ld_sim, int n_img, int n_cap, int caps_per_img,
+ALADIN_API size_t aladin_recall_workspace_bytes(int n_cap);
+ALADIN_API int aladin_recall_ranks(const float* sim, int64_t ld_sim, int n_img, int n_cap, int caps_per_img,
                         int32_t* rank_i2t, int32_t* top1_i2t, int32_t* rank_t2i, int32_t* top1_t2i,
                         void* workspace, void* stream);
+
+/* Top-k lists: for each of n_q queries the indices (out_idx, n_q x k int32, -1 past n_c) and optionally the
+ * scores (out_val, may be NULL) of its k largest candidates M[q * q_stride + c * c_stride], c < n_c, in
+ * descending order, ties -> lower index first.  With M = sim (n_img x n_cap), q_stride = 1, c_stride = ld_sim,
+ * k = 50 it is the `top50` table t2i returns, reference alad/evaluation.py:262,309.  n_c <= 36864. */
+ALADIN_API int aladin_topk(const float* M, int64_t q_stride, int64_t c_stride, int n_q, int n_c, int k, int32_t* out_idx,
+                float* out_val, void* stream);
 
 /* Fused retrieval: the same four outputs as aladin_sim_matrix + aladin_recall_ranks straight from the
  * embeddings, without ever writing the (n_img x n_cap) score matrix (reference
@@ -261,8 +295,8 @@ int aladin_recall_ranks(const float* sim, int64_t ld_sim, int n_img, int n_cap, 
  * scores come from the GEMM kernel itself run on the band of tiles that holds them, and the full GEMM's
  * epilogue counts, per image row and per caption column, the scores that beat them (integer and
  * packed-max atomics: independent of the tile order, bit-identical to the two-step path). */
-size_t aladin_retrieval_workspace_bytes(int n_img, int n_cap, int D);
-int aladin_retrieval_ranks(const float* img, int64_t img_row_stride, const float* cap, int64_t cap_row_stride, int n_img,
+ALADIN_API size_t aladin_retrieval_workspace_bytes(int n_img, int n_cap, int D);
+ALADIN_API int aladin_retrieval_ranks(const float* img, int64_t img_row_stride, const float* cap, int64_t cap_row_stride, int n_img,
                            int n_cap, int D, int caps_per_img, int32_t* rank_i2t, int32_t* top1_i2t, int32_t* rank_t2i,
                            int32_t* top1_t2i, void* workspace, void* stream);
 

@@ -429,6 +429,16 @@ def compute_recall(img_embs, cap_embs):
     return r1, r5, r10, r1i, r5i, r10i, r1 + r5 + r10 + r1i + r5i + r10i
 
 
+def recall_1k_5fold(img_embs, cap_embs):
+    """recall_1k_5fold_test, alad/recall_auxiliary.py:90-130: recall_test on five consecutive 5000-row folds
+    (torch.split(.., 5000), :99-100), the six recalls averaged over the folds (:117-123)."""
+    img_embs, cap_embs = np.asarray(img_embs), np.asarray(cap_embs)
+    res = np.array([compute_recall(img_embs[5000 * k:5000 * (k + 1)], cap_embs[5000 * k:5000 * (k + 1)])[:6] for k in range(5)],
+                   dtype=np.float64)
+    r = [float(v) for v in res.mean(0)]
+    return tuple(r) + (sum(r),)
+
+
 def i2t(images, captions, img_len, cap_len, sim='matching', return_ranks=False,
         aggregation='MrSw'):
     """alad/evaluation.py:158-241.  sim='matching' is the sim_function=None branch (:196, slot-0

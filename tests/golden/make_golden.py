@@ -152,9 +152,98 @@ def gen_eval():
             out['t2i_%s_metrics' % tag] = np.array(m, dtype=np.float64)
             out['t2i_%s_ranks' % tag] = ranks
             out['t2i_%s_top1' % tag] = top50[:, 0]
+            out['t2i_%s_top50' % tag] = top50.astype(np.int16)
     finally:
         torch.Tensor.cuda = saved_cuda
     save('eval_sets', **out)
+
+
+COCO1K = dict(n_img=1000, D=64, seed=71, base_weight=0.36, img_len_range=(20, 60), cap_len_range=(8, 26), n_full=8)
+
+
+def gen_eval_coco1k():
+    """COCO-1k sized alignment-head retrieval (1000 images x 5000 captions, sets padded to 71 positions as
+    encode_data leaves them) through the reference's own i2t / t2i loops with its alignment_sim_fn closure
+    (alad/evaluation.py:158-327, train.py:493-509: cap_batches=5, im_batches=1).  Besides ranks / top
+    lists the file keeps, per query, the smallest gap between a ground-truth score and any competitor in
+    the reference's OWN fp32 scores: queries whose gap is at the level of fp32 rounding are the ones
+    whose rank the reference itself does not resolve (a different summation order moves them)."""
+    import time
+    kw = dict(COCO1K)
+    n_img, D, seed = kw.pop('n_img'), kw.pop('D'), kw.pop('seed')
+    images, captions, img_len, cap_len = synth.eval_sets(n_img, D, seed, **kw)
+    out = dict(n_img=n_img, D=D, seed=seed, images_checksum=synth.checksum(images), captions_checksum=synth.checksum(captions),
+               img_len=np.array(img_len, dtype=np.int16), cap_len=np.array(cap_len, dtype=np.int16),
+               **{'gen_' + k: np.array(v) for k, v in kw.items()})
+    crit = ref_loss.AlignmentContrastiveLoss(aggregation='MrSw')
+    N = 5 * n_img
+    S_i2t = np.zeros((n_img, N), dtype=np.float32)           # rows as i2t sees them (1 image x N/5 captions per call)
+    S_t2i = np.zeros((n_img, N), dtype=np.float32)           # columns as t2i sees them (n_img images x 5 captions per call)
+    state = {'mode': None, 'row': 0, 'chunk': 0, 'col': 0}
+
+    def sim_fn(img, cap, il, cl):
+        with torch.no_grad():
+            sc = crit(img, cap, il, cl, return_loss=False, return_similarity_mat=True)
+        if state['mode'] == 'i2t':
+            w = sc.shape[1]
+            S_i2t[state['row'], state['chunk'] * w:(state['chunk'] + 1) * w] = sc.numpy()[0]
+            state['chunk'] += 1
+            if state['chunk'] == 5:
+                state['chunk'] = 0
+                state['row'] += 1
+        else:
+            S_t2i[:, state['col']:state['col'] + 5] = sc.numpy()
+            state['col'] += 5
+        return sc
+
+    saved_cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        t0 = time.time()
+        state['mode'] = 'i2t'
+        m, (ranks, top1) = ref_eval.i2t(t(images), t(captions), img_len, cap_len, return_ranks=True, sim_function=sim_fn,
+                                        cap_batches=5)
+        print('reference i2t: %.0f s' % (time.time() - t0), m)
+        out['i2t_metrics'] = np.array(m, dtype=np.float64)
+        out['i2t_ranks'] = ranks.astype(np.int16)
+        out['i2t_top1'] = top1.astype(np.int16)
+        t0 = time.time()
+        state['mode'] = 't2i'
+        m, (ranks, top50) = ref_eval.t2i(t(images), t(captions), img_len, cap_len, return_ranks=True, sim_function=sim_fn,
+                                         im_batches=1)
+        print('reference t2i: %.0f s' % (time.time() - t0), m)
+        out['t2i_metrics'] = np.array(m, dtype=np.float64)
+        out['t2i_ranks'] = ranks.astype(np.int16)
+        out['t2i_top10'] = top50[:, :10].astype(np.int16)
+    finally:
+        torch.Tensor.cuda = saved_cuda
+    assert state['row'] == n_img and state['col'] == N
+    print('max |S_i2t - S_t2i| of the reference\'s two call shapes: %.3g' % np.abs(S_i2t - S_t2i).max())
+    # per-query resolution of the reference's own scores
+    cols = np.arange(N)
+    # i2t: rank = min over the 5 ground truths of their positions = #(scores above the LARGEST ground truth), so
+    # only competitors of that one decide the rank
+    gts = S_i2t[np.arange(n_img)[:, None], 5 * np.arange(n_img)[:, None] + np.arange(5)[None, :]]      # (n_img, 5)
+    best = gts.argmax(1)
+    d = np.abs(S_i2t.astype(np.float64) - gts.max(1)[:, None].astype(np.float64))
+    d[np.arange(n_img), 5 * np.arange(n_img) + best] = np.inf
+    gap_i2t = d.min(1)
+    gt = S_t2i[cols // 5, cols]
+    d = np.abs(S_t2i.astype(np.float64) - gt[None, :].astype(np.float64))
+    d[cols // 5, cols] = np.inf
+    gap_t2i = d.min(0)
+    srt = np.sort(S_t2i.astype(np.float64), axis=0)[::-1][:11]               # (11, N)
+    out['t2i_top10_gap'] = (srt[:-1] - srt[1:]).min(0).astype(np.float32)
+    srt = np.sort(S_i2t.astype(np.float64), axis=1)[:, ::-1][:, :2]
+    out['i2t_top1_gap'] = (srt[:, 0] - srt[:, 1]).astype(np.float32)
+    out['i2t_gap'] = gap_i2t.astype(np.float32)
+    out['t2i_gap'] = gap_t2i.astype(np.float32)
+    # a sample of the reference's scores themselves (every 20th image, every 10th caption) for a direct comparison
+    out['S_sample'] = S_i2t[0::20, 0::10].copy()
+    out['S_diag'] = S_i2t[cols // 5, cols].copy()
+    print('gaps below 1e-5: i2t %d, t2i %d; below 1e-6: %d, %d' % ((gap_i2t < 1e-5).sum(), (gap_t2i < 1e-5).sum(),
+                                                                    (gap_i2t < 1e-6).sum(), (gap_t2i < 1e-6).sum()))
+    save('eval_coco1k', **out)
 
 
 # --------------------------------------------------------------------- matching / distillation
@@ -300,11 +389,28 @@ def gen_recall():
         save(name, **out)
 
 
+def gen_recall_5fold():
+    """recall_1k_5fold_test + recall_test (alad/recall_auxiliary.py:72-130) on 25 000 rows = five 5000-row folds."""
+    n_img, D, seed, sigma = 5000, 64, 63, 3.2
+    img, cap = synth.retrieval_embeddings(n_img, D, seed, sigma)
+    out = dict(n_img=n_img, D=D, seed=seed, sigma=sigma, img_checksum=synth.checksum(img), cap_checksum=synth.checksum(cap))
+    out['recall_1k_5fold_test'] = np.array(ref_recall.recall_1k_5fold_test(t(img), t(cap)), dtype=np.float64)
+    out['recall_test_fold0'] = np.array(ref_recall.recall_test(t(img[:5000]), t(cap[:5000]), None, None), dtype=np.float64)
+    save('recall_5fold', **out)
+
+
 if __name__ == '__main__':
+    only = sys.argv[1:]
+    if only:                                   # e.g. `make_golden.py gen_eval_coco1k` regenerates one family
+        for name in only:
+            globals()[name]()
+        sys.exit(0)
     gen_alignment()
     gen_eval()
+    gen_eval_coco1k()
     gen_matching()
     gen_distill()
     gen_order_sim()
     gen_model()
     gen_recall()
+    gen_recall_5fold()

@@ -23,6 +23,21 @@ def test_library_exports_every_declared_symbol():
     assert lib.aladin_version() == _lib.ABI_VERSION
 
 
+def test_library_exports_nothing_but_the_declared_symbols():
+    """The converse: the product library's dynamic symbol table holds the header's entry points and nothing
+    else -- no debug probes, no kernel handles, no C++ helpers (-fvisibility=hidden + csrc/exports.map) -- and
+    reads no environment variable (tuning knobs and timing-only ablation kernels live in the separate
+    libaladin_hip_diag.so, `make -C aladin_amd/csrc diag`)."""
+    import subprocess
+    from aladin_amd import _lib
+    _lib.load()
+    out = subprocess.run(['nm', '-D', '--defined-only', _lib.LIB_PATH], check=True, capture_output=True, text=True).stdout
+    exported = {ln.split()[-1] for ln in out.splitlines() if ln.strip()}
+    assert exported == set(_lib.SYMBOLS), exported ^ set(_lib.SYMBOLS)
+    und = subprocess.run(['nm', '-D', '--undefined-only', _lib.LIB_PATH], check=True, capture_output=True, text=True).stdout
+    assert 'getenv' not in und
+
+
 def test_geometry_headline_and_edges():
     from aladin_amd import _lib, ops
     g = ops.align_geometry(256, 256, 34, 50, 768)
@@ -32,6 +47,10 @@ def test_geometry_headline_and_edges():
     assert (g.mtiles, g.rem, g.tp16) == (3, 0, 6)
     g = ops.align_geometry(3, 7, 3, 5, 8)
     assert (g.Rq, g.Tq, g.mtiles, g.rem, g.tp16, g.Dp) == (2, 2, 1, 0, 1, 64)
+    gs = ops.align_geometry(256, 256, 34, 50, 768, precision='split')          # hi/lo split operands: three K segments per row
+    g = ops.align_geometry(256, 256, 34, 50, 768)
+    assert gs.split == 1 and g.split == 0 and gs.Dp == 3 * g.Dp and gs.xm_bytes == 3 * g.xm_bytes and gs.e_bytes == g.e_bytes
+    assert (gs.xm_rows, gs.xe_rows, gs.y_rows) == (g.xm_rows, g.xe_rows, g.y_rows)
     assert g.Bi_pad % g.img_unit == 0 and g.Bc_pad % g.cap_unit == 0 and g.Bi_pad >= 3 and g.Bc_pad >= 7
     for args in ((1, 1, 1, 50, 8), (1, 1, 34, 3, 8), (0, 1, 34, 50, 8), (1, 1, 200, 50, 8)):
         with pytest.raises(RuntimeError):

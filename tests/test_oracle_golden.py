@@ -182,6 +182,39 @@ def test_eval_i2t_t2i():
         assert np.array_equal(r, g['t2i_%s_ranks' % tag]) and np.array_equal(t1, g['t2i_%s_top1' % tag])
 
 
+def test_recall_1k_5fold():
+    g = load_golden('recall_5fold')
+    from aladin_amd import synth
+    img, cap = synth.retrieval_embeddings(int(g['n_img']), int(g['D']), int(g['seed']), float(g['sigma']))
+    assert abs(synth.checksum(cap) - float(g['cap_checksum'])) <= 1e-6 * abs(float(g['cap_checksum']))
+    close(O.recall_1k_5fold(img, cap), g['recall_1k_5fold_test'], rtol=0, atol=1e-9)
+    close(O.compute_recall(img[:5000], cap[:5000]), g['recall_test_fold0'], rtol=0, atol=1e-9)
+
+
+def test_oracle_on_coco1k_sized_fixture_sample():
+    """eval_coco1k.npz (1000 images x 5000 captions through the reference's own i2t / t2i loops): the oracle is
+    checked on the stored sample of the reference's score matrix (every 20th image x every 10th caption, incl.
+    images that fill the 71-position set) and on a block of its diagonal; at full size the fixture is the
+    checker itself (GPU tier)."""
+    g = load_golden('eval_coco1k')
+    from aladin_amd import synth
+    n_img = int(g['n_img'])
+    images, captions, il, cl = synth.eval_sets(n_img, int(g['D']), int(g['seed']), base_weight=float(g['gen_base_weight']),
+                                               img_len_range=tuple(int(v) for v in g['gen_img_len_range']),
+                                               cap_len_range=tuple(int(v) for v in g['gen_cap_len_range']),
+                                               n_full=int(g['gen_n_full']))
+    assert il == [int(v) for v in g['img_len']] and cl == [int(v) for v in g['cap_len']]
+    assert abs(synth.checksum(captions) - float(g['captions_checksum'])) <= 1e-6 * abs(float(g['captions_checksum']))
+    assert sum(1 for v in il[0::5] if v == 71) == int(g['gen_n_full'])
+    S = O.alignment_scores(images[0::100], captions[0::10], il[0::100], cl[0::10])
+    close(S, g['S_sample'], rtol=2e-6, atol=4e-6)
+    blk = O.alignment_scores(images[0:200:5], captions[0:200], il[0:200:5], cl[0:200])
+    close(blk[np.arange(200) // 5, np.arange(200)], g['S_diag'][:200], rtol=2e-6, atol=4e-6)
+    # the fixture is self-consistent: its metrics follow from its ranks
+    for d in ('i2t', 't2i'):
+        close(O._metrics(g[d + '_ranks'].astype(np.float64)), g[d + '_metrics'][:5], rtol=0, atol=1e-9)
+
+
 @pytest.mark.parametrize('name', ALIGN_GOLDENS)
 def test_scan_sentences_scores(name):
     """aggregation='scan-sentences' (alad/loss.py:136-149): scores for every case (ragged included)."""
