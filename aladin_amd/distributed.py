@@ -21,6 +21,60 @@ import torch
 import torch.distributed as dist
 
 
+class PhaseRecorder:
+    """Device-side timeline of one sharded step, for bench.py --gpus N (config.phases_ms): mark(name) drops an
+    event on the current stream at a phase boundary; summary() gives the mean milliseconds between consecutive
+    marks per phase name.  Collective phases measure what the compute stream WAITED for the exchange (their
+    overlap with scoring is the point of the design), not the wire time."""
+
+    def __init__(self):
+        self.steps = []
+        self._cur = None
+
+    def begin(self):
+        self._cur = [('start', self._event())]
+
+    @staticmethod
+    def _event():
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        return ev
+
+    def mark(self, name):
+        if self._cur is not None:
+            self._cur.append((name, self._event()))
+
+    def end(self):
+        if self._cur is not None:
+            self.steps.append(self._cur)
+            self._cur = None
+
+    def summary(self):
+        torch.cuda.synchronize()
+        tot, order = {}, []
+        for st in self.steps:
+            for (_, e0), (name, e1) in zip(st[:-1], st[1:]):
+                if name not in tot:
+                    tot[name] = 0.0
+                    order.append(name)
+                tot[name] += e0.elapsed_time(e1)
+        n = max(len(self.steps), 1)
+        return {k: round(tot[k] / n, 4) for k in order}
+
+
+_RECORDER = [None]
+
+
+def set_phase_recorder(rec):
+    """Install (or with None remove) a PhaseRecorder that the fast sharded step marks its phases on."""
+    _RECORDER[0] = rec
+
+
+def _mark(name):
+    if _RECORDER[0] is not None:
+        _RECORDER[0].mark(name)
+
+
 def _world(group):
     return dist.get_world_size(group), dist.get_rank(group)
 
@@ -199,8 +253,12 @@ class _ShardedTriplet(torch.autograd.Function):
         T = s.shape[1]
         g_loc, g_glob, ok = _local_and_global_geometry(B, W, R, T, D)
         if not ok:
-            raise ValueError('aladin_amd.distributed: the fast path needs a per-rank batch that is a multiple of 64 '
-                             '(got %d); use sharded_alignment_loss(..., fast=False)' % B)
+            # the gathered packed operands must be the plain concatenation of the per-rank ones: the per-rank batch
+            # has to fill whole image tiles (B % img_unit == 0) and whole 64-row side-operand groups
+            raise ValueError('aladin_amd.distributed: sharded_alignment_loss_fast needs a per-rank batch whose packed '
+                             'image operand concatenates across ranks (B a multiple of 64 covers every shape; got '
+                             'B=%d, tile unit %d); use sharded_alignment_loss(), the composable path, instead'
+                             % (B, g_loc.img_unit))
         im_c = im.contiguous()
         xm, xe = ops.pack_images(im_c, im_len_t, g_loc)
         xm_all = torch.empty(W * xm.numel(), dtype=xm.dtype, device=im.device)
@@ -221,26 +279,38 @@ class _ShardedTriplet(torch.autograd.Function):
         # The local images' block does not need the exchange: score it while the gathers are in flight,
         # then the rank ranges before and after this rank.
         y = ops.pack_captions(s, s_len_t, g_glob)
+        _mark('pack+issue_gathers')
         S_blk = torch.empty((W * B, B), dtype=torch.float32, device=im.device)
         ops.scores_from_packed(xm, xe, y, g_loc, out=S_blk[r * B:(r + 1) * B])
+        _mark('local_block')
         for w_ in gathers:
             w_.wait()
+        _mark('gather_wait')
         rank_scores_rows(xm_all, xe_all, y, S_blk, 0, r, B, R, T, D)
         rank_scores_rows(xm_all, xe_all, y, S_blk, r + 1, W - 1 - r, B, R, T, D)
+        _mark('remote_rows')
         parts = torch.empty((W * S_blk.shape[0], B), dtype=S_blk.dtype, device=im.device)
         dist.all_gather_into_tensor(parts, S_blk, group=group)
+        if work is not None:
+            # The raw-set gather was issued BEFORE the score-block gather on the same communicator, so it has
+            # completed by now: joining it here costs nothing and leaves no collective writing into im_all behind
+            # this call if backward() is never run.
+            work.wait()
+        _mark('S_allgather')
         S_full = parts.view(W, W * B, B).permute(1, 0, 2).reshape(W * B, W * B)
         loss, dS_full, _ = ops._hinge_raw(S_full, margin, max_violation, need)
+        _mark('hinge')
         ctx.exchange = None
         if need and sparse:
             ex = SparseImageExchange(dS_full, B, group)
             im_need = ex.fetch(im_c)
+            _mark('sparse_plan+fetch')
             dS_need = dS_full.index_select(0, ex.need_idx)[:, r * B:(r + 1) * B].contiguous()
             ctx.save_for_backward(im_need, il_all.index_select(0, ex.need_idx), s, s_len_t, dS_need)
             ctx.exchange, ctx.im_shape = ex, tuple(im.shape)
         elif need:
             ctx.save_for_backward(im_all, il_all, s, s_len_t, dS_full, xm_all, xe_all, y)
-            ctx.work, ctx.g_glob, ctx.group = work, g_glob, group
+            ctx.g_glob, ctx.group = g_glob, group
         ctx.mark_non_differentiable(S_full)
         ctx.set_materialize_grads(False)
         return loss, S_full
@@ -253,20 +323,25 @@ class _ShardedTriplet(torch.autograd.Function):
             from . import ops
             im_need, il_need, s, s_len_t, dS_need = ctx.saved_tensors
             gscale = g_loss.to(torch.float32).contiguous()
+            _mark('bwd_start')
             if im_need.shape[0]:
                 d_im_need, d_s = ops._align_backward(im_need, s, il_need, s_len_t, dS_need, gscale=gscale)
             else:                                  # no violation anywhere in this caption block
                 d_im_need, d_s = torch.zeros_like(im_need), torch.zeros_like(s)
-            return ctx.exchange.give_back(d_im_need, ctx.im_shape), d_s, None, None, None, None, None, None
+            _mark('bwd_compute_compact')
+            d_im = ctx.exchange.give_back(d_im_need, ctx.im_shape)
+            _mark('bwd_give_back')
+            return d_im, d_s, None, None, None, None, None, None
         im_all, il_all, s, s_len_t, dS_full, xm_all, xe_all, y = ctx.saved_tensors
         W, r = _world(ctx.group)
-        if ctx.work is not None:
-            ctx.work.wait()
+        _mark('bwd_start')
         d_im_all, d_s = rank_backward_block(im_all, il_all, s, s_len_t, dS_full, r, ctx.g_glob, xm_all, xe_all, y,
                                             gscale=g_loss.to(torch.float32).contiguous())
+        _mark('bwd_compute_dense')
         B = s.shape[0]
         d_im = torch.empty((B,) + tuple(d_im_all.shape[1:]), dtype=d_im_all.dtype, device=d_im_all.device)
         dist.reduce_scatter_tensor(d_im, d_im_all, group=ctx.group)
+        _mark('bwd_reduce_scatter')
         return d_im, d_s, None, None, None, None, None, None
 
 
@@ -276,7 +351,12 @@ def sharded_alignment_loss_fast(im_set, s_seq, im_len, s_len, margin=0.2, max_vi
     fp16 (13 MB per rank at B=256 instead of 27 MB), one fused autograd node, and for the backward
     either the pair-driven SparseImageExchange (max_violation) or the raw all-gather overlapped with
     scoring + reduce-scatter (dense dS); ``exchange`` = 'auto' | 'sparse' | 'dense' overrides the choice.
-    Returns (loss, S_full.detach())."""
+    Returns (loss, S_full.detach()).
+
+    Gradient convention: the loss is the GLOBAL-batch loss, replicated on every rank, and each rank receives
+    d(loss)/d(its own inputs) in full -- the sum over ranks of the per-rank parameter gradients is the
+    single-device gradient.  A data-parallel wrapper that AVERAGES gradients (DistributedDataParallel's default)
+    therefore ends up with 1/W of it: scale the loss by the world size, or reduce with a sum."""
     if exchange not in ('auto', 'sparse', 'dense'):
         raise ValueError("aladin_amd.distributed: exchange must be 'auto', 'sparse' or 'dense'")
     from . import ops

@@ -11,19 +11,23 @@ Inputs are resident in HBM before the timed region.  value = (N*256)^2 pairs / s
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
+Timing protocol (so that a short driver run and a long builder run report the same number):
+  1. clock-settling pre-roll: the step is replayed for --preroll-s seconds (default 1.0) whatever --warmup says
+     -- the chip needs ~0.5 s of load before it holds its working clock;
+  2. W untimed warm-up steps;
+  3. the K-step region (barrier + synchronize on both sides, MAX over ranks) is timed --repeats times
+     (default 5); ms_per_step / value are the MEDIAN region, min / max are in `config`.
 Prints ONE JSON line on rank 0 (see DESIGN.md section "Measurement" for every field).
 """
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-
-import numpy as np
-import torch
 
 B, R, T, D = 256, 34, 50, 768
 FLOPS_PER_PAIR = 2 * (R - 1) * (T - 3) * D           # 2,382,336 (SURVEY.md section 8(d))
@@ -35,22 +39,26 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=2000)
     ap.add_argument('--warmup', type=int, default=200)
+    ap.add_argument('--repeats', type=int, default=5, help='how many times the --steps region is timed (median reported)')
+    ap.add_argument('--preroll-s', type=float, default=1.0, help='clock-settling pre-roll before the warm-up, seconds')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-eval', action='store_true', help='skip the configs[2] (retrieval) secondary timing')
     ap.add_argument('--eager', action='store_true', help='do not capture the step in a HIP graph')
     ap.add_argument('--force-sharded', action='store_true',
                     help='self-test: run the multi-GPU (sharded, RCCL) step even with one rank')
     ap.add_argument('--exchange', default='tune', choices=['tune', 'dense', 'sparse'],
                     help='multi-GPU backward exchange of d(image sets): dense reduce-scatter, pair-driven sparse '
                          'all-to-all, or time both during warm-up and keep the faster (default)')
-    ap.add_argument('--cpu-batch', type=int, default=96, help='batch of the bounded CPU-baseline sample')
     return ap.parse_args()
 
 
-def kernel_roofline(im, s, il, sl, iters=50):
-    """Average duration of the dominant kernel (align_scores_kernel) measured with HIP events on
+def kernel_roofline(im, s, il, sl, groups=5, iters=100):
+    """Average duration of the dominant kernel (align_scores16_kernel) measured with HIP events on
     the stream it is launched on (torch's current stream), on the packed operands of the bench
     batch.  The side GEMM (33rd region of every image, 1/33 of the work, its own kernel) is run
-    once and reused, so each timed launch contracts 32 regions x 47 words x 768 per pair."""
+    once and reused, so each timed launch contracts 32 regions x 47 words x 768 per pair.
+    `groups` event-bracketed groups of `iters` launches; the median group is reported."""
+    import torch
     from aladin_amd import ops
     dev = im.device
     geom = ops.align_geometry(B, B, R, T, D)
@@ -59,31 +67,35 @@ def kernel_roofline(im, s, il, sl, iters=50):
     out = torch.empty((B, B), dtype=torch.float32, device=dev)
     e_scr = torch.empty(geom.e_bytes, dtype=torch.uint8, device=dev)
     ops.scores_from_packed(xm, xe, y, geom, out, e_scr)                       # side GEMM + score kernel
-    for _ in range(5):
+    for _ in range(200):
         ops.scores_from_packed(xm, xe, y, geom, out, e_scr, reuse_side=True)  # score kernel alone
     torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(iters):
-        ops.scores_from_packed(xm, xe, y, geom, out, e_scr, reuse_side=True)
-    e1.record()
-    torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / iters
+    ms_groups = []
+    for _ in range(groups):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            ops.scores_from_packed(xm, xe, y, geom, out, e_scr, reuse_side=True)
+        e1.record()
+        torch.cuda.synchronize()
+        ms_groups.append(e0.elapsed_time(e1) / iters)
+    ms = statistics.median(ms_groups)
     flops = B * B * 2 * 32 * (T - 3) * D
     achieved = flops / (ms * 1e-3) / 1e12
     traffic, src = pmc_traffic('align_scores16_kernel')
-    return {'bound': 'mfma', 'traffic_source': src, 'kernel': 'align_scores16_kernel<true> (256x384 tile, v_mfma_f32_16x16x32_f16)', 'achieved': round(achieved, 2), 'peak': PEAK_TFLOPS,
-            'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_TFLOPS, 4), 'traffic': traffic,
-            'kernel_us': round(ms * 1e3, 2), 'flops_per_launch': flops}
+    return {'bound': 'mfma', 'traffic_source': src, 'kernel': 'align_scores16_kernel<true> (256x384 tile, v_mfma_f32_16x16x32_f16)',
+            'achieved': round(achieved, 2), 'peak': PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_TFLOPS, 4),
+            'traffic': traffic, 'kernel_us': round(ms * 1e3, 2), 'kernel_us_min_max': [round(min(ms_groups) * 1e3, 2), round(max(ms_groups) * 1e3, 2)],
+            'flops_per_launch': flops}
 
 
 def pmc_traffic(kernel_substr):
     """HBM-side bytes per launch of the dominant kernel from the newest committed PMC summary
-    (profiles/*_pmc.json, written by tools/collect_pmc.sh from separate rocprofv3 --pmc passes with
+    (profiles/*_pmc.json, written by tools/materialise_profiles.py from separate rocprofv3 --pmc passes with
     the gfx950 FETCH_SIZE x2 correction).  bench.py cannot run the profiler on itself, so it
     reports the committed measurement and names its file; None if there is none."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc.json')), key=os.path.getmtime)
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc.json')))
     for f in reversed(files):
         try:
             ks = json.load(open(f))['kernels']
@@ -95,28 +107,76 @@ def pmc_traffic(kernel_substr):
     return None, None
 
 
-def cpu_baseline(batch):
-    """The reference's dataflow (oracle/faithful_torch.py) on the host cores, bounded sample."""
+def cpu_baseline():
+    """BASELINE.json configs[0] verbatim: B=16, R=34, T=50, D=768 random tensors through the reference's
+    AlignmentContrastiveLoss dataflow (oracle/faithful_torch.py restates alad/loss.py:79-159 op for op and is
+    pinned to the reference's outputs by tests/test_oracle_golden.py), forward and forward+backward, on the
+    host cores.  Thread counts {8, 32, all} are tried and the BEST is reported (B^2 tiny bmm's oversubscribe
+    a big host).  The faithful B=256 run (SURVEY 8(d) CPU timing plan) takes minutes and ~40 GB: it is a
+    one-off, tools/cpu_baseline_sweep.py, whose committed result is attached as `b256`."""
+    import torch
     sys.path.insert(0, os.path.join(ROOT, 'oracle'))
     import faithful_torch as FT
     from aladin_amd import synth
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
-    im, s, il, sl = synth.alignment_batch(batch, R, T, D, seed=1234, ragged=False)
+    nproc = os.cpu_count() or 1
+    im, s, il, sl = synth.alignment_batch(16, R, T, D, seed=1234, ragged=False)
     a, b = torch.from_numpy(im), torch.from_numpy(s)
-    FT.alignment_triplet_step(a, b, il, sl, 0.2, True)            # warm-up
-    reps, t0 = 0, time.time()
-    while reps < 3 or (time.time() - t0 < 10.0 and reps < 20):
-        FT.alignment_triplet_step(a, b, il, sl, 0.2, True)
-        reps += 1
-    dt = (time.time() - t0) / reps
-    return {'value': round(batch * batch / dt, 1), 'unit': 'pairs/s', 'cores': torch.get_num_threads(), 'kind': 'port',
-            'sample': 'faithful expand+bmm+mask restatement of alad/loss.py:79-159 (oracle/faithful_torch.py), '
-                      'fwd+bwd, B=%d R=34 T=50 D=768 fp32, %d reps, %.3f s/step' % (batch, reps, dt)}
+    sweep = {}
+    for th in sorted({min(8, nproc), min(32, nproc), nproc}):
+        torch.set_num_threads(th)
+        res = {}
+        for tag, bwd in (('fwd', False), ('fwd_bwd', True)):
+            for _ in range(2):
+                FT.alignment_triplet_step(a, b, il, sl, 0.2, True, backward=bwd)       # warm-ups
+            reps, t0 = 0, time.perf_counter()
+            while reps < 10 or (time.perf_counter() - t0 < 1.5 and reps < 200):
+                FT.alignment_triplet_step(a, b, il, sl, 0.2, True, backward=bwd)
+                reps += 1
+            res[tag] = (time.perf_counter() - t0) / reps
+        sweep[th] = res
+    best = min(sweep, key=lambda k: sweep[k]['fwd_bwd'])
+    out = {'value': round(256 / sweep[best]['fwd_bwd'], 1), 'unit': 'pairs/s', 'cores': best, 'kind': 'port',
+           'fwd_only_value': round(256 / min(v['fwd'] for v in sweep.values()), 1), 'host_cores': nproc,
+           'sample': 'BASELINE configs[0] verbatim: B=16 R=34 T=50 D=768 fp32 through the reference dataflow '
+                     '(expand + bmm + masks, oracle/faithful_torch.py), fwd+bwd, >=10 reps after 2 warm-ups, best of threads '
+                     + str(sorted(sweep)) + ': %.1f ms/step at %d threads' % (sweep[best]['fwd_bwd'] * 1e3, best),
+           'sweep_ms': {str(k): {t: round(v * 1e3, 2) for t, v in r.items()} for k, r in sweep.items()}}
+    b256 = os.path.join(ROOT, 'profiles', 'r02_cpu_baseline_b256.json')
+    if os.path.exists(b256):
+        try:
+            out['b256'] = json.load(open(b256))
+        except Exception:
+            pass
+    return out
+
+
+def eval_config3(dev):
+    """Secondary field: BASELINE configs[2] -- 5000 img x 25000 cap x 768 matching-head retrieval, scores + ranks
+    of both directions in one fused pass (aladin_retrieval_ranks; the 500 MB matrix is never written)."""
+    import torch
+    from aladin_amd import ops
+    g = torch.Generator(device='cpu').manual_seed(7)
+    img = torch.nn.functional.normalize(torch.randn(5000, D, generator=g), dim=1).to(dev)
+    cap = torch.nn.functional.normalize(img.repeat_interleave(5, 0) + 0.05 * torch.randn(25000, D, generator=g).to(dev), dim=1)
+    for _ in range(3):
+        ops.retrieval_ranks(img, cap)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        ops.retrieval_ranks(img, cap)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 10
+    return {'workload': 'configs[2]: 5000x25000x768 matching-head retrieval, fused scores + i2t/t2i ranks', 'ms': round(ms, 4),
+            'pairs_per_s': round(5000 * 25000 / (ms * 1e-3), 1), 'tflops_algorithmic': round(2 * 5000 * 25000 * D / (ms * 1e-3) / 1e12, 1)}
 
 
 def main():
     args = parse()
+    # before anything initialises the HIP runtime: the host driver only supports dmabuf IPC
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    import torch
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -128,8 +188,8 @@ def main():
         raise SystemExit('bench.py needs an MI355X (no GPU visible); there is no CPU fallback')
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
-    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     sharded = world > 1 or args.force_sharded
+    dist = None
     if sharded:
         import torch.distributed as dist
         if world == 1:
@@ -141,7 +201,7 @@ def main():
 
     from aladin_amd import synth
     from aladin_amd.loss import AlignmentContrastiveLoss
-    from aladin_amd.distributed import sharded_alignment_loss_fast
+    from aladin_amd import distributed as AD
 
     im_np, s_np, il, sl = synth.alignment_batch(B, R, T, D, seed=1234 + 17 * rank, ragged=False)
     im = torch.from_numpy(im_np).to(dev).requires_grad_(True)
@@ -155,7 +215,7 @@ def main():
         im.grad = None
         s.grad = None
         if sharded:
-            loss, _ = sharded_alignment_loss_fast(im, s, il, sl, 0.2, True, exchange=exchange[0])
+            loss, _ = AD.sharded_alignment_loss_fast(im, s, il, sl, 0.2, True, exchange=exchange[0])
         else:
             loss = crit(im, s, il, sl)
         loss.backward()
@@ -163,9 +223,15 @@ def main():
 
     def fence():
         if sharded:
-            import torch.distributed as dist
             dist.barrier()
         torch.cuda.synchronize()
+
+    def agree_max(x):
+        if not sharded:
+            return x
+        tt = torch.tensor([x], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        return float(tt.item())
 
     # The step is ~10 short launches; eager Python issue time (~0.24 ms) is close to the GPU time, so
     # the step is captured once into a HIP graph (the C ABI neither allocates nor synchronises) and
@@ -195,74 +261,101 @@ def main():
     if sharded and args.exchange == 'tune':
         # Both exchanges give the same gradients (tests/); which is faster depends on the world size and
         # the fabric.  Time a few untimed steps of each, agree on the MAX over ranks, keep the winner.
-        import torch.distributed as dist
         for mode in ('dense', 'sparse'):
             exchange[0] = mode
+            failed, elapsed = 0.0, float('inf')
             try:
                 for _ in range(3):
                     step()
+                torch.cuda.synchronize()
+            except Exception as exc:
+                print('bench: exchange %r failed on rank %d (%s); not used' % (mode, rank, exc), file=sys.stderr)
+                failed = 1.0
+            # every rank learns whether ANY rank failed before the next collective is entered: a rank that
+            # failed mid-step and one that did not would otherwise meet in different collectives and hang
+            if agree_max(failed) == 0.0:
                 fence()
                 t0 = time.perf_counter()
                 for _ in range(8):
                     step()
                 fence()
-                elapsed = time.perf_counter() - t0
-            except Exception as exc:                  # same code on every rank: they fail (or not) together
-                print('bench: exchange %r failed on rank %d (%s); not used' % (mode, rank, exc), file=sys.stderr)
-                elapsed = float('inf')
-            tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            tuned[mode] = float(tt.item()) / 8 * 1e3
+                elapsed = agree_max(time.perf_counter() - t0)
+            tuned[mode] = elapsed / 8 * 1e3
+        if all(v == float('inf') for v in tuned.values()):
+            raise SystemExit('bench: both backward exchanges failed; see stderr')
         exchange[0] = min(tuned, key=tuned.get)
+
+    # 1. clock-settling pre-roll (independent of --warmup)
+    t_pre, n_pre = time.perf_counter(), 0
+    while time.perf_counter() - t_pre < args.preroll_s:
+        for _ in range(50):
+            run()
+        torch.cuda.synchronize()
+        n_pre += 50
+    # 2. warm-up
     for _ in range(args.warmup):
         run()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = run()
-    fence()
-    dt = time.perf_counter() - t0
-    if sharded:
-        import torch.distributed as dist
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-    ms = dt / args.steps * 1e3
+    # 3. the K-step region, `repeats` times
+    region_ms = []
+    loss = None
+    for _ in range(max(1, args.repeats)):
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            loss = run()
+        fence()
+        region_ms.append(agree_max(time.perf_counter() - t0) / args.steps * 1e3)
+    ms = statistics.median(region_ms)
     pairs = (B * world) ** 2
     value = pairs / (ms * 1e-3)
 
+    phases = None
     if sharded:
+        rec = AD.PhaseRecorder()
+        AD.set_phase_recorder(rec)
+        for _ in range(10):
+            rec.begin()
+            step()
+            rec.mark('autograd_tail')
+            rec.end()
+        AD.set_phase_recorder(None)
+        phases = rec.summary()
         # RCCL prints a version banner through C stdio when the communicator comes up; on a pipe it would
         # surface at exit, AFTER the JSON line.  Push it out now so the JSON line is the last line of stdout.
         # Every rank does it, and rank 0 prints only after all of them have (barrier).
         import ctypes
-        import torch.distributed as dist
         sys.stdout.flush()
         ctypes.CDLL(None).fflush(None)
         dist.barrier()
     if rank == 0:
         roof = kernel_roofline(im.detach(), s.detach(), il, sl)
+        cfg = {'workload': 'configs[1]: alignment-head triplet loss forward+backward, B=256 synthetic '
+                           'features per GPU (R=34,T=50,D=768, full lengths)' +
+                           ('' if world == 1 else '; configs[3]: global %dx%d matrix, images all-gathered '
+                            'over RCCL, caption-block sharding' % (B * world, B * world)),
+               'global_pairs_per_step': pairs, 'loss': float(loss.detach()), 'launch': launch,
+               'timing': {'preroll_s': args.preroll_s, 'preroll_steps': n_pre, 'repeats': len(region_ms), 'statistic': 'median',
+                          'ms_per_step_min': round(min(region_ms), 4), 'ms_per_step_max': round(max(region_ms), 4)},
+               'step_tflops_algorithmic': round(value * FLOPS_PER_PAIR / 1e12, 2)}
+        if sharded:
+            cfg['bwd_exchange'] = exchange[0]
+            cfg['bwd_exchange_tuning_ms'] = {k: (round(v, 4) if v != float('inf') else None) for k, v in tuned.items()}
+            cfg['phases_ms'] = phases          # rank 0's device timeline of one step (10-step mean), see PhaseRecorder
+        if world == 1 and not args.no_eval:
+            try:
+                cfg['eval_config3'] = eval_config3(dev)
+            except Exception as exc:
+                cfg['eval_config3'] = {'error': str(exc)}
         out = {
             'metric': 'alignment image-text pairs/sec (BxB scores, triplet loss fwd+bwd) at B=256/GPU,R=34,T=50,D=768',
             'value': round(value, 1), 'unit': 'pairs/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(ms, 4), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f16', 'data': 'synthetic',
-            'config': {'workload': 'configs[1]: alignment-head triplet loss forward+backward, B=256 synthetic '
-                                   'features per GPU (R=34,T=50,D=768, full lengths)' +
-                                   ('' if world == 1 else '; configs[3]: global %dx%d matrix, images all-gathered '
-                                    'over RCCL, caption-block sharding' % (B * world, B * world)),
-                       'global_pairs_per_step': pairs, 'loss': float(loss.detach()), 'launch': launch,
-                       **({} if not sharded else {'bwd_exchange': exchange[0],
-                                                  'bwd_exchange_tuning_ms': {k: (round(v, 4) if v != float('inf') else None)
-                                                                             for k, v in tuned.items()}}),
-                       'step_tflops_algorithmic': round(value * FLOPS_PER_PAIR / 1e12, 2)},
-            'roofline': roof,
+            'dtype': 'f16', 'data': 'synthetic', 'config': cfg, 'roofline': roof,
         }
         if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(args.cpu_batch)
+            out['cpu_baseline'] = cpu_baseline()
         print(json.dumps(out), flush=True)
     if sharded:
-        import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()
 

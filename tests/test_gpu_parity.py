@@ -586,8 +586,8 @@ def test_alignment_head_retrieval_coco1k(eval_precision):
     # top lists
     ok = g['i2t_top1_gap'] > TAU
     np.testing.assert_array_equal(t1_i[ok], g['i2t_top1'].astype(np.float64)[ok])
-    ok = g['t2i_top10_gap'] > TAU
-    assert ok.mean() > 0.99
+    ok = g['t2i_top10_gap'] > TAU                                   # ten gaps per caption: ~1 % of the captions have a close pair
+    assert ok.mean() > 0.98
     np.testing.assert_array_equal(top50[ok, :10], g['t2i_top10'].astype(np.float64)[ok])
     # the scores themselves against a sample of the reference's matrix and its diagonal
     S = E.compute_sim_matrix(images_d[0::5], captions_d, il[0::5], cl, mode='alignment').cpu().numpy()
