@@ -202,7 +202,17 @@ __global__ __launch_bounds__(256) void bwd_pair_argmax16_kernel(
     f32x16 acc[1][1];
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[0][0][r] = 0.f;
-    gemm_mainloop<PairCfg, PAIR_STAGES>(a1, y + by * Dp, Dp, Dp / 64, pair_smem, acc, a2, 32);
+    // pieces nobody reads are not fetched: of the 32-row side segment only the 8-row piece(s) holding image i's
+    // rem rows, of the 64 word rows only those overlapping the caption's [co, co + tpad).  A wave's piece c covers
+    // rows 8 * (wave + 4c) of the stage: c = 0 main regions, c = 1 side segment, c = 2 / 3 word rows 8w.. / 32 + 8w..
+    uint32_t skip = 0;
+    {
+      const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+      if (!rem || wv < (eo >> 3) || wv > ((eo + rem - 1) >> 3)) skip |= 2u;
+      if (8 * wv + 8 <= co || 8 * wv >= co + tpad) skip |= 4u;
+      if (32 + 8 * wv + 8 <= co || 32 + 8 * wv >= co + tpad) skip |= 8u;
+    }
+    gemm_mainloop<PairCfg, PAIR_STAGES>(a1, y + by * Dp, Dp, Dp / 64, pair_smem, acc, a2, 32, skip);
     __syncthreads();                                   // ring no longer read: re-use it as blk
     {
       const int w = wn * 32 + l5 - co;
@@ -362,7 +372,9 @@ __global__ __launch_bounds__(256) void bwd_rows_kernel(
   __shared__ int lst_p[4][ROWS_LIST];
   __shared__ float lst_g[4][ROWS_LIST];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int64_t row = (int64_t)blockIdx.x * 4 + wave;
+  // XCD-compact row order: the rows of one sample gather from the same few partner samples, so they should meet in
+  // ONE L2 (workgroups are dealt round-robin over the 8 XCDs; xcd_remap hands each XCD a contiguous range of rows)
+  const int64_t row = (int64_t)xcd_remap(blockIdx.x, gridDim.x) * 4 + wave;
   const int64_t n_im_rows = (int64_t)Bi * R;
   if (row >= n_im_rows + (int64_t)Bc * T) return;
   const bool is_img = row < n_im_rows;

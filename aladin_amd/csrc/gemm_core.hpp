@@ -47,12 +47,16 @@ __device__ __forceinline__ uint32_t stage_lane_offset(int64_t ldk, int wave, int
   return (uint32_t)(((int64_t)r * ldk + logical * 8) * 2);
 }
 
+// skip (wave-uniform bit mask over this wave's pieces c = 0 .. CHUNKS_PER_WAVE-1): pieces whose rows nobody reads are
+// not fetched (the backward pair kernel: most of the 32-row side segment, the rows past a 48-word caption);
+// their LDS rows keep stale data, which only reaches accumulator rows / columns that are never looked at.
 template <class Cfg, int C0 = 0, int C1 = Cfg::CHUNKS_PER_WAVE>
 __device__ __forceinline__ void gemm_stage(const half_t* __restrict__ a_rows, const half_t* __restrict__ a_rows2, int a_split,
                                            const half_t* __restrict__ b_rows, int64_t ldk, int kt, char* stage, int wave,
-                                           uint32_t lane_off) {
+                                           uint32_t lane_off, uint32_t skip = 0) {
 #pragma unroll
   for (int c = C0; c < C1; ++c) {
+    if ((skip >> c) & 1u) continue;
     const int chunk = wave + c * Cfg::NWAVES;              // wave-uniform
     const int row0 = chunk * 8;
     const half_t* base;
@@ -109,8 +113,10 @@ __device__ __forceinline__ void wait_vmcnt(int n) {
 template <class Cfg, int NS = 2, bool SPREAD = false, int ABLATE = 0, bool PIPE = false, bool PRIO = false>
 __device__ __forceinline__ void gemm_mainloop(const half_t* __restrict__ a_rows, const half_t* __restrict__ b_rows,
                                               int64_t ldk, int ktiles, char* smem, f32x16 (&acc)[Cfg::WM][Cfg::WN],
-                                              const half_t* __restrict__ a_rows2 = nullptr, int a_split = Cfg::BM) {
+                                              const half_t* __restrict__ a_rows2 = nullptr, int a_split = Cfg::BM,
+                                              uint32_t skip = 0) {
   static_assert(NS >= 2 && Cfg::CHUNKS_PER_WAVE * (NS - 2) <= 32, "ring too deep for the vmcnt dispatcher");
+  const int n_issued = Cfg::CHUNKS_PER_WAVE - __builtin_popcount(skip);       // LDS-DMA instructions per wave and K step
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   const int wm = wave / Cfg::WGN, wn = wave % Cfg::WGN;
@@ -120,15 +126,15 @@ __device__ __forceinline__ void gemm_mainloop(const half_t* __restrict__ a_rows,
 
 #pragma unroll
   for (int st = 0; st < NS - 1; ++st)
-    if (st < ktiles) gemm_stage<Cfg>(a_rows, a_rows2, a_split, b_rows, ldk, st, smem + st * Cfg::STAGE_BYTES, wave, lane_off);
+    if (st < ktiles) gemm_stage<Cfg>(a_rows, a_rows2, a_split, b_rows, ldk, st, smem + st * Cfg::STAGE_BYTES, wave, lane_off, skip);
   for (int kt = 0; kt < ktiles; ++kt) {
     const int ahead = ktiles - 1 - kt;                                   // groups issued after step kt's
-    wait_vmcnt(Cfg::CHUNKS_PER_WAVE * (ahead < NS - 2 ? ahead : NS - 2));
+    wait_vmcnt(n_issued * (ahead < NS - 2 ? ahead : NS - 2));
     __builtin_amdgcn_s_barrier();
     const char* cur = smem + (kt % NS) * Cfg::STAGE_BYTES;
     const bool refill = (ABLATE != 1) && (kt + NS - 1 < ktiles);      // ABLATE 1: timing-only build without refills
     char* nxt = smem + ((kt + NS - 1) % NS) * Cfg::STAGE_BYTES;
-    if (!SPREAD && refill) gemm_stage<Cfg>(a_rows, a_rows2, a_split, b_rows, ldk, kt + NS - 1, nxt, wave, lane_off);
+    if (!SPREAD && refill) gemm_stage<Cfg>(a_rows, a_rows2, a_split, b_rows, ldk, kt + NS - 1, nxt, wave, lane_off, skip);
     if constexpr (PIPE && Cfg::WM == 2 && Cfg::WN >= 4) {
       // Software-pipelined 16-deep steps.  Step kk runs the four MFMAs on (a0,a1) x (b0,b1) first;
       // b0,b1 are then dead and are refilled with step kk+1's values together with a second pair

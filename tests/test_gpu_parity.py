@@ -1118,6 +1118,83 @@ def test_sharded_fast_path_rank_logic_emulated_world3():
     np.testing.assert_allclose(torch.cat(d_caps).cpu().numpy(), b.grad.cpu().numpy(), rtol=1e-5, atol=1e-8)
 
 
+def test_config3_per_rank_block_and_eight_emulated_ranks(eval_precision):
+    """BASELINE configs[3] as far as one GPU goes: per-GPU B=256, world 8 -> global 2048 x 2048.
+    (1) the block a rank really scores -- all 2048 images x its 256 captions, D=768 -- against the oracle;
+    (2) every one of the 8 ranks' pure pieces of the fast sharded step (aladin_amd.distributed), driven on this
+        one GPU with concatenation standing in for the all-gather and a sum for the reduce-scatter: the eight
+        column blocks are BIT-EQUAL to the single-device 2048 x 2048 matrix, the loss is bit-equal, and the
+        summed gradients (dense exchange and pair-driven compact exchange) equal the single-device ones."""
+    if eval_precision != 'fp16':
+        pytest.skip('differentiable path: fp16 operands either way; run once')
+    from aladin_amd import distributed as DD, ops, synth
+    from aladin_amd.loss import AlignmentContrastiveLoss
+    W, B, R, Tn, D = 8, 256, 34, 50, 768
+    d = dev()
+    parts = [synth.alignment_batch(B, R, Tn, D, seed=1234 + 17 * r, ragged=True) for r in range(W)]     # bench.py's per-rank seeds
+    im = np.concatenate([p[0] for p in parts])
+    s = np.concatenate([p[1] for p in parts])
+    il = [v for p in parts for v in p[2]]
+    sl = [v for p in parts for v in p[3]]
+    g_loc, g_glob, ok = DD._local_and_global_geometry(B, W, R, Tn, D)
+    assert ok and (g_glob.Bi, g_glob.Bc) == (W * B, B)
+    ims = [T(p[0]) for p in parts]
+    caps = [T(p[1]) for p in parts]
+    ilt = [ops.lengths_tensor(p[2], d) for p in parts]
+    slt = [ops.lengths_tensor(p[3], d) for p in parts]
+    packs = [ops.pack_images(ims[r], ilt[r], g_loc) for r in range(W)]
+    xm_all, xe_all = torch.cat([p[0] for p in packs]), torch.cat([p[1] for p in packs])
+    il_all, im_all = torch.cat(ilt), torch.cat(ims)
+    blocks = [DD.rank_scores_block(xm_all, xe_all, caps[r], slt[r], g_glob) for r in range(W)]
+    # (1) rank 3's real block against the oracle (1.25 TFLOP on the host), fp16 tolerance; and in split precision
+    r0 = 3
+    ref_blk = O.alignment_scores(im, s[r0 * B:(r0 + 1) * B], il, sl[r0 * B:(r0 + 1) * B])
+    assert_scores_close(blocks[r0][0].cpu().numpy(), ref_blk)
+    with torch.no_grad():
+        S_split = ops.alignment_scores(im_all, caps[r0], il, sl[r0 * B:(r0 + 1) * B], precision='split')
+    np.testing.assert_allclose(S_split.cpu().numpy(), ref_blk, rtol=0, atol=3e-5)       # the oracle itself is fp32 here
+    # (2a) overlapped form == one launch, for every rank
+    for r in range(W):
+        y = blocks[r][1]
+        S_blk = torch.full((W * B, B), float('nan'), device=d)
+        ops.scores_from_packed(packs[r][0], packs[r][1], y, g_loc, out=S_blk[r * B:(r + 1) * B])
+        DD.rank_scores_rows(xm_all, xe_all, y, S_blk, 0, r, B, R, Tn, D)
+        DD.rank_scores_rows(xm_all, xe_all, y, S_blk, r + 1, W - 1 - r, B, R, Tn, D)
+        assert torch.equal(S_blk, blocks[r][0])
+    # (2b) the eight column blocks are the single-device matrix, bit for bit; same loss
+    S_full = torch.cat([b[0] for b in blocks], dim=1)
+    a, b = T(im).requires_grad_(True), T(s).requires_grad_(True)
+    ref_loss, ref_S = AlignmentContrastiveLoss(0.2, 'dot', True, 'MrSw')(a, b, il, sl, return_similarity_mat=True)
+    ref_loss.backward()
+    assert torch.equal(S_full, ref_S.detach())
+    loss, dS_full, _ = ops._hinge_raw(S_full, 0.2, True, True)
+    assert torch.equal(loss, ref_loss.detach())
+    assert int((dS_full != 0).sum()) <= 3 * W * B
+    # (2c) dense exchange: every rank's contribution to d(all image sets), summed
+    d_im_all = torch.zeros_like(im_all)
+    d_caps = []
+    for r in range(W):
+        gi, gs = DD.rank_backward_block(im_all, il_all, caps[r], slt[r], dS_full, r, g_glob, xm_all, xe_all, blocks[r][1])
+        d_im_all += gi
+        d_caps.append(gs)
+    scale = float(a.grad.abs().max())
+    np.testing.assert_allclose(d_im_all.cpu().numpy(), a.grad.cpu().numpy(), rtol=1e-5, atol=1e-6 * scale)
+    np.testing.assert_allclose(torch.cat(d_caps).cpu().numpy(), b.grad.cpu().numpy(), rtol=1e-5, atol=1e-6 * scale)
+    # (2d) pair-driven exchange: each rank differentiates its block against ONLY the image sets it pairs with
+    d_im_sp = torch.zeros_like(im_all)
+    needed = []
+    for r in range(W):
+        blk = dS_full[:, r * B:(r + 1) * B]
+        need = torch.nonzero((blk != 0).any(dim=1)).flatten()
+        needed.append(int(need.numel()))
+        gi, gs = ops._align_backward(im_all.index_select(0, need), caps[r], il_all.index_select(0, need), slt[r],
+                                     blk.index_select(0, need).contiguous())
+        d_im_sp.index_add_(0, need, gi)
+        np.testing.assert_allclose(gs.cpu().numpy(), d_caps[r].cpu().numpy(), rtol=1e-5, atol=1e-6 * scale)
+    assert max(needed) < 0.5 * W * B, needed                      # ~600 of 2048 sets per caption block
+    np.testing.assert_allclose(d_im_sp.cpu().numpy(), a.grad.cpu().numpy(), rtol=1e-5, atol=1e-6 * scale)
+
+
 @pytest.mark.parametrize('W,mv', [(4, True), (2, False)])
 def test_sharded_sparse_exchange_compact_backward_emulated(W, mv):
     """What each rank does under SparseImageExchange, emulated on one GPU: differentiate its caption

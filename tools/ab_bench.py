@@ -30,7 +30,7 @@ def main():
         for name, path in libs:
             env = dict(os.environ, ALADIN_LIB=os.path.abspath(path))
             out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', str(args.steps), '--warmup',
-                                  str(max(10, args.steps // 10)), '--no-cpu-baseline'], env=env, capture_output=True, text=True)
+                                  str(max(10, args.steps // 10)), '--no-cpu-baseline', '--no-eval', '--repeats', '3'], env=env, capture_output=True, text=True)
             line = [l for l in out.stdout.splitlines() if l.startswith('{')]
             if not line:
                 print(name, 'FAILED', out.stderr[-300:])
