@@ -3,10 +3,11 @@ criteria of aladin_amd.loss.
 
 Scope: `forward`, `forward_loss` and the attribute protocol
 (`logger`, `Eiters`, `losses_types`, `losses_weights`, `*_criterion`, `distillation_loss`) are
-re-stated; the VinVL/Oscar backbone (`JointTextImageTransformerEncoder`, alad_model.py:29-247) is
-host PyTorch code outside the hot path and is INJECTED as `encoder` -- any module returning the
-reference's 7-tuple (img_glob (B,D), cap_glob (B,D), img_set (R,B,D), cap_seq (T,B,D), img_len,
-cap_len, reg_loss).  `StandInEncoder` is a random-init substitute used by smoke tests and bench.
+re-stated; the encoder (`JointTextImageTransformerEncoder`, alad_model.py:29-247) is host PyTorch
+code: aladin_amd/encoder.py provides it -- matching head `final_projection_net` included -- around
+an INJECTED VinVL/Oscar `backbone` (the BERT itself is out of scope), or any `encoder` module returning
+the reference's 7-tuple (img_glob (B,D), cap_glob (B,D), img_set (R,B,D), cap_seq (T,B,D), img_len,
+cap_len, reg_loss) can be passed.  `StandInEncoder` is a headless random-init test stub.
 """
 import torch
 from torch import nn
@@ -15,8 +16,15 @@ from .loss import AlignmentContrastiveLoss, ContrastiveLoss, DistillationLoss, l
 
 
 class ALADModel(nn.Module):
-    def __init__(self, config, oscar_checkpoint=None, encoder=None):
+    def __init__(self, config, oscar_checkpoint=None, encoder=None, backbone=None):
+        """encoder: any module with the 7-tuple contract of JointTextImageTransformerEncoder; or backbone: the
+        VinVL/Oscar model (anything with the `.bert(...)` call of alad_model.py:129,139), around which
+        aladin_amd.encoder.JointTextImageTransformerEncoder -- matching head included -- is built here as
+        the reference does at :259."""
         super().__init__()
+        if encoder is None and backbone is not None:
+            from .encoder import JointTextImageTransformerEncoder
+            encoder = JointTextImageTransformerEncoder(config, backbone)
         self.img_txt_enc = encoder                                   # alad_model.py:259 (injected here)
         training = config['training']
         self.losses_types = training['loss-type'].split('-')          # :265

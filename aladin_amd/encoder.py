@@ -1,0 +1,148 @@
+"""The step immediately before the hot path: the matching head
+`final_projection_net` and the hand-off from the backbone to the 7-tuple the loss heads consume.
+
+    JointTextImageTransformerEncoder   <- alad/alad_model.py:29-247 for the model section every shipped YAML
+                                          uses (teran-layers 0, no depth aggregation, post-layers 0): the
+                                          backbone's last hidden states are sliced to the batch maxima
+                                          (:174-175), run through the 2-layer nn.TransformerEncoder matching
+                                          head with key-padding masks (:104-108, :231-233), slot 0 is taken,
+                                          sets are F.normalize'd and globals l2norm'd (:237-241)
+    slot0_transformer                  the head evaluated for what the model consumes -- output row 0 only
+
+The VinVL / Oscar BERT itself (`oscar/modeling/modeling_bert.py:150-279` over the un-vendored
+`transformers@067923d`) stays out of scope: it is INJECTED as `backbone`, any module with the
+`.bert(input_ids=, attention_mask=, token_type_ids=, img_feats=) -> (sequence_output, ...)` call the reference
+makes (alad_model.py:129,139).  `StandInBackbone` is a random-init substitute with that call surface for smoke
+tests; it is not a model of VinVL ("parity unpinned" for the backbone).
+
+This module is host code on PyTorch-ROCm (north_star: "host code stays Python on PyTorch-ROCm for the
+backbone"); parameter names equal the reference's, so `img_txt_enc.final_projection_net.*` entries of a
+reference checkpoint load unchanged.  Only `l2norm` runs in this package's HIP kernels.
+"""
+import torch
+from torch import nn
+from torch.nn import functional as F
+
+
+def _layer_full(layer, x, pad_mask):
+    """One post-norm nn.TransformerEncoderLayer (the reference's: relu, norm_first=False, batch_first=False) on
+    the whole (S, B, D) sequence, written out so that it never takes torch's inference fast path (whose
+    nested-tensor form zeroes padded rows): x = LN1(x + drop(SA(x))); x = LN2(x + drop(W2 drop(relu(W1 x))))."""
+    a = layer.self_attn(x, x, x, key_padding_mask=pad_mask, need_weights=False)[0]
+    x = layer.norm1(x + layer.dropout1(a))
+    f = layer.linear2(layer.dropout(F.relu(layer.linear1(x))))
+    return layer.norm2(x + layer.dropout2(f))
+
+
+def _layer_row0(layer, x, pad_mask):
+    """The same layer evaluated for OUTPUT ROW 0 only -> (B, D).  Keys and values still come from every
+    position, but the query projection, the attention rows, the output projection, both LayerNorms and the
+    feed-forward block are computed for slot 0 alone: 1/S of the layer's work past the K/V projection, which
+    is all the model reads of the last layer (alad_model.py:231-233 take `[0]`)."""
+    mha = layer.self_attn
+    S, B, D = x.shape
+    H, hd = mha.num_heads, D // mha.num_heads
+    w, b = mha.in_proj_weight, mha.in_proj_bias
+    q = F.linear(x[0], w[:D], b[:D])                                   # (B, D)
+    kv = F.linear(x, w[D:], b[D:])                                     # (S, B, 2D)
+    k, v = kv[..., :D], kv[..., D:]
+    q = q.view(B, H, hd) * (hd ** -0.5)
+    k = k.reshape(S, B, H, hd)
+    v = v.reshape(S, B, H, hd)
+    att = torch.einsum('bhd,sbhd->bhs', q, k)
+    if pad_mask is not None:
+        att = att.masked_fill(pad_mask[:, None, :], float('-inf'))
+    att = F.dropout(torch.softmax(att, dim=-1), p=mha.dropout, training=layer.training)
+    ctx = torch.einsum('bhs,sbhd->bhd', att, v).reshape(B, D)
+    a = mha.out_proj(ctx)
+    y = layer.norm1(x[0] + layer.dropout1(a))
+    f = layer.linear2(layer.dropout(F.relu(layer.linear1(y))))
+    return layer.norm2(y + layer.dropout2(f))
+
+
+def slot0_transformer(encoder, x, pad_mask):
+    """`encoder(x, src_key_padding_mask=pad_mask)[0]` for an nn.TransformerEncoder built as the reference builds
+    its heads (alad_model.py:104-108): all layers but the last on the full sequence, the last one for row 0."""
+    layers = list(encoder.layers)
+    for layer in layers[:-1]:
+        x = _layer_full(layer, x, pad_mask)
+    out = _layer_row0(layers[-1], x, pad_mask)
+    return encoder.norm(out) if encoder.norm is not None else out
+
+
+def _pad_mask(lengths, max_len, device):
+    """True at padded positions (alad_model.py:152-160), built on the device without the per-sample Python loop."""
+    lens = torch.as_tensor([int(v) for v in lengths], device=device)
+    return torch.arange(max_len, device=device)[None, :] >= lens[:, None]
+
+
+class JointTextImageTransformerEncoder(nn.Module):
+    """reference alad/alad_model.py:29-247, for the configurations the shipped YAMLs select.
+
+    forward(examples_imgs, examples_txts) takes the reference's collated tuples
+        examples_txts = (input_ids, attention_mask, token_type_ids, <unused>, cap_len)
+        examples_imgs = (input_ids, attention_mask, token_type_ids, img_feats, <unused>, feat_len)
+    and returns (img_glob (B,D), cap_glob (B,D), img_set (R,B,D), cap_seq (T,B,D), feat_len, cap_len, reg_loss)."""
+
+    def __init__(self, config, backbone):
+        super().__init__()
+        m = config['model']
+        if m.get('teran-layers', 0) != 0 or m.get('post-layers', 0) != 0 or m.get('depth-aggregation-alignment') \
+                or m.get('depth-aggregation-matching') or m.get('depth-aggregation'):
+            raise NotImplementedError('aladin_amd: only the model section of the shipped configs is provided '
+                                      '(teran-layers 0, post-layers 0, no depth aggregation; alad/configs/*.yaml:10-16)')
+        self.oscar_model = backbone                                   # alad_model.py:43 (injected instead of from_pretrained)
+        self.freeze_teran = m.get('freeze-teran', False)
+        embed_size = m['embed-size']
+        self.embed_size = embed_size
+        layer = nn.TransformerEncoderLayer(d_model=embed_size, nhead=4, dim_feedforward=embed_size, dropout=m['dropout'])
+        self.final_projection_net = nn.TransformerEncoder(layer, num_layers=m['tern-layers'], enable_nested_tensor=False)      # :104-108
+        self.l1_regularization = 'regularizehidden' in config['training']['loss-type']
+        if self.l1_regularization:
+            raise NotImplementedError("aladin_amd: 'regularizehidden' needs the backbone's hidden states (alad_model.py:222-227)")
+
+    def forward(self, examples_imgs, examples_txts):
+        from .loss import l2norm
+        with torch.set_grad_enabled(torch.is_grad_enabled() and not self.freeze_teran):        # :121-123
+            txt_out = self.oscar_model.bert(input_ids=examples_txts[0], attention_mask=examples_txts[1],
+                                            token_type_ids=examples_txts[2], img_feats=None)
+            img_out = self.oscar_model.bert(input_ids=examples_imgs[0], attention_mask=examples_imgs[1],
+                                            token_type_ids=examples_imgs[2], img_feats=examples_imgs[3])
+        cap_len, feat_len = examples_txts[4], examples_imgs[5]
+        n_tok = examples_txts[0].shape[1]                              # max_language_token_len (:147)
+        max_cap, max_img = max(cap_len), max(feat_len)
+        dev = txt_out[0].device
+        txt_mask, img_mask = _pad_mask(cap_len, max_cap, dev), _pad_mask(feat_len, max_img, dev)
+        c_emb = txt_out[0][:, :max_cap].permute(1, 0, 2)               # (T, B, D)   :174
+        i_emb = img_out[0][:, n_tok:n_tok + max_img].permute(1, 0, 2)  # (R, B, D)   :175
+        cap_glob = slot0_transformer(self.final_projection_net, c_emb, txt_mask)     # :231-233
+        img_glob = slot0_transformer(self.final_projection_net, i_emb, img_mask)
+        img_set = F.normalize(i_emb, p=2, dim=2)                       # :237-238 (teran-layers 0: the sets are the backbone's)
+        cap_seq = F.normalize(c_emb, p=2, dim=2)
+        return l2norm(img_glob), l2norm(cap_glob), img_set, cap_seq, feat_len, cap_len, 0      # :240-247
+
+
+class StandInBackbone(nn.Module):
+    """Random-init substitute with the call surface of `ImageBertForSequenceClassification.bert`
+    (oscar/modeling/modeling_bert.py:150-279): word embeddings for the token ids, a linear map of the
+    2054-wide region features appended after them, LayerNorm; returns (sequence_output,).  It exists so that
+    the head and ALADModel.forward can be driven end to end at the shipped shapes without the VinVL checkpoint
+    -- it is NOT a model of the backbone."""
+
+    def __init__(self, hidden=768, feat_dim=2054, vocab=30522, seed=0):
+        super().__init__()
+        g = torch.Generator().manual_seed(seed)
+        self.word = nn.Embedding(vocab, hidden)
+        self.img = nn.Linear(feat_dim, hidden)
+        self.norm = nn.LayerNorm(hidden)
+        with torch.no_grad():
+            self.word.weight.copy_(torch.randn(vocab, hidden, generator=g))
+            self.img.weight.copy_(torch.randn(hidden, feat_dim, generator=g) / feat_dim ** 0.5)
+            self.img.bias.zero_()
+        self.bert = self._bert
+
+    def _bert(self, input_ids, attention_mask=None, token_type_ids=None, img_feats=None):
+        x = self.word(input_ids)
+        if img_feats is not None:
+            x = torch.cat([x, self.img(img_feats)], dim=1)
+        return (self.norm(x),)

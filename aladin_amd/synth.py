@@ -130,6 +130,22 @@ def eval_sets(n_img, D=64, seed=31, L=71, base_weight=0.25, sigma=3.0, img_len_r
     return images, captions, [int(v) for v in np.repeat(img_len, 5)], [int(v) for v in cap_len]
 
 
+def module_parameters(named_shapes, seed, scale=0.03):
+    """Deterministic values for a module's parameters, keyed by name: {name: float32 array}.  Matrices ~N(0, scale^2),
+    biases ~N(0, (scale/3)^2), LayerNorm gains (names ending in 'norm1.weight' / 'norm2.weight' / 'norm.weight') 1 + 0.1 N(0,1).
+    Used to give the matching head identical weights in the golden generator and in the tests."""
+    out = {}
+    for k, (name, shape) in enumerate(named_shapes):
+        z = normal(tuple(shape), seed + 131 * k)
+        if name.endswith('weight') and 'norm' in name.split('.')[-2]:
+            out[name] = (1.0 + 0.1 * z).astype(np.float32)
+        elif name.endswith('bias'):
+            out[name] = (scale / 3.0 * z).astype(np.float32)
+        else:
+            out[name] = (scale * z).astype(np.float32)
+    return out
+
+
 def checksum(a):
     """Order-sensitive float64 checksum used to pin the generator inside golden files."""
     a = np.asarray(a, dtype=np.float64).ravel()

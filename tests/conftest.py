@@ -46,3 +46,30 @@ SQUARE_ALIGN_GOLDENS = [n for n in ALIGN_GOLDENS if n != 'align_rect']
 @pytest.fixture(scope='session')
 def golden():
     return load_golden
+
+
+def matching_head_case(g, device):
+    """Inputs, weights and upstream gradients of tests/golden/matching_head.npz (see make_golden.gen_matching_head):
+    -> (encoder with the golden's head weights and a fake backbone, txt_seq, img_seq, cap_len, feat_len, n_tok, w)."""
+    import torch
+    from aladin_amd import synth
+    from aladin_amd.encoder import JointTextImageTransformerEncoder
+    D, B, n_tok, n_reg, seed = (int(g[k]) for k in ('D', 'B', 'n_tok', 'n_reg', 'seed'))
+    cap_len, feat_len = [int(v) for v in g['cap_len']], [int(v) for v in g['feat_len']]
+    a = torch.from_numpy(synth.normal((B, n_tok, D), seed)).to(device).requires_grad_(True)
+    b = torch.from_numpy(synth.normal((B, n_tok + n_reg, D), seed + 1)).to(device).requires_grad_(True)
+
+    class FakeBackbone(torch.nn.Module):
+        def bert(self, input_ids, attention_mask, token_type_ids, img_feats):
+            return (a,) if img_feats is None else (b,)
+    cfg = {'model': {'embed-size': D, 'teran-layers': 0, 'tern-layers': 2, 'post-layers': 0, 'dropout': 0.1,
+                     'shared-transformer': True}, 'training': {'loss-type': 'alignment-distillation', 'measure': 'dot'}}
+    enc = JointTextImageTransformerEncoder(cfg, FakeBackbone()).to(device).eval()
+    named = [(n, tuple(p.shape)) for n, p in enc.final_projection_net.named_parameters()]
+    vals = synth.module_parameters(named, seed + 7)
+    with torch.no_grad():
+        for n, p in enc.final_projection_net.named_parameters():
+            p.copy_(torch.from_numpy(vals[n]))
+    shapes = [(B, D), (B, D), (max(feat_len), B, D), (max(cap_len), B, D)]
+    w = [torch.from_numpy(synth.normal(sh, seed + 20 + k)).to(device) for k, sh in enumerate(shapes)]
+    return enc, a, b, cap_len, feat_len, n_tok, w

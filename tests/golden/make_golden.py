@@ -373,6 +373,62 @@ def gen_model():
     save('model_forward', **out)
 
 
+# ------------------------------------------------------------ matching head + encoder hand-off
+def gen_matching_head():
+    """The reference's OWN JointTextImageTransformerEncoder.forward (alad/alad_model.py:119-247) driven with a fake
+    backbone that returns prepared hidden states: pins the slicing to the batch maxima, the key-padding masks, the
+    2-layer nn.TransformerEncoder matching head (d 768, nhead 4, ffn 768), slot 0, F.normalize / l2norm -- forward
+    values and gradients w.r.t. the backbone's outputs and the head's parameters (eval mode: dropout off)."""
+    am = import_alad_model()
+    D, B, n_tok, n_reg, seed = 768, 5, 14, 20, 81
+    cap_len = [14, 9, 11, 6, 12]
+    feat_len = [17, 20, 12, 20, 15]
+    txt_seq = synth.normal((B, n_tok, D), seed)
+    img_seq = synth.normal((B, n_tok + n_reg, D), seed + 1)
+    enc = am.JointTextImageTransformerEncoder.__new__(am.JointTextImageTransformerEncoder)
+    torch.nn.Module.__init__(enc)
+    enc.freeze_teran = False
+    enc.depth_aggregation_alignment = enc.depth_aggregation_matching = False
+    enc.text_aggregation_type = enc.img_aggregation_type = None
+    enc.l1_regularization = False
+    enc.post_oscar_transformer = None
+    enc.shared_transformer = True
+    layer = torch.nn.TransformerEncoderLayer(d_model=D, nhead=4, dim_feedforward=D, dropout=0.1)         # alad_model.py:104-106
+    enc.final_projection_net = torch.nn.TransformerEncoder(layer, num_layers=2)
+    named = [(n, tuple(p.shape)) for n, p in enc.final_projection_net.named_parameters()]
+    vals = synth.module_parameters(named, seed + 7)
+    with torch.no_grad():
+        for n, p in enc.final_projection_net.named_parameters():
+            p.copy_(t(vals[n]))
+    a, b = t(txt_seq).requires_grad_(True), t(img_seq).requires_grad_(True)
+
+    class FakeBert:
+        def bert(self, input_ids, attention_mask, token_type_ids, img_feats):
+            return (a,) if img_feats is None else (b,)
+    enc.oscar_model = FakeBert()
+    enc.eval()
+    ids = torch.zeros((B, n_tok), dtype=torch.long)
+    examples_txts = (ids, None, None, None, cap_len)
+    examples_imgs = (ids, None, None, torch.zeros((B, n_reg, 4)), None, feat_len)
+    img_glob, cap_glob, img_set, cap_seq, fl, cl, reg = enc(examples_imgs, examples_txts)
+    assert fl == feat_len and cl == cap_len and reg == 0
+    w = [synth.normal(tuple(x.shape), seed + 20 + k) for k, x in enumerate((img_glob, cap_glob, img_set, cap_seq))]
+    (img_glob * t(w[0])).sum().add((cap_glob * t(w[1])).sum()).add(0.05 * (img_set * t(w[2])).sum()) \
+        .add(0.05 * (cap_seq * t(w[3])).sum()).backward()
+    out = dict(D=D, B=B, n_tok=n_tok, n_reg=n_reg, seed=seed, cap_len=np.array(cap_len), feat_len=np.array(feat_len),
+               param_names=np.array([n for n, _ in named]), img_glob=img_glob.detach().numpy(), cap_glob=cap_glob.detach().numpy(),
+               img_set_shape=np.array(img_set.shape), cap_seq_shape=np.array(cap_seq.shape),
+               img_set_s=img_set.detach().numpy()[:, :, ::16], cap_seq_s=cap_seq.detach().numpy()[:, :, ::16],
+               d_txt_seq_s=a.grad.numpy()[:, :, ::16], d_img_seq_s=b.grad.numpy()[:, :, ::16],
+               d_txt_seq_abs=float(a.grad.abs().sum()), d_img_seq_abs=float(b.grad.abs().sum()))
+    for n, p in enc.final_projection_net.named_parameters():
+        g = p.grad.numpy()
+        key = n.replace('.', '__')
+        out['dp_abs__' + key] = float(np.abs(g).sum())
+        out['dp_s__' + key] = g.reshape(-1)[::max(1, g.size // 512)][:512].copy()
+    save('matching_head', **out)
+
+
 # --------------------------------------------------------------------------------------- recall
 def gen_recall():
     for name, n_img, D, seed, sigma in (('recall_n500', 100, 64, 61, 3.5),
@@ -412,5 +468,6 @@ if __name__ == '__main__':
     gen_distill()
     gen_order_sim()
     gen_model()
+    gen_matching_head()
     gen_recall()
     gen_recall_5fold()

@@ -1267,6 +1267,86 @@ def test_sharded_fast_path_under_rccl_world1():
             dist.destroy_process_group()
 
 
+def test_matching_head_and_encoder_handoff_vs_reference(eval_precision):
+    """aladin_amd.encoder.JointTextImageTransformerEncoder -- slicing to the batch maxima,
+    key-padding masks, the 2-layer transformer matching head evaluated for slot 0, F.normalize of the sets, HIP
+    l2norm of the globals -- against the 7-tuple and the gradients the REFERENCE's own encoder forward produced
+    on the same fake-backbone states and head weights (tests/golden/matching_head.npz)."""
+    if eval_precision != 'fp16':
+        pytest.skip('no alignment scores involved; run once')
+    from conftest import matching_head_case
+    g = load_golden('matching_head')
+    enc, a, b, cap_len, feat_len, n_tok, w = matching_head_case(g, dev())
+    B, n_reg = int(g['B']), int(g['n_reg'])
+    ids = torch.zeros((B, n_tok), dtype=torch.long, device=dev())
+    img_glob, cap_glob, img_set, cap_seq, fl, cl, reg = enc((ids, None, None, torch.zeros((B, n_reg, 4), device=dev()), None, feat_len),
+                                                            (ids, None, None, None, cap_len))
+    assert fl == feat_len and cl == cap_len and reg == 0
+    assert list(img_set.shape) == list(g['img_set_shape']) and list(cap_seq.shape) == list(g['cap_seq_shape'])
+    np.testing.assert_allclose(img_glob.detach().cpu().numpy(), g['img_glob'], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(cap_glob.detach().cpu().numpy(), g['cap_glob'], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(img_set.detach().cpu().numpy()[:, :, ::16], g['img_set_s'], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(cap_seq.detach().cpu().numpy()[:, :, ::16], g['cap_seq_s'], rtol=1e-5, atol=1e-6)
+    ((img_glob * w[0]).sum() + (cap_glob * w[1]).sum() + 0.05 * (img_set * w[2]).sum() + 0.05 * (cap_seq * w[3]).sum()).backward()
+    for got, key in ((a.grad, 'd_txt_seq'), (b.grad, 'd_img_seq')):
+        ref = g[key + '_s']
+        scale = float(np.abs(ref).max())
+        np.testing.assert_allclose(got.cpu().numpy()[:, :, ::16], ref, rtol=1e-3, atol=2e-5 * scale)
+        np.testing.assert_allclose(float(got.abs().sum()), float(g[key + '_abs']), rtol=1e-4)
+    for n, p in enc.final_projection_net.named_parameters():
+        np.testing.assert_allclose(float(p.grad.abs().sum()), float(g['dp_abs__' + n.replace('.', '__')]), rtol=2e-4)
+
+
+def test_config4_shape_level_step_with_the_real_head(eval_precision):
+    """BASELINE configs[4] as far as it goes offline: alad-alignment-and-matching-distill.yaml's sections (values
+    copied from the YAML: they are configuration data), batch size 32, a random-init stand-in for the VinVL BERT,
+    the REAL matching head and the HIP alignment / distillation heads: forward + backward of ALADModel.forward,
+    gradients reach the head and the backbone; epoch gating of the distillation term as in the reference."""
+    if eval_precision != 'fp16':
+        pytest.skip('training step; run once')
+    from aladin_amd.alad_model import ALADModel
+    from aladin_amd.encoder import StandInBackbone
+    from aladin_amd.evaluation import LogCollector
+    config = {'dataset': {'name': 'coco'},
+              'model': {'name': 'teran', 'embed-size': 768, 'text-aggregation': 'first', 'image-aggregation': 'first',
+                        'freeze-teran': False, 'teran-layers': 0, 'tern-layers': 2, 'post-layers': 0, 'exclude-stopwords': False,
+                        'shared-transformer': True, 'depth-aggregation-alignment': False, 'depth-aggregation-matching': False,
+                        'dropout': 0.1},
+              'training': {'lr': 0.00001, 'grad-clip': 2.0, 'max-violation': True, 'loss-type': 'alignment-distillation',
+                           'loss-weights': [1, 1], 'alignment-mode': 'MrSw', 'distillation-mode': 'listnet',
+                           'activate_distillation_after': 0, 'measure': 'dot', 'margin': 0.2, 'bs': 32}}
+    torch.manual_seed(0)
+    model = ALADModel(config, backbone=StandInBackbone(hidden=768, feat_dim=2054, vocab=3000)).to(dev())
+    model.logger = LogCollector()
+    model.train()
+    bs, n_tok, n_reg = 32, 35, 50
+    rng = np.random.default_rng(1)
+    cap_len = [int(v) for v in rng.integers(6, n_tok + 1, bs)]
+    feat_len = [int(v) for v in rng.integers(10, n_reg + 1, bs)]
+    cap_len[0], feat_len[1] = n_tok, n_reg
+    ids = torch.from_numpy(rng.integers(0, 3000, (bs, n_tok))).to(dev())
+    feats = torch.from_numpy(rng.standard_normal((bs, n_reg, 2054)).astype(np.float32)).to(dev())
+    examples_txts = (ids, None, None, None, cap_len)
+    examples_imgs = (ids, None, None, feats, None, feat_len)
+    loss, d = model(examples_imgs, examples_txts, epoch=3, distill_epoch=2)
+    assert list(d.keys()) == ['alignment', 'distillation'] and torch.isfinite(loss)
+    loss.backward()
+    head = model.img_txt_enc.final_projection_net
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() and float(p.grad.abs().sum()) > 0 for p in head.parameters())
+    assert float(model.img_txt_enc.oscar_model.word.weight.grad.abs().sum()) > 0
+    assert list(model.logger.meters.keys()) == ['Eit', 'alignment_loss', 'distillation_loss']
+    loss0, d0 = model(examples_imgs, examples_txts, epoch=0, distill_epoch=2)        # distillation popped before distill_epoch (:442-444)
+    assert list(d0.keys()) == ['alignment']
+    # evaluation hand-off: encode_data over a loader of such batches, then both retrieval heads
+    from aladin_amd import evaluation as E
+
+    class _Loader(list):
+        dataset = list(range(bs))
+    model.eval()
+    img_embs, cap_embs, il, cl = E.encode_data(model, _Loader([(examples_imgs, examples_txts)]), logging=None)
+    assert img_embs.shape == (bs, 71, 768) and il == feat_len and cl == cap_len
+
+
 def test_degenerate_lengths_and_zero_vectors():
     """Edge cases the reference's masks define (alad/loss.py:89-116): a caption with s_len = 3 has no
     scored word (its column of S is exactly 0), s_len = 4 one word, im_len = 2 one region, im_len = 1
