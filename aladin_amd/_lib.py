@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # ALADIN_LIB points at an alternative build of the same ABI (kernel A/B runs, tools/ab_bench.py)
 LIB_PATH = os.environ.get('ALADIN_LIB') or os.path.join(_HERE, 'lib', 'libaladin_hip.so')
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 PRECISION_FP16, PRECISION_SPLIT = 0, 1      # ALADIN_PRECISION_* of include/aladin_hip.h
 
 # every symbol include/aladin_hip.h declares (tests check that the library exports all of them)
@@ -19,7 +19,7 @@ SYMBOLS = [
     'aladin_align_pack_images',
     'aladin_align_pack_captions', 'aladin_align_pack_both', 'aladin_align_scores', 'aladin_align_scores_ex',
     'aladin_align_bwd_workspace_bytes',
-    'aladin_align_bwd', 'aladin_align_bwd_packed', 'aladin_hinge_workspace_bytes', 'aladin_hinge_fwd_bwd',
+    'aladin_align_bwd', 'aladin_align_bwd_packed', 'aladin_align_bwd_packed_strided', 'aladin_hinge_workspace_bytes', 'aladin_hinge_fwd_bwd',
     'aladin_hinge_fused',
     'aladin_listnet_workspace_bytes', 'aladin_listnet_fwd_bwd',
     'aladin_distill_workspace_bytes', 'aladin_distill_mse_fwd_bwd', 'aladin_distill_contrastive_fwd_bwd',
@@ -31,6 +31,7 @@ SYMBOLS = [
     'aladin_scan_workspace_bytes', 'aladin_scan_fwd', 'aladin_scan_bwd',
     'aladin_store_row_width', 'aladin_store_append', 'aladin_align_pack_store_x', 'aladin_align_pack_store_y',
     'aladin_store_row_width_mode', 'aladin_store_append_mode', 'aladin_topk',
+    'aladin_heads_small_workspace_bytes', 'aladin_heads_small_fwd', 'aladin_heads_small_bwd',
 ]
 
 
@@ -62,6 +63,8 @@ def _declare(lib):
         'aladin_align_bwd_workspace_bytes': (sz, [i32, i32, i32, i32, i32]),
         'aladin_align_bwd': (C.c_int, [p, i64, i64, p, p, i64, i64, p, i32, i32, i32, i32, i32, p, i64, p, p, p, p, p]),
         'aladin_align_bwd_packed': (C.c_int, [p, i64, i64, p, p, i64, i64, p, p, i64, p, p, p, p, G, p, p, p, p, p, p]),
+        'aladin_align_bwd_packed_strided': (C.c_int, [p, i64, i64, p, p, i64, i64, p, p, i64, p, p, p, p, G, p, p, p, i64, i64, p, i64, i64,
+                                                      p, p]),
         'aladin_hinge_workspace_bytes': (sz, [i32]),
         'aladin_hinge_fwd_bwd': (C.c_int, [p, i64, i32, f32, i32, p, p, p, p]),
         'aladin_hinge_fused': (C.c_int, [p, i64, i32, f32, i32, p, p, p, p, p, p]),
@@ -90,6 +93,10 @@ def _declare(lib):
         'aladin_store_row_width_mode': (C.c_int, [i32, i32]),
         'aladin_store_append_mode': (C.c_int, [p, i64, i64, p, i32, i32, i32, i32, p, p, i32, p]),
         'aladin_topk': (C.c_int, [p, i64, i64, i32, i32, i32, p, p, p]),
+        'aladin_heads_small_workspace_bytes': (sz, [i32]),
+        'aladin_heads_small_fwd': (C.c_int, [p, i64, p, i64, p, i64, i32, i32, f32, i32, i32, f32, f32, f32, f32, f32, p, p, p, p, p, p,
+                                             p, p, p, p]),
+        'aladin_heads_small_bwd': (C.c_int, [p, i64, p, i64, i32, i32, p, p, f32, p, p, f32, p, i64, p, f32, p, p, p, p]),
         'aladin_align_pack_store_x': (C.c_int, [p, p, p, p, G, p, p, p]),
         'aladin_align_pack_store_y': (C.c_int, [p, p, p, p, G, p, p]),
         'aladin_recall_workspace_bytes': (sz, [i32]),

@@ -12,7 +12,8 @@ cap_len, reg_loss) can be passed.  `StandInEncoder` is a headless random-init te
 import torch
 from torch import nn
 
-from .loss import AlignmentContrastiveLoss, ContrastiveLoss, DistillationLoss, l2norm
+from . import ops
+from .loss import AlignmentContrastiveLoss, ContrastiveLoss, DistillationLoss, dot_sim, l2norm
 
 
 class ALADModel(nn.Module):
@@ -51,6 +52,7 @@ class ALADModel(nn.Module):
         self.Eiters = 0
         self.config = config
         self.logger = None
+        self.pending_log = None
 
     def forward_emb(self, example_imgs, example_txts):
         """reference alad_model.py:325-348 (host->device copies + encoder call)."""
@@ -62,19 +64,40 @@ class ALADModel(nn.Module):
             example_txts = [c.cuda() if isinstance(c, torch.Tensor) else c for c in example_txts]
         return self.img_txt_enc(example_imgs, example_txts)
 
-    def forward_loss(self, img_emb, cap_emb, img_emb_set, cap_emb_seq, img_lengths, cap_lengths, reg_loss):
+    def forward_loss(self, img_emb, cap_emb, img_emb_set, cap_emb_seq, img_lengths, cap_lengths, reg_loss, log=True):
         """reference alad_model.py:371-428.  Same terms, same insertion order, same logger keys; the
-        per-term `.item()` host syncs of the reference are batched into one device->host copy."""
+        per-term `.item()` host syncs of the reference are batched into one device->host copy.
+        log=False (used under HIP-graph capture, where a host sync is illegal: aladin_amd.graphs) skips the
+        logger update and leaves the (key, tensor, n) triples in `self.pending_log` for `flush_log()`.
+        The length arguments may be Python lists (as the reference passes them) or int32 device tensors."""
         losses = {}
         logged = []                                                   # (key, tensor, n)
         img_emb_set = img_emb_set.permute(1, 0, 2)                    # :377-378  (S,B,D) -> (B,S,D) views
         cap_emb_seq = cap_emb_seq.permute(1, 0, 2)
 
         wants_matching = 'matching' in self.config['training']['loss-type']      # :381 (substring test on the string)
-        sim = getattr(self.matching_criterion, 'sim', None)
-        if wants_matching or sim is None:
-            matching_loss, matching_mat = self.matching_criterion(img_emb, cap_emb, return_similarity_mat=True)   # :380
-        else:
+        wants_align = 'alignment' in self.losses_types or 'distillation' in self.losses_types
+        wants_distill = 'distillation' in self.losses_types
+        mc = self.matching_criterion
+        sim = getattr(mc, 'sim', None)
+
+        # The alignment head first: its score matrix is the distillation teacher.  (The reference computes the
+        # matching term first, :380; the terms are independent, and `losses` / the logger are filled in the
+        # reference's order below.)
+        if wants_align:                                               # :385-390
+            alignment_loss, teacher_scores = self.alignment_criterion(
+                img_emb_set, cap_emb_seq, img_lengths, cap_lengths, return_similarity_mat=True)
+
+        # Small batches (every shipped YAML: bs 32) with the shipped 'dot' measure and listnet distillation: matching
+        # scores, their hinge and the distillation loss in ONE forward / ONE backward launch (ops.small_batch_match_distill)
+        small = (img_emb.shape[0] <= ops.SMALL_BATCH_MAX and sim is dot_sim and 'selfaggregation' not in self.losses_types
+                 and (not wants_distill or self.distillation_loss.mode == 'listnet') and (wants_matching or wants_distill))
+        if small:
+            matching_loss, distillation_loss, matching_mat = ops.small_batch_match_distill(
+                img_emb, cap_emb, teacher_scores if wants_distill else None, mc.margin, mc.max_violation, want_hinge=wants_matching)
+        elif wants_matching or sim is None:
+            matching_loss, matching_mat = mc(img_emb, cap_emb, return_similarity_mat=True)   # :380
+        elif wants_distill or 'selfaggregation' in self.losses_types:
             # the reference computes the matching hinge here and drops it (:380-381); only the score matrix
             # is used further down (distillation student, :405), so the two hinge launches are skipped
             matching_mat = sim(img_emb, cap_emb)
@@ -82,20 +105,18 @@ class ALADModel(nn.Module):
             losses['matching'] = matching_loss
             logged.append(('matching_loss', matching_loss, img_emb.size(0)))
 
-        if 'alignment' in self.losses_types or 'distillation' in self.losses_types:       # :385-390
-            alignment_loss, teacher_scores = self.alignment_criterion(
-                img_emb_set, cap_emb_seq, img_lengths, cap_lengths, return_similarity_mat=True)
-            if 'alignment' in self.losses_types:
-                losses['alignment'] = alignment_loss
-                logged.append(('alignment_loss', alignment_loss, img_emb_set.size(0)))
+        if 'alignment' in self.losses_types:
+            losses['alignment'] = alignment_loss
+            logged.append(('alignment_loss', alignment_loss, img_emb_set.size(0)))
 
         if 'selfaggregation' in self.losses_types:                    # :397-402
-            matching_loss, matching_mat = self.matching_criterion(img_emb, cap_emb, return_similarity_mat=True)
+            matching_loss, matching_mat = mc(img_emb, cap_emb, return_similarity_mat=True)
             losses['selfaggregation'] = matching_loss
             logged.append(('self_attention_loss', matching_loss, img_emb.size(0)))
 
-        if 'distillation' in self.losses_types:                       # :404-408
-            distillation_loss = self.distillation_loss(teacher_scores, matching_mat)
+        if wants_distill:                                             # :404-408
+            if not small:
+                distillation_loss = self.distillation_loss(teacher_scores, matching_mat)
             losses['distillation'] = distillation_loss
             logged.append(('distillation_loss', distillation_loss, img_emb.size(0)))
 
@@ -106,11 +127,69 @@ class ALADModel(nn.Module):
             losses['regularizehidden'] = reg_loss
             logged.append(('regularize_hidden_loss', reg_loss, img_emb.size(0)))
 
+        self.pending_log = logged
+        if log:
+            self.flush_log()
+        return losses
+
+    def flush_log(self):
+        """Push the loss terms of the last forward_loss(log=False) call to `self.logger` (one device->host copy)."""
+        logged, self.pending_log = getattr(self, 'pending_log', None), None
         if self.logger is not None and logged:
-            vals = torch.stack([t.detach().reshape(()).to(torch.float32) for _, t, _ in logged]).tolist()
+            vals = torch.stack([torch.as_tensor(t).detach().reshape(()).to(torch.float32) for _, t, _ in logged]).tolist()
             for (key, _, n), v in zip(logged, vals):
                 self.logger.update(key, v, n)
-        return losses
+
+    def weighted_total(self, loss_dict, epoch=0, distill_epoch=2):
+        """reference alad_model.py:442-453: drop the distillation term before `distill_epoch` (when another term
+        exists), then the fixed-weight sum, or 0.5 * sum(L e^-w + w) for 'auto' weights.  Mutates loss_dict like
+        the reference."""
+        if epoch < distill_epoch and len(loss_dict) > 1:              # :442-444
+            loss_dict.pop('distillation', None)
+        loss = 0
+        if self.auto_weight:                                          # :445-449
+            for k in loss_dict:
+                loss += loss_dict[k] * torch.exp(-self.losses_weights[k]) + self.losses_weights[k]
+            loss *= 0.5
+        else:                                                         # :450-453
+            for k in loss_dict:
+                loss += loss_dict[k] * self.losses_weights[k]
+        return loss
+
+    def _fused_heads_ok(self, img_emb):
+        """The single-node small-batch step (ops.small_batch_loss_heads) covers what every shipped YAML trains with:
+        bs <= 64, measure 'dot', 'MrSw' alignment, listnet distillation, fixed loss weights."""
+        types = set(self.losses_types)
+        return (img_emb.shape[0] <= ops.SMALL_BATCH_MAX and not self.auto_weight and types <= {'matching', 'alignment', 'distillation'}
+                and getattr(self.matching_criterion, 'sim', None) is dot_sim
+                and ('alignment' not in types and 'distillation' not in types or self.alignment_criterion.aggregation == 'MrSw')
+                and ('distillation' not in types or self.distillation_loss.mode == 'listnet'))
+
+    def forward_loss_total(self, img_emb, cap_emb, img_emb_set, cap_emb_seq, img_lengths, cap_lengths, reg_loss, epoch=0,
+                           distill_epoch=2, log=True):
+        """forward_loss + the weighted sum of forward (alad_model.py:371-428 + :442-453) -> (loss, loss_dict).
+        For the shipped configurations at bs <= 64 the whole thing is ONE autograd node (three head launches, no
+        element-wise glue): the terms of `loss_dict` are then detached values for logging, `loss` carries the graph.
+        Otherwise it is forward_loss followed by weighted_total."""
+        if not self._fused_heads_ok(img_emb):
+            d = self.forward_loss(img_emb, cap_emb, img_emb_set, cap_emb_seq, img_lengths, cap_lengths, reg_loss, log=log)
+            return self.weighted_total(d, epoch, distill_epoch), d
+        wants_matching = 'matching' in self.config['training']['loss-type']
+        heads = [k for k in ('matching', 'alignment', 'distillation')
+                 if (k in self.losses_types) and (k != 'matching' or wants_matching)]
+        logged_heads = list(heads)
+        if epoch < distill_epoch and len(heads) > 1 and 'distillation' in heads:       # :442-444
+            heads.remove('distillation')
+        total, terms, _, _ = ops.small_batch_loss_heads(
+            img_emb, cap_emb, img_emb_set.permute(1, 0, 2), cap_emb_seq.permute(1, 0, 2), img_lengths, cap_lengths,
+            self.matching_criterion.margin, self.matching_criterion.max_violation, logged_heads, 
+            {k: (self.losses_weights[k] if k in heads else 0.0) for k in logged_heads})
+        idx = {'matching': 0, 'alignment': 1, 'distillation': 2}
+        names = {'matching': 'matching_loss', 'alignment': 'alignment_loss', 'distillation': 'distillation_loss'}
+        self.pending_log = [(names[k], terms[idx[k]], img_emb.size(0)) for k in logged_heads]
+        if log:
+            self.flush_log()
+        return total, {k: terms[idx[k]] for k in heads}
 
     def forward(self, example_imgs, example_txts, epoch=0, distill_epoch=2):
         """reference alad_model.py:430-454."""
@@ -119,20 +198,8 @@ class ALADModel(nn.Module):
             self.logger.update('Eit', self.Eiters)
         img_emb_aggr, cap_emb_aggr, img_feats, cap_feats, img_lengths, cap_lengths, regul_loss = \
             self.forward_emb(example_imgs, example_txts)
-        loss_dict = self.forward_loss(img_emb_aggr, cap_emb_aggr, img_feats, cap_feats, img_lengths, cap_lengths,
-                                      regul_loss)
-        if epoch < distill_epoch and len(loss_dict) > 1:              # :442-444
-            loss_dict.pop('distillation', None)
-        if self.auto_weight:                                          # :445-449
-            loss = 0
-            for k in loss_dict:
-                loss += loss_dict[k] * torch.exp(-self.losses_weights[k]) + self.losses_weights[k]
-            loss *= 0.5
-        else:                                                         # :450-453
-            loss = 0
-            for k in loss_dict:
-                loss += loss_dict[k] * self.losses_weights[k]
-        return loss, loss_dict
+        return self.forward_loss_total(img_emb_aggr, cap_emb_aggr, img_feats, cap_feats, img_lengths, cap_lengths, regul_loss,
+                                       epoch, distill_epoch)
 
 
 class StandInEncoder(nn.Module):

@@ -368,7 +368,7 @@ __global__ __launch_bounds__(256) void bwd_rows_kernel(
     const float* __restrict__ s, int64_t s_sb, int64_t s_st, const int32_t* __restrict__ s_len, int Bi, int Bc, int R,
     int T, int D, const float* __restrict__ dS, int64_t ld, const float* __restrict__ gscale,
     const uint8_t* __restrict__ table, int tstride, float* __restrict__ d_im, float* __restrict__ d_s, int x_tail,
-    int y_tail) {
+    int y_tail, int64_t dim_sb, int64_t dim_sr, int64_t ds_sb, int64_t ds_st) {
   __shared__ int lst_p[4][ROWS_LIST];
   __shared__ float lst_g[4][ROWS_LIST];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -383,8 +383,10 @@ __global__ __launch_bounds__(256) void bwd_rows_kernel(
   int own_b, own_p;           // owner sample and position inside it
   float* out;
   const float* xrow;
-  if (is_img) { own_b = (int)(row / R); own_p = (int)(row % R); out = d_im + row * D; xrow = im + own_b * im_sb + (int64_t)own_p * im_sr; }
-  else { const int64_t q = row - n_im_rows; own_b = (int)(q / T); own_p = (int)(q % T); out = d_s + q * D; xrow = s + own_b * s_sb + (int64_t)own_p * s_st; }
+  // the gradients are written in the caller's layout (strides in floats): the model hands (S,B,D) sets as permuted
+  // (B,S,D) views (alad_model.py:377-378) and autograd would otherwise re-lay 66 MB per step with two copy kernels
+  if (is_img) { own_b = (int)(row / R); own_p = (int)(row % R); out = d_im + own_b * dim_sb + own_p * dim_sr; xrow = im + own_b * im_sb + (int64_t)own_p * im_sr; }
+  else { const int64_t q = row - n_im_rows; own_b = (int)(q / T); own_p = (int)(q % T); out = d_s + own_b * ds_sb + own_p * ds_st; xrow = s + own_b * s_sb + (int64_t)own_p * s_st; }
   const int idx = own_p - 1;  // region / word index inside the alignment
   int L;
   if (is_img) { L = im_len[own_b] - 1 - x_tail; L = L < 0 ? 0 : (L > Rq ? Rq : L); }
@@ -535,7 +537,14 @@ static int align_bwd_impl(const float* im, int64_t im_sb, int64_t im_sr, const i
                           int64_t s_sb, int64_t s_st, const int32_t* s_len, int Bi, int Bc, int R, int T, int D,
                           const float* dS, int64_t ld_dS, const float* gscale, const void* xm, const void* xe,
                           const void* y, const aladin_align_geom* g, const int32_t* pairs_in, const int32_t* count_in,
-                          float* d_im, float* d_s, void* workspace, void* stream, int x_tail = 0, int y_tail = 2) {
+                          float* d_im, float* d_s, void* workspace, void* stream, int x_tail = 0, int y_tail = 2,
+                          int64_t dim_sb = 0, int64_t dim_sr = 0, int64_t ds_sb = 0, int64_t ds_st = 0) {
+  if (dim_sb == 0 && dim_sr == 0) { dim_sb = (int64_t)R * D; dim_sr = D; }          // contiguous (Bi, R, D) / (Bc, T, D) outputs
+  if (ds_sb == 0 && ds_st == 0) { ds_sb = (int64_t)T * D; ds_st = D; }
+  if (dim_sb % 4 || dim_sr % 4 || ds_sb % 4 || ds_st % 4 || ((uintptr_t)d_im & 15) || ((uintptr_t)d_s & 15)) {
+    aladin_set_error("align_bwd: gradient rows must be 16-byte aligned (strides %lld %lld %lld %lld)", (long long)dim_sb, (long long)dim_sr, (long long)ds_sb, (long long)ds_st);
+    return ALADIN_ERR_ARG;
+  }
   if (!im || !s || !im_len || !s_len || !dS || !d_im || !d_s || !workspace) { aladin_set_error("align_bwd: null argument"); return ALADIN_ERR_ARG; }
   if (Bi < 1 || Bc < 1 || R < 2 + x_tail || T < 2 + y_tail || D < 1 || ld_dS < Bc) { aladin_set_error("align_bwd: bad sizes"); return ALADIN_ERR_ARG; }
   const int Rq = R - 1 - x_tail;
@@ -587,7 +596,7 @@ static int align_bwd_impl(const float* im, int64_t im_sb, int64_t im_sr, const i
   const int nch = (D + 255) / 256;
 #define LAUNCH_ROWS(N)                                                                                                  \
   hipLaunchKernelGGL(bwd_rows_kernel<N>, dim3(rgrid), dim3(256), 0, st, im, im_sb, im_sr, im_len, s, s_sb, s_st, s_len, \
-                     Bi, Bc, R, T, D, dS, ld_dS, gscale, ws.table, tstride, d_im, d_s, x_tail, y_tail)
+                     Bi, Bc, R, T, D, dS, ld_dS, gscale, ws.table, tstride, d_im, d_s, x_tail, y_tail, dim_sb, dim_sr, ds_sb, ds_st)
   switch (nch) {
     case 1: LAUNCH_ROWS(1); break;
     case 2: LAUNCH_ROWS(2); break;
@@ -616,4 +625,19 @@ extern "C" int aladin_align_bwd_packed(const float* im, int64_t im_sb, int64_t i
   return align_bwd_impl(im, im_sb, im_sr, im_len, s, s_sb, s_st, s_len, geom->Bi, geom->Bc, geom->R, geom->T, geom->D, dS,
                         ld_dS, gscale, xm, xe, y, geom, pairs, pair_count, d_im, d_s, workspace, stream, geom->x_tail,
                         geom->y_tail);
+}
+
+extern "C" int aladin_align_bwd_packed_strided(const float* im, int64_t im_sb, int64_t im_sr, const int32_t* im_len, const float* s,
+                                               int64_t s_sb, int64_t s_st, const int32_t* s_len, const float* dS, int64_t ld_dS,
+                                               const float* gscale, const void* xm, const void* xe, const void* y,
+                                               const aladin_align_geom* geom, const int32_t* pairs, const int32_t* pair_count,
+                                               float* d_im, int64_t d_im_stride_b, int64_t d_im_stride_r, float* d_s,
+                                               int64_t d_s_stride_b, int64_t d_s_stride_t, void* workspace, void* stream) {
+  if (!geom) { aladin_set_error("align_bwd_packed_strided: null geometry"); return ALADIN_ERR_ARG; }
+  if (geom->split) { aladin_set_error("align_bwd_packed_strided: split-precision operands are forward-only (evaluation); pack with ALADIN_PRECISION_FP16"); return ALADIN_ERR_UNSUPPORTED; }
+  if (d_im_stride_b < 1 || d_im_stride_r < 1 || d_s_stride_b < 1 || d_s_stride_t < 1) { aladin_set_error("align_bwd_packed_strided: bad output strides"); return ALADIN_ERR_ARG; }
+  return align_bwd_impl(im, im_sb, im_sr, im_len, s, s_sb, s_st, s_len, geom->Bi, geom->Bc, geom->R, geom->T, geom->D, dS,
+                        ld_dS, gscale, (xm && y) ? xm : nullptr, xe, (xm && y) ? y : nullptr, (xm && y) ? geom : nullptr, pairs,
+                        pair_count, d_im, d_s, workspace, stream, geom->x_tail, geom->y_tail, d_im_stride_b, d_im_stride_r,
+                        d_s_stride_b, d_s_stride_t);
 }

@@ -6,6 +6,7 @@
 //            its two backward products)
 #include "../../include/aladin_hip.h"
 #include "common.hpp"
+#include "sgemm_tile.hpp"
 
 // ------------------------------------------------------------------------------------------------
 // block-wide reductions (256 threads = 4 waves)
@@ -252,42 +253,17 @@ extern "C" int aladin_listnet_fwd_bwd(const float* teacher, int64_t ld_t, const 
 }
 
 // ------------------------------------------------------------------------------------------------
-// strided fp32 GEMM on v_mfma_f32_32x32x2_f32 (exact fp32 fma chain).  64 x 64 tile per workgroup
-// (4 waves, one 32x32 accumulator each), 32-deep K slabs staged through LDS with bounds checks.
+// strided fp32 GEMM on v_mfma_f32_32x32x2_f32: one sgemm_tile_64 (sgemm_tile.hpp) per 64 x 64 output tile.
 // ------------------------------------------------------------------------------------------------
-#define SG_KB 32
-__global__ __launch_bounds__(256) void sgemm_strided_kernel(int M, int N, int K, const float* __restrict__ A, int64_t a_rs,
-                                                            int64_t a_cs, const float* __restrict__ Bm, int64_t b_rs,
-                                                            int64_t b_cs, float* __restrict__ C, int64_t ldc) {
-  __shared__ float As[SG_KB][65];      // [k][m]
-  __shared__ float Bs[SG_KB][65];      // [k][n]
+__global__ __launch_bounds__(1024) void sgemm_strided_kernel(int M, int N, int K, const float* __restrict__ A, int64_t a_rs,
+                                                             int64_t a_cs, const float* __restrict__ Bm, int64_t b_rs,
+                                                             int64_t b_cs, float* __restrict__ C, int64_t ldc) {
+  extern __shared__ __attribute__((aligned(16))) char sg_smem[];
   const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+  f32x16 acc;
+  if (!sgemm_tile_64(M, N, K, A, a_rs, a_cs, Bm, b_rs, b_cs, m0, n0, sg_smem, acc)) return;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int wm = wave >> 1, wn = wave & 1;
-  f32x16 acc;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  const bool a_kfast = (a_cs == 1), b_kfast = (b_rs == 1);
-  for (int k0 = 0; k0 < K; k0 += SG_KB) {
-    __syncthreads();
-    for (int e = threadIdx.x; e < 64 * SG_KB; e += 256) {
-      int m, k;
-      if (a_kfast) { k = e % SG_KB; m = e / SG_KB; } else { m = e % 64; k = e / 64; }
-      const int gm = m0 + m, gk = k0 + k;
-      As[k][m] = (gm < M && gk < K) ? A[gm * a_rs + gk * a_cs] : 0.f;
-      int n, kb;
-      if (b_kfast) { kb = e % SG_KB; n = e / SG_KB; } else { n = e % 64; kb = e / 64; }
-      const int gn = n0 + n, gkb = k0 + kb;
-      Bs[kb][n] = (gn < N && gkb < K) ? Bm[gkb * b_rs + gn * b_cs] : 0.f;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int kk = 0; kk < SG_KB; kk += 2) {
-      const float a = As[kk + (lane >> 5)][wm * 32 + (lane & 31)];
-      const float b = Bs[kk + (lane >> 5)][wn * 32 + (lane & 31)];
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
-    }
-  }
   const int col = n0 + wn * 32 + (lane & 31);
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
@@ -299,7 +275,9 @@ __global__ __launch_bounds__(256) void sgemm_strided_kernel(int M, int N, int K,
 extern "C" int aladin_sgemm_strided(int M, int N, int K, const float* A, int64_t a_rs, int64_t a_cs, const float* B,
                                     int64_t b_rs, int64_t b_cs, float* C, int64_t ldc, void* stream) {
   if (!A || !B || !C || M < 1 || N < 1 || K < 1 || ldc < N) { aladin_set_error("sgemm_strided: bad argument (M=%d N=%d K=%d)", M, N, K); return ALADIN_ERR_ARG; }
-  hipLaunchKernelGGL(sgemm_strided_kernel, dim3(cdiv(N, 64), cdiv(M, 64)), dim3(256), 0, (hipStream_t)stream, M, N, K, A,
+  static unsigned long long lds_reserved = 0;
+  if (int rc = aladin_reserve_lds((const void*)sgemm_strided_kernel, SG_LDS_BYTES, &lds_reserved, "sgemm_strided")) return rc;
+  hipLaunchKernelGGL(sgemm_strided_kernel, dim3(cdiv(N, 64), cdiv(M, 64)), dim3(1024), SG_LDS_BYTES, (hipStream_t)stream, M, N, K, A,
                      a_rs, a_cs, B, b_rs, b_cs, C, ldc);
   return aladin_check_launch("sgemm_strided_kernel");
 }

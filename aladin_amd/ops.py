@@ -184,6 +184,14 @@ def _align_forward(im, s, im_len_t, s_len_t, x_tail=0, y_tail=2, precision=None)
     return scores_from_packed(xm, xe, y, geom), (geom, xm, xe, y)
 
 
+def _grad_like(x):
+    """Gradient buffer in x's own layout when x is a dense permutation with a unit inner stride (the model's
+    (S,B,D)->(B,S,D) views): autograd then hands it to the leaf without a re-layout copy.  Contiguous otherwise."""
+    if x.stride(-1) == 1 and torch.ops.aten.is_non_overlapping_and_dense(x) and all(st % 4 == 0 for st in x.stride()[:-1]):
+        return torch.empty_like(x, dtype=torch.float32)
+    return torch.empty(tuple(x.shape), dtype=torch.float32, device=x.device)
+
+
 def _align_backward(im, s, im_len_t, s_len_t, dS, gscale=None, packed=None, pairs=None, x_tails=(0, 2)):
     lib = _lib.load()
     im = _rows_inner_contig(im)
@@ -192,26 +200,21 @@ def _align_backward(im, s, im_len_t, s_len_t, dS, gscale=None, packed=None, pair
     ld_dS = dS.shape[1]            # (not stride(0): a contiguous (1, n) view may report any leading stride)
     Bi, R, D = im.shape
     Bc, T, _ = s.shape
-    d_im = torch.empty((Bi, R, D), dtype=torch.float32, device=im.device)
-    d_s = torch.empty((Bc, T, D), dtype=torch.float32, device=im.device)
+    d_im, d_s = _grad_like(im), _grad_like(s)
     ws = _workspace(lib.aladin_align_bwd_workspace_bytes(Bi, Bc, R, T, D), im.device)
     if packed is None:
         if x_tails != (0, 2):
             raise NotImplementedError('aladin_amd: the stand-alone backward entry point is the image/caption form')
-    if packed is not None:
-        geom, xm, xe, y = packed
-        _lib.check(lib.aladin_align_bwd_packed(_ptr(im), im.stride(0), im.stride(1), _ptr(im_len_t),
-                                               _ptr(s), s.stride(0), s.stride(1), _ptr(s_len_t),
-                                               _ptr(dS), ld_dS, _ptr(gscale), _ptr(xm), _ptr(xe), _ptr(y),
-                                               C.byref(geom), _ptr(pairs[0] if pairs else None),
-                                               _ptr(pairs[1] if pairs else None), _ptr(d_im), _ptr(d_s), _ptr(ws),
-                                               _stream()),
-                   'align_bwd_packed')
+        geom, xm, xe, y = align_geometry(Bi, Bc, R, T, D), None, None, None
     else:
-        _lib.check(lib.aladin_align_bwd(_ptr(im), im.stride(0), im.stride(1), _ptr(im_len_t),
-                                        _ptr(s), s.stride(0), s.stride(1), _ptr(s_len_t), Bi, Bc, R, T, D,
-                                        _ptr(dS), ld_dS, _ptr(gscale), _ptr(d_im), _ptr(d_s), _ptr(ws),
-                                        _stream()), 'align_bwd')
+        geom, xm, xe, y = packed
+    _lib.check(lib.aladin_align_bwd_packed_strided(_ptr(im), im.stride(0), im.stride(1), _ptr(im_len_t),
+                                                   _ptr(s), s.stride(0), s.stride(1), _ptr(s_len_t),
+                                                   _ptr(dS), ld_dS, _ptr(gscale), _ptr(xm), _ptr(xe), _ptr(y),
+                                                   C.byref(geom), _ptr(pairs[0] if pairs else None),
+                                                   _ptr(pairs[1] if pairs else None), _ptr(d_im), d_im.stride(0), d_im.stride(1),
+                                                   _ptr(d_s), d_s.stride(0), d_s.stride(1), _ptr(ws), _stream()),
+               'align_bwd_packed_strided')
     return d_im, d_s
 
 
@@ -639,6 +642,170 @@ def dot_scores(im, s):
     if im.dim() != 2 or s.dim() != 2 or im.shape[1] != s.shape[1]:
         raise ValueError('aladin_amd: (Bi,D) and (Bc,D) embeddings expected')
     return _DotScores.apply(im, s)
+
+
+# ------------------------------------------------------------------------------------------------
+# small-batch matching + distillation (B <= 64: the batch size of every shipped YAML is 32)
+# ------------------------------------------------------------------------------------------------
+SMALL_BATCH_MAX = 64
+HEAD_MATCH_HINGE, HEAD_ALIGN_HINGE, HEAD_LISTNET = 1, 2, 4      # ALADIN_HEAD_* of include/aladin_hip.h
+
+
+def _heads_small_fwd(im, s, S, margin, max_violation, flags, temperature, eps, weights, want_grads, want_pairs):
+    """Launch aladin_heads_small_fwd -> dict of its outputs (see include/aladin_hip.h)."""
+    lib = _lib.load()
+    B = (im if im is not None else S).shape[0]
+    dev = (im if im is not None else S).device
+    D = im.shape[1] if im is not None else 1
+    out = {'M': torch.empty((B, B), dtype=torch.float32, device=dev) if flags & (HEAD_MATCH_HINGE | HEAD_LISTNET) else None,
+           'terms': torch.empty(3, dtype=torch.float32, device=dev),             # [matching, alignment, listnet]
+           'total': torch.empty((), dtype=torch.float32, device=dev)}
+    f32 = dict(dtype=torch.float32, device=dev)
+    out['dMh'] = torch.empty((B, B), **f32) if (want_grads and flags & HEAD_MATCH_HINGE) else None
+    out['dMl'] = torch.empty((B, B), **f32) if (want_grads and flags & HEAD_LISTNET) else None
+    out['dS'] = torch.empty((B, B), **f32) if (want_grads and flags & HEAD_ALIGN_HINGE) else None
+    out['pairs'] = None
+    if want_pairs and out['dS'] is not None:
+        out['pairs'] = (torch.empty(B * B, dtype=torch.int32, device=dev), torch.empty(1, dtype=torch.int32, device=dev))
+    ws = _workspace(lib.aladin_heads_small_workspace_bytes(B), dev)
+    _lib.check(lib.aladin_heads_small_fwd(_ptr(im), _ld(im) if im is not None else 0, _ptr(s), _ld(s) if s is not None else 0,
+                                          _ptr(S), _ld(S) if S is not None else 0, B, D, float(margin), int(bool(max_violation)),
+                                          int(flags), float(temperature), float(eps), float(weights[0]), float(weights[1]),
+                                          float(weights[2]), _ptr(out['M']), _ptr(out['terms']), _ptr(out['total']),
+                                          _ptr(out['dMh']), _ptr(out['dMl']), _ptr(out['dS']),
+                                          _ptr(out['pairs'][0] if out['pairs'] else None),
+                                          _ptr(out['pairs'][1] if out['pairs'] else None), _ptr(ws), _stream()), 'heads_small_fwd')
+    return out
+
+
+class _SmallMatchDistill(torch.autograd.Function):
+    """(hinge loss on M, listnet loss of M against the teacher, M) with M = im @ s.T, in two forward launches and
+    one backward launch (csrc/small_batch.hip).  Either loss may be switched off (returns a zero scalar)."""
+
+    @staticmethod
+    def forward(ctx, im, s, teacher, margin, max_violation, want_hinge, temperature, eps):
+        im = im if im.stride(1) == 1 else im.contiguous()
+        s = s if s.stride(1) == 1 else s.contiguous()
+        t = None
+        if teacher is not None:
+            t = teacher if teacher.stride(1) == 1 else teacher.contiguous()
+        flags = (HEAD_MATCH_HINGE if want_hinge else 0) | (HEAD_LISTNET if t is not None else 0)
+        need = any(ctx.needs_input_grad[:2])
+        if not flags:                                         # scores only
+            return im.new_zeros(()), im.new_zeros(()), _DotScores.apply(im, s)
+        o = _heads_small_fwd(im, s, t, margin, max_violation, flags, temperature, eps, (1.0, 1.0, 1.0), need, False)
+        ctx.save_for_backward(im, s, o['dMh'], o['dMl'])
+        ctx.set_materialize_grads(False)
+        return o['terms'][0], o['terms'][2], o['M']
+
+    @staticmethod
+    def backward(ctx, g_h, g_l, g_M):
+        im, s, dMh, dMl = ctx.saved_tensors
+        if (g_h is None or dMh is None) and (g_l is None or dMl is None) and g_M is None:
+            return (None,) * 8
+        B, D = im.shape
+        d_im = torch.empty((B, D), dtype=torch.float32, device=im.device) if ctx.needs_input_grad[0] else None
+        d_s = torch.empty((B, D), dtype=torch.float32, device=im.device) if ctx.needs_input_grad[1] else None
+        gh = g_h.to(torch.float32).contiguous() if (g_h is not None and dMh is not None) else None
+        gl = g_l.to(torch.float32).contiguous() if (g_l is not None and dMl is not None) else None
+        gM = (g_M if g_M.stride(1) == 1 else g_M.contiguous()) if g_M is not None else None
+        _lib.check(_lib.load().aladin_heads_small_bwd(_ptr(im), _ld(im), _ptr(s), _ld(s), B, D,
+                                                      _ptr(dMh if gh is not None else None), _ptr(gh), 1.0,
+                                                      _ptr(dMl if gl is not None else None), _ptr(gl), 1.0, _ptr(gM),
+                                                      _ld(gM) if gM is not None else 0, _ptr(None), 0.0, _ptr(None),
+                                                      _ptr(d_im), _ptr(d_s), _stream()), 'heads_small_bwd')
+        return d_im, d_s, None, None, None, None, None, None
+
+
+class _SmallHeads(torch.autograd.Function):
+    """The whole loss-head step at B <= 64 as ONE autograd node: alignment scores (pack, side GEMM, score kernel),
+    then the three heads and their fixed-weight sum (alad_model.py:450-453) in two launches; backward = one launch for
+    the matching side + the two alignment backward kernels.  No element-wise glue kernels at all.
+    Returns (total, terms[3] = matching / alignment / distillation, S, M); only `total` is differentiable."""
+
+    @staticmethod
+    def forward(ctx, img_emb, cap_emb, im, s, im_len_t, s_len_t, margin, max_violation, flags, weights, temperature, eps):
+        need_sets = any(ctx.needs_input_grad[2:4])
+        need_embs = any(ctx.needs_input_grad[0:2])
+        S, packed = None, None
+        if flags & (HEAD_ALIGN_HINGE | HEAD_LISTNET):
+            if need_sets and flags & HEAD_ALIGN_HINGE:
+                _check_backward_supported(im, s, 0, 2)
+            S, packed = _align_forward(im, s, im_len_t, s_len_t)
+        a = b = None
+        if flags & (HEAD_MATCH_HINGE | HEAD_LISTNET):
+            a = img_emb if img_emb.stride(1) == 1 else img_emb.contiguous()
+            b = cap_emb if cap_emb.stride(1) == 1 else cap_emb.contiguous()
+        o = _heads_small_fwd(a, b, S, margin, max_violation, flags, temperature, eps, weights, need_sets or need_embs, True)
+        ctx.flags, ctx.weights = flags, weights
+        ctx.geom = packed[0] if packed is not None else None
+        ctx.pairs = o['pairs']
+        pk = packed[1:] if packed is not None else (None, None, None)
+        ctx.save_for_backward(a, b, im, s, im_len_t, s_len_t, pk[0], pk[1], pk[2], o['dMh'], o['dMl'], o['dS'])
+        ctx.set_materialize_grads(False)
+        terms = o['terms']
+        ctx.mark_non_differentiable(*[t for t in (terms, S, o['M']) if t is not None])       # one call: it replaces the set
+        return o['total'], terms, S, o['M']
+
+    @staticmethod
+    def backward(ctx, g_total, _g_terms, _g_S, _g_M):
+        if g_total is None:
+            return (None,) * 12
+        a, b, im, s, im_len_t, s_len_t, xm, xe, y, dMh, dMl, dS = ctx.saved_tensors
+        flags, w = ctx.flags, ctx.weights
+        g = g_total.to(torch.float32).contiguous()
+        d_a = d_b = d_im = d_s = None
+        scale = torch.empty(1, dtype=torch.float32, device=g.device) if dS is not None else None
+        if a is not None:
+            B, D = a.shape
+            d_a = torch.empty((B, D), dtype=torch.float32, device=a.device) if ctx.needs_input_grad[0] else None
+            d_b = torch.empty((B, D), dtype=torch.float32, device=a.device) if ctx.needs_input_grad[1] else None
+            _lib.check(_lib.load().aladin_heads_small_bwd(_ptr(a), _ld(a), _ptr(b), _ld(b), B, D, _ptr(dMh), _ptr(g), float(w[0]),
+                                                          _ptr(dMl), _ptr(g), float(w[2]), _ptr(None), 0, _ptr(g), float(w[1]),
+                                                          _ptr(scale), _ptr(d_a), _ptr(d_b), _stream()), 'heads_small_bwd')
+        elif scale is not None:
+            scale = g * float(w[1])
+        if dS is not None and any(ctx.needs_input_grad[2:4]):
+            d_im, d_s = _align_backward(im, s, im_len_t, s_len_t, dS, gscale=scale, packed=(ctx.geom, xm, xe, y), pairs=ctx.pairs)
+        return d_a, d_b, d_im, d_s, None, None, None, None, None, None, None, None
+
+
+def small_batch_loss_heads(img_emb, cap_emb, im_set, s_seq, im_len, s_len, margin, max_violation, heads, weights,
+                           temperature=6.0, eps=1e-10):
+    """The loss heads of one training step at B <= SMALL_BATCH_MAX in a single autograd node.
+    heads: subset of {'matching', 'alignment', 'distillation'}; weights: dict head -> fixed loss weight.
+    -> (total = sum_k w_k L_k  [differentiable], terms (3,) = matching / alignment / distillation values, S, M)."""
+    flags = (HEAD_MATCH_HINGE if 'matching' in heads else 0) | (HEAD_ALIGN_HINGE if 'alignment' in heads else 0) | \
+        (HEAD_LISTNET if 'distillation' in heads else 0)
+    if not flags:
+        raise ValueError('aladin_amd: no loss head selected')
+    _require_gpu(img_emb, cap_emb)
+    if img_emb.shape[0] > SMALL_BATCH_MAX:
+        raise ValueError('aladin_amd: small_batch_loss_heads takes B <= %d' % SMALL_BATCH_MAX)
+    im_len_t = s_len_t = None
+    if flags & (HEAD_ALIGN_HINGE | HEAD_LISTNET):
+        im_len_t, s_len_t = _check_sets(im_set, s_seq, im_len, s_len)
+        if not (im_set.shape[0] == s_seq.shape[0] == img_emb.shape[0]):
+            raise ValueError('aladin_amd: the loss heads need one image set, one caption and one embedding pair per sample')
+    w = (float(weights.get('matching', 0.0)), float(weights.get('alignment', 0.0)), float(weights.get('distillation', 0.0)))
+    return _SmallHeads.apply(img_emb, cap_emb, im_set, s_seq, im_len_t, s_len_t, margin, max_violation, flags, w, temperature, eps)
+
+
+def small_batch_match_distill(im, s, teacher, margin, max_violation, want_hinge=True, temperature=6.0, eps=1e-10):
+    """-> (hinge_loss, listnet_loss, M) for B <= SMALL_BATCH_MAX unit-norm global embeddings im, s (B, D):
+    M = im @ s.T (alad/loss.py:8-11), the VSE++ hinge on it (:42-67, if want_hinge) and the ListNet distillation from
+    `teacher` (:427-445, detached; None = no distillation) -- two launches per step instead of about twelve."""
+    _require_gpu(im, s)
+    if im.dim() != 2 or s.dim() != 2 or im.shape != s.shape:
+        raise ValueError('aladin_amd: two (B, D) embedding matrices of equal shape expected')
+    if im.shape[0] > SMALL_BATCH_MAX:
+        raise ValueError('aladin_amd: small_batch_match_distill takes B <= %d' % SMALL_BATCH_MAX)
+    if teacher is not None:
+        _require_gpu(teacher)
+        if tuple(teacher.shape) != (im.shape[0], im.shape[0]):
+            raise ValueError('aladin_amd: teacher scores must be (B, B)')
+        teacher = teacher.detach()
+    return _SmallMatchDistill.apply(im, s, teacher, margin, max_violation, want_hinge, temperature, eps)
 
 
 # ------------------------------------------------------------------------------------------------

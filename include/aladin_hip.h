@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define ALADIN_ABI_VERSION 4
+#define ALADIN_ABI_VERSION 5
 
 /* The library is built with -fvisibility=hidden: the entry points declared here are its ONLY exports. */
 #if defined(__GNUC__)
@@ -138,6 +138,19 @@ ALADIN_API int aladin_align_bwd_packed(const float* im, int64_t im_stride_b, int
                             const int32_t* pairs, const int32_t* pair_count,
                             float* d_im, float* d_s, void* workspace, void* stream);
 
+/* Same, writing the gradients in the CALLER'S layout: d_im[b * d_im_stride_b + r * d_im_stride_r + d] and likewise d_s
+ * (strides in floats, multiples of 4, unit inner stride).  The reference hands the sets as permuted (S,B,D)->(B,S,D)
+ * views (alad/alad_model.py:377-378); gradients produced in that layout spare autograd two re-layout copies (66 MB per
+ * step at B = 256).  xm / xe / y may be NULL (then geom only supplies the sizes and tails and the exact fp32 recompute
+ * of aladin_align_bwd runs). */
+ALADIN_API int aladin_align_bwd_packed_strided(const float* im, int64_t im_stride_b, int64_t im_stride_r, const int32_t* im_len,
+                                               const float* s, int64_t s_stride_b, int64_t s_stride_t, const int32_t* s_len,
+                                               const float* dS, int64_t ld_dS, const float* gscale, const void* xm, const void* xe,
+                                               const void* y, const aladin_align_geom* geom, const int32_t* pairs,
+                                               const int32_t* pair_count, float* d_im, int64_t d_im_stride_b,
+                                               int64_t d_im_stride_r, float* d_s, int64_t d_s_stride_b, int64_t d_s_stride_t,
+                                               void* workspace, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * 'sum' / 'mean' pooling (alad/loss.py:120-123): sum_r sum_w <im^,s^> = <sum_r im^, sum_w s^>.
  * normsum: out[b][:] = sum over positions 1 .. len[b]-1-tail of the L2-normalised rows of x (B,N,D);
@@ -171,6 +184,37 @@ ALADIN_API size_t aladin_listnet_workspace_bytes(int B);
 ALADIN_API int aladin_listnet_fwd_bwd(const float* teacher, int64_t ld_t, const float* student, int64_t ld_s, int B,
                            float temperature, float eps, float* loss, float* d_student,
                            void* workspace, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Loss heads at the shipped batch size (B <= 64; every YAML trains with bs 32): three launches instead of the
+ * ~15 few-microsecond kernels of the general path (csrc/small_batch.hip).  `flags` selects the heads:
+ *   ALADIN_HEAD_MATCH_HINGE  M = img . cap^T (dot_sim, alad/loss.py:8-11) and the VSE++ hinge on it (:42-67)
+ *   ALADIN_HEAD_ALIGN_HINGE  the same hinge on the alignment scores S (B x B, from aladin_align_scores)
+ *   ALADIN_HEAD_LISTNET      ListNet distillation of M from the teacher S (:427-445; also computes M)
+ * fwd (2 launches) writes M (B x B contiguous; needed by MATCH_HINGE / LISTNET), terms[3] = {matching hinge,
+ * alignment hinge, listnet} (0 for a head that is off), *total = sum of the selected terms times w_* (the
+ * fixed-weight sum of alad_model.py:450-453; may be NULL), and -- each optional -- dM_hinge, dM_listnet (B x B),
+ * dS (B x B) with the non-zero pair list pairs / pair_count of the alignment hinge, in the form
+ * aladin_align_bwd_packed takes.  workspace: aladin_heads_small_workspace_bytes(B).
+ * bwd (1 launch): d_img = C . cap, d_cap = C^T . img, C = *g_hinge * w_hinge * dM_hinge + *g_listnet * w_listnet *
+ * dM_listnet + g_M (every term optional: NULL = absent; g_* are DEVICE scalars, g_M a (B x B) upstream gradient of M);
+ * align_scale_out (may be NULL) receives *g_align * w_align, the `gscale` of the alignment backward.
+ * d_img / d_cap: (B x D) contiguous, either may be NULL.
+ * ------------------------------------------------------------------------------------------- */
+#define ALADIN_HEAD_MATCH_HINGE 1
+#define ALADIN_HEAD_ALIGN_HINGE 2
+#define ALADIN_HEAD_LISTNET 4
+ALADIN_API size_t aladin_heads_small_workspace_bytes(int B);
+ALADIN_API int aladin_heads_small_fwd(const float* img, int64_t ld_img, const float* cap, int64_t ld_cap, const float* S,
+                                      int64_t ld_S, int B, int D, float margin, int max_violation, int flags, float temperature,
+                                      float eps, float w_match, float w_align, float w_dist, float* M, float* terms, float* total,
+                                      float* dM_hinge, float* dM_listnet, float* dS, int32_t* pairs, int32_t* pair_count,
+                                      void* workspace, void* stream);
+ALADIN_API int aladin_heads_small_bwd(const float* img, int64_t ld_img, const float* cap, int64_t ld_cap, int B, int D,
+                                      const float* dM_hinge, const float* g_hinge, float w_hinge, const float* dM_listnet,
+                                      const float* g_listnet, float w_listnet, const float* g_M, int64_t ld_gM,
+                                      const float* g_align, float w_align, float* align_scale_out, float* d_img, float* d_cap,
+                                      void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Device-resident evaluation store (replaces the (N, 71, D) fp32 host buffers that encode_data fills,

@@ -598,6 +598,15 @@ def test_alignment_head_retrieval_coco1k(eval_precision):
     assert torch.equal(E.compute_sim_matrix(si.view(slice(0, None, 5)), sc, mode='alignment').cpu(), torch.from_numpy(S))
 
 
+def _fill_store(sets, lens, tail, precision, batch=4):
+    from aladin_amd.store import PackedSetStore
+    st = PackedSetStore(sets.shape[2], tail, dev(), capacity_rows=64, precision=precision)
+    for k0 in range(0, sets.shape[0], batch):
+        k1 = min(sets.shape[0], k0 + batch)
+        st.append(T(sets[k0:k1, :max(lens[k0:k1])]), lens[k0:k1])
+    return st
+
+
 def test_trimmed_grid_keeps_the_zero_fill_of_the_longest_image(eval_precision):
     """A word whose cosine with EVERY region of an image is negative contributes max(negatives, 0) = 0 when the
     image is shorter than the padded set (masked regions are zero-filled and take part in the max,
@@ -622,7 +631,7 @@ def test_trimmed_grid_keeps_the_zero_fill_of_the_longest_image(eval_precision):
     tol = 2e-6 if eval_precision == 'split' else 2e-3
     np.testing.assert_allclose(S, ref, rtol=0, atol=tol)
     # ... and the same from packed stores
-    si, sc = _fill_stores(images, captions, il, cl, batch=4, precision=eval_precision)
+    si, sc = _fill_store(images, il, 0, eval_precision), _fill_store(captions, cl, 2, eval_precision)
     np.testing.assert_array_equal(E.compute_sim_matrix(si, sc, mode='alignment').cpu().numpy(), S)
     # an image that fills the padded set keeps its negative maximum
     images[1, 33:] = images[1, 1:39]
@@ -632,7 +641,7 @@ def test_trimmed_grid_keeps_the_zero_fill_of_the_longest_image(eval_precision):
     assert ref[1, 4] < O.alignment_scores(images, captions, [20, 70, 33, 12, 33, 25], cl, dtype=np.float64)[1, 4] - 0.1
     S = E.compute_sim_matrix(images, captions, il, cl, mode='alignment').cpu().numpy()
     np.testing.assert_allclose(S, ref, rtol=0, atol=tol)
-    si, sc = _fill_stores(images, captions, il, cl, batch=4, precision=eval_precision)
+    si, sc = _fill_store(images, il, 0, eval_precision), _fill_store(captions, cl, 2, eval_precision)
     np.testing.assert_array_equal(E.compute_sim_matrix(si, sc, mode='alignment').cpu().numpy(), S)
 
 
@@ -1038,7 +1047,7 @@ def test_leftover_regions_as_side_rows(R):
     a2, b2 = T(im[:n]).requires_grad_(True), T(s[:n]).requires_grad_(True)
     loss, S2 = ops.alignment_triplet_loss(a2, b2, il[:n], sl[:n], 0.2, True)
     loss.backward()
-    ref_loss, dS = O.hinge_loss(S2.cpu().numpy(), 0.2, True, return_grad=True)
+    ref_loss, dS = O.hinge_loss(S2.detach().cpu().numpy(), 0.2, True, return_grad=True)
     np.testing.assert_allclose(loss.item(), ref_loss, rtol=1e-5)
     ra, rb = torch.from_numpy(im[:n]).double().requires_grad_(True), torch.from_numpy(s[:n]).double().requires_grad_(True)
     (FT.alignment_scores_faithful(ra, rb, il[:n], sl[:n]) * torch.from_numpy(dS).double()).sum().backward()
@@ -1345,6 +1354,157 @@ def test_config4_shape_level_step_with_the_real_head(eval_precision):
     model.eval()
     img_embs, cap_embs, il, cl = E.encode_data(model, _Loader([(examples_imgs, examples_txts)]), logging=None)
     assert img_embs.shape == (bs, 71, 768) and il == feat_len and cl == cap_len
+
+
+@pytest.mark.parametrize('loss_type,weights', [('alignment-distillation', [1, 1]), ('alignment-distillation-matching', [1, 1, 0.1])])
+def test_graphed_loss_step_equals_eager(eval_precision, loss_type, weights):
+    """aladin_amd.graphs.GraphedLossStep (HIP-graph replay of forward_loss + weighted sum + backward at the shipped
+    batch size 32) gives the eager path's loss, terms, logger entries and input gradients bit for bit, on fresh data and
+    fresh lengths of the captured shape, before and after the distillation epoch."""
+    if eval_precision != 'fp16':
+        pytest.skip('training step; run once')
+    from aladin_amd import synth
+    from aladin_amd.alad_model import ALADModel
+    from aladin_amd.evaluation import LogCollector
+    from aladin_amd.graphs import GraphedLossStep
+    config = {'training': {'loss-type': loss_type, 'loss-weights': weights, 'margin': 0.2, 'measure': 'dot',
+                           'max-violation': True, 'alignment-mode': 'MrSw', 'distillation-mode': 'listnet'}}
+    B, R, Tn, D = 32, 34, 50, 768
+    model = ALADModel(config)
+    step = GraphedLossStep(model)
+    for seed, epoch in ((1, 5), (2, 5), (3, 0), (4, 0), (5, 5)):
+        im, s, il, sl = synth.structured_alignment_batch(B, R, Tn, D, seed=seed, noise=3.0, ragged=True)
+        ge, gc = synth.global_embeddings(B, D, seed=seed + 50, noise=1.0)
+        outs = []
+        for graphed in (False, True):
+            t = [T(ge).requires_grad_(True), T(gc).requires_grad_(True), T(im.transpose(1, 0, 2).copy()).requires_grad_(True),
+                 T(s.transpose(1, 0, 2).copy()).requires_grad_(True)]
+            model.logger = LogCollector()
+            if graphed:
+                loss, d = step(t[0], t[1], t[2], t[3], il, sl, epoch=epoch, distill_epoch=2)
+            else:
+                d = model.forward_loss(t[0], t[1], t[2], t[3], il, sl, 0)
+                loss = model.weighted_total(d, epoch, 2)
+            (2.0 * loss).backward()                           # a power of two: scaling before or after the kernels gives the same bits
+            outs.append((loss.detach().clone(), {k: v.detach().clone() for k, v in d.items()}, [None if x.grad is None else x.grad.clone() for x in t],
+                         {k: m.val for k, m in model.logger.meters.items()}))
+        (l0, d0, g0, log0), (l1, d1, g1, log1) = outs
+        assert torch.equal(l0, l1) and list(d0) == list(d1) and log0 == log1
+        assert all(torch.equal(d0[k], d1[k]) for k in d0)
+        for a, b in zip(g0, g1):
+            if a is None or b is None:                                 # no active term depends on that input
+                assert (a is None or float(a.abs().max()) == 0.0) and (b is None or float(b.abs().max()) == 0.0)
+            else:
+                assert torch.equal(a, b)
+    assert len(step._cache) == 2                                     # one graph per (shape, distillation active)
+
+
+@pytest.mark.parametrize('B,D', [(5, 64), (32, 768), (64, 768), (33, 100)])
+@pytest.mark.parametrize('mv', [True, False])
+def test_small_batch_fused_heads_equal_the_separate_kernels(eval_precision, B, D, mv):
+    """ops.small_batch_match_distill (B <= 64: one forward + one backward launch) against the separate kernels
+    (exact-fp32 sgemm + hinge + listnet, each pinned to the reference's goldens) and against the oracle."""
+    if eval_precision != 'fp16':
+        pytest.skip('matching / distillation heads; run once')
+    from aladin_amd import ops, synth
+    from aladin_amd.loss import ContrastiveLoss, DistillationLoss
+    ge, gc = synth.global_embeddings(B, D, seed=700 + B, noise=0.7)
+    teacher = (synth.normal((B, B), 800 + B) * 0.8 + 3.0 * np.eye(B, dtype=np.float32) + 4.0).astype(np.float32)
+    w = 0.05 * synth.normal((B, B), 900 + B)
+    res = []
+    for fused in (True, False):
+        a, b = T(ge).requires_grad_(True), T(gc).requires_grad_(True)
+        if fused:
+            lh, ll, M = ops.small_batch_match_distill(a, b, T(teacher), 0.2, mv)
+        else:
+            lh, M = ContrastiveLoss(0.2, 'dot', mv)(a, b, return_similarity_mat=True)
+            ll = DistillationLoss('listnet')(T(teacher), M)
+        (0.7 * lh + 1.3 * ll + (M * T(w)).sum()).backward()
+        res.append((lh.item(), ll.item(), M.detach().cpu().numpy(), a.grad.cpu().numpy(), b.grad.cpu().numpy()))
+    (h1, l1, M1, da1, db1), (h0, l0, M0, da0, db0) = res
+    np.testing.assert_allclose(M1, M0, rtol=0, atol=1e-6)
+    np.testing.assert_allclose([h1, l1], [h0, l0], rtol=2e-6, atol=1e-6)
+    scale = max(float(np.abs(da0).max()), float(np.abs(db0).max()))
+    np.testing.assert_allclose(da1, da0, rtol=1e-5, atol=2e-6 * scale)
+    np.testing.assert_allclose(db1, db0, rtol=1e-5, atol=2e-6 * scale)
+    # oracle: scores, both losses
+    Mo = O.dot_scores(ge, gc)
+    np.testing.assert_allclose(M1, Mo, rtol=0, atol=2e-6)
+    np.testing.assert_allclose(h1, O.hinge_loss(Mo, 0.2, mv), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(l1, O.listnet_loss(teacher, Mo), rtol=1e-5, atol=1e-6)
+    # heads switched off
+    a, b = T(ge).requires_grad_(True), T(gc).requires_grad_(True)
+    lh, ll, M = ops.small_batch_match_distill(a, b, None, 0.2, mv)
+    assert ll.item() == 0.0 and abs(lh.item() - h0) <= 2e-6 * max(1.0, abs(h0))
+    lh.backward()
+    assert torch.isfinite(a.grad).all()
+    a, b = T(ge).requires_grad_(True), T(gc).requires_grad_(True)
+    lh, ll, M = ops.small_batch_match_distill(a, b, T(teacher), 0.2, mv, want_hinge=False)
+    assert lh.item() == 0.0 and abs(ll.item() - l0) <= 2e-6 * max(1.0, abs(l0))
+    with pytest.raises(ValueError):
+        ops.small_batch_match_distill(T(np.zeros((65, 8), np.float32)), T(np.zeros((65, 8), np.float32)), None, 0.2, True)
+
+
+@pytest.mark.parametrize('heads', [('matching', 'alignment', 'distillation'), ('alignment', 'distillation'), ('alignment',),
+                                   ('matching',), ('distillation',), ('matching', 'distillation')])
+def test_small_batch_single_node_step_equals_the_composition(eval_precision, heads):
+    """ops.small_batch_loss_heads (the whole loss-head step of a bs <= 64 batch as one autograd node, weights inside)
+    against the same terms composed from the separate differentiable pieces."""
+    if eval_precision != 'fp16':
+        pytest.skip('training step; run once')
+    from aladin_amd import ops, synth
+    B, R, Tn, D = 32, 34, 50, 768
+    im, s, il, sl = synth.structured_alignment_batch(B, R, Tn, D, seed=321, noise=3.0, ragged=True)
+    ge, gc = synth.global_embeddings(B, D, seed=322, noise=1.0)
+    weights = {'matching': 0.1, 'alignment': 1.0, 'distillation': 0.75}
+    ten = lambda: [T(ge).requires_grad_(True), T(gc).requires_grad_(True), T(im).requires_grad_(True), T(s).requires_grad_(True)]
+    t1 = ten()
+    total, terms, S, M = ops.small_batch_loss_heads(t1[0], t1[1], t1[2], t1[3], il, sl, 0.2, True, heads, weights)
+    (2.0 * total).backward()
+    t0 = ten()
+    ref, vals = 0, [0.0, 0.0, 0.0]
+    if 'alignment' in heads or 'distillation' in heads:
+        la, S0 = ops.alignment_triplet_loss(t0[2], t0[3], il, sl, 0.2, True)
+    if 'matching' in heads or 'distillation' in heads:
+        lm, ld, M0 = ops.small_batch_match_distill(t0[0], t0[1], S0 if 'distillation' in heads else None, 0.2, True,
+                                                   want_hinge='matching' in heads)
+    if 'matching' in heads:
+        ref, vals[0] = ref + lm * weights['matching'], float(lm.detach())
+    if 'alignment' in heads:
+        ref, vals[1] = ref + la * weights['alignment'], float(la.detach())
+    if 'distillation' in heads:
+        ref, vals[2] = ref + ld * weights['distillation'], float(ld.detach())
+    (2.0 * ref).backward()
+    np.testing.assert_allclose(float(total), float(ref), rtol=1e-6)
+    np.testing.assert_allclose(terms.cpu().numpy(), vals, rtol=1e-6, atol=1e-7)
+    for a, b in zip(t1, t0):
+        if b.grad is None:
+            assert a.grad is None or float(a.grad.abs().max()) == 0.0
+        else:
+            scale = float(b.grad.abs().max())
+            np.testing.assert_allclose(a.grad.cpu().numpy(), b.grad.cpu().numpy(), rtol=1e-5, atol=1e-6 * scale)
+
+
+def test_forward_loss_small_and_large_batch_paths_agree_with_the_modules(eval_precision):
+    """ALADModel.forward_loss takes the fused small-batch path for B <= 64 and the separate kernels above it: both give
+    the terms the criterion modules give on their own."""
+    if eval_precision != 'fp16':
+        pytest.skip('training step; run once')
+    from aladin_amd import synth
+    from aladin_amd.alad_model import ALADModel
+    config = {'training': {'loss-type': 'alignment-distillation-matching', 'loss-weights': [1, 1, 0.1], 'margin': 0.2,
+                           'measure': 'dot', 'max-violation': True, 'alignment-mode': 'MrSw', 'distillation-mode': 'listnet'}}
+    model = ALADModel(config)
+    for B in (48, 80):
+        im, s, il, sl = synth.structured_alignment_batch(B, 20, 24, 128, seed=60 + B, noise=2.0, ragged=True)
+        ge, gc = synth.global_embeddings(B, 128, seed=70 + B)
+        d = model.forward_loss(T(ge), T(gc), T(im).permute(1, 0, 2), T(s).permute(1, 0, 2), il, sl, 0)
+        assert list(d) == ['matching', 'alignment', 'distillation']
+        lm, M = model.matching_criterion(T(ge), T(gc), return_similarity_mat=True)
+        la, S = model.alignment_criterion(T(im), T(s), il, sl, return_similarity_mat=True)
+        ld = model.distillation_loss(S, M)
+        np.testing.assert_allclose([float(d['matching']), float(d['alignment']), float(d['distillation'])],
+                                   [float(lm), float(la), float(ld)], rtol=2e-6, atol=1e-6)
 
 
 def test_degenerate_lengths_and_zero_vectors():

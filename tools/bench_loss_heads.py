@@ -66,7 +66,8 @@ def main():
     from aladin_amd import synth
     from aladin_amd.loss import AlignmentContrastiveLoss, ContrastiveLoss, DistillationLoss
     dev = torch.device('cuda:0')
-    for B in (32, 256):
+    batches = [int(v) for v in sys.argv[1:]] or [32, 256]
+    for B in batches:
         im, s, il, sl = synth.alignment_batch(B, 34, 50, 768, seed=7, ragged=True)
         gi, gc = synth.global_embeddings(B, 768, seed=8)
         a = torch.from_numpy(im).to(dev).requires_grad_(True)
@@ -92,11 +93,30 @@ def main():
             S = ref_alignment(a, b, il, sl)
             (ref_hinge(S) + ref_listnet(S, M)).backward()
 
+        # the same step captured once into a HIP graph and replayed (aladin_amd.graphs.GraphedLossStep over ALADModel.forward_loss)
+        from aladin_amd.alad_model import ALADModel
+        from aladin_amd.graphs import GraphedLossStep
+        model = ALADModel({'training': {'loss-type': 'alignment-distillation', 'loss-weights': [1, 1], 'margin': 0.2, 'measure': 'dot',
+                                        'max-violation': True, 'alignment-mode': 'MrSw', 'distillation-mode': 'listnet'}})
+        gstep = GraphedLossStep(model)
+        a_s, b_s = a.detach().permute(1, 0, 2).contiguous().requires_grad_(True), b.detach().permute(1, 0, 2).contiguous().requires_grad_(True)
+
+        def graphed():
+            for t in (a_s, b_s, x, y):
+                t.grad = None
+            loss, _ = gstep(x, y, a_s, b_s, il, sl, epoch=5)
+            loss.backward()
+
+        def graph_only():                                       # the captured kernels alone (no input copies, no autograd glue)
+            next(iter(gstep._cache.values())).graph.replay()
+
+        graphed()
         with torch.no_grad():
             l1 = float(ac(a, b, il, sl)) + float(dc(ac(a, b, il, sl, return_loss=False, return_similarity_mat=True), x.mm(y.t())))
             Sr = ref_alignment(a, b, il, sl)
             l2 = float(ref_hinge(Sr)) + float(ref_listnet(Sr, x.mm(y.t())))
-        print(json.dumps({'batch': B, 'hip_ms': round(timed(ours, 50), 4), 'torch_rocm_eager_ms': round(timed(ref, 10), 3),
+        print(json.dumps({'batch': B, 'hip_ms': round(timed(ours, 50), 4), 'hip_graphed_step_ms': round(timed(graphed, 200), 4),
+                          'hip_graph_replay_only_ms': round(timed(graph_only, 500), 4), 'torch_rocm_eager_ms': round(timed(ref, 10), 3),
                           'loss_hip': round(l1, 5), 'loss_eager': round(l2, 5)}), flush=True)
 
 
