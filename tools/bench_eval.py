@@ -47,48 +47,64 @@ def main():
     images, captions, il, cl = synth.eval_sets(n, 768, seed=9)
     ia = torch.from_numpy(images[0::5]).to(dev)
     ca = torch.from_numpy(captions).to(dev)
+    images_d = torch.from_numpy(images).to(dev)
     ilen = il[0::5]
-    ms_align = timed(lambda: E.compute_sim_matrix(ia, ca, ilen, cl, mode='alignment'), iters=5)
-    ms_align_padded = timed(lambda: ops.alignment_scores(ia, ca, ilen, cl), iters=3)
     pairs = n * 5 * n
-    print(json.dumps({'workload': 'alignment-head grid 1000x5000, sets padded to L=71, trimmed to the longest real length',
-                      'ms': round(ms_align, 3), 'pairs_per_s': round(pairs / ms_align * 1e3, 1),
-                      'ms_untrimmed_70x68': round(ms_align_padded, 3)}))
-    # the same grid from the packed 16-bit stores (aladin_amd/store.py): operands are row copies
     from aladin_amd.store import PackedSetStore
-    si, sc = PackedSetStore(768, 0, dev), PackedSetStore(768, 2, dev)
-    for k0 in range(0, images.shape[0], 500):
-        si.append(torch.from_numpy(images[k0:k0 + 500]).to(dev), il[k0:k0 + 500])
-        sc.append(ca[k0:k0 + 500], cl[k0:k0 + 500])
-    view = si.view(slice(0, None, 5))
-    assert torch.equal(E.compute_sim_matrix(view, sc, mode='alignment'), E.compute_sim_matrix(ia, ca, ilen, cl, mode='alignment'))
-    ms_store = timed(lambda: E.compute_sim_matrix(view, sc, mode='alignment'), iters=5)
-    print(json.dumps({'workload': 'alignment-head grid 1000x5000 from PackedSetStore (fp16, packed by true length), bit-identical scores',
-                      'ms': round(ms_store, 3), 'pairs_per_s': round(pairs / ms_store * 1e3, 1),
-                      'store_MB': round((si.nbytes() + sc.nbytes()) / 2 ** 20, 1),
-                      'dense_fp32_MB': round((images.nbytes + captions.nbytes) / 2 ** 20, 1)}))
+    for prec in ('split', 'fp16'):                       # 'split' = the rank-exact evaluation default, 'fp16' = training operands
+        ops.set_eval_precision(prec)
+        ms_align = timed(lambda: E.compute_sim_matrix(ia, ca, ilen, cl, mode='alignment'), iters=5)
+        print(json.dumps({'workload': 'alignment-head grid 1000x5000 (sets padded to L=71; trimmed to the real lengths + one masked region), precision ' + prec,
+                          'ms': round(ms_align, 3), 'pairs_per_s': round(pairs / ms_align * 1e3, 1)}))
+        # i2t + t2i drivers on device-resident (N, 71, D) tensors: one grid (memoised), ranks, top-50 lists
+        def drivers():
+            E.clear_eval_cache()
+            E.i2t(images_d, ca, il, cl, sim_function='alignment')
+            return E.t2i(images_d, ca, il, cl, sim_function='alignment', return_ranks=True)
+        ms_drv = timed(drivers, iters=3, warm=1)
+        print(json.dumps({'workload': 'i2t + t2i (alignment head, COCO-1k protocol, ranks + top-50, metrics on the host), precision ' + prec,
+                          'ms': round(ms_drv, 3)}))
+        # the same grid from the packed stores (aladin_amd/store.py): operands are row copies
+        si, sc = PackedSetStore(768, 0, dev, precision=prec), PackedSetStore(768, 2, dev, precision=prec)
+        for k0 in range(0, images.shape[0], 500):
+            si.append(images_d[k0:k0 + 500], il[k0:k0 + 500])
+            sc.append(ca[k0:k0 + 500], cl[k0:k0 + 500])
+        view = si.view(slice(0, None, 5))
+        assert torch.equal(E.compute_sim_matrix(view, sc, mode='alignment'), E.compute_sim_matrix(ia, ca, ilen, cl, mode='alignment'))
+        ms_store = timed(lambda: E.compute_sim_matrix(view, sc, mode='alignment'), iters=5)
+        print(json.dumps({'workload': 'alignment-head grid 1000x5000 from PackedSetStore (packed by true length), bit-identical scores, precision ' + prec,
+                          'ms': round(ms_store, 3), 'pairs_per_s': round(pairs / ms_store * 1e3, 1),
+                          'store_MB': round((si.nbytes() + sc.nbytes()) / 2 ** 20, 1),
+                          'dense_fp32_MB': round((images.nbytes + captions.nbytes) / 2 ** 20, 1)}))
+    ops.set_eval_precision('fp16')
+    ms_align_padded = timed(lambda: ops._align_forward(ia, ca, ops.lengths_tensor(ilen, dev), ops.lengths_tensor(cl, dev))[0], iters=3)
+    print(json.dumps({'workload': 'the same grid scored on the padded 70 x 68 blocks (no trimming), fp16', 'ms': round(ms_align_padded, 3)}))
 
     # COCO-5k sized alignment-head retrieval (5000 images x 25000 captions, lengths as in COCO: 12..34 regions,
     # 7..30 tokens) from packed stores filled batch by batch on the device; device-generated features.
     g = torch.Generator(device=dev).manual_seed(5)
     il5 = torch.randint(12, 35, (5000,), generator=g, device=dev).tolist()
     cl5 = torch.randint(7, 31, (25000,), generator=g, device=dev).tolist()
-    si5, sc5 = PackedSetStore(768, 0, dev, capacity_rows=5000 * 34), PackedSetStore(768, 2, dev, capacity_rows=25000 * 28)
-    for k0 in range(0, 5000, 500):
-        si5.append(torch.randn((500, 34, 768), generator=g, device=dev), il5[k0:k0 + 500])
-    for k0 in range(0, 25000, 500):
-        sc5.append(torch.randn((500, 30, 768), generator=g, device=dev), cl5[k0:k0 + 500])
-    torch.cuda.synchronize()
+    for prec in ('split', 'fp16'):
+        si5 = PackedSetStore(768, 0, dev, capacity_rows=5000 * 34, precision=prec)
+        sc5 = PackedSetStore(768, 2, dev, capacity_rows=25000 * 28, precision=prec)
+        g.manual_seed(5)
+        for k0 in range(0, 5000, 500):
+            si5.append(torch.randn((500, 34, 768), generator=g, device=dev), il5[k0:k0 + 500])
+        for k0 in range(0, 25000, 500):
+            sc5.append(torch.randn((500, 30, 768), generator=g, device=dev), cl5[k0:k0 + 500])
+        torch.cuda.synchronize()
 
-    def full():
-        S5 = E.compute_sim_matrix(si5, sc5, mode='alignment')
-        return ops.recall_ranks(S5)
+        def full():
+            S5 = E.compute_sim_matrix(si5, sc5, mode='alignment')
+            return ops.recall_ranks(S5)
 
-    ms_full = timed(full, iters=3, warm=1)
-    print(json.dumps({'workload': 'COCO-5k sized alignment-head retrieval: 5000 x 25000 grid from PackedSetStores + all four rank outputs',
-                      'ms': round(ms_full, 2), 'pairs_per_s': round(5000 * 25000 / ms_full * 1e3, 1),
-                      'store_MB': round((si5.nbytes() + sc5.nbytes()) / 2 ** 20, 1),
-                      'reference_buffers_MB': round((5000 * 5 + 25000) * 71 * 768 * 4 / 2 ** 20, 1)}))
+        ms_full = timed(full, iters=3, warm=1)
+        print(json.dumps({'workload': 'COCO-5k sized alignment-head retrieval: 5000 x 25000 grid from PackedSetStores + all four rank outputs, precision ' + prec,
+                          'ms': round(ms_full, 2), 'pairs_per_s': round(5000 * 25000 / ms_full * 1e3, 1),
+                          'store_MB': round((si5.nbytes() + sc5.nbytes()) / 2 ** 20, 1),
+                          'reference_buffers_MB': round((5000 * 5 + 25000) * 71 * 768 * 4 / 2 ** 20, 1)}))
+        del si5, sc5
 
 
 if __name__ == '__main__':
