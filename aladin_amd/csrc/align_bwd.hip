@@ -372,9 +372,10 @@ __global__ __launch_bounds__(256) void bwd_rows_kernel(
   __shared__ int lst_p[4][ROWS_LIST];
   __shared__ float lst_g[4][ROWS_LIST];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  // XCD-compact row order: the rows of one sample gather from the same few partner samples, so they should meet in
-  // ONE L2 (workgroups are dealt round-robin over the 8 XCDs; xcd_remap hands each XCD a contiguous range of rows)
-  const int64_t row = (int64_t)xcd_remap(blockIdx.x, gridDim.x) * 4 + wave;
+  // plain round-robin of the rows over the XCDs.  (An XCD-compact order -- every XCD a contiguous range of rows, so
+  // that a sample's rows meet their partners in ONE L2 -- cut the traffic 302 -> 265 MB but ran 57.6 vs 50.3 us:
+  // a sample's rows then queue on the same few memory channels; measured r02l, not kept.)
+  const int64_t row = (int64_t)blockIdx.x * 4 + wave;
   const int64_t n_im_rows = (int64_t)Bi * R;
   if (row >= n_im_rows + (int64_t)Bc * T) return;
   const bool is_img = row < n_im_rows;
