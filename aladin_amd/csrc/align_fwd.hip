@@ -548,6 +548,17 @@ __global__ __launch_bounds__(512) void align_scores16_kernel(const half_t* __res
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) acc[rt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  if constexpr (HAS_E && REMC == 1 && Q == 1) {
+    // The epilogue's side-row values E[img][cols] were written by the side GEMM on OTHER XCDs: pull this tile's 12
+    // lines per wave (2 images x 192 columns) into this XCD's L2 now, so that the epilogue's loads do not pay an HBM /
+    // fabric round trip 25 us from here.  The data itself is dropped: one LDS-DMA dword per lane into the piece of
+    // stage 1 that this same wave overwrites with its own (later, in-order) refill.
+    const int wave_u = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane_p = threadIdx.x & 63;
+    const int img_p = (mb * 4 + wave_u / 2) * 2 + ((lane_p % 12) / 6);
+    const float* src = E + (int64_t)img_p * ldE + (int64_t)nb * Cfg::BN + (wave_u % 2) * 192 + (lane_p % 6) * 32;
+    __builtin_amdgcn_global_load_lds(GLOBAL_PTR(src), LDS_PTR(smem + Cfg::STAGE_BYTES + wave_u * 1024), 4, 0, 0);
+  }
   unsigned long long pt0 = 0, pr0 = 0, pt1 = 0, pr1 = 0;
   if constexpr (PROBE) { pt0 = __builtin_amdgcn_s_memtime(); pr0 = __builtin_amdgcn_s_memrealtime(); }
   gemm_mainloop16<Cfg, true>(xm + (int64_t)mb * Cfg::BM * ldk, y + (int64_t)nb * Cfg::BN * ldk, ldk, ktiles, smem, acc);
