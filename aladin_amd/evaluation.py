@@ -271,7 +271,7 @@ def _memo_key(images, captions, img_lenghts, cap_lenghts, measure, sim_function)
             return ('t', x.data_ptr(), tuple(x.shape), x._version, str(x.device))
         if _is_store(x):
             st = getattr(x, 'store', x)
-            return ('s', id(st), st.n_rows, len(st), tuple(getattr(x, 'ids', ())[:4]), len(x))
+            return ('s', id(st), st.n_rows, len(st), hash(tuple(getattr(x, 'ids', ()))), len(x))
         return ('o', id(x))
     fn = sim_function if (sim_function is None or isinstance(sim_function, str)) else id(sim_function)
     return (ident(images), ident(captions), hash(tuple(int(v) for v in img_lenghts)) if img_lenghts is not None else None,
