@@ -31,7 +31,7 @@ SYMBOLS = [
     'aladin_scan_workspace_bytes', 'aladin_scan_fwd', 'aladin_scan_bwd',
     'aladin_store_row_width', 'aladin_store_append', 'aladin_align_pack_store_x', 'aladin_align_pack_store_y',
     'aladin_store_row_width_mode', 'aladin_store_append_mode', 'aladin_topk',
-    'aladin_heads_small_workspace_bytes', 'aladin_heads_small_fwd', 'aladin_heads_small_bwd',
+    'aladin_loss_total', 'aladin_grad_combine', 'aladin_heads_small_workspace_bytes', 'aladin_heads_small_fwd', 'aladin_heads_small_bwd',
 ]
 
 
@@ -93,6 +93,8 @@ def _declare(lib):
         'aladin_store_row_width_mode': (C.c_int, [i32, i32]),
         'aladin_store_append_mode': (C.c_int, [p, i64, i64, p, i32, i32, i32, i32, p, p, i32, p]),
         'aladin_topk': (C.c_int, [p, i64, i64, i32, i32, i32, p, p, p]),
+        'aladin_loss_total': (C.c_int, [p, f32, p, f32, p, f32, p, p]),
+        'aladin_grad_combine': (C.c_int, [i64, p, f32, p, f32, p, p, f32, p, p]),
         'aladin_heads_small_workspace_bytes': (sz, [i32]),
         'aladin_heads_small_fwd': (C.c_int, [p, i64, p, i64, p, i64, i32, i32, f32, i32, i32, f32, f32, f32, f32, f32, p, p, p, p, p, p,
                                              p, p, p, p]),

@@ -157,10 +157,10 @@ class ALADModel(nn.Module):
         return loss
 
     def _fused_heads_ok(self, img_emb):
-        """The single-node small-batch step (ops.small_batch_loss_heads) covers what every shipped YAML trains with:
-        bs <= 64, measure 'dot', 'MrSw' alignment, listnet distillation, fixed loss weights."""
+        """The single-node step (ops.loss_heads) covers what every shipped YAML trains with: measure 'dot', 'MrSw'
+        alignment, listnet distillation, fixed loss weights (three head launches at bs <= 64, the general kernels above)."""
         types = set(self.losses_types)
-        return (img_emb.shape[0] <= ops.SMALL_BATCH_MAX and not self.auto_weight and types <= {'matching', 'alignment', 'distillation'}
+        return (not self.auto_weight and types <= {'matching', 'alignment', 'distillation'}
                 and getattr(self.matching_criterion, 'sim', None) is dot_sim
                 and ('alignment' not in types and 'distillation' not in types or self.alignment_criterion.aggregation == 'MrSw')
                 and ('distillation' not in types or self.distillation_loss.mode == 'listnet'))
@@ -168,8 +168,8 @@ class ALADModel(nn.Module):
     def forward_loss_total(self, img_emb, cap_emb, img_emb_set, cap_emb_seq, img_lengths, cap_lengths, reg_loss, epoch=0,
                            distill_epoch=2, log=True):
         """forward_loss + the weighted sum of forward (alad_model.py:371-428 + :442-453) -> (loss, loss_dict).
-        For the shipped configurations at bs <= 64 the whole thing is ONE autograd node (three head launches, no
-        element-wise glue): the terms of `loss_dict` are then detached values for logging, `loss` carries the graph.
+        For the shipped configurations the whole thing is ONE autograd node (no element-wise glue; three head launches at
+        bs <= 64): the terms of `loss_dict` are then detached values for logging, `loss` carries the graph.
         Otherwise it is forward_loss followed by weighted_total."""
         if not self._fused_heads_ok(img_emb):
             d = self.forward_loss(img_emb, cap_emb, img_emb_set, cap_emb_seq, img_lengths, cap_lengths, reg_loss, log=log)

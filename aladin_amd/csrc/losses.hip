@@ -253,6 +253,49 @@ extern "C" int aladin_listnet_fwd_bwd(const float* teacher, int64_t ld_t, const 
 }
 
 // ------------------------------------------------------------------------------------------------
+// The weighted sum of the loss terms (alad_model.py:450-453) and its backward without element-wise glue launches:
+//   loss_total      total = sum_k w_k * term_k over up to three device scalars (NULL = absent), separate mul / add
+//   grad_combine    out[e] = *g * (wa * A[e] + wb * B[e])  (A, B: the dLoss/dM matrices of the matching hinge and of
+//                   ListNet; either may be NULL) and *scale_out = *g * w_scale (the alignment backward's gscale)
+// ------------------------------------------------------------------------------------------------
+__global__ void loss_total_kernel(const float* a, float wa, const float* b, float wb, const float* c, float wc, float* total) {
+  float acc = 0.f;
+  if (a) acc = __fadd_rn(acc, __fmul_rn(*a, wa));
+  if (b) acc = __fadd_rn(acc, __fmul_rn(*b, wb));
+  if (c) acc = __fadd_rn(acc, __fmul_rn(*c, wc));
+  *total = acc;
+}
+
+__global__ __launch_bounds__(256) void grad_combine_kernel(int64_t n, const float* __restrict__ g, float wa, const float* __restrict__ A,
+                                                           float wb, const float* __restrict__ Bm, float* __restrict__ out,
+                                                           float w_scale, float* __restrict__ scale_out) {
+  const float gv = *g;
+  if (blockIdx.x == 0 && threadIdx.x == 0 && scale_out) *scale_out = gv * w_scale;
+  if (!out) return;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+    float v = 0.f;
+    if (A) v += gv * wa * A[e];
+    if (Bm) v += gv * wb * Bm[e];
+    out[e] = v;
+  }
+}
+
+extern "C" int aladin_loss_total(const float* a, float wa, const float* b, float wb, const float* c, float wc, float* total,
+                                 void* stream) {
+  if (!total) { aladin_set_error("loss_total: null output"); return ALADIN_ERR_ARG; }
+  hipLaunchKernelGGL(loss_total_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, a, wa, b, wb, c, wc, total);
+  return aladin_check_launch("loss_total_kernel");
+}
+
+extern "C" int aladin_grad_combine(int64_t n, const float* g, float wa, const float* A, float wb, const float* B, float* out,
+                                   float w_scale, float* scale_out, void* stream) {
+  if (!g || n < 0 || (n > 0 && out && !A && !B) || (!out && !scale_out)) { aladin_set_error("grad_combine: bad argument"); return ALADIN_ERR_ARG; }
+  int grid = (int)((n + 1023) / 1024); if (grid < 1) grid = 1; if (grid > 1024) grid = 1024;
+  hipLaunchKernelGGL(grad_combine_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, n, g, wa, A, wb, B, out, w_scale, scale_out);
+  return aladin_check_launch("grad_combine_kernel");
+}
+
+// ------------------------------------------------------------------------------------------------
 // strided fp32 GEMM on v_mfma_f32_32x32x2_f32: one sgemm_tile_64 (sgemm_tile.hpp) per 64 x 64 output tile.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void sgemm_strided_kernel(int M, int N, int K, const float* __restrict__ A, int64_t a_rs,

@@ -236,13 +236,14 @@ class _AlignScores(torch.autograd.Function):
         return d_im, d_s, None, None, None, None
 
 
-def _hinge_raw(scores, margin, max_violation, want_grad, want_pairs=False):
-    """-> (loss, dS or None, pairs or None); pairs = (int32 list of non-zero i*B+j, int32 count)."""
+def _hinge_raw(scores, margin, max_violation, want_grad, want_pairs=False, loss_out=None):
+    """-> (loss, dS or None, pairs or None); pairs = (int32 list of non-zero i*B+j, int32 count).
+    loss_out: a one-element float32 view the kernel writes the loss into (instead of a fresh scalar)."""
     lib = _lib.load()
     B = scores.shape[0]
     sc = scores if scores.stride(1) == 1 else scores.contiguous()
     dev = scores.device
-    loss = torch.empty((), dtype=torch.float32, device=dev)
+    loss = loss_out if loss_out is not None else torch.empty((), dtype=torch.float32, device=dev)
     dS = torch.empty((B, B), dtype=torch.float32, device=dev) if want_grad else None
     ws = _workspace(lib.aladin_hinge_workspace_bytes(B), dev)
     pairs = None
@@ -770,9 +771,91 @@ class _SmallHeads(torch.autograd.Function):
         return d_a, d_b, d_im, d_s, None, None, None, None, None, None, None, None
 
 
+class _BigHeads(torch.autograd.Function):
+    """_SmallHeads for B > 64: the same single autograd node over the general kernels -- alignment scores + fused hinge,
+    exact-fp32 matching GEMM, hinge and ListNet on it, aladin_loss_total for the weighted sum; backward =
+    aladin_grad_combine (upstream gradient x weights x dLoss/dM, and the alignment backward's scale) + two GEMMs + the
+    alignment backward.  No element-wise torch kernels."""
+
+    @staticmethod
+    def forward(ctx, img_emb, cap_emb, im, s, im_len_t, s_len_t, margin, max_violation, flags, weights, temperature, eps):
+        lib = _lib.load()
+        need_sets = any(ctx.needs_input_grad[2:4])
+        need_embs = any(ctx.needs_input_grad[0:2])
+        dev = img_emb.device
+        B = img_emb.shape[0]
+        terms = torch.empty(3, dtype=torch.float32, device=dev)          # slots of absent heads are never read
+        S = packed = dS = pairs = None
+        if flags & (HEAD_ALIGN_HINGE | HEAD_LISTNET):
+            if need_sets and flags & HEAD_ALIGN_HINGE:
+                _check_backward_supported(im, s, 0, 2)
+            S, packed = _align_forward(im, s, im_len_t, s_len_t)
+            if flags & HEAD_ALIGN_HINGE:
+                _, dS, pairs = _hinge_raw(S, margin, max_violation, need_sets, want_pairs=True, loss_out=terms[1:2])
+        a = b = M = dMh = dMl = None
+        if flags & (HEAD_MATCH_HINGE | HEAD_LISTNET):
+            a = img_emb if img_emb.stride(1) == 1 else img_emb.contiguous()
+            b = cap_emb if cap_emb.stride(1) == 1 else cap_emb.contiguous()
+            M = torch.empty((B, B), dtype=torch.float32, device=dev)
+            _sgemm(B, B, a.shape[1], a, a.stride(0), a.stride(1), b, b.stride(1), b.stride(0), M)
+            if flags & HEAD_MATCH_HINGE:
+                _, dMh, _ = _hinge_raw(M, margin, max_violation, need_embs, loss_out=terms[0:1])
+            if flags & HEAD_LISTNET:
+                dMl = torch.empty((B, B), dtype=torch.float32, device=dev) if need_embs else None
+                ws = _workspace(lib.aladin_listnet_workspace_bytes(B), dev)
+                _lib.check(lib.aladin_listnet_fwd_bwd(_ptr(S), _ld(S), _ptr(M), _ld(M), B, float(temperature), float(eps),
+                                                      C.c_void_p(terms.data_ptr() + 8), _ptr(dMl), _ptr(ws), _stream()),
+                           'listnet_fwd_bwd')
+        total = torch.empty((), dtype=torch.float32, device=dev)
+        tp = terms.data_ptr()
+        _lib.check(lib.aladin_loss_total(C.c_void_p(tp) if flags & HEAD_MATCH_HINGE else C.c_void_p(0), float(weights[0]),
+                                         C.c_void_p(tp + 4) if flags & HEAD_ALIGN_HINGE else C.c_void_p(0), float(weights[1]),
+                                         C.c_void_p(tp + 8) if flags & HEAD_LISTNET else C.c_void_p(0), float(weights[2]),
+                                         _ptr(total), _stream()), 'loss_total')
+        ctx.flags, ctx.weights = flags, weights
+        ctx.geom = packed[0] if packed is not None else None
+        ctx.pairs = pairs
+        pk = packed[1:] if packed is not None else (None, None, None)
+        ctx.save_for_backward(a, b, im, s, im_len_t, s_len_t, pk[0], pk[1], pk[2], dMh, dMl, dS)
+        ctx.set_materialize_grads(False)
+        ctx.mark_non_differentiable(*[t for t in (terms, S, M) if t is not None])
+        return total, terms, S, M
+
+    @staticmethod
+    def backward(ctx, g_total, _g_terms, _g_S, _g_M):
+        if g_total is None:
+            return (None,) * 12
+        lib = _lib.load()
+        a, b, im, s, im_len_t, s_len_t, xm, xe, y, dMh, dMl, dS = ctx.saved_tensors
+        w = ctx.weights
+        g = g_total.to(torch.float32).contiguous()
+        dev = g.device
+        d_a = d_b = d_im = d_s = None
+        want_m = (dMh is not None or dMl is not None) and any(ctx.needs_input_grad[0:2])
+        want_a = dS is not None and any(ctx.needs_input_grad[2:4])
+        C_tot = torch.empty_like(dMh if dMh is not None else dMl) if want_m else None
+        scale = torch.empty(1, dtype=torch.float32, device=dev) if want_a else None
+        if want_m or want_a:
+            n = C_tot.numel() if C_tot is not None else 0
+            _lib.check(lib.aladin_grad_combine(n, _ptr(g), float(w[0]), _ptr(dMh), float(w[2]), _ptr(dMl), _ptr(C_tot), float(w[1]),
+                                               _ptr(scale), _stream()), 'grad_combine')
+        if want_m:
+            B, D = a.shape
+            if ctx.needs_input_grad[0]:
+                d_a = torch.empty((B, D), dtype=torch.float32, device=dev)
+                _sgemm(B, D, B, C_tot, C_tot.stride(0), 1, b, b.stride(0), b.stride(1), d_a)          # C @ cap
+            if ctx.needs_input_grad[1]:
+                d_b = torch.empty((B, D), dtype=torch.float32, device=dev)
+                _sgemm(B, D, B, C_tot, 1, C_tot.stride(0), a, a.stride(0), a.stride(1), d_b)          # C.T @ img
+        if want_a:
+            d_im, d_s = _align_backward(im, s, im_len_t, s_len_t, dS, gscale=scale, packed=(ctx.geom, xm, xe, y), pairs=ctx.pairs)
+        return d_a, d_b, d_im, d_s, None, None, None, None, None, None, None, None
+
+
 def small_batch_loss_heads(img_emb, cap_emb, im_set, s_seq, im_len, s_len, margin, max_violation, heads, weights,
                            temperature=6.0, eps=1e-10):
-    """The loss heads of one training step at B <= SMALL_BATCH_MAX in a single autograd node.
+    """The loss heads of one training step in a single autograd node (three head launches at B <= SMALL_BATCH_MAX,
+    the general kernels above it -- either way no element-wise glue).
     heads: subset of {'matching', 'alignment', 'distillation'}; weights: dict head -> fixed loss weight.
     -> (total = sum_k w_k L_k  [differentiable], terms (3,) = matching / alignment / distillation values, S, M)."""
     flags = (HEAD_MATCH_HINGE if 'matching' in heads else 0) | (HEAD_ALIGN_HINGE if 'alignment' in heads else 0) | \
@@ -780,15 +863,17 @@ def small_batch_loss_heads(img_emb, cap_emb, im_set, s_seq, im_len, s_len, margi
     if not flags:
         raise ValueError('aladin_amd: no loss head selected')
     _require_gpu(img_emb, cap_emb)
-    if img_emb.shape[0] > SMALL_BATCH_MAX:
-        raise ValueError('aladin_amd: small_batch_loss_heads takes B <= %d' % SMALL_BATCH_MAX)
     im_len_t = s_len_t = None
     if flags & (HEAD_ALIGN_HINGE | HEAD_LISTNET):
         im_len_t, s_len_t = _check_sets(im_set, s_seq, im_len, s_len)
         if not (im_set.shape[0] == s_seq.shape[0] == img_emb.shape[0]):
             raise ValueError('aladin_amd: the loss heads need one image set, one caption and one embedding pair per sample')
     w = (float(weights.get('matching', 0.0)), float(weights.get('alignment', 0.0)), float(weights.get('distillation', 0.0)))
-    return _SmallHeads.apply(img_emb, cap_emb, im_set, s_seq, im_len_t, s_len_t, margin, max_violation, flags, w, temperature, eps)
+    node = _SmallHeads if img_emb.shape[0] <= SMALL_BATCH_MAX else _BigHeads
+    return node.apply(img_emb, cap_emb, im_set, s_seq, im_len_t, s_len_t, margin, max_violation, flags, w, temperature, eps)
+
+
+loss_heads = small_batch_loss_heads            # the single-node step at any batch size
 
 
 def small_batch_match_distill(im, s, teacher, margin, max_violation, want_hinge=True, temperature=6.0, eps=1e-10):

@@ -185,6 +185,18 @@ ALADIN_API int aladin_listnet_fwd_bwd(const float* teacher, int64_t ld_t, const 
                            float temperature, float eps, float* loss, float* d_student,
                            void* workspace, void* stream);
 
+/* The fixed-weight sum of the loss terms (alad_model.py:450-453) and its backward without element-wise glue launches
+ * (any batch size; the B <= 64 heads below do this inside their own kernels).
+ *   aladin_loss_total    *total = wa * *a + wb * *b + wc * *c over up to three DEVICE scalars (NULL = absent)
+ *   aladin_grad_combine  out[e] = *g * (wa * A[e] + wb * B[e]), e < n (A / B may be NULL; out may be NULL), and
+ *                        *scale_out = *g * w_scale (may be NULL): the upstream gradient of the total applied to the
+ *                        dLoss/dM matrices of the matching hinge and of ListNet, and turned into the alignment
+ *                        backward's gscale, in one launch. */
+ALADIN_API int aladin_loss_total(const float* a, float wa, const float* b, float wb, const float* c, float wc, float* total,
+                                 void* stream);
+ALADIN_API int aladin_grad_combine(int64_t n, const float* g, float wa, const float* A, float wb, const float* B, float* out,
+                                   float w_scale, float* scale_out, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Loss heads at the shipped batch size (B <= 64; every YAML trains with bs 32): three launches instead of the
  * ~15 few-microsecond kernels of the general path (csrc/small_batch.hip).  `flags` selects the heads:
