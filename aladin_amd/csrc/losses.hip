@@ -119,12 +119,24 @@ __global__ __launch_bounds__(256) void hinge_finish_kernel(const float* __restri
         if (dS) dS[(int64_t)i * B + j] = g;
       }
       if (pairs) {                                        // list of non-zero pairs for the alignment backward
+        // ONE atomic per workgroup and 256 columns (the four waves' counts meet in LDS): every workgroup hits the
+        // same counter, and a returning atomic per wave (~770 of them at B = 256) serialised there
+        __shared__ int wcnt[4];
+        __shared__ int wbase;
         const unsigned long long mask = __ballot(g != 0.f);
-        if (mask) {
-          int base = 0;
-          if (lane == 0) base = atomicAdd(pair_count, __popcll(mask));
-          base = __shfl(base, 0, 64);
-          if (g != 0.f) pairs[base + __popcll(mask & ((1ull << lane) - 1))] = i * B + j;
+        const int wv = threadIdx.x >> 6;
+        __syncthreads();                                   // previous iteration's readers are done with wcnt / wbase
+        if (lane == 0) wcnt[wv] = __popcll(mask);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+          const int tot = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+          wbase = tot ? atomicAdd(pair_count, tot) : 0;
+        }
+        __syncthreads();
+        if (g != 0.f) {
+          int base = wbase;
+          for (int q = 0; q < wv; ++q) base += wcnt[q];
+          pairs[base + __popcll(mask & ((1ull << lane) - 1))] = i * B + j;
         }
       }
     }
