@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""The alignment triplet step with the sum-of-violations hinge (max_violation=False: dS dense, every pair differentiated;
+no shipped config) at B = 64 / 256, next to the hardest-negative hinge.  Prints one JSON line per batch size."""
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from aladin_amd import synth
+from aladin_amd.loss import AlignmentContrastiveLoss
+
+
+def timed(fn, steps):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps * 1e3
+
+
+def main():
+    dev = torch.device('cuda:0')
+    for B in (64, 256):
+        im, s, il, sl = synth.alignment_batch(B, 34, 50, 768, seed=1234)
+        a = torch.from_numpy(im).to(dev).requires_grad_(True)
+        b = torch.from_numpy(s).to(dev).requires_grad_(True)
+        out = {'batch': B}
+        for mv in (True, False):
+            crit = AlignmentContrastiveLoss(0.2, 'dot', mv, 'MrSw')
+
+            def step():
+                a.grad = None
+                b.grad = None
+                crit(a, b, il, sl).backward()
+            out['max_violation_%s_ms' % mv] = round(timed(step, 30), 4)
+        print(json.dumps(out), flush=True)
+
+
+if __name__ == '__main__':
+    main()
