@@ -130,6 +130,35 @@ def eval_sets(n_img, D=64, seed=31, L=71, base_weight=0.25, sigma=3.0, img_len_r
     return images, captions, [int(v) for v in np.repeat(img_len, 5)], [int(v) for v in cap_len]
 
 
+def encoder_batches(n_img=50, D=64, seed=91, batch=32, max_regions=40, max_tokens=30):
+    """What an encoder hands `encode_data` batch by batch (reference alad/evaluation.py:104-130): for every batch the
+    7-tuple of forward_emb -- global embeddings (b, D), sets (S_batch, b, D) sliced to THAT batch's longest sample, length
+    lists -- over N = 5 * n_img (image, caption) rows in COCO order (each image repeated for its 5 captions).
+    -> list of dicts with numpy arrays; a pure function of its arguments."""
+    N = 5 * n_img
+    img_len = np.repeat(integers((n_img,), 8, max_regions, seed + 1), 5)
+    cap_len = integers((N,), 6, max_tokens, seed + 2)
+    base = 0.3 * normal((n_img, 1, D), seed + 3)
+    reg = np.repeat(normal((n_img, max_regions, D), seed + 4) + base, 5, axis=0)
+    tok = normal((N, max_tokens, D), seed + 5) + np.repeat(base, 5, axis=0)
+    g_img, g_cap = retrieval_embeddings(n_img, D, seed + 6, sigma=2.5)
+    out = []
+    for k0 in range(0, N, batch):
+        k1 = min(N, k0 + batch)
+        il, cl = [int(v) for v in img_len[k0:k1]], [int(v) for v in cap_len[k0:k1]]
+        i_set = reg[k0:k1, :max(il)].astype(np.float32).copy()
+        c_seq = tok[k0:k1, :max(cl)].astype(np.float32).copy()
+        for r, n_ in enumerate(il):
+            i_set[r, n_:] = 0
+        for r, n_ in enumerate(cl):
+            c_seq[r, n_:] = 0
+        i_set /= np.maximum(np.linalg.norm(i_set, axis=2, keepdims=True), 1e-12)       # the encoder F.normalize's its sets
+        c_seq /= np.maximum(np.linalg.norm(c_seq, axis=2, keepdims=True), 1e-12)
+        out.append(dict(img_glob=g_img[k0:k1], cap_glob=g_cap[k0:k1], img_set=np.ascontiguousarray(i_set.transpose(1, 0, 2)),
+                        cap_seq=np.ascontiguousarray(c_seq.transpose(1, 0, 2)), img_len=il, cap_len=cl))
+    return out
+
+
 def module_parameters(named_shapes, seed, scale=0.03):
     """Deterministic values for a module's parameters, keyed by name: {name: float32 array}.  Matrices ~N(0, scale^2),
     biases ~N(0, (scale/3)^2), LayerNorm gains (names ending in 'norm1.weight' / 'norm2.weight' / 'norm.weight') 1 + 0.1 N(0,1).

@@ -373,6 +373,48 @@ def gen_model():
     save('model_forward', **out)
 
 
+# --------------------------------------------------------------------- encode_data -> i2t / t2i pipeline
+def gen_eval_pipeline():
+    """The reference's evaluation pipeline end to end (alad/evaluation.py:80-327): its own encode_data over a loader of
+    encoder batches (a fake model whose forward_emb returns prepared 7-tuples), then its own i2t / t2i on the buffers it
+    filled, matching head and alignment head."""
+    batches = synth.encoder_batches()
+    N = sum(len(b['img_len']) for b in batches)
+
+    class FakeModel:
+        logger = None
+
+        def eval(self):
+            pass
+
+        def forward_emb(self, example_imgs, example_txts):
+            b = batches[int(example_txts[0][0])]
+            return (t(b['img_glob']), t(b['cap_glob']), t(b['img_set']), t(b['cap_seq']), list(b['img_len']), list(b['cap_len']), 0)
+
+    class Loader(list):
+        dataset = list(range(N))
+    loader = Loader([((torch.zeros((len(b['img_len']), 1)),), (torch.full((len(b['img_len']),), k),)) for k, b in enumerate(batches)])
+    img_embs, cap_embs, il, cl = ref_eval.encode_data(FakeModel(), loader, logging=lambda *_: None)
+    out = dict(N=N, img_embs_checksum=synth.checksum(img_embs.numpy()), cap_embs_checksum=synth.checksum(cap_embs.numpy()),
+               img_embs_s=img_embs.numpy()[:, :, ::8], cap_embs_s=cap_embs.numpy()[:, :, ::8], img_len=np.array(il), cap_len=np.array(cl))
+    crit = ref_loss.AlignmentContrastiveLoss(aggregation='MrSw')
+
+    def sim_fn(img, cap, a, b):
+        with torch.no_grad():
+            return crit(img, cap, a, b, return_loss=False, return_similarity_mat=True)
+    saved_cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        for tag, fn in (('match', None), ('align', sim_fn)):
+            m, (ranks, top1) = ref_eval.i2t(img_embs, cap_embs, il, cl, return_ranks=True, sim_function=fn, cap_batches=5)
+            out['i2t_%s_metrics' % tag], out['i2t_%s_ranks' % tag], out['i2t_%s_top1' % tag] = np.array(m, dtype=np.float64), ranks, top1
+            m, (ranks, top50) = ref_eval.t2i(img_embs, cap_embs, il, cl, return_ranks=True, sim_function=fn, im_batches=1)
+            out['t2i_%s_metrics' % tag], out['t2i_%s_ranks' % tag], out['t2i_%s_top1' % tag] = np.array(m, dtype=np.float64), ranks, top50[:, 0]
+    finally:
+        torch.Tensor.cuda = saved_cuda
+    save('eval_pipeline', **out)
+
+
 # ------------------------------------------------------------ matching head + encoder hand-off (SURVEY 8(f) row 4)
 def gen_matching_head():
     """The reference's OWN JointTextImageTransformerEncoder.forward (alad/alad_model.py:119-247) driven with a fake
@@ -464,6 +506,7 @@ if __name__ == '__main__':
     gen_alignment()
     gen_eval()
     gen_eval_coco1k()
+    gen_eval_pipeline()
     gen_matching()
     gen_distill()
     gen_order_sim()

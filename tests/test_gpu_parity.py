@@ -615,6 +615,51 @@ def _fill_store(sets, lens, tail, precision, batch=4):
     return st
 
 
+def test_eval_pipeline_encode_data_to_ranks_vs_reference(eval_precision):
+    """The evaluation pipeline end to end against the REFERENCE's own (tests/golden/eval_pipeline.npz: its encode_data over a
+    loader of encoder batches, then its i2t / t2i): our encode_data fills the same (N, 71, D) buffers (on the device) bit
+    for bit, and both heads give the reference's ranks from them -- and from the packed stores of encode_data_packed."""
+    from aladin_amd import synth
+    from aladin_amd import evaluation as E
+    g = load_golden('eval_pipeline')
+    batches = synth.encoder_batches()
+    N = int(g['N'])
+
+    class FakeModel:
+        logger = None
+
+        def eval(self):
+            pass
+
+        def forward_emb(self, example_imgs, example_txts):
+            b = batches[int(example_txts[0][0])]
+            return (T(b['img_glob']), T(b['cap_glob']), T(b['img_set']), T(b['cap_seq']), list(b['img_len']), list(b['cap_len']), 0)
+
+    class Loader(list):
+        dataset = list(range(N))
+    loader = Loader([((torch.zeros((len(b['img_len']), 1)),), (torch.full((len(b['img_len']),), k),)) for k, b in enumerate(batches)])
+    img_embs, cap_embs, il, cl = E.encode_data(FakeModel(), loader, logging=None)
+    assert img_embs.is_cuda and tuple(img_embs.shape) == (N, 71, 64)
+    assert il == [int(v) for v in g['img_len']] and cl == [int(v) for v in g['cap_len']]
+    np.testing.assert_array_equal(img_embs.cpu().numpy()[:, :, ::8], g['img_embs_s'])
+    np.testing.assert_array_equal(cap_embs.cpu().numpy()[:, :, ::8], g['cap_embs_s'])
+    assert abs(synth.checksum(cap_embs.cpu().numpy()) - float(g['cap_embs_checksum'])) <= 1e-9 * abs(float(g['cap_embs_checksum']))
+    si, sc, il2, cl2 = E.encode_data_packed(FakeModel(), loader, logging=None, precision=eval_precision)
+    assert il2 == il and cl2 == cl
+    for tag, fn in (('match', None), ('align', 'alignment')):
+        if tag == 'align' and eval_precision != 'split':
+            continue                                   # fp16 operands: near-ties may swap (measured in the coco1k test)
+        for srcs in ((img_embs, cap_embs), (si, sc)):
+            m, (r, t1) = E.i2t(srcs[0], srcs[1], il, cl, return_ranks=True, sim_function=fn)
+            np.testing.assert_array_equal(r, g['i2t_%s_ranks' % tag])
+            np.testing.assert_array_equal(t1, g['i2t_%s_top1' % tag])
+            np.testing.assert_allclose(m, g['i2t_%s_metrics' % tag], atol=1e-9)
+            m, (r, top50) = E.t2i(srcs[0], srcs[1], il, cl, return_ranks=True, sim_function=fn)
+            np.testing.assert_array_equal(r, g['t2i_%s_ranks' % tag])
+            np.testing.assert_array_equal(top50[:, 0], g['t2i_%s_top1' % tag])
+            np.testing.assert_allclose(m, g['t2i_%s_metrics' % tag], atol=1e-9)
+
+
 def test_trimmed_grid_keeps_the_zero_fill_of_the_longest_image(eval_precision):
     """A word whose cosine with EVERY region of an image is negative contributes max(negatives, 0) = 0 when the
     image is shorter than the padded set (masked regions are zero-filled and take part in the max,

@@ -182,6 +182,34 @@ def test_eval_i2t_t2i():
         assert np.array_equal(r, g['t2i_%s_ranks' % tag]) and np.array_equal(t1, g['t2i_%s_top1' % tag])
 
 
+def test_oracle_on_the_eval_pipeline_fixture():
+    """eval_pipeline.npz: the reference's encode_data buffers rebuilt from the generator (position 0 = global embedding,
+    sets zero-padded to 71) and the oracle's i2t / t2i on them for both heads."""
+    g = load_golden('eval_pipeline')
+    from aladin_amd import synth
+    batches = synth.encoder_batches()
+    N = int(g['N'])
+    img = np.zeros((N, 71, 64), np.float32)
+    cap = np.zeros((N, 71, 64), np.float32)
+    il, cl, k0 = [], [], 0
+    for b in batches:
+        n = len(b['img_len'])
+        img[k0:k0 + n, :b['img_set'].shape[0]] = b['img_set'].transpose(1, 0, 2)          # alad/evaluation.py:124-125
+        cap[k0:k0 + n, :b['cap_seq'].shape[0]] = b['cap_seq'].transpose(1, 0, 2)
+        img[k0:k0 + n, 0], cap[k0:k0 + n, 0] = b['img_glob'], b['cap_glob']             # :127-128
+        il += b['img_len']
+        cl += b['cap_len']
+        k0 += n
+    assert np.array_equal(img[:, :, ::8], g['img_embs_s']) and np.array_equal(cap[:, :, ::8], g['cap_embs_s'])
+    for tag, sim in (('match', 'matching'), ('align', 'alignment')):
+        m, (r, t1) = O.i2t(img, cap, il, cl, sim, return_ranks=True)
+        assert np.array_equal(r, g['i2t_%s_ranks' % tag]) and np.array_equal(t1, g['i2t_%s_top1' % tag])
+        close(m, g['i2t_%s_metrics' % tag], rtol=0, atol=1e-9)
+        m, (r, t1) = O.t2i(img, cap, il, cl, sim, return_ranks=True)
+        assert np.array_equal(r, g['t2i_%s_ranks' % tag]) and np.array_equal(t1, g['t2i_%s_top1' % tag])
+        close(m, g['t2i_%s_metrics' % tag], rtol=0, atol=1e-9)
+
+
 def test_recall_1k_5fold():
     g = load_golden('recall_5fold')
     from aladin_amd import synth
