@@ -7,7 +7,7 @@ re-stated; the encoder (`JointTextImageTransformerEncoder`, alad_model.py:29-247
 code: aladin_amd/encoder.py provides it -- matching head `final_projection_net` included -- around
 an INJECTED VinVL/Oscar `backbone` (the BERT itself is out of scope), or any `encoder` module returning
 the reference's 7-tuple (img_glob (B,D), cap_glob (B,D), img_set (R,B,D), cap_seq (T,B,D), img_len,
-cap_len, reg_loss) can be passed.  `StandInEncoder` is a headless random-init test stub.
+cap_len, reg_loss) can be passed.  (Random-init stand-ins for smoke tests live in tests/standins.py.)
 """
 import torch
 from torch import nn
@@ -200,32 +200,3 @@ class ALADModel(nn.Module):
             self.forward_emb(example_imgs, example_txts)
         return self.forward_loss_total(img_emb_aggr, cap_emb_aggr, img_feats, cap_feats, img_lengths, cap_lengths, regul_loss,
                                        epoch, distill_epoch)
-
-
-class StandInEncoder(nn.Module):
-    """Random-init substitute for JointTextImageTransformerEncoder with the same OUTPUT contract
-    (reference alad_model.py:121-247): region features (B,R,F) + box counts, token ids (B,T) +
-    token counts -> the 7-tuple, sets L2-normalised (:237-238), globals l2norm'd (:240-241).
-    It exists so that ALADModel.forward can be exercised end to end without the VinVL checkpoint;
-    it is NOT a model of the backbone."""
-
-    def __init__(self, feat_dim=2054, embed=768, vocab=30522, seed=0):
-        super().__init__()
-        g = torch.Generator().manual_seed(seed)
-        self.img_proj = nn.Linear(feat_dim, embed)
-        self.tok_emb = nn.Embedding(vocab, embed)
-        with torch.no_grad():
-            self.img_proj.weight.copy_(torch.randn(embed, feat_dim, generator=g) / feat_dim ** 0.5)
-            self.img_proj.bias.zero_()
-            self.tok_emb.weight.copy_(torch.randn(vocab, embed, generator=g))
-
-    def forward(self, example_imgs, example_txts):
-        img_feat, img_len = example_imgs
-        tok_ids, cap_len = example_txts
-        i_emb = self.img_proj(img_feat)[:, :max(img_len)]             # slice to the batch maximum (:174-175)
-        c_emb = self.tok_emb(tok_ids)[:, :max(cap_len)]
-        img_glob = l2norm(i_emb.mean(1))
-        cap_glob = l2norm(c_emb.mean(1))
-        i_set = nn.functional.normalize(i_emb, p=2, dim=2).permute(1, 0, 2)     # (R,B,D)
-        c_seq = nn.functional.normalize(c_emb, p=2, dim=2).permute(1, 0, 2)     # (T,B,D)
-        return img_glob, cap_glob, i_set, c_seq, list(img_len), list(cap_len), 0

@@ -12,8 +12,8 @@
 The VinVL / Oscar BERT itself (`oscar/modeling/modeling_bert.py:150-279` over the un-vendored
 `transformers@067923d`) stays out of scope: it is INJECTED as `backbone`, any module with the
 `.bert(input_ids=, attention_mask=, token_type_ids=, img_feats=) -> (sequence_output, ...)` call the reference
-makes (alad_model.py:129,139).  `StandInBackbone` is a random-init substitute with that call surface for smoke
-tests; it is not a model of VinVL ("parity unpinned" for the backbone).
+makes (alad_model.py:129,139) ("parity unpinned" for the backbone; tests/standins.py holds a random-init
+substitute with that call surface for the shape-level tests).
 
 This module is host code on PyTorch-ROCm (north_star: "host code stays Python on PyTorch-ROCm for the
 backbone"); parameter names equal the reference's, so `img_txt_enc.final_projection_net.*` entries of a
@@ -120,29 +120,3 @@ class JointTextImageTransformerEncoder(nn.Module):
         img_set = F.normalize(i_emb, p=2, dim=2)                       # :237-238 (teran-layers 0: the sets are the backbone's)
         cap_seq = F.normalize(c_emb, p=2, dim=2)
         return l2norm(img_glob), l2norm(cap_glob), img_set, cap_seq, feat_len, cap_len, 0      # :240-247
-
-
-class StandInBackbone(nn.Module):
-    """Random-init substitute with the call surface of `ImageBertForSequenceClassification.bert`
-    (oscar/modeling/modeling_bert.py:150-279): word embeddings for the token ids, a linear map of the
-    2054-wide region features appended after them, LayerNorm; returns (sequence_output,).  It exists so that
-    the head and ALADModel.forward can be driven end to end at the shipped shapes without the VinVL checkpoint
-    -- it is NOT a model of the backbone."""
-
-    def __init__(self, hidden=768, feat_dim=2054, vocab=30522, seed=0):
-        super().__init__()
-        g = torch.Generator().manual_seed(seed)
-        self.word = nn.Embedding(vocab, hidden)
-        self.img = nn.Linear(feat_dim, hidden)
-        self.norm = nn.LayerNorm(hidden)
-        with torch.no_grad():
-            self.word.weight.copy_(torch.randn(vocab, hidden, generator=g))
-            self.img.weight.copy_(torch.randn(hidden, feat_dim, generator=g) / feat_dim ** 0.5)
-            self.img.bias.zero_()
-        self.bert = self._bert
-
-    def _bert(self, input_ids, attention_mask=None, token_type_ids=None, img_feats=None):
-        x = self.word(input_ids)
-        if img_feats is not None:
-            x = torch.cat([x, self.img(img_feats)], dim=1)
-        return (self.norm(x),)

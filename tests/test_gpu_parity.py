@@ -809,7 +809,7 @@ def test_packed_store_scores_are_bit_identical_and_smaller():
 def test_encode_data_packed_matches_encode_data():
     """The two embedding stores, filled by the same stand-in encoder, score identically."""
     from aladin_amd import evaluation as E
-    from aladin_amd.alad_model import StandInEncoder
+    from standins import StandInEncoder
 
     class _Model(torch.nn.Module):
         def __init__(self):
@@ -1370,7 +1370,7 @@ def test_config4_shape_level_step_with_the_real_head(eval_precision):
     if eval_precision != 'fp16':
         pytest.skip('training step; run once')
     from aladin_amd.alad_model import ALADModel
-    from aladin_amd.encoder import StandInBackbone
+    from standins import StandInBackbone
     from aladin_amd.evaluation import LogCollector
     config = {'dataset': {'name': 'coco'},
               'model': {'name': 'teran', 'embed-size': 768, 'text-aggregation': 'first', 'image-aggregation': 'first',

@@ -60,7 +60,8 @@ def test_row0_equals_full_transformer_encoder():
 def test_state_dict_names_match_the_reference_head():
     """`img_txt_enc.final_projection_net.*` keys of a reference checkpoint load unchanged (the golden stores the
     reference head's parameter names)."""
-    from aladin_amd.encoder import JointTextImageTransformerEncoder, StandInBackbone
+    from aladin_amd.encoder import JointTextImageTransformerEncoder
+    from standins import StandInBackbone
     g = load_golden('matching_head')
     cfg = {'model': {'embed-size': 768, 'teran-layers': 0, 'tern-layers': 2, 'post-layers': 0, 'dropout': 0.1,
                      'shared-transformer': True}, 'training': {'loss-type': 'alignment-distillation', 'measure': 'dot'}}
