@@ -13,7 +13,7 @@ import torch
 from torch import nn
 
 from . import ops
-from .loss import AlignmentContrastiveLoss, ContrastiveLoss, DistillationLoss, dot_sim, l2norm
+from .loss import AlignmentContrastiveLoss, ContrastiveLoss, DistillationLoss, dot_sim
 
 
 class ALADModel(nn.Module):
