@@ -155,27 +155,51 @@ __global__ __launch_bounds__(256) void bwd_pair_argmax_kernel(
 #define AMBIG_MARGIN 2.2e-3f      // > 2 * 2^-10: two fp16-operand cosines of unit vectors
 
 using PairCfg = GemmCfg<2, 2, 1, 1>;      // 64 x 64 block per pair: [32 main regions | extra-region segment] x 64 word rows
+// LDS ring depth of the pair kernel: 3 stages (48 KB: three workgroups per CU, the <= 3B pairs of a B = 256 step run in one
+// round).  Measured and not kept: 4 stages at B = 256 (+14 us: only two workgroups per CU), 6 stages for bs <= 85 (no change:
+// tools/pair_probe.py shows the K loop at 6.5 us of a workgroup's 19).
 #define PAIR_STAGES 3
 
 // Requires mtiles == 1 and 16*tp16 <= 64 (every training shape); other shapes use the fp32 kernel.
+#ifdef ALADIN_DIAG
+// phase stamps of the pair kernel (diagnostic build only; tools/pair_probe.py): 8 words per workgroup =
+// s_memrealtime at entry / after the header loads / after the MFMA phase / after the word scan / after the exact
+// candidates / at exit, then the candidate count
+__device__ unsigned long long g_pair_probe[8 * 1024];
+extern "C" __attribute__((visibility("default"))) int aladin_debug_read_pair_probe(unsigned long long* host_out, int n_blocks) {
+  if (!host_out || n_blocks < 1 || n_blocks > 1024) { aladin_set_error("debug_read_pair_probe: bad argument"); return ALADIN_ERR_ARG; }
+  if (hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_pair_probe), (size_t)n_blocks * 64) != hipSuccess) { aladin_set_error("debug_read_pair_probe: copy failed"); return ALADIN_ERR_HIP; }
+  return ALADIN_OK;
+}
+#define PAIR_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 1024) g_pair_probe[8 * blockIdx.x + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define PAIR_STAMP(k) do { } while (0)
+#endif
+
 __global__ __launch_bounds__(256) void bwd_pair_argmax16_kernel(
     const half_t* __restrict__ xm, const half_t* __restrict__ xe, const half_t* __restrict__ y, int Dp, int rem,
     int tpad, int xe_rows, int y_rows, const float* __restrict__ im, int64_t im_sb, int64_t im_sr,
     const int32_t* __restrict__ im_len, const float* __restrict__ s, int64_t s_sb, int64_t s_st,
     const int32_t* __restrict__ s_len, int Bc, int Rq, int Tq, int D, const int* __restrict__ counter,
-    const int* __restrict__ pairs, uint8_t* __restrict__ table, int tstride, int blk_rows, int blk_ld, int x_tail,
+    const int* __restrict__ pairs, uint8_t* __restrict__ table, int tstride, int x_tail,
     int y_tail) {
-  // dynamic LDS: the operand ring of the MFMA phase, re-used afterwards as the score block
-  // blk[(blk_rows + 2) x blk_ld] (the two extra rows carry per-word scratch).
+  // dynamic LDS: the operand ring of the MFMA phase
   extern __shared__ __attribute__((aligned(16))) char pair_smem[];
-  float* blk_mem = reinterpret_cast<float*>(pair_smem);
-#define BLK(r, c) blk_mem[(r) * blk_ld + (c)]
-  __shared__ float cand_val[CAND_MAX];
+  // 2 KB shared by the scan's per-wave top-2 records and the exact candidate values (disjoint lifetimes, a barrier between):
+  // the kernel's static + ring LDS must stay under 160 KB / 3 for three workgroups per CU
+  __shared__ float cand_top[CAND_MAX];
+  float* cand_val = cand_top;
+  float (*top_b1)[64] = reinterpret_cast<float (*)[64]>(cand_top);
+  float (*top_b2)[64] = reinterpret_cast<float (*)[64]>(cand_top + 128);
+  int (*top_a1)[64] = reinterpret_cast<int (*)[64]>(cand_top + 256);
   __shared__ uint8_t cand_w[CAND_MAX], cand_r[CAND_MAX];
   __shared__ int ncand;
+  __shared__ uint8_t word_amb[64], word_res[64];
+  __shared__ unsigned long long ovf_key[64];            // serial decisions taken when the candidate list is full
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int h = lane >> 5, l5 = lane & 31;
   const int wm = wave >> 1, wn = wave & 1;
+  PAIR_STAMP(0);
   const int count = *counter;
   // The pair list groups the pairs of one image (hinge_finish / bwd_compact emit row chunks), and blocks
   // are dealt round-robin over the 8 XCDs: give each XCD a CONTIGUOUS eighth of the list so that pairs
@@ -188,7 +212,9 @@ __global__ __launch_bounds__(256) void bwd_pair_argmax16_kernel(
     int Li = im_len[i] - 1 - x_tail; Li = Li < 0 ? 0 : (Li > Rq ? Rq : Li);
     int Lj = s_len[j] - 1 - y_tail; Lj = Lj < 0 ? 0 : (Lj > Tq ? Tq : Lj);
     __syncthreads();                                   // everyone is done with the previous pair's blk
+    if (Li + Lj >= 0) PAIR_STAMP(1);
     if (threadIdx.x == 0) ncand = 0;
+    if (threadIdx.x < 64) { word_amb[threadIdx.x] = 0; word_res[threadIdx.x] = NO_GRAD; ovf_key[threadIdx.x] = 0ull; }
     // operand panels: rows [0,32) = the image's 32 main regions, rows [32,64) = 32 consecutive rows
     // of the extra-region operand containing image i's rem rows at offset eo; 64 caption-word rows
     // starting at by (the caption's words sit at column offset co)
@@ -197,8 +223,8 @@ __global__ __launch_bounds__(256) void bwd_pair_argmax16_kernel(
     const int64_t yrow = (int64_t)j * tpad;
     const int64_t by = yrow < (int64_t)y_rows - 64 ? yrow : (int64_t)y_rows - 64;
     const int co = (int)(yrow - by);
-    const half_t* a1 = xm + (int64_t)i * 32 * Dp;
-    const half_t* a2 = rem ? xe + (int64_t)be * Dp : a1;
+    const half_t* pa1 = xm + (int64_t)i * 32 * Dp;
+    const half_t* pa2 = rem ? xe + (int64_t)be * Dp : pa1;
     f32x16 acc[1][1];
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[0][0][r] = 0.f;
@@ -212,56 +238,75 @@ __global__ __launch_bounds__(256) void bwd_pair_argmax16_kernel(
       if (8 * wv + 8 <= co || 8 * wv >= co + tpad) skip |= 4u;
       if (32 + 8 * wv + 8 <= co || 32 + 8 * wv >= co + tpad) skip |= 8u;
     }
-    gemm_mainloop<PairCfg, PAIR_STAGES>(a1, y + by * Dp, Dp, Dp / 64, pair_smem, acc, a2, 32, skip);
-    __syncthreads();                                   // ring no longer read: re-use it as blk
-    {
-      const int w = wn * 32 + l5 - co;
+    gemm_mainloop<PairCfg, PAIR_STAGES>(pa1, y + by * Dp, Dp, Dp / 64, pair_smem, acc, pa2, 32, skip);
+    PAIR_STAMP(2);
+    // Per word: approximate winner, runner-up and the candidates that need an exact look — straight from the
+    // accumulators.  A lane holds 16 regions of ONE word (column l5 of its wave's 32 x 32 block): top-2 in registers,
+    // merged with the other half-wave (shuffle) and with the wave holding the other 32 rows (through LDS).
+    const int wcol = wn * 32 + l5;                       // column of the 64-word panel
+    const int wd = wcol - co;                            // word index in the caption
+    const bool wvalid = wd >= 0 && wd < Lj && Li > 0;
+    float b1 = -INFINITY, b2 = -INFINITY;
+    int a1 = 255;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (w >= 0 && w < blk_ld) {
-          if (wm == 0) BLK(row, w) = acc[0][0][r];
-          else if (row >= eo && row < eo + rem) BLK(32 + row - eo, w) = acc[0][0][r];
-        }
-      }
-    }
-    __syncthreads();
-    // per word: approximate winner, runner-up, and the list of candidates that need an exact look
-    uint8_t res = NO_GRAD;
-    bool ambiguous = false;
-    const int w = threadIdx.x;
-    if (w < Lj && Li > 0) {
-      float b1 = BLK(0, w), b2 = -INFINITY;
-      int a1 = 0;
-      for (int r = 1; r < Li; ++r) {
-        const float v = BLK(r, w);
-        if (v > b1) { b2 = b1; b1 = v; a1 = r; }
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+      const int reg = wm == 0 ? row : ((row >= eo && row < eo + rem) ? 32 + row - eo : 255);
+      const float v = acc[0][0][r];
+      if (reg < Li) {
+        if (v > b1) { b2 = b1; b1 = v; a1 = reg; }
         else if (v > b2) b2 = v;
       }
-      ambiguous = (b1 - b2 < AMBIG_MARGIN) || (Li < Rq && fabsf(b1) < AMBIG_MARGIN);
-      if (!ambiguous) res = (Li < Rq && b1 <= 0.f) ? NO_GRAD : (uint8_t)a1;
-      else {
-        float best = -INFINITY;
-        int arg = 0;
-        for (int r = 0; r < Li; ++r) {
-          if (BLK(r, w) > b1 - AMBIG_MARGIN) {
+    }
+#define TOP2_MERGE(ob1, oa1, ob2)                                                              \
+    do {                                                                                       \
+      if ((ob1) > b1 || ((ob1) == b1 && (oa1) < a1)) { b2 = fmaxf(b1, (ob2)); b1 = (ob1); a1 = (oa1); } \
+      else b2 = fmaxf(b2, (ob1));                                                              \
+    } while (0)
+    {
+      const float ob1 = __shfl_xor(b1, 32, 64), ob2 = __shfl_xor(b2, 32, 64);
+      const int oa1 = __shfl_xor(a1, 32, 64);
+      TOP2_MERGE(ob1, oa1, ob2);
+    }
+    if (h == 0) { top_b1[wm][wcol] = b1; top_b2[wm][wcol] = b2; top_a1[wm][wcol] = a1; }
+    __syncthreads();
+    {
+      const float ob1 = top_b1[wm ^ 1][wcol], ob2 = top_b2[wm ^ 1][wcol];
+      const int oa1 = top_a1[wm ^ 1][wcol];
+      TOP2_MERGE(ob1, oa1, ob2);
+    }
+#undef TOP2_MERGE
+    if (wvalid) {
+      const bool amb = (b1 - b2 < AMBIG_MARGIN) || (Li < Rq && fabsf(b1) < AMBIG_MARGIN);
+      if (wm == 0 && h == 0) {
+        word_amb[wd] = amb ? 1 : 0;
+        word_res[wd] = (Li < Rq && b1 <= 0.f) ? NO_GRAD : (uint8_t)a1;
+      }
+      if (amb) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+          const int reg = wm == 0 ? row : ((row >= eo && row < eo + rem) ? 32 + row - eo : 255);
+          if (reg < Li && acc[0][0][r] > b1 - AMBIG_MARGIN) {
             const int slot = atomicAdd(&ncand, 1);
-            if (slot < CAND_MAX) { cand_w[slot] = (uint8_t)w; cand_r[slot] = (uint8_t)r; }
+            if (slot < CAND_MAX) { cand_w[slot] = (uint8_t)wd; cand_r[slot] = (uint8_t)reg; }
             else {                                       // list full (degenerate inputs): decide here, serially
-              const float* x = im + i * im_sb + (int64_t)(r + 1) * im_sr;
-              const float* yv = s + j * s_sb + (int64_t)(w + 1) * s_st;
+              const float* x = im + i * im_sb + (int64_t)(reg + 1) * im_sr;
+              const float* yv = s + j * s_sb + (int64_t)(wd + 1) * s_st;
               float sxy = 0.f, sxx = 0.f;
               for (int c = 0; c < D; ++c) { sxy += x[c] * yv[c]; sxx += x[c] * x[c]; }
               const float v = sxy / fmaxf(sqrtf(sxx), 1e-12f);
-              if (v > best) { best = v; arg = r; }
+              // larger value first, then the lower region: one 64-bit max
+              uint32_t u = __float_as_uint(v);
+              u ^= (u >> 31) ? 0xFFFFFFFFu : 0x80000000u;
+              atomicMax(&ovf_key[wd], ((unsigned long long)u << 32) | (unsigned long long)(255 - reg));
             }
           }
         }
-        BLK(blk_rows + 1, w) = best;                     // stash the serial part's result in the scratch rows
-        BLK(blk_rows, w) = (float)arg;
       }
     }
     __syncthreads();
+    PAIR_STAMP(3);
     const int nc = ncand < CAND_MAX ? ncand : CAND_MAX;
     // exact fp32 cosines of the listed candidates, four per wave per trip (eight rows in flight)
     for (int e0 = wave * 4; e0 < nc; e0 += 16) {
@@ -291,21 +336,36 @@ __global__ __launch_bounds__(256) void bwd_pair_argmax16_kernel(
       }
     }
     __syncthreads();
-    if (ambiguous) {
-      float best = BLK(blk_rows + 1, w);
-      int arg = (int)BLK(blk_rows, w);
-      for (int e = 0; e < nc; ++e)
-        if (cand_w[e] == (uint8_t)w) {
-          const float v = cand_val[e];
-          const int r = cand_r[e];
-          if (v > best || (v == best && r < arg)) { best = v; arg = r; }
+    PAIR_STAMP(4);
+#ifdef ALADIN_DIAG
+    if (threadIdx.x == 0 && blockIdx.x < 1024) g_pair_probe[8 * blockIdx.x + 6] = (unsigned long long)nc;
+#endif
+    const int w = threadIdx.x;
+    uint8_t res = NO_GRAD;
+    if (w < 64) {
+      res = word_res[w];
+      if (word_amb[w]) {
+        float best = -INFINITY;
+        int arg = 0;
+        if (const unsigned long long key = ovf_key[w]) {
+          uint32_t u = (uint32_t)(key >> 32);
+          u ^= (u >> 31) ? 0x80000000u : 0xFFFFFFFFu;
+          best = __uint_as_float(u);
+          arg = 255 - (int)(key & 0xFFull);
         }
-      res = (Li < Rq && best <= 0.f) ? NO_GRAD : (uint8_t)arg;
+        for (int e = 0; e < nc; ++e)
+          if (cand_w[e] == (uint8_t)w) {
+            const float v = cand_val[e];
+            const int r = cand_r[e];
+            if (v > best || (v == best && r < arg)) { best = v; arg = r; }
+          }
+        res = (Li < Rq && best <= 0.f) ? NO_GRAD : (uint8_t)arg;
+      }
     }
     if (w < tstride) table[((int64_t)i * Bc + j) * tstride + w] = res;
+    PAIR_STAMP(5);
   }
 }
-#undef BLK
 
 // ------------------------------------------------------------------------------------------------
 // 3. row gather + normalise backward.  One wave per output row; lane owns float4 columns
@@ -577,14 +637,10 @@ static int align_bwd_impl(const float* im, int64_t im_sb, int64_t im_sr, const i
   }
   int pgrid = (int)(n < 2048 ? n : 2048);
   if (packed) {
-    const int blk_rows = 32 + g->rem;
-    const int blk_ld = 65;
-    size_t lds = (size_t)(blk_rows + 2) * blk_ld * 4;
-    if (lds < (size_t)PAIR_STAGES * PairCfg::STAGE_BYTES) lds = (size_t)PAIR_STAGES * PairCfg::STAGE_BYTES;
-    hipLaunchKernelGGL(bwd_pair_argmax16_kernel, dim3(pgrid), dim3(256), lds, st, (const half_t*)xm, (const half_t*)xe,
-                       (const half_t*)y, g->Dp, g->rem, 16 * g->tp16, (int)g->xe_rows, (int)g->y_rows, im, im_sb, im_sr,
-                       im_len, s, s_sb, s_st, s_len, Bc, Rq, Tq, D, ws.counter, ws.pairs, ws.table, tstride, blk_rows,
-                       blk_ld, x_tail, y_tail);
+    hipLaunchKernelGGL(bwd_pair_argmax16_kernel, dim3(pgrid), dim3(256), (size_t)PAIR_STAGES * PairCfg::STAGE_BYTES, st,
+                       (const half_t*)xm, (const half_t*)xe, (const half_t*)y, g->Dp, g->rem, 16 * g->tp16, (int)g->xe_rows,
+                       (int)g->y_rows, im, im_sb, im_sr, im_len, s, s_sb, s_st, s_len, Bc, Rq, Tq, D, ws.counter, ws.pairs,
+                       ws.table, tstride, x_tail, y_tail);
     rc = aladin_check_launch("bwd_pair_argmax16_kernel");
   } else {
     hipLaunchKernelGGL(bwd_pair_argmax_kernel, dim3(pgrid), dim3(256), 0, st, im, im_sb, im_sr, im_len, s, s_sb, s_st,
