@@ -151,7 +151,7 @@ __global__ __launch_bounds__(256) void bwd_pair_argmax_kernel(
 // ------------------------------------------------------------------------------------------------
 // 2b. fast path: fp16 MFMA block from the packed operands + exact re-decision of close calls
 // ------------------------------------------------------------------------------------------------
-#define CAND_MAX 512
+#define CAND_MAX 4096             // 64 x 64 accumulator elements per pair: every one of them may be a close call
 #define AMBIG_MARGIN 2.2e-3f      // > 2 * 2^-10: two fp16-operand cosines of unit vectors
 
 using PairCfg = GemmCfg<2, 2, 1, 1>;      // 64 x 64 block per pair: [32 main regions | extra-region segment] x 64 word rows
@@ -185,17 +185,16 @@ __global__ __launch_bounds__(256) void bwd_pair_argmax16_kernel(
     int y_tail) {
   // dynamic LDS: the operand ring of the MFMA phase
   extern __shared__ __attribute__((aligned(16))) char pair_smem[];
-  // 2 KB shared by the scan's per-wave top-2 records and the exact candidate values (disjoint lifetimes, a barrier between):
-  // the kernel's static + ring LDS must stay under 160 KB / 3 for three workgroups per CU
-  __shared__ float cand_top[CAND_MAX];
-  float* cand_val = cand_top;
-  float (*top_b1)[64] = reinterpret_cast<float (*)[64]>(cand_top);
-  float (*top_b2)[64] = reinterpret_cast<float (*)[64]>(cand_top + 128);
-  int (*top_a1)[64] = reinterpret_cast<int (*)[64]>(cand_top + 256);
-  __shared__ uint8_t cand_w[CAND_MAX], cand_r[CAND_MAX];
+  // The candidate list of the exact phase lives in the ring, which is dead once every wave has left the K loop (the
+  // barrier of the top-2 merge): 64 x 64 entries, one per accumulator element, so it cannot overflow.
+  float* cand_val = reinterpret_cast<float*>(pair_smem);
+  uint8_t* cand_w = reinterpret_cast<uint8_t*>(pair_smem) + 4 * CAND_MAX;
+  uint8_t* cand_r = cand_w + CAND_MAX;
+  static_assert(6 * CAND_MAX <= PAIR_STAGES * PairCfg::STAGE_BYTES, "candidate list must fit in the ring");
+  __shared__ float top_b1[2][64], top_b2[2][64];
+  __shared__ int top_a1[2][64];
   __shared__ int ncand;
   __shared__ uint8_t word_amb[64], word_res[64];
-  __shared__ unsigned long long ovf_key[64];            // serial decisions taken when the candidate list is full
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int h = lane >> 5, l5 = lane & 31;
   const int wm = wave >> 1, wn = wave & 1;
@@ -214,7 +213,7 @@ __global__ __launch_bounds__(256) void bwd_pair_argmax16_kernel(
     __syncthreads();                                   // everyone is done with the previous pair's blk
     if (Li + Lj >= 0) PAIR_STAMP(1);
     if (threadIdx.x == 0) ncand = 0;
-    if (threadIdx.x < 64) { word_amb[threadIdx.x] = 0; word_res[threadIdx.x] = NO_GRAD; ovf_key[threadIdx.x] = 0ull; }
+    if (threadIdx.x < 64) { word_amb[threadIdx.x] = 0; word_res[threadIdx.x] = NO_GRAD; }
     // operand panels: rows [0,32) = the image's 32 main regions, rows [32,64) = 32 consecutive rows
     // of the extra-region operand containing image i's rem rows at offset eo; 64 caption-word rows
     // starting at by (the caption's words sit at column offset co)
@@ -288,19 +287,9 @@ __global__ __launch_bounds__(256) void bwd_pair_argmax16_kernel(
           const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
           const int reg = wm == 0 ? row : ((row >= eo && row < eo + rem) ? 32 + row - eo : 255);
           if (reg < Li && acc[0][0][r] > b1 - AMBIG_MARGIN) {
-            const int slot = atomicAdd(&ncand, 1);
-            if (slot < CAND_MAX) { cand_w[slot] = (uint8_t)wd; cand_r[slot] = (uint8_t)reg; }
-            else {                                       // list full (degenerate inputs): decide here, serially
-              const float* x = im + i * im_sb + (int64_t)(reg + 1) * im_sr;
-              const float* yv = s + j * s_sb + (int64_t)(wd + 1) * s_st;
-              float sxy = 0.f, sxx = 0.f;
-              for (int c = 0; c < D; ++c) { sxy += x[c] * yv[c]; sxx += x[c] * x[c]; }
-              const float v = sxy / fmaxf(sqrtf(sxx), 1e-12f);
-              // larger value first, then the lower region: one 64-bit max
-              uint32_t u = __float_as_uint(v);
-              u ^= (u >> 31) ? 0xFFFFFFFFu : 0x80000000u;
-              atomicMax(&ovf_key[wd], ((unsigned long long)u << 32) | (unsigned long long)(255 - reg));
-            }
+            const int slot = atomicAdd(&ncand, 1);           // < 64 * 64 = CAND_MAX by construction
+            cand_w[slot] = (uint8_t)wd;
+            cand_r[slot] = (uint8_t)reg;
           }
         }
       }
@@ -325,8 +314,10 @@ __global__ __launch_bounds__(256) void bwd_pair_argmax16_kernel(
         for (int q = 0; q < 4; ++q) { a[q] = *reinterpret_cast<const float4*>(xp[q] + c); b[q] = *reinterpret_cast<const float4*>(yp[q] + c); }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          sxy[q] += a[q].x * b[q].x + a[q].y * b[q].y + a[q].z * b[q].z + a[q].w * b[q].w;
-          sxx[q] += a[q].x * a[q].x + a[q].y * a[q].y + a[q].z * a[q].z + a[q].w * a[q].w;
+          // explicit fma chains: left to the compiler's contraction the four unrolled copies came out with different
+          // roundings, and identical regions (exact ties -> the lower region must win) evaluated 1 ulp apart
+          sxy[q] = fmaf(a[q].w, b[q].w, fmaf(a[q].z, b[q].z, fmaf(a[q].y, b[q].y, fmaf(a[q].x, b[q].x, sxy[q]))));
+          sxx[q] = fmaf(a[q].w, a[q].w, fmaf(a[q].z, a[q].z, fmaf(a[q].y, a[q].y, fmaf(a[q].x, a[q].x, sxx[q]))));
         }
       }
 #pragma unroll
@@ -347,12 +338,6 @@ __global__ __launch_bounds__(256) void bwd_pair_argmax16_kernel(
       if (word_amb[w]) {
         float best = -INFINITY;
         int arg = 0;
-        if (const unsigned long long key = ovf_key[w]) {
-          uint32_t u = (uint32_t)(key >> 32);
-          u ^= (u >> 31) ? 0x80000000u : 0xFFFFFFFFu;
-          best = __uint_as_float(u);
-          arg = 255 - (int)(key & 0xFFull);
-        }
         for (int e = 0; e < nc; ++e)
           if (cand_w[e] == (uint8_t)w) {
             const float v = cand_val[e];

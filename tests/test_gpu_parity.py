@@ -1605,6 +1605,39 @@ def test_degenerate_lengths_and_zero_vectors():
         np.testing.assert_allclose(got, want, rtol=1e-3, atol=3e-5 * scale)
 
 
+def test_backward_exact_ties_and_full_candidate_list():
+    """Duplicated regions make exact fp32 ties: the argmax the backward records must be the FIRST maximal region
+    (numpy / the oracle; alad/loss.py:117 `max` over regions), also when every region of an image is the same
+    vector — 33 x 47 close calls for one pair, more than the pair kernel's candidate list holds, so its serial
+    fall-back decides — and when two regions coincide."""
+    from aladin_amd import ops, synth
+    B, R, Tn, D = 6, 34, 50, 768
+    im, s, il, sl = synth.alignment_batch(B, R, Tn, D, seed=818, ragged=False)
+    im[0, 1:] = im[0, 1]                # every region of image 0 identical
+    im[1, 9] = im[1, 5]                 # one duplicated region
+    im[2, 1:] = im[2, 1] * np.linspace(1.0, 2.0, R - 1, dtype=np.float32)[:, None]   # same direction, different norms: cosines tie up to rounding
+    a, b = T(im).requires_grad_(True), T(s).requires_grad_(True)
+    S = ops.alignment_scores(a, b, il, sl)
+    S_np = S.detach().cpu().numpy()
+    assert_scores_close(S_np, O.alignment_scores(im, s, il, sl), atol_rel=1e-3, scale='max')
+    dS = np.zeros((B, B), dtype=np.float32)
+    dS[0, 0], dS[0, 3], dS[1, 1], dS[1, 4], dS[2, 2], dS[3, 0], dS[4, 5] = 1.0, -0.5, 1.0, 0.25, -1.0, 0.75, 2.0
+    (S * T(dS)).sum().backward()
+    ga, gb = a.grad.cpu().numpy(), b.grad.cpu().numpy()
+    dim, ds = O.alignment_scores_backward(im, s, il, sl, dS)
+    # image 0 / image 1: exact ties -> first region takes the gradient, exactly as the oracle
+    assert np.all(ga[0, 2:] == 0) and np.abs(ga[0, 1]).max() > 0
+    for k in (0, 1, 3, 4, 5):
+        scale = max(1e-9, float(np.abs(dim[k]).max()))
+        np.testing.assert_allclose(ga[k], dim[k], rtol=1e-3, atol=3e-5 * scale)
+    scale = max(1e-9, float(np.abs(ds).max()))
+    np.testing.assert_allclose(gb[[0, 1, 3, 4, 5]], ds[[0, 1, 3, 4, 5]], rtol=1e-3, atol=3e-5 * scale)
+    # image 2: the fp32 cosines of parallel regions differ in the last bit; whichever the reference's rounding picks,
+    # the caption gradient is the same vector (the regions normalise to one direction) and finite
+    assert np.isfinite(ga[2]).all()
+    np.testing.assert_allclose(gb[2], ds[2], rtol=2e-3, atol=1e-4 * scale)
+
+
 def test_non_contiguous_and_unaligned_inputs():
     """Strided views with a contiguous feature axis are consumed in place; anything else is copied by
     the wrapper (results must not depend on the memory layout)."""
