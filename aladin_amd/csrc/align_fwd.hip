@@ -121,6 +121,26 @@ __device__ __forceinline__ void pack_row(const float* __restrict__ src, half_t* 
     for (int c = lane * 8; c < width; c += 64 * 8) *reinterpret_cast<half8*>(dst + c) = half8{0, 0, 0, 0, 0, 0, 0, 0};
     return;
   }
+  if (vec4 && !seg && D <= 1024) {
+    // the whole row in registers (<= 4 float4 per lane): one read of the source, the loads of a row all in flight at once
+    float4 v[4];
+    float ss = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int c = lane * 4 + 256 * k;
+      v[k] = c < D ? *reinterpret_cast<const float4*>(src + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) ss += v[k].x * v[k].x + v[k].y * v[k].y + v[k].z * v[k].z + v[k].w * v[k].w;
+    ss = wave_sum(ss);
+    const float inv = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int c = lane * 4 + 256 * k;
+      if (c < Dp) *reinterpret_cast<half4*>(dst + c) = half4{(half_t)(v[k].x * inv), (half_t)(v[k].y * inv), (half_t)(v[k].z * inv), (half_t)(v[k].w * inv)};
+    }
+    return;
+  }
   float ss = 0.f;
   if (vec4) {
     for (int c = lane * 4; c < D; c += 256) {
