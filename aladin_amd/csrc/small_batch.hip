@@ -69,22 +69,53 @@ __global__ __launch_bounds__(256) void heads_small_stats_kernel(const float* __r
   const bool need_m = (flags & (SB_MATCH_HINGE | SB_LISTNET)) != 0;
   if (need_m) {
     const bool vec = (D % 4 == 0) && (ld_i % 4 == 0) && (ld_c % 4 == 0) && (((uintptr_t)img & 15) == 0) && (((uintptr_t)cap & 15) == 0);
-    for (int p = wave; p < B; p += 4) {
-      const float* a = img + (int64_t)(is_row ? q : p) * ld_i;
-      const float* b = cap + (int64_t)(is_row ? p : q) * ld_c;
-      float acc = 0.f;
-      if (vec) {
-        for (int c = lane * 4; c < D; c += 256) {
-          const float4 x = *reinterpret_cast<const float4*>(a + c), y = *reinterpret_cast<const float4*>(b + c);
-          acc += x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
-        }
-      } else {
-        for (int c = lane; c < D; c += 64) acc += a[c] * b[c];
+    const float* fixed = is_row ? img + (int64_t)q * ld_i : cap + (int64_t)q * ld_c;    // this vector's own embedding
+    const float* other = is_row ? cap : img;
+    const int64_t ld_o = is_row ? ld_c : ld_i;
+    if (vec && D <= 1024) {
+      // own row in registers; four partner rows per trip with all their loads in flight (the dots of a vector are a
+      // chain of memory latencies otherwise: 8 trips per wave at B = 32 measured 12.5 us for this kernel)
+      float4 f[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int c = lane * 4 + 256 * k;
+        f[k] = c < D ? *reinterpret_cast<const float4*>(fixed + c) : make_float4(0.f, 0.f, 0.f, 0.f);
       }
-      acc = wave_sum(acc);
-      if (lane == 0) {
-        mvec[p] = acc;
-        if (is_row) M_out[q * B + p] = acc;
+      for (int p0 = wave; p0 < B; p0 += 16) {
+        float4 o[4][4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int p = p0 + 4 * u < B ? p0 + 4 * u : p0;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const int c = lane * 4 + 256 * k;
+            o[u][k] = c < D ? *reinterpret_cast<const float4*>(other + (int64_t)p * ld_o + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          float acc = 0.f;
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            acc = fmaf(f[k].w, o[u][k].w, fmaf(f[k].z, o[u][k].z, fmaf(f[k].y, o[u][k].y, fmaf(f[k].x, o[u][k].x, acc))));
+          acc = wave_sum(acc);
+          const int p = p0 + 4 * u;
+          if (lane == 0 && p < B) {
+            mvec[p] = acc;
+            if (is_row) M_out[q * B + p] = acc;
+          }
+        }
+      }
+    } else {
+      for (int p = wave; p < B; p += 4) {
+        const float* b = other + (int64_t)p * ld_o;
+        float acc = 0.f;
+        for (int c = lane; c < D; c += 64) acc = fmaf(fixed[c], b[c], acc);
+        acc = wave_sum(acc);
+        if (lane == 0) {
+          mvec[p] = acc;
+          if (is_row) M_out[q * B + p] = acc;
+        }
       }
     }
   }
