@@ -495,18 +495,18 @@ static int scores_wgm() {
 //                      images into the two half-waves, one 16-lane exchange finishes the 32 rows
 //   sum over words   : a caption is exactly TP16 column tiles -> in-lane adds, then a 16-lane reduction
 // ------------------------------------------------------------------------------------------------
-template <bool HAS_E, int TP16, int Q, int REMC>
+template <bool HAS_E, int TP16, int Q, int REMC, int WGM = 4, int WGN = 2>
 __device__ __forceinline__ void scores16_epilogue(f32x4 (&acc)[4][12], int mb, int nb, const float* __restrict__ E,
                                                   int64_t ldE, int rem, float* __restrict__ S, int64_t ldS, int Bi, int Bc) {
-  using Cfg = GemmCfg<4, 2, 2, 6>;
+  using Cfg = GemmCfg<WGM, WGN, 2, 6>;
   constexpr int CT = 12;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int wm = wave / 2, wn = wave % 2;
+  const int wm = wave / WGN, wn = wave % WGN;
   const int half = lane >> 5, l4 = lane & 15;
   static_assert(Q == 1 || Q == 2, "one or two 32-row region tiles per image");
   // Q == 1: the wave's 64 rows are two images (lanes 0-31 finish image 0, lanes 32-63 image 1);
   // Q == 2: they are ONE image (R' in 34..64, or 65 with the side row)
-  const int img = (Q == 1) ? (mb * 4 + wm) * 2 + half : mb * 4 + wm;
+  const int img = (Q == 1) ? (mb * WGM + wm) * 2 + half : mb * WGM + wm;
   // REMC == 1: exactly one side row per image, known at compile time (the headline class: a run-time trip
   // count here costs the whole kernel ~10 %); REMC == 0: `rem` side rows, run-time loop
   if constexpr (REMC == 1) rem = 1;
@@ -541,7 +541,7 @@ __device__ __forceinline__ void scores16_epilogue(f32x4 (&acc)[4][12], int mb, i
     }
     v[ct / TP16] += m;
   }
-  const int cap = (nb * 2 + wn) * NC;
+  const int cap = (nb * WGN + wn) * NC;
 #pragma unroll
   for (int c = 0; c < NC; ++c) {
     float t = v[c];
@@ -551,12 +551,17 @@ __device__ __forceinline__ void scores16_epilogue(f32x4 (&acc)[4][12], int mb, i
   }
 }
 
-template <bool HAS_E, int TP16 = 3, bool PROBE = false, int Q = 1, int REMC = 1>
-__global__ __launch_bounds__(512) void align_scores16_kernel(const half_t* __restrict__ xm, const half_t* __restrict__ y,
+// WGM x WGN waves of 64 x 192 each: 4 x 2 with a double buffer is the kernel above; 2 x 1 (128 x 192, two waves) with a
+// three-stage ring is the SMALL-GRID variant: when the 256 x 384 tiling leaves most CUs idle (B <= 64: at most 64
+// workgroups) a workgroup's 12 K steps are a chain of exposed memory latencies (24 us at B = 32, the same as B = 256's
+// whole wave of tiles), and a second K step in flight on four times as many CUs halves it.  Same MFMA shape, same K
+// order, same epilogue: a score is bit-identical whichever variant computed it.
+template <bool HAS_E, int TP16 = 3, bool PROBE = false, int Q = 1, int REMC = 1, int WGM = 4, int WGN = 2, int NS = 2>
+__global__ __launch_bounds__(WGM * WGN * 64) void align_scores16_kernel(const half_t* __restrict__ xm, const half_t* __restrict__ y,
                                                              const float* __restrict__ E, int64_t ldE,
                                                              float* __restrict__ S, int64_t ldS, int Bi, int Bc,
                                                              int64_t ldk, int ktiles, int n_nblk, int n_blocks, int rem) {
-  using Cfg = GemmCfg<4, 2, 2, 6>;
+  using Cfg = GemmCfg<WGM, WGN, 2, 6>;
   constexpr int RT = 4, CT = 12;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int mb, nb;
@@ -568,7 +573,7 @@ __global__ __launch_bounds__(512) void align_scores16_kernel(const half_t* __res
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) acc[rt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  if constexpr (HAS_E && REMC == 1 && Q == 1) {
+  if constexpr (HAS_E && REMC == 1 && Q == 1 && WGM == 4 && WGN == 2 && NS == 2) {
     // The epilogue's side-row values E[img][cols] were written by the side GEMM on OTHER XCDs: pull this tile's 12
     // lines per wave (2 images x 192 columns) into this XCD's L2 now, so that the epilogue's loads do not pay an HBM /
     // fabric round trip 25 us from here.  The data itself is dropped: one LDS-DMA dword per lane into the piece of
@@ -581,10 +586,10 @@ __global__ __launch_bounds__(512) void align_scores16_kernel(const half_t* __res
   }
   unsigned long long pt0 = 0, pr0 = 0, pt1 = 0, pr1 = 0;
   if constexpr (PROBE) { pt0 = __builtin_amdgcn_s_memtime(); pr0 = __builtin_amdgcn_s_memrealtime(); }
-  gemm_mainloop16<Cfg, true>(xm + (int64_t)mb * Cfg::BM * ldk, y + (int64_t)nb * Cfg::BN * ldk, ldk, ktiles, smem, acc);
+  gemm_mainloop16<Cfg, true, NS>(xm + (int64_t)mb * Cfg::BM * ldk, y + (int64_t)nb * Cfg::BN * ldk, ldk, ktiles, smem, acc);
   if constexpr (PROBE) { pt1 = __builtin_amdgcn_s_memtime(); pr1 = __builtin_amdgcn_s_memrealtime(); }
 
-  scores16_epilogue<HAS_E, TP16, Q, REMC>(acc, mb, nb, E, ldE, rem, S, ldS, Bi, Bc);
+  scores16_epilogue<HAS_E, TP16, Q, REMC, WGM, WGN>(acc, mb, nb, E, ldE, rem, S, ldS, Bi, Bc);
 #ifdef ALADIN_DIAG
   if constexpr (PROBE) {
     __syncthreads();
@@ -601,22 +606,32 @@ __global__ __launch_bounds__(512) void align_scores16_kernel(const half_t* __res
 #endif
 }
 
-template <bool HAS_E, int TP16 = 3, bool PROBE = false, int Q = 1, int REMC = 1>
-static int launch_scores16(const aladin_align_geom* g, const half_t* xm, const half_t* y, const float* E, float* S,
-                           int64_t ldS, hipStream_t stream) {
-  using Cfg = GemmCfg<4, 2, 2, 6>;
+template <bool HAS_E, int TP16, bool PROBE, int Q, int REMC, int WGM, int WGN, int NS>
+static int launch_scores16_cfg(const aladin_align_geom* g, const half_t* xm, const half_t* y, const float* E, float* S,
+                               int64_t ldS, hipStream_t stream) {
+  using Cfg = GemmCfg<WGM, WGN, 2, 6>;
   const int n_mblk = (int)(g->xm_rows / Cfg::BM), n_nblk = (int)(g->y_rows / Cfg::BN);
   if ((int64_t)n_mblk * Cfg::BM != g->xm_rows || (int64_t)n_nblk * Cfg::BN != g->y_rows) {
     aladin_set_error("align_scores16: packed rows do not tile");
     return ALADIN_ERR_ARG;
   }
-  auto kern = align_scores16_kernel<HAS_E, TP16, PROBE, Q, REMC>;
+  auto kern = align_scores16_kernel<HAS_E, TP16, PROBE, Q, REMC, WGM, WGN, NS>;
   static unsigned long long lds_reserved = 0;
-  if (int rc = aladin_reserve_lds((const void*)kern, Cfg::LDS_BYTES, &lds_reserved, "align_scores16")) return rc;
+  if (int rc = aladin_reserve_lds((const void*)kern, NS * Cfg::STAGE_BYTES, &lds_reserved, "align_scores16")) return rc;
   const int n_blocks = n_mblk * n_nblk;
-  hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(Cfg::THREADS), Cfg::LDS_BYTES, stream, xm, y, E, g->y_rows, S, ldS, g->Bi,
+  hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(Cfg::THREADS), NS * Cfg::STAGE_BYTES, stream, xm, y, E, g->y_rows, S, ldS, g->Bi,
                      g->Bc, (int64_t)g->Dp, g->Dp / 64, n_nblk, n_blocks, g->rem);
   return aladin_check_launch("align_scores16_kernel");
+}
+
+template <bool HAS_E, int TP16 = 3, bool PROBE = false, int Q = 1, int REMC = 1>
+static int launch_scores16(const aladin_align_geom* g, const half_t* xm, const half_t* y, const float* E, float* S,
+                           int64_t ldS, hipStream_t stream) {
+  // small grids (<= 64 tiles of 256 x 384, i.e. B <= 64 at the headline shape): the 128 x 192 / three-stage variant
+  if constexpr (!PROBE)
+    if ((g->xm_rows / 256) * (g->y_rows / 384) <= 64)
+      return launch_scores16_cfg<HAS_E, TP16, false, Q, REMC, 2, 1, 3>(g, xm, y, E, S, ldS, stream);
+  return launch_scores16_cfg<HAS_E, TP16, PROBE, Q, REMC, 4, 2, 2>(g, xm, y, E, S, ldS, stream);
 }
 
 template <int WGM, int WM, int Q, int TP16, bool HAS_E, int SM, int SCHED = 1>

@@ -222,7 +222,8 @@ __device__ __forceinline__ half8 lds_frag16(const char* stage, int row, int k32,
   return *reinterpret_cast<const half8*>(stage + row * 128 + phys * 16);
 }
 
-template <class Cfg, bool SPREAD = true>
+// NS = 2 is the headline double buffer; NS = 3 (small-batch tile, 2 waves per workgroup) keeps two K steps in flight.
+template <class Cfg, bool SPREAD = true, int NS = 2>
 __device__ __forceinline__ void gemm_mainloop16(const half_t* __restrict__ a_rows, const half_t* __restrict__ b_rows,
                                                 int64_t ldk, int ktiles, char* smem,
                                                 f32x4 (&acc)[2 * Cfg::WM][2 * Cfg::WN]) {
@@ -236,14 +237,22 @@ __device__ __forceinline__ void gemm_mainloop16(const half_t* __restrict__ a_row
   const int a_row0 = wm * Cfg::WM * 32 + (lane & 15);
   const int b_row0 = Cfg::BM + wn * Cfg::WN * 32 + (lane & 15);
 
-  gemm_stage<Cfg>(a_rows, nullptr, Cfg::BM, b_rows, ldk, 0, smem, wave, lane_off);
+  static_assert(NS >= 2 && CPW * (NS - 2) <= 32, "ring too deep for the vmcnt dispatcher");
+  constexpr int LEAD = NS - 1;                        // K steps between a refill and its use
+#pragma unroll
+  for (int st = 0; st < LEAD; ++st)
+    if (st < ktiles) gemm_stage<Cfg>(a_rows, nullptr, Cfg::BM, b_rows, ldk, st, smem + st * Cfg::STAGE_BYTES, wave, lane_off);
   for (int kt = 0; kt < ktiles; ++kt) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (NS == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else {
+      const int ahead = ktiles - 1 - kt;              // stages issued after step kt's: they may still be in flight
+      wait_vmcnt(CPW * (ahead < NS - 2 ? ahead : NS - 2));
+    }
     __builtin_amdgcn_s_barrier();
-    const char* cur = smem + (kt & 1) * Cfg::STAGE_BYTES;
-    const bool refill = kt + 1 < ktiles;
-    char* nxt = smem + ((kt + 1) & 1) * Cfg::STAGE_BYTES;
-    if (!SPREAD && refill) gemm_stage<Cfg>(a_rows, nullptr, Cfg::BM, b_rows, ldk, kt + 1, nxt, wave, lane_off);
+    const char* cur = smem + (kt % NS) * Cfg::STAGE_BYTES;
+    const bool refill = kt + LEAD < ktiles;
+    char* nxt = smem + ((kt + LEAD) % NS) * Cfg::STAGE_BYTES;
+    if (!SPREAD && refill) gemm_stage<Cfg>(a_rows, nullptr, Cfg::BM, b_rows, ldk, kt + LEAD, nxt, wave, lane_off);
 
     // Three clusters of 16 MFMAs (RT row tiles x 4 column tiles = 256 pipe cycles) per 32-deep step.
     // B fragments alternate between two register groups of four; the next group's reads are issued
@@ -263,7 +272,7 @@ __device__ __forceinline__ void gemm_mainloop16(const half_t* __restrict__ a_row
 #pragma unroll
       for (int j = 0; j < 4; ++j) bB[j] = lds_frag16(cur, b_row0 + (4 + j) * 16, k32, lane);
       if (SPREAD && refill) {
-        if (k32 == 1) gemm_stage<Cfg, (6 * CPW) / 10, (8 * CPW) / 10>(a_rows, nullptr, Cfg::BM, b_rows, ldk, kt + 1, nxt, wave, lane_off);
+        if (k32 == 1) gemm_stage<Cfg, (6 * CPW) / 10, (8 * CPW) / 10>(a_rows, nullptr, Cfg::BM, b_rows, ldk, kt + LEAD, nxt, wave, lane_off);
       }
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_setprio(1);
@@ -278,8 +287,8 @@ __device__ __forceinline__ void gemm_mainloop16(const half_t* __restrict__ a_row
 #pragma unroll
       for (int j = 0; j < 4; ++j) bA[j] = lds_frag16(cur, b_row0 + (8 + j) * 16, k32, lane);
       if (SPREAD && refill) {
-        if (k32 == 0) gemm_stage<Cfg, 0, (3 * CPW) / 10>(a_rows, nullptr, Cfg::BM, b_rows, ldk, kt + 1, nxt, wave, lane_off);
-        else gemm_stage<Cfg, (8 * CPW) / 10, CPW>(a_rows, nullptr, Cfg::BM, b_rows, ldk, kt + 1, nxt, wave, lane_off);
+        if (k32 == 0) gemm_stage<Cfg, 0, (3 * CPW) / 10>(a_rows, nullptr, Cfg::BM, b_rows, ldk, kt + LEAD, nxt, wave, lane_off);
+        else gemm_stage<Cfg, (8 * CPW) / 10, CPW>(a_rows, nullptr, Cfg::BM, b_rows, ldk, kt + LEAD, nxt, wave, lane_off);
       }
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_setprio(1);
@@ -296,7 +305,7 @@ __device__ __forceinline__ void gemm_mainloop16(const half_t* __restrict__ a_row
         for (int j = 0; j < 4; ++j) bB[j] = lds_frag16(cur, b_row0 + j * 16, 1, lane);
       }
       if (SPREAD && refill) {
-        if (k32 == 0) gemm_stage<Cfg, (3 * CPW) / 10, (6 * CPW) / 10>(a_rows, nullptr, Cfg::BM, b_rows, ldk, kt + 1, nxt, wave, lane_off);
+        if (k32 == 0) gemm_stage<Cfg, (3 * CPW) / 10, (6 * CPW) / 10>(a_rows, nullptr, Cfg::BM, b_rows, ldk, kt + LEAD, nxt, wave, lane_off);
       }
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_setprio(1);
