@@ -44,6 +44,7 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-eval', action='store_true', help='skip the configs[2] (retrieval) secondary timing')
     ap.add_argument('--eager', action='store_true', help='do not capture the step in a HIP graph')
+    ap.add_argument('--graph', action='store_true', help='always replay the captured HIP graph (default: the faster of graph / eager in a short trial)')
     ap.add_argument('--force-sharded', action='store_true',
                     help='self-test: run the multi-GPU (sharded, RCCL) step even with one rank')
     ap.add_argument('--exchange', default='tune', choices=['tune', 'dense', 'sparse'],
@@ -178,6 +179,10 @@ def main():
     args = parse()
     # before anything initialises the HIP runtime: the host driver only supports dmabuf IPC
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    # HIP-runtime setting for graph replay: with "graph packet capture" on (this ROCm's default) the replay of the 7-kernel
+    # step costs ~4 us more than with it off (0.2357 vs 0.2316 ms, alternated three times on one box,
+    # profiles/r02_ab_experiments.txt).  Read once when the runtime starts; an exported value wins.
+    os.environ.setdefault('DEBUG_CLR_GRAPH_PACKET_CAPTURE', '0')
     import torch
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -212,6 +217,9 @@ def main():
 
     exchange = ['dense' if args.exchange == 'tune' else args.exchange]
     tuned = {}
+    # dloss/dloss = 1, allocated once: `loss.backward()` with no argument makes autograd fill a fresh ones_like(loss)
+    # every step (one more 4.5 us launch in a 0.23 ms step); the gradients are the same
+    seed = torch.ones((), dtype=torch.float32, device=dev)
 
     def step():
         im.grad = None
@@ -220,7 +228,7 @@ def main():
             loss, _ = AD.sharded_alignment_loss_fast(im, s, il, sl, 0.2, True, exchange=exchange[0])
         else:
             loss = crit(im, s, il, sl)
-        loss.backward()
+        loss.backward(gradient=seed)
         return loss
 
     def fence():
@@ -235,10 +243,10 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         return float(tt.item())
 
-    # The step is ~10 short launches; eager Python issue time (~0.24 ms) is close to the GPU time, so
-    # the step is captured once into a HIP graph (the C ABI neither allocates nor synchronises) and
-    # replayed.  Same kernels, same work; --eager keeps the plain path.  Multi-GPU stays eager
-    # (collectives).
+    # The step is 7 short launches; eager Python issue time (~0.22 ms) is close to the GPU time, so
+    # the step is also captured once into a HIP graph (the C ABI neither allocates nor synchronises);
+    # a trial below picks replay or eager issue.  Same kernels, same work; --eager / --graph force one.
+    # Multi-GPU stays eager (collectives).
     launch = 'eager'
     run = step
     if not sharded and not args.eager:
@@ -251,7 +259,7 @@ def main():
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
                 static_loss = crit(im, s, il, sl)
-                static_loss.backward()
+                static_loss.backward(gradient=seed)
 
             def run():
                 graph.replay()
@@ -286,6 +294,28 @@ def main():
         if all(v == float('inf') for v in tuned.values()):
             raise SystemExit('bench: both backward exchanges failed; see stderr')
         exchange[0] = min(tuned, key=tuned.get)
+
+    # Graph replay or eager issue?  Same kernels either way.  Replay has no host cost but the runtime spends a few us more
+    # between the nodes of a graph than between kernels queued on a stream; eager issue is faster as long as the host
+    # (0.216 ms of Python + launches per step, measured) stays ahead of the GPU.  A short interleaved trial decides.
+    launch_trial = None
+    if launch == 'hipgraph' and not args.graph:
+        def trial(fn, n=300):
+            fence()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                fn()
+            fence()
+            return (time.perf_counter() - t0) / n * 1e3
+        for fn in (run, step):
+            trial(fn, 600)                                   # settle the clock before comparing
+        launch_trial = {'hipgraph': min(trial(run), trial(run)), 'eager': min(trial(step), trial(step))}
+        for _ in range(2):
+            launch_trial['hipgraph'] = min(launch_trial['hipgraph'], trial(run))
+            launch_trial['eager'] = min(launch_trial['eager'], trial(step))
+        if launch_trial['eager'] < launch_trial['hipgraph']:
+            launch, run = 'eager', step
+        launch_trial = {k: round(v, 4) for k, v in launch_trial.items()}
 
     # 1. clock-settling pre-roll (independent of --warmup)
     t_pre, n_pre = time.perf_counter(), 0
@@ -335,7 +365,8 @@ def main():
                            'features per GPU (R=34,T=50,D=768, full lengths)' +
                            ('' if world == 1 else '; configs[3]: global %dx%d matrix, images all-gathered '
                             'over RCCL, caption-block sharding' % (B * world, B * world)),
-               'global_pairs_per_step': pairs, 'loss': float(loss.detach()), 'launch': launch,
+               'global_pairs_per_step': pairs, 'loss': float(loss.detach()), 'launch': launch, 'backward_seed': 'preallocated ones',
+               'launch_trial_ms': launch_trial, 'hip_env': {'DEBUG_CLR_GRAPH_PACKET_CAPTURE': os.environ.get('DEBUG_CLR_GRAPH_PACKET_CAPTURE')},
                'timing': {'preroll_s': args.preroll_s, 'preroll_steps': n_pre, 'repeats': len(region_ms), 'statistic': 'median',
                           'ms_per_step_min': round(min(region_ms), 4), 'ms_per_step_max': round(max(region_ms), 4)},
                'step_tflops_algorithmic': round(value * FLOPS_PER_PAIR / 1e12, 2)}
