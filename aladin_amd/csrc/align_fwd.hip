@@ -628,9 +628,16 @@ template <bool HAS_E, int TP16 = 3, bool PROBE = false, int Q = 1, int REMC = 1>
 static int launch_scores16(const aladin_align_geom* g, const half_t* xm, const half_t* y, const float* E, float* S,
                            int64_t ldS, hipStream_t stream) {
   // small grids (<= 64 tiles of 256 x 384, i.e. B <= 64 at the headline shape): the 128 x 192 / three-stage variant
-  if constexpr (!PROBE)
+  if constexpr (!PROBE) {
+#ifdef ALADIN_DIAG
+    // ALADIN_SCORE_VARIANT=1 / 2: force the two-wave 128 x 192 tile with a 2- / 3-stage ring at any size (experiments)
+    static const int variant = diag_env("ALADIN_SCORE_VARIANT", 0);
+    if (variant == 1) return launch_scores16_cfg<HAS_E, TP16, false, Q, REMC, 2, 1, 2>(g, xm, y, E, S, ldS, stream);
+    if (variant == 2) return launch_scores16_cfg<HAS_E, TP16, false, Q, REMC, 2, 1, 3>(g, xm, y, E, S, ldS, stream);
+#endif
     if ((g->xm_rows / 256) * (g->y_rows / 384) <= 64)
       return launch_scores16_cfg<HAS_E, TP16, false, Q, REMC, 2, 1, 3>(g, xm, y, E, S, ldS, stream);
+  }
   return launch_scores16_cfg<HAS_E, TP16, PROBE, Q, REMC, 4, 2, 2>(g, xm, y, E, S, ldS, stream);
 }
 
