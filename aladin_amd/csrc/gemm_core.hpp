@@ -325,3 +325,101 @@ __device__ __forceinline__ void gemm_mainloop16(const half_t* __restrict__ a_row
     }
   }
 }
+
+// ================================================================================================
+// The same loop for a TALL wave tile: 128 x 96 per wave (8 row tiles x 6 column tiles of 16 x 16; workgroup 2 x 4 waves =
+// the same 256 x 384 tile, same LDS image, same accumulator count).  A wave reads 8 + 6 = 14 fragments per 32-deep
+// step instead of 4 + 12 = 16: the loop's LDS traffic (fragment reads + LDS-DMA fill) is what the no-MFMA ablation
+// shows it bound by next to the matrix pipe (2688 of 3072 pipe cycles per K step at 128 B / clk / CU), and the square-er
+// tile lowers it to 2432.  Three clusters of 16 MFMAs per 32-deep step: 8 row tiles x 2 column tiles; the A fragments
+// stay in registers, the B fragments alternate between two pairs.
+// ================================================================================================
+template <class Cfg, bool SPREAD = true>
+__device__ __forceinline__ void gemm_mainloop16_tall(const half_t* __restrict__ a_rows, const half_t* __restrict__ b_rows,
+                                                     int64_t ldk, int ktiles, char* smem,
+                                                     f32x4 (&acc)[2 * Cfg::WM][2 * Cfg::WN]) {
+  constexpr int RT = 2 * Cfg::WM, CT = 2 * Cfg::WN;
+  static_assert(RT == 8 && CT == 6, "written for a 128 x 96 wave tile");
+  constexpr int CPW = Cfg::CHUNKS_PER_WAVE;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  const int wm = wave / Cfg::WGN, wn = wave % Cfg::WGN;
+  const uint32_t lane_off = stage_lane_offset<Cfg>(ldk, wave, lane);
+  const int a_row0 = wm * Cfg::WM * 32 + (lane & 15);
+  const int b_row0 = Cfg::BM + wn * Cfg::WN * 32 + (lane & 15);
+
+  gemm_stage<Cfg>(a_rows, nullptr, Cfg::BM, b_rows, ldk, 0, smem, wave, lane_off);
+  for (int kt = 0; kt < ktiles; ++kt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    const char* cur = smem + (kt & 1) * Cfg::STAGE_BYTES;
+    const bool refill = kt + 1 < ktiles;
+    char* nxt = smem + ((kt + 1) & 1) * Cfg::STAGE_BYTES;
+    if (!SPREAD && refill) gemm_stage<Cfg>(a_rows, nullptr, Cfg::BM, b_rows, ldk, kt + 1, nxt, wave, lane_off);
+
+    half8 a[RT], bA[2], bB[2];
+    // the first MFMAs of the step need a[0], bA[0], bA[1], then a[1] ...: ask in that order (LDS returns in order)
+    bA[0] = lds_frag16(cur, b_row0, 0, lane);
+    a[0] = lds_frag16(cur, a_row0, 0, lane);
+    bA[1] = lds_frag16(cur, b_row0 + 16, 0, lane);
+#pragma unroll
+    for (int rt = 1; rt < RT; ++rt) a[rt] = lds_frag16(cur, a_row0 + rt * 16, 0, lane);
+#pragma unroll
+    for (int k32 = 0; k32 < 2; ++k32) {
+      // ---- cluster 0: column tiles 0, 1 (bA), row-tile-major; fetch 2, 3 into bB
+#pragma unroll
+      for (int j = 0; j < 2; ++j) bB[j] = lds_frag16(cur, b_row0 + (2 + j) * 16, k32, lane);
+      if (SPREAD && refill) {
+        if (k32 == 1) gemm_stage<Cfg, (6 * CPW) / 10, (8 * CPW) / 10>(a_rows, nullptr, Cfg::BM, b_rows, ldk, kt + 1, nxt, wave, lane_off);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[rt][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[rt], bA[j], acc[rt][j], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- cluster 1: column tiles 2, 3 (bB); fetch 4, 5 into bA
+#pragma unroll
+      for (int j = 0; j < 2; ++j) bA[j] = lds_frag16(cur, b_row0 + (4 + j) * 16, k32, lane);
+      if (SPREAD && refill) {
+        if (k32 == 0) gemm_stage<Cfg, 0, (3 * CPW) / 10>(a_rows, nullptr, Cfg::BM, b_rows, ldk, kt + 1, nxt, wave, lane_off);
+        else gemm_stage<Cfg, (8 * CPW) / 10, CPW>(a_rows, nullptr, Cfg::BM, b_rows, ldk, kt + 1, nxt, wave, lane_off);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+          acc[rt][2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[rt], bB[j], acc[rt][2 + j], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- cluster 2: column tiles 4, 5 (bA), row-tile-major; fetch the next 32-deep step's first fragments
+      if (k32 == 0) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) bB[j] = lds_frag16(cur, b_row0 + j * 16, 1, lane);
+      }
+      if (SPREAD && refill) {
+        if (k32 == 0) gemm_stage<Cfg, (3 * CPW) / 10, (6 * CPW) / 10>(a_rows, nullptr, Cfg::BM, b_rows, ldk, kt + 1, nxt, wave, lane_off);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[rt][4 + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[rt], bA[j], acc[rt][4 + j], 0, 0, 0);
+        if (k32 == 0) a[rt] = lds_frag16(cur, a_row0 + rt * 16, 1, lane);      // a[rt] is dead: reuse its register
+      }
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (k32 == 0) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) bA[j] = bB[j];
+      }
+    }
+  }
+}

@@ -54,7 +54,7 @@ def parse():
 
 
 def kernel_roofline(im, s, il, sl, groups=5, iters=100):
-    """Average duration of the dominant kernel (align_scores16_kernel) measured with HIP events on
+    """Average duration of the dominant kernel (align_scores16_tall_kernel) measured with HIP events on
     the stream it is launched on (torch's current stream), on the packed operands of the bench
     batch.  The side GEMM (33rd region of every image, 1/33 of the work, its own kernel) is run
     once and reused, so each timed launch contracts 32 regions x 47 words x 768 per pair.
@@ -83,8 +83,8 @@ def kernel_roofline(im, s, il, sl, groups=5, iters=100):
     ms = statistics.median(ms_groups)
     flops = B * B * 2 * 32 * (T - 3) * D
     achieved = flops / (ms * 1e-3) / 1e12
-    traffic, src = pmc_traffic('align_scores16_kernel')
-    return {'bound': 'mfma', 'traffic_source': src, 'kernel': 'align_scores16_kernel<true> (256x384 tile, v_mfma_f32_16x16x32_f16)',
+    traffic, src = pmc_traffic('align_scores16_tall_kernel')
+    return {'bound': 'mfma', 'traffic_source': src, 'kernel': 'align_scores16_tall_kernel<true,3,1> (256x384 tile, 8 waves of 128x96, v_mfma_f32_16x16x32_f16)',
             'achieved': round(achieved, 2), 'peak': PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_TFLOPS, 4),
             'traffic': traffic, 'kernel_us': round(ms * 1e3, 2), 'kernel_us_min_max': [round(min(ms_groups) * 1e3, 2), round(max(ms_groups) * 1e3, 2)],
             'flops_per_launch': flops}
