@@ -12,7 +12,9 @@
 #include "../../include/aladin_hip.h"
 #include "gemm_core.hpp"
 
-using SimCfg = GemmCfg<4, 2, 2, 6>;       // 256 x 384 tile, 8 waves x (64 x 192), v_mfma_f32_16x16x32_f16 body (gemm_core.hpp)
+using SimCfg = GemmCfg<2, 4, 4, 3>;       // 256 x 384 tile, 8 waves x (128 x 96), v_mfma_f32_16x16x32_f16 body (gemm_mainloop16_tall, gemm_core.hpp:
+                                          // 14 instead of 16 LDS fragment reads per 32-deep step; an accumulator's bits do not depend on the wave tiling)
+constexpr int SIM_RT = 2 * SimCfg::WM, SIM_CT = 2 * SimCfg::WN;      // 16 x 16 accumulator tiles per wave: 8 x 6
 
 struct SimWs {
   float* scale;      // [0] = 2^ea, [1] = 2^eb, [2] = absmax(img), [3] = absmax(cap)  (256 B block)
@@ -149,28 +151,29 @@ __global__ __launch_bounds__(512) void sim_gemm_kernel(const half_t* __restrict_
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int mb, nb;
   tile_coords(blockIdx.x, n_blocks / n_nblk, n_nblk, 4, mb, nb);
-  f32x4 acc[4][12];
+  constexpr int RT = SIM_RT, CT = SIM_CT;
+  f32x4 acc[RT][CT];
 #pragma unroll
-  for (int rt = 0; rt < 4; ++rt)
+  for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-    for (int ct = 0; ct < 12; ++ct) acc[rt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
-  gemm_mainloop16<Cfg>(a + (int64_t)mb * Cfg::BM * ldk, b + (int64_t)nb * Cfg::BN * ldk, ldk, ktiles, smem, acc);
+    for (int ct = 0; ct < CT; ++ct) acc[rt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+  gemm_mainloop16_tall<Cfg>(a + (int64_t)mb * Cfg::BM * ldk, b + (int64_t)nb * Cfg::BN * ldk, ldk, ktiles, smem, acc);
   const float unscale = 1.0f / (scale[0] * scale[1]);   // exact: powers of two
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int wm = wave / Cfg::WGN, wn = wave % Cfg::WGN;
   // 16x16 C tile: col = lane & 15, row = 4 * (lane >> 4) + reg
-  const int row0 = mb * Cfg::BM + wm * 64 + 4 * (lane >> 4);
-  const int col0 = nb * Cfg::BN + wn * 192 + (lane & 15);
+  const int row0 = mb * Cfg::BM + wm * (RT * 16) + 4 * (lane >> 4);
+  const int col0 = nb * Cfg::BN + wn * (CT * 16) + (lane & 15);
   if constexpr (MODE == SIM_STORE) {
 #pragma unroll
-    for (int rt = 0; rt < 4; ++rt)
+    for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg) {
         const int row = row0 + rt * 16 + reg;
         if (row >= n_img) continue;
         float* out = sim + (int64_t)row * ld;
 #pragma unroll
-        for (int ct = 0; ct < 12; ++ct) {
+        for (int ct = 0; ct < CT; ++ct) {
           const int col = col0 + ct * 16;
           if (col < n_cap) out[col] = acc[rt][ct][reg] * unscale;
         }
@@ -206,10 +209,10 @@ __global__ __launch_bounds__(512) void sim_gemm_kernel(const half_t* __restrict_
       l_gcol[e] = (c < n_cap) ? ra.gt[c] * rescale : INFINITY;
     }
     __syncthreads();
-    const int lrow0 = wm * 64 + 4 * (lane >> 4), lcol0 = wn * 192 + (lane & 15);
-    // ---- rows: lanes with the same lane >> 4 share a row; 12 columns each
+    const int lrow0 = wm * (RT * 16) + 4 * (lane >> 4), lcol0 = wn * (CT * 16) + (lane & 15);
+    // ---- rows: lanes with the same lane >> 4 share a row; CT columns each
 #pragma unroll
-    for (int rt = 0; rt < 4; ++rt)
+    for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg) {
         const int row = row0 + rt * 16 + reg, lrow = lrow0 + rt * 16 + reg;
@@ -217,7 +220,7 @@ __global__ __launch_bounds__(512) void sim_gemm_kernel(const half_t* __restrict_
         int cnt = 0;
         float best = -INFINITY;
 #pragma unroll
-        for (int ct = 0; ct < 12; ++ct) {
+        for (int ct = 0; ct < CT; ++ct) {
           const float v = (col0 + ct * 16 < n_cap) ? acc[rt][ct][reg] : -INFINITY;    // pad columns never count, never win
           cnt += (v > g);
           best = fmaxf(best, v);
@@ -230,7 +233,7 @@ __global__ __launch_bounds__(512) void sim_gemm_kernel(const half_t* __restrict_
         // the maximum's first column: this lane's first hit (columns ascend with ct), then the smallest over the 16 lanes
         int besti = 0x7fffffff;
 #pragma unroll
-        for (int ct = 11; ct >= 0; --ct)
+        for (int ct = CT - 1; ct >= 0; --ct)
           if (col0 + ct * 16 < n_cap && acc[rt][ct][reg] == best) besti = col0 + ct * 16;
 #pragma unroll
         for (int o = 8; o > 0; o >>= 1) { const int oi = __shfl_xor(besti, o, 64); besti = oi < besti ? oi : besti; }
@@ -241,13 +244,13 @@ __global__ __launch_bounds__(512) void sim_gemm_kernel(const half_t* __restrict_
       }
     // ---- columns: lanes with the same lane & 15 share a column; 16 rows each
 #pragma unroll
-    for (int ct = 0; ct < 12; ++ct) {
+    for (int ct = 0; ct < CT; ++ct) {
       const int col = col0 + ct * 16, lcol = lcol0 + ct * 16;
       const float g = l_gcol[lcol];
       int cnt = 0;
       float best = -INFINITY;
 #pragma unroll
-      for (int rt = 0; rt < 4; ++rt)
+      for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
           const float v = (row0 + rt * 16 + reg < n_img) ? acc[rt][ct][reg] : -INFINITY;
@@ -261,7 +264,7 @@ __global__ __launch_bounds__(512) void sim_gemm_kernel(const half_t* __restrict_
       }
       int besti = 0x7fffffff;
 #pragma unroll
-      for (int rt = 3; rt >= 0; --rt)
+      for (int rt = RT - 1; rt >= 0; --rt)
 #pragma unroll
         for (int reg = 3; reg >= 0; --reg)
           if (row0 + rt * 16 + reg < n_img && acc[rt][ct][reg] == best) besti = row0 + rt * 16 + reg;     // rows ascend with (rt, reg)
