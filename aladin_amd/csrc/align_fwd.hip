@@ -15,6 +15,11 @@
 //                max-over-regions is an in-lane max over the 16 accumulator registers plus one
 //                half-wave exchange, and sum-over-words is a 32-lane shuffle reduction.  The
 //                B x B x R' x T' tensor of the reference never exists.
+//                Variants of the 16x16x32 body on the same 256 x 384 workgroup tile and LDS image (scores are
+//                bit-identical across them: same MFMA shape, K order and epilogue arithmetic):
+//                  align_scores16_tall_kernel   8 waves of 128 x 96 (headline class: 14 LDS fragment reads per 32-deep step)
+//                  align_scores16_kernel<4,2,2> 8 waves of 64 x 192 (16 reads; classes whose captions do not tile 96 columns)
+//                  align_scores16_kernel<2,1,3> 128 x 192 tile, two waves, three-stage ring: grids of <= 64 big tiles (B <= 64)
 // side GEMM      R' = 33 = 32 + 1: the 33rd region of every image is gathered into one extra
 //                operand (one row per image) whose plain GEMM against the captions (E) is folded
 //                into the max by the score kernel -- 33/32 of the MFMA work instead of 64/32.
