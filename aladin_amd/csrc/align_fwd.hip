@@ -560,7 +560,7 @@ __device__ __forceinline__ void scores16_epilogue(f32x4 (&acc)[4][12], int mb, i
 // The same operations in the same order per score as scores16_epilogue -- in-lane max over an image's 2 row tiles x 4
 // registers, permlane32_swap pairing two images into the half-waves, one 16-lane exchange; in-lane adds over a caption's
 // column tiles, then the 16-lane sum -- so the scores are bit-identical.
-template <bool HAS_E, int TP16, int REMC>
+template <bool HAS_E, int TP16, int REMC, int Q = 1>
 __device__ __forceinline__ void scores16_epilogue_tall(f32x4 (&acc)[8][6], int mb, int nb, const float* __restrict__ E,
                                                        int64_t ldE, int rem, float* __restrict__ S, int64_t ldS, int Bi, int Bc) {
   using Cfg = GemmCfg<2, 4, 4, 3>;
@@ -574,7 +574,8 @@ __device__ __forceinline__ void scores16_epilogue_tall(f32x4 (&acc)[8][6], int m
   const int cap = (nb * 4 + wn) * NC;
 #pragma unroll
   for (int p = 0; p < 2; ++p) {
-    const int img = (mb * 2 + wm) * 4 + 2 * p + half;
+    // Q == 1: the pair's 64 rows are two images (lanes 0-31 finish the first, 32-63 the second); Q == 2: one image
+    const int img = (Q == 1) ? (mb * 2 + wm) * 4 + 2 * p + half : (mb * 2 + wm) * 2 + p;
     const float* e = HAS_E ? E + (int64_t)img * rem * ldE + (int64_t)nb * Cfg::BN + wn * 96 + l4 : nullptr;
     float v[NC];
 #pragma unroll
@@ -585,9 +586,16 @@ __device__ __forceinline__ void scores16_epilogue_tall(f32x4 (&acc)[8][6], int m
       p0 = fmaxf(p0, fmaxf(fmaxf(acc[4 * p + 1][ct][0], acc[4 * p + 1][ct][1]), fmaxf(acc[4 * p + 1][ct][2], acc[4 * p + 1][ct][3])));
       float p1 = fmaxf(fmaxf(acc[4 * p + 2][ct][0], acc[4 * p + 2][ct][1]), fmaxf(acc[4 * p + 2][ct][2], acc[4 * p + 2][ct][3]));
       p1 = fmaxf(p1, fmaxf(fmaxf(acc[4 * p + 3][ct][0], acc[4 * p + 3][ct][1]), fmaxf(acc[4 * p + 3][ct][2], acc[4 * p + 3][ct][3])));
-      auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(p0), __float_as_uint(p1), false, false);
-      float m = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
-      m = fmaxf(m, __shfl_xor(m, 16, 64));
+      float m;
+      if constexpr (Q == 1) {
+        auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(p0), __float_as_uint(p1), false, false);
+        m = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+        m = fmaxf(m, __shfl_xor(m, 16, 64));
+      } else {
+        m = fmaxf(p0, p1);
+        m = fmaxf(m, __shfl_xor(m, 16, 64));
+        m = fmaxf(m, __shfl_xor(m, 32, 64));
+      }
       if constexpr (HAS_E && REMC == 1) m = fmaxf(m, e[ct * 16]);
       if constexpr (HAS_E && REMC != 1) {
 #pragma unroll
@@ -600,12 +608,12 @@ __device__ __forceinline__ void scores16_epilogue_tall(f32x4 (&acc)[8][6], int m
       float t = v[c];
 #pragma unroll
       for (int o = 8; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
-      if ((lane & 31) == 0 && img < Bi && cap + c < Bc) S[(int64_t)img * ldS + cap + c] = t;
+      if ((lane & (Q == 1 ? 31 : 63)) == 0 && img < Bi && cap + c < Bc) S[(int64_t)img * ldS + cap + c] = t;
     }
   }
 }
 
-template <bool HAS_E, int TP16, int REMC>
+template <bool HAS_E, int TP16, int REMC, int Q = 1>
 __global__ __launch_bounds__(512) void align_scores16_tall_kernel(const half_t* __restrict__ xm, const half_t* __restrict__ y,
                                                                   const float* __restrict__ E, int64_t ldE,
                                                                   float* __restrict__ S, int64_t ldS, int Bi, int Bc,
@@ -619,7 +627,7 @@ __global__ __launch_bounds__(512) void align_scores16_tall_kernel(const half_t* 
   for (int rt = 0; rt < 8; ++rt)
 #pragma unroll
     for (int ct = 0; ct < 6; ++ct) acc[rt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
-  if constexpr (HAS_E && REMC == 1) {
+  if constexpr (HAS_E && REMC == 1 && Q == 1) {
     // pull this tile's side-row values into this XCD's L2 now (see align_scores16_kernel): per wave 4 images x 96 columns
     // = 12 lines of 32 floats; dropped into the piece of stage 1 this wave's own refill overwrites later
     const int wave_u = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -629,10 +637,10 @@ __global__ __launch_bounds__(512) void align_scores16_tall_kernel(const half_t* 
     __builtin_amdgcn_global_load_lds(GLOBAL_PTR(src), LDS_PTR(smem + Cfg::STAGE_BYTES + wave_u * 1024), 4, 0, 0);
   }
   gemm_mainloop16_tall<Cfg, true>(xm + (int64_t)mb * Cfg::BM * ldk, y + (int64_t)nb * Cfg::BN * ldk, ldk, ktiles, smem, acc);
-  scores16_epilogue_tall<HAS_E, TP16, REMC>(acc, mb, nb, E, ldE, rem, S, ldS, Bi, Bc);
+  scores16_epilogue_tall<HAS_E, TP16, REMC, Q>(acc, mb, nb, E, ldE, rem, S, ldS, Bi, Bc);
 }
 
-template <bool HAS_E, int TP16, int REMC>
+template <bool HAS_E, int TP16, int REMC, int Q = 1>
 static int launch_scores16_tall(const aladin_align_geom* g, const half_t* xm, const half_t* y, const float* E, float* S,
                                 int64_t ldS, hipStream_t stream) {
   using Cfg = GemmCfg<2, 4, 4, 3>;
@@ -641,7 +649,7 @@ static int launch_scores16_tall(const aladin_align_geom* g, const half_t* xm, co
     aladin_set_error("align_scores16: packed rows do not tile");
     return ALADIN_ERR_ARG;
   }
-  auto kern = align_scores16_tall_kernel<HAS_E, TP16, REMC>;
+  auto kern = align_scores16_tall_kernel<HAS_E, TP16, REMC, Q>;
   static unsigned long long lds_reserved = 0;
   if (int rc = aladin_reserve_lds((const void*)kern, Cfg::LDS_BYTES, &lds_reserved, "align_scores16_tall")) return rc;
   const int n_blocks = n_mblk * n_nblk;
@@ -737,9 +745,9 @@ static int launch_scores16(const aladin_align_geom* g, const half_t* xm, const h
 #endif
     if ((g->xm_rows / 256) * (g->y_rows / 384) <= 64)
       return launch_scores16_cfg<HAS_E, TP16, false, Q, REMC, 2, 1, 3>(g, xm, y, E, S, ldS, stream);
-    // one 32-row region tile per image and captions that tile a 96-column strip: the 128 x 96 wave tile (14 instead of 16
+    // captions that tile a 96-column strip (one or two 32-row region tiles per image): the 128 x 96 wave tile (14 instead of 16
     // fragment reads per 32-deep step; -2.4 % on the kernel, bit-identical scores)
-    if constexpr (Q == 1 && 6 % TP16 == 0) return launch_scores16_tall<HAS_E, TP16, REMC>(g, xm, y, E, S, ldS, stream);
+    if constexpr (6 % TP16 == 0) return launch_scores16_tall<HAS_E, TP16, REMC, Q>(g, xm, y, E, S, ldS, stream);
   }
   return launch_scores16_cfg<HAS_E, TP16, PROBE, Q, REMC, 4, 2, 2>(g, xm, y, E, S, ldS, stream);
 }
