@@ -907,6 +907,26 @@ def test_large_batch_equals_its_blocks():
             assert torch.equal(S[i0:i0 + blk, j0:j0 + blk], part), (i0, j0)
 
 
+def test_small_grid_score_variant_is_bit_identical():
+    """Grids of at most 64 of the 256 x 384 tiles (B <= 64 at the headline shape) run the two-wave 128 x 192 /
+    three-stage variant of the score kernel, larger ones the eight-wave 128 x 96-wave-tile kernel: same MFMA shape, K
+    order and epilogue arithmetic, so a 96 x 96 matrix must equal its 32 x 32 and 48 x 96 blocks bit for bit, with
+    and without the side row (R' = 33 / 32), full and ragged."""
+    from aladin_amd import ops, synth
+    for R, ragged, seed in ((34, False, 901), (33, True, 902), (34, True, 903)):
+        B = 96
+        im, s, il, sl = synth.alignment_batch(B, R, 50, 768, seed=seed, ragged=ragged)
+        a, b = T(im), T(s)
+        S = ops.alignment_scores(a, b, il, sl)
+        for (bi, bj) in ((32, 32), (48, 96), (96, 40)):
+            for i0 in range(0, B, bi):
+                for j0 in range(0, B, bj):
+                    ii, jj = slice(i0, min(B, i0 + bi)), slice(j0, min(B, j0 + bj))
+                    il_b, sl_b = list(il[ii]), list(sl[jj])
+                    part = ops.alignment_scores(a[ii], b[jj], il_b, sl_b)
+                    assert torch.equal(S[ii, jj], part), (R, ragged, bi, bj, i0, j0)
+
+
 def test_l2norm_and_cosine_measure():
     """l2norm (alad/utils.py:134-139: no eps, zero row -> NaN) forward / backward, and measure='cosine'."""
     from aladin_amd.loss import ContrastiveLoss, l2norm
