@@ -491,6 +491,41 @@ static int scores_wgm() {
   return v;
 }
 
+// sum over the 16 lanes of a row with DPP rotations instead of four ds_bpermute round trips.  t += ror(t, 8) pairs lane i
+// with i ^ 8; the row is then periodic with period 8, so ror 4 pairs i with i ^ 4, and so on: the same additions in the same
+// order as the xor butterfly (8, 4, 2, 1) -- bit-identical sums.
+__device__ __forceinline__ float row16_sum(float t) {
+  t += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t), 0x128, 0xF, 0xF, false));   // row_ror:8
+  t += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t), 0x124, 0xF, 0xF, false));   // row_ror:4
+  t += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t), 0x122, 0xF, 0xF, false));   // row_ror:2
+  t += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t), 0x121, 0xF, 0xF, false));   // row_ror:1
+  return t;
+}
+
+// IEEE-754-2019 maximum (v_maximum3_f32 on gfx950): unlike fmaxf / maxNum it needs no canonicalising v_max x, x, x of its
+// inputs in IEEE mode (a third of the epilogue's VALU instructions), and like torch.max it propagates a NaN
+__device__ __forceinline__ float vmax(float a, float b) { return __builtin_elementwise_maximum(a, b); }
+
+// max over lane i and lane i ^ 16 without the ds_bpermute round trip: v_permlane16_swap exchanges the odd 16-lane rows of its
+// first operand with the even rows of its second; fed the same value twice it leaves [r0 r0 r2 r2] and [r1 r1 r3 r3]
+__device__ __forceinline__ float max_xor16(float m) {
+  auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(m), __float_as_uint(m), false, false);
+  return vmax(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+}
+__device__ __forceinline__ float max_xor32(float m) {
+  auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(m), __float_as_uint(m), false, false);
+  return vmax(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+}
+
+// max of the eight values a lane holds of one image and one column (two 16-row tiles x four registers), written as a chain
+// so that the compiler emits v_max3_f32 (4 instructions instead of 7; max is exact in any order)
+__device__ __forceinline__ float max8(const f32x4& a, const f32x4& b) {
+  float t = vmax(vmax(a[0], a[1]), a[2]);
+  t = vmax(vmax(t, a[3]), b[0]);
+  t = vmax(vmax(t, b[1]), b[2]);
+  return vmax(t, b[3]);
+}
+
 // ------------------------------------------------------------------------------------------------
 // score kernel, v_mfma_f32_16x16x32_f16 body, for every class with one or two 32-row region tiles per image
 // (R' <= 64, plus the side row: Q = 1 -> a wave's 64 rows are two images, Q = 2 -> one) and captions of TP16 = 1, 2, 3, 4 or 6 sixteen-word tiles (headline: 3 = 48 words):
@@ -523,35 +558,31 @@ __device__ __forceinline__ void scores16_epilogue(f32x4 (&acc)[4][12], int mb, i
   for (int c = 0; c < NC; ++c) v[c] = 0.f;
 #pragma unroll
   for (int ct = 0; ct < CT; ++ct) {
-    float p0 = fmaxf(fmaxf(acc[0][ct][0], acc[0][ct][1]), fmaxf(acc[0][ct][2], acc[0][ct][3]));
-    p0 = fmaxf(p0, fmaxf(fmaxf(acc[1][ct][0], acc[1][ct][1]), fmaxf(acc[1][ct][2], acc[1][ct][3])));
-    float p1 = fmaxf(fmaxf(acc[2][ct][0], acc[2][ct][1]), fmaxf(acc[2][ct][2], acc[2][ct][3]));
-    p1 = fmaxf(p1, fmaxf(fmaxf(acc[3][ct][0], acc[3][ct][1]), fmaxf(acc[3][ct][2], acc[3][ct][3])));
+    const float p0 = max8(acc[0][ct], acc[1][ct]);
+    const float p1 = max8(acc[2][ct], acc[3][ct]);
     float m;
     if constexpr (Q == 1) {
       // rows are spread over the four 16-lane quarters; gather image 0 into lanes 0-31, image 1 into 32-63
       auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(p0), __float_as_uint(p1), false, false);
-      m = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
-      m = fmaxf(m, __shfl_xor(m, 16, 64));
+      m = vmax(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+      m = max_xor16(m);
     } else {
-      m = fmaxf(p0, p1);                                           // all 64 rows belong to the image
-      m = fmaxf(m, __shfl_xor(m, 16, 64));
-      m = fmaxf(m, __shfl_xor(m, 32, 64));
+      m = vmax(p0, p1);                                           // all 64 rows belong to the image
+      m = max_xor16(m);
+      m = max_xor32(m);
     }
-    if constexpr (HAS_E && REMC == 1) m = fmaxf(m, e[ct * 16]);
+    if constexpr (HAS_E && REMC == 1) m = vmax(m, e[ct * 16]);
     if constexpr (HAS_E && REMC != 1) {
       // branch-free: max is idempotent, so rows past the last side row re-read it (k clamped to rem - 1)
 #pragma unroll
-      for (int k = 0; k < 8; ++k) m = fmaxf(m, e[(int64_t)(k < rem ? k : rem - 1) * ldE + ct * 16]);
+      for (int k = 0; k < 8; ++k) m = vmax(m, e[(int64_t)(k < rem ? k : rem - 1) * ldE + ct * 16]);
     }
     v[ct / TP16] += m;
   }
   const int cap = (nb * WGN + wn) * NC;
 #pragma unroll
   for (int c = 0; c < NC; ++c) {
-    float t = v[c];
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+    const float t = row16_sum(v[c]);
     if ((lane & (Q == 1 ? 31 : 63)) == 0 && img < Bi && cap + c < Bc) S[(int64_t)img * ldS + cap + c] = t;
   }
 }
@@ -582,32 +613,28 @@ __device__ __forceinline__ void scores16_epilogue_tall(f32x4 (&acc)[8][6], int m
     for (int c = 0; c < NC; ++c) v[c] = 0.f;
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) {
-      float p0 = fmaxf(fmaxf(acc[4 * p][ct][0], acc[4 * p][ct][1]), fmaxf(acc[4 * p][ct][2], acc[4 * p][ct][3]));
-      p0 = fmaxf(p0, fmaxf(fmaxf(acc[4 * p + 1][ct][0], acc[4 * p + 1][ct][1]), fmaxf(acc[4 * p + 1][ct][2], acc[4 * p + 1][ct][3])));
-      float p1 = fmaxf(fmaxf(acc[4 * p + 2][ct][0], acc[4 * p + 2][ct][1]), fmaxf(acc[4 * p + 2][ct][2], acc[4 * p + 2][ct][3]));
-      p1 = fmaxf(p1, fmaxf(fmaxf(acc[4 * p + 3][ct][0], acc[4 * p + 3][ct][1]), fmaxf(acc[4 * p + 3][ct][2], acc[4 * p + 3][ct][3])));
+      const float p0 = max8(acc[4 * p][ct], acc[4 * p + 1][ct]);
+      const float p1 = max8(acc[4 * p + 2][ct], acc[4 * p + 3][ct]);
       float m;
       if constexpr (Q == 1) {
         auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(p0), __float_as_uint(p1), false, false);
-        m = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
-        m = fmaxf(m, __shfl_xor(m, 16, 64));
+        m = vmax(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+        m = max_xor16(m);
       } else {
-        m = fmaxf(p0, p1);
-        m = fmaxf(m, __shfl_xor(m, 16, 64));
-        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        m = vmax(p0, p1);
+        m = max_xor16(m);
+        m = max_xor32(m);
       }
-      if constexpr (HAS_E && REMC == 1) m = fmaxf(m, e[ct * 16]);
+      if constexpr (HAS_E && REMC == 1) m = vmax(m, e[ct * 16]);
       if constexpr (HAS_E && REMC != 1) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) m = fmaxf(m, e[(int64_t)(k < rem ? k : rem - 1) * ldE + ct * 16]);
+        for (int k = 0; k < 8; ++k) m = vmax(m, e[(int64_t)(k < rem ? k : rem - 1) * ldE + ct * 16]);
       }
       v[ct / TP16] += m;
     }
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
-      float t = v[c];
-#pragma unroll
-      for (int o = 8; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+      const float t = row16_sum(v[c]);
       if ((lane & (Q == 1 ? 31 : 63)) == 0 && img < Bi && cap + c < Bc) S[(int64_t)img * ldS + cap + c] = t;
     }
   }
