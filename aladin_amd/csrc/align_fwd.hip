@@ -136,7 +136,7 @@ __device__ __forceinline__ void pack_row(const float* __restrict__ src, half_t* 
       v[k] = c < D ? *reinterpret_cast<const float4*>(src + c) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 #pragma unroll
-    for (int k = 0; k < 4; ++k) ss += v[k].x * v[k].x + v[k].y * v[k].y + v[k].z * v[k].z + v[k].w * v[k].w;
+    for (int k = 0; k < 4; ++k) ss = sumsq4(ss, v[k]);
     ss = wave_sum(ss);
     const float inv = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
 #pragma unroll
@@ -150,10 +150,10 @@ __device__ __forceinline__ void pack_row(const float* __restrict__ src, half_t* 
   if (vec4) {
     for (int c = lane * 4; c < D; c += 256) {
       const float4 v = *reinterpret_cast<const float4*>(src + c);
-      ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+      ss = sumsq4(ss, v);
     }
   } else {
-    for (int c = lane; c < D; c += 64) ss += src[c] * src[c];
+    for (int c = lane; c < D; c += 64) ss = fmaf(src[c], src[c], ss);
   }
   ss = wave_sum(ss);
   const float inv = 1.0f / fmaxf(sqrtf(ss), 1e-12f);        // F.normalize eps (alad/loss.py:80-81)
@@ -489,17 +489,6 @@ static int scores_spread() {
 static int scores_wgm() {
   static const int v = diag_env("ALADIN_ALIGN_WGM", 4) == 2 ? 2 : 4;
   return v;
-}
-
-// sum over the 16 lanes of a row with DPP rotations instead of four ds_bpermute round trips.  t += ror(t, 8) pairs lane i
-// with i ^ 8; the row is then periodic with period 8, so ror 4 pairs i with i ^ 4, and so on: the same additions in the same
-// order as the xor butterfly (8, 4, 2, 1) -- bit-identical sums.
-__device__ __forceinline__ float row16_sum(float t) {
-  t += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t), 0x128, 0xF, 0xF, false));   // row_ror:8
-  t += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t), 0x124, 0xF, 0xF, false));   // row_ror:4
-  t += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t), 0x122, 0xF, 0xF, false));   // row_ror:2
-  t += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t), 0x121, 0xF, 0xF, false));   // row_ror:1
-  return t;
 }
 
 // IEEE-754-2019 maximum (v_maximum3_f32 on gfx950): unlike fmaxf / maxNum it needs no canonicalising v_max x, x, x of its

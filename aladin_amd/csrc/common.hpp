@@ -27,21 +27,44 @@ int aladin_reserve_lds(const void* kernel, int bytes, unsigned long long* done, 
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 #define GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
 
+// Cross-lane reductions without the LDS crossbar (ds_bpermute: ~100 cycles a step, six dependent steps per wave reduction).
+// v_permlane32_swap / v_permlane16_swap (gfx950) fed the same value twice leave [lo lo] / [hi hi] (resp. [r0 r0 r2 r2] /
+// [r1 r1 r3 r3]): their sum / max is v (op) v[lane ^ 32] (resp. ^ 16) on every lane.  Inside a 16-lane row, DPP row_ror 8, 4,
+// 2, 1: after the ^ 8 step the row has period 8, so a rotation by 4 pairs lane i with i ^ 4, and so on.  The operations and
+// their order are those of the xor butterfly 32, 16, 8, 4, 2, 1 (only operands commuted): results are bit-identical to it.
+#define ALADIN_ROW_ROR(v, n) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x120 + (n), 0xF, 0xF, false))
+__device__ __forceinline__ float row16_sum(float t) {
+  t += ALADIN_ROW_ROR(t, 8);
+  t += ALADIN_ROW_ROR(t, 4);
+  t += ALADIN_ROW_ROR(t, 2);
+  t += ALADIN_ROW_ROR(t, 1);
+  return t;
+}
+__device__ __forceinline__ float half_wave_sum(float v) {      // sum over the 32 lanes of each half-wave separately
+  auto s16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return row16_sum(__uint_as_float(s16[0]) + __uint_as_float(s16[1]));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  auto s32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return half_wave_sum(__uint_as_float(s32[0]) + __uint_as_float(s32[1]));
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  auto s32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = fmaxf(__uint_as_float(s32[0]), __uint_as_float(s32[1]));
+  auto s16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = fmaxf(__uint_as_float(s16[0]), __uint_as_float(s16[1]));
+  v = fmaxf(v, ALADIN_ROW_ROR(v, 8));
+  v = fmaxf(v, ALADIN_ROW_ROR(v, 4));
+  v = fmaxf(v, ALADIN_ROW_ROR(v, 2));
+  v = fmaxf(v, ALADIN_ROW_ROR(v, 1));
   return v;
 }
-// sum over the 32 lanes of each half-wave separately
-__device__ __forceinline__ float half_wave_sum(float v) {
-#pragma unroll
-  for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+
+// Sum of squares accumulated with an explicit fma chain.  The packed operands of a row must not depend on WHICH kernel
+// normalised it (dense pack, evaluation store): left as `ss += x*x + y*y + ...` the compiler contracts each site on its own,
+// and two sites agreed bit for bit only by luck.
+__device__ __forceinline__ float sumsq4(float ss, const float4& v) {
+  return fmaf(v.w, v.w, fmaf(v.z, v.z, fmaf(v.y, v.y, fmaf(v.x, v.x, ss))));
 }
 
 // XCD-aware bijective block remap (8 XCDs, blocks are dealt round-robin over them): gives each

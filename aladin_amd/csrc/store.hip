@@ -31,10 +31,10 @@ __global__ __launch_bounds__(256) void store_append_kernel(const float* __restri
   if (vec4) {
     for (int c = lane * 4; c < D; c += 256) {
       const float4 v = *reinterpret_cast<const float4*>(x + c);
-      ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+      ss = sumsq4(ss, v);
     }
   } else {
-    for (int c = lane; c < D; c += 64) ss += x[c] * x[c];
+    for (int c = lane; c < D; c += 64) ss = fmaf(x[c], x[c], ss);
   }
   ss = wave_sum(ss);
   const float inv = 1.0f / fmaxf(sqrtf(ss), 1e-12f);                     // same arithmetic as pack_row (align_fwd.hip)
