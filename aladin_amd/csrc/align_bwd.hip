@@ -263,8 +263,8 @@ __global__ __launch_bounds__(256) void bwd_pair_argmax16_kernel(
       else b2 = fmaxf(b2, (ob1));                                                              \
     } while (0)
     {
-      const float ob1 = __shfl_xor(b1, 32, 64), ob2 = __shfl_xor(b2, 32, 64);
-      const int oa1 = __shfl_xor(a1, 32, 64);
+      const float ob1 = lane_xor32(b1), ob2 = lane_xor32(b2);
+      const int oa1 = lane_xor32(a1);
       TOP2_MERGE(ob1, oa1, ob2);
     }
     if (h == 0) { top_b1[wm][wcol] = b1; top_b2[wm][wcol] = b2; top_a1[wm][wcol] = a1; }
@@ -486,11 +486,11 @@ __global__ __launch_bounds__(256) void bwd_rows_kernel(
           const int k0 = __ffsll((long long)todo) - 1; todo &= todo - 1;
           int k1 = -1;
           if (todo) { k1 = __ffsll((long long)todo) - 1; todo &= todo - 1; }
-          const int p_0 = __shfl(my_p, k0, 64), r_0 = __shfl((int)my_rho, k0, 64);
-          const float g_0 = __shfl(my_g, k0, 64);
+          const int p_0 = lane_bcast(my_p, k0), r_0 = lane_bcast((int)my_rho, k0);
+          const float g_0 = lane_bcast(my_g, k0);
           const int kk1 = k1 < 0 ? k0 : k1;
-          const int p_1 = __shfl(my_p, kk1, 64), r_1 = __shfl((int)my_rho, kk1, 64);
-          const float g_1 = k1 < 0 ? 0.f : __shfl(my_g, kk1, 64);
+          const int p_1 = lane_bcast(my_p, kk1), r_1 = lane_bcast((int)my_rho, kk1);
+          const float g_1 = k1 < 0 ? 0.f : lane_bcast(my_g, kk1);
           const float* x0 = im + p_0 * im_sb + (int64_t)(r_0 + 1) * im_sr;
           const float* x1 = k1 < 0 ? nullptr : im + p_1 * im_sb + (int64_t)(r_1 + 1) * im_sr;
           gather2<NCH>(x0, g_0, x1, g_1, D, lane, acc);
@@ -520,10 +520,10 @@ __global__ __launch_bounds__(256) void bwd_rows_kernel(
         float pend_g = 0.f;
         while (live) {
           const int k = __ffsll((long long)live) - 1; live &= live - 1;
-          const int pk = __shfl(my_p, k, 64);
-          const float gk = __shfl(my_g, k, 64);
-          unsigned long long lo = __shfl((unsigned)(hit_lo & 0xffffffffu), k, 64) | ((unsigned long long)__shfl((unsigned)(hit_lo >> 32), k, 64) << 32);
-          unsigned long long hi = __shfl((unsigned)(hit_hi & 0xffffffffu), k, 64) | ((unsigned long long)__shfl((unsigned)(hit_hi >> 32), k, 64) << 32);
+          const int pk = lane_bcast(my_p, k);
+          const float gk = lane_bcast(my_g, k);
+          unsigned long long lo = lane_bcast((unsigned)(hit_lo & 0xffffffffu), k) | ((unsigned long long)lane_bcast((unsigned)(hit_lo >> 32), k) << 32);
+          unsigned long long hi = lane_bcast((unsigned)(hit_hi & 0xffffffffu), k) | ((unsigned long long)lane_bcast((unsigned)(hit_hi >> 32), k) << 32);
           for (int part = 0; part < 2; ++part) {
             unsigned long long bits = part == 0 ? lo : hi;
             while (bits) {

@@ -60,6 +60,18 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// Broadcast of lane k's value, k WAVE-UNIFORM: v_readlane_b32 (a few cycles, result in an SGPR) instead of __shfl's
+// ds_bpermute round trip through the LDS crossbar.
+__device__ __forceinline__ int lane_bcast(int v, int k) { return __builtin_amdgcn_readlane(v, k); }
+__device__ __forceinline__ unsigned lane_bcast(unsigned v, int k) { return (unsigned)__builtin_amdgcn_readlane((int)v, k); }
+__device__ __forceinline__ float lane_bcast(float v, int k) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), k)); }
+// value of lane ^ 32 (any use, not only commutative reductions)
+__device__ __forceinline__ float lane_xor32(float v) {
+  auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);     // [lo lo], [hi hi]
+  return __uint_as_float((threadIdx.x & 32) ? sw[0] : sw[1]);
+}
+__device__ __forceinline__ int lane_xor32(int v) { return __float_as_int(lane_xor32(__int_as_float(v))); }
+
 // Sum of squares accumulated with an explicit fma chain.  The packed operands of a row must not depend on WHICH kernel
 // normalised it (dense pack, evaluation store): left as `ss += x*x + y*y + ...` the compiler contracts each site on its own,
 // and two sites agreed bit for bit only by luck.
