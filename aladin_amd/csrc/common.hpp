@@ -72,6 +72,24 @@ __device__ __forceinline__ float lane_xor32(float v) {
 }
 __device__ __forceinline__ int lane_xor32(int v) { return __float_as_int(lane_xor32(__int_as_float(v))); }
 
+__device__ __forceinline__ float lane_xor16(float v) {
+  auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);     // [r0 r0 r2 r2], [r1 r1 r3 r3]
+  return __uint_as_float((threadIdx.x & 16) ? sw[0] : sw[1]);
+}
+__device__ __forceinline__ int lane_xor16(int v) { return __float_as_int(lane_xor16(__int_as_float(v))); }
+// (max value, smallest index attaining it) over the 64 lanes of a wave, in every lane.  The combine is symmetric, so after
+// each step partners agree and the DPP rotations act as the xor butterfly (see row16_sum).
+__device__ __forceinline__ void wave_argmax(float& v, int& idx) {
+#define ALADIN_ARGMAX_STEP(OV, OI) do { const float ov_ = (OV); const int oi_ = (OI); if (ov_ > v || (ov_ == v && oi_ < idx)) { v = ov_; idx = oi_; } } while (0)
+  ALADIN_ARGMAX_STEP(lane_xor32(v), lane_xor32(idx));
+  ALADIN_ARGMAX_STEP(lane_xor16(v), lane_xor16(idx));
+  ALADIN_ARGMAX_STEP(ALADIN_ROW_ROR(v, 8), __builtin_amdgcn_update_dpp(0, idx, 0x128, 0xF, 0xF, false));
+  ALADIN_ARGMAX_STEP(ALADIN_ROW_ROR(v, 4), __builtin_amdgcn_update_dpp(0, idx, 0x124, 0xF, 0xF, false));
+  ALADIN_ARGMAX_STEP(ALADIN_ROW_ROR(v, 2), __builtin_amdgcn_update_dpp(0, idx, 0x122, 0xF, 0xF, false));
+  ALADIN_ARGMAX_STEP(ALADIN_ROW_ROR(v, 1), __builtin_amdgcn_update_dpp(0, idx, 0x121, 0xF, 0xF, false));
+#undef ALADIN_ARGMAX_STEP
+}
+
 // Sum of squares accumulated with an explicit fma chain.  The packed operands of a row must not depend on WHICH kernel
 // normalised it (dense pack, evaluation store): left as `ss += x*x + y*y + ...` the compiler contracts each site on its own,
 // and two sites agreed bit for bit only by luck.

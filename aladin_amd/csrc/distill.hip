@@ -88,12 +88,7 @@ __global__ __launch_bounds__(256) void tcon_pick_kernel(const float* __restrict_
     if (t == q) v = 0.f;
     if (v > best || (v == best && t < besti)) { best = v; besti = t; }
   }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    const float ov = __shfl_xor(best, o, 64);
-    const int oi = __shfl_xor(besti, o, 64);
-    if (ov > best || (ov == best && oi < besti)) { best = ov; besti = oi; }
-  }
+  wave_argmax(best, besti);
   if ((threadIdx.x & 63) == 0) { redv[threadIdx.x >> 6] = best; redi[threadIdx.x >> 6] = besti; }
   __syncthreads();
   if (threadIdx.x == 0) {

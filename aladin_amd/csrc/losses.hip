@@ -33,12 +33,7 @@ __device__ __forceinline__ float block_max(float v, float* red) {
 }
 // (max value, smallest index attaining it)
 __device__ __forceinline__ void block_argmax(float& v, int& idx, float* redv, int* redi) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    const float ov = __shfl_xor(v, o, 64);
-    const int oi = __shfl_xor(idx, o, 64);
-    if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
-  }
+  wave_argmax(v, idx);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   __syncthreads();
   if (lane == 0) { redv[wave] = v; redi[wave] = idx; }

@@ -27,16 +27,6 @@
 
 namespace {
 
-// (max value, smallest index attaining it) over the 64 lanes of a wave
-__device__ __forceinline__ void wave_argmax(float& v, int& idx) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    const float ov = __shfl_xor(v, o, 64);
-    const int oi = __shfl_xor(idx, o, 64);
-    if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
-  }
-}
-
 // VSE++ hinge statistics of one row / column vector held a lane per element (alad/loss.py:49-67)
 __device__ __forceinline__ void hinge_vector_stats(float m, float diag, int q, int B, float margin, int max_violation, int lane,
                                                    float* out) {
