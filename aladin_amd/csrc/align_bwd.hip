@@ -22,6 +22,7 @@
 //                     -- get exact zeros, as in the reference).
 #include "../../include/aladin_hip.h"
 #include "gemm_core.hpp"
+#include "hinge_common.hpp"
 
 #define NO_GRAD 255
 
@@ -176,13 +177,30 @@ extern "C" __attribute__((visibility("default"))) int aladin_debug_read_pair_pro
 #define PAIR_STAMP(k) do { } while (0)
 #endif
 
+// SRC == 0: the pairs come from a list (hinge_finish / bwd_compact).
+// SRC == 1: MERGED with the second pass of the hardest-negative hinge.  The pairs follow from the hinge's row / column
+//   statistics directly -- (q, q), (q, argmax_j of row q), (argmax_i of column q, q), each if its term is active -- so the
+//   argmax table no longer waits for hinge_finish: workgroups [0, n_pair_blocks) recompute pairs, the rest run
+//   hinge_finish_body (loss, dense dloss/dS for the row kernel).  One launch less per step, and the element-wise pass
+//   runs under the pair workgroups.
+struct PairHinge {
+  const float* S; int64_t ld; float margin; const float* val; const int* arg; float* loss; float* dS; int B; int n_pair_blocks;
+};
+template <int SRC>
 __global__ __launch_bounds__(256) void bwd_pair_argmax16_kernel(
     const half_t* __restrict__ xm, const half_t* __restrict__ xe, const half_t* __restrict__ y, int Dp, int rem,
     int tpad, int xe_rows, int y_rows, const float* __restrict__ im, int64_t im_sb, int64_t im_sr,
     const int32_t* __restrict__ im_len, const float* __restrict__ s, int64_t s_sb, int64_t s_st,
     const int32_t* __restrict__ s_len, int Bc, int Rq, int Tq, int D, const int* __restrict__ counter,
     const int* __restrict__ pairs, uint8_t* __restrict__ table, int tstride, int x_tail,
-    int y_tail) {
+    int y_tail, PairHinge hf) {
+  if constexpr (SRC == 1) {
+    if ((int)blockIdx.x >= hf.n_pair_blocks) {
+      hinge_finish_body((int)blockIdx.x - hf.n_pair_blocks, (int)gridDim.x - hf.n_pair_blocks, hf.S, hf.ld, hf.B, hf.margin, 1,
+                        hf.val, hf.arg, hf.loss, hf.dS, nullptr, nullptr);
+      return;
+    }
+  }
   // dynamic LDS: the operand ring of the MFMA phase
   extern __shared__ __attribute__((aligned(16))) char pair_smem[];
   // The candidate list of the exact phase lives in the ring, which is dead once every wave has left the K loop (the
@@ -199,15 +217,31 @@ __global__ __launch_bounds__(256) void bwd_pair_argmax16_kernel(
   const int h = lane >> 5, l5 = lane & 31;
   const int wm = wave >> 1, wn = wave & 1;
   PAIR_STAMP(0);
-  const int count = *counter;
+  const int count = SRC == 1 ? 3 * hf.B : *counter;
+  const int stride = SRC == 1 ? hf.n_pair_blocks : (int)gridDim.x;
   // The pair list groups the pairs of one image (hinge_finish / bwd_compact emit row chunks), and blocks
   // are dealt round-robin over the 8 XCDs: give each XCD a CONTIGUOUS eighth of the list so that pairs
   // sharing an image panel meet in the same L2.
   const int per_xcd = (count + 7) >> 3;
-  for (int b = blockIdx.x; b < 8 * per_xcd; b += gridDim.x) {
+  for (int b = blockIdx.x; b < 8 * per_xcd; b += stride) {
     const int p = (b & 7) * per_xcd + (b >> 3);
     if (p >= count) continue;                          // uniform per workgroup
-    const int i = pairs[p] / Bc, j = pairs[p] % Bc;
+    int i, j;
+    if constexpr (SRC == 1) {
+      // sample q's three candidates are neighbours in p: (q, q) and (q, j*) share image q's panel in one L2
+      const int q = p / 3, t = p - 3 * q, B = hf.B;
+      const float vr = hf.val[q], vc = hf.val[B + q];
+      bool active;
+      if (t == 0) { i = q; j = q; active = vr > 0.f || vc > 0.f; }
+      else if (t == 1) { i = q; j = hf.arg[q]; active = vr > 0.f; }
+      else {
+        i = q; j = q; active = vc > 0.f;
+        if (active) { i = hf.arg[B + q]; active = !(hf.val[i] > 0.f && hf.arg[i] == q); }   // else already listed as image i's row pair
+      }
+      if (!active) continue;                           // uniform per workgroup
+    } else {
+      i = pairs[p] / Bc; j = pairs[p] % Bc;
+    }
     int Li = im_len[i] - 1 - x_tail; Li = Li < 0 ? 0 : (Li > Rq ? Rq : Li);
     int Lj = s_len[j] - 1 - y_tail; Lj = Lj < 0 ? 0 : (Lj > Tq ? Tq : Lj);
     __syncthreads();                                   // everyone is done with the previous pair's blk
@@ -579,15 +613,28 @@ __global__ __launch_bounds__(256) void bwd_rows_kernel(
   }
 }
 
+// phases of align_bwd_impl: everything (list or compaction -> pair argmax -> rows); the rows alone (the table is already in the
+// workspace); or hinge statistics + the merged [pair argmax | hinge finish] kernel (forward of the fused triplet node)
+enum { BWD_ALL = 0, BWD_ROWS = 1, BWD_HINGE_ARGMAX = 2 };
+struct HingeArgs { const float* S; int64_t ldS; float margin; float* loss; float* dS; void* workspace; };
+
 static int align_bwd_impl(const float* im, int64_t im_sb, int64_t im_sr, const int32_t* im_len, const float* s,
                           int64_t s_sb, int64_t s_st, const int32_t* s_len, int Bi, int Bc, int R, int T, int D,
                           const float* dS, int64_t ld_dS, const float* gscale, const void* xm, const void* xe,
                           const void* y, const aladin_align_geom* g, const int32_t* pairs_in, const int32_t* count_in,
                           float* d_im, float* d_s, void* workspace, void* stream, int x_tail = 0, int y_tail = 2,
-                          int64_t dim_sb = 0, int64_t dim_sr = 0, int64_t ds_sb = 0, int64_t ds_st = 0) {
+                          int64_t dim_sb = 0, int64_t dim_sr = 0, int64_t ds_sb = 0, int64_t ds_st = 0,
+                          int phase = BWD_ALL, const HingeArgs* ha = nullptr) {
+  if (phase == BWD_HINGE_ARGMAX) {                        // no gradients yet: the argmax table (and the hinge) only
+    if (!ha || !ha->S || !ha->loss || !ha->dS || !ha->workspace || Bi != Bc || ha->ldS < Bc) { aladin_set_error("hinge_argmax: bad argument"); return ALADIN_ERR_ARG; }
+    dS = ha->dS; ld_dS = Bc;
+    static float dummy_target;                            // the gradient pointers are not touched in this phase
+    d_im = d_s = &dummy_target;
+    dim_sb = dim_sr = ds_sb = ds_st = 4;
+  }
   if (dim_sb == 0 && dim_sr == 0) { dim_sb = (int64_t)R * D; dim_sr = D; }          // contiguous (Bi, R, D) / (Bc, T, D) outputs
   if (ds_sb == 0 && ds_st == 0) { ds_sb = (int64_t)T * D; ds_st = D; }
-  if (dim_sb % 4 || dim_sr % 4 || ds_sb % 4 || ds_st % 4 || ((uintptr_t)d_im & 15) || ((uintptr_t)d_s & 15)) {
+  if (phase != BWD_HINGE_ARGMAX && (dim_sb % 4 || dim_sr % 4 || ds_sb % 4 || ds_st % 4 || ((uintptr_t)d_im & 15) || ((uintptr_t)d_s & 15))) {
     aladin_set_error("align_bwd: gradient rows must be 16-byte aligned (strides %lld %lld %lld %lld)", (long long)dim_sb, (long long)dim_sr, (long long)ds_sb, (long long)ds_st);
     return ALADIN_ERR_ARG;
   }
@@ -610,7 +657,24 @@ static int align_bwd_impl(const float* im, int64_t im_sb, int64_t im_sr, const i
   bwd_ws_layout(Bi, Bc, Tq, (char*)workspace, &ws);
   const int64_t n = (int64_t)Bi * Bc;
   int rc = ALADIN_OK;
-  if (pairs_in && count_in) {                           // list already built by aladin_hinge_fused
+  if (phase == BWD_HINGE_ARGMAX) {
+    if (!packed) { aladin_set_error("hinge_argmax: needs the packed fp16 operands of a one-region-tile class (mtiles == 1, <= 64 padded words)"); return ALADIN_ERR_UNSUPPORTED; }
+    rc = aladin_internal_hinge_stats(ha->S, ha->ldS, Bc, ha->margin, 1, ha->workspace, nullptr, st);
+    if (rc) return rc;
+    const float* val = (const float*)ha->workspace;
+    const int* arg = (const int*)(val + 2 * (size_t)Bc);
+    int npb = (3 * Bc + 7) / 8 * 8; if (npb > 2048) npb = 2048;
+    const int nfin = Bc < 1024 ? Bc : 1024;
+    const PairHinge hf = {ha->S, ha->ldS, ha->margin, val, arg, ha->loss, ha->dS, Bc, npb};
+    hipLaunchKernelGGL(bwd_pair_argmax16_kernel<1>, dim3(npb + nfin), dim3(256), (size_t)PAIR_STAGES * PairCfg::STAGE_BYTES, st,
+                       (const half_t*)xm, (const half_t*)xe, (const half_t*)y, g->Dp, g->rem, 16 * g->tp16, (int)g->xe_rows,
+                       (int)g->y_rows, im, im_sb, im_sr, im_len, s, s_sb, s_st, s_len, Bc, Rq, Tq, D, nullptr, nullptr,
+                       ws.table, tstride, x_tail, y_tail, hf);
+    return aladin_check_launch("bwd_pair_argmax16_kernel<hinge>");
+  }
+  if (phase == BWD_ROWS) {
+    // the argmax table of this problem is already in the workspace (aladin_hinge_argmax_fused)
+  } else if (pairs_in && count_in) {                    // list already built by aladin_hinge_fused
     ws.pairs = const_cast<int*>(pairs_in);
     ws.counter = const_cast<int*>(count_in);
   } else {
@@ -621,11 +685,12 @@ static int align_bwd_impl(const float* im, int64_t im_sb, int64_t im_sr, const i
     if (rc) return rc;
   }
   int pgrid = (int)(n < 2048 ? n : 2048);
-  if (packed) {
-    hipLaunchKernelGGL(bwd_pair_argmax16_kernel, dim3(pgrid), dim3(256), (size_t)PAIR_STAGES * PairCfg::STAGE_BYTES, st,
+  if (phase == BWD_ROWS) {
+  } else if (packed) {
+    hipLaunchKernelGGL(bwd_pair_argmax16_kernel<0>, dim3(pgrid), dim3(256), (size_t)PAIR_STAGES * PairCfg::STAGE_BYTES, st,
                        (const half_t*)xm, (const half_t*)xe, (const half_t*)y, g->Dp, g->rem, 16 * g->tp16, (int)g->xe_rows,
                        (int)g->y_rows, im, im_sb, im_sr, im_len, s, s_sb, s_st, s_len, Bc, Rq, Tq, D, ws.counter, ws.pairs,
-                       ws.table, tstride, x_tail, y_tail);
+                       ws.table, tstride, x_tail, y_tail, PairHinge{});
     rc = aladin_check_launch("bwd_pair_argmax16_kernel");
   } else {
     hipLaunchKernelGGL(bwd_pair_argmax_kernel, dim3(pgrid), dim3(256), 0, st, im, im_sb, im_sr, im_len, s, s_sb, s_st,
@@ -682,4 +747,29 @@ extern "C" int aladin_align_bwd_packed_strided(const float* im, int64_t im_sb, i
                         ld_dS, gscale, (xm && y) ? xm : nullptr, xe, (xm && y) ? y : nullptr, (xm && y) ? geom : nullptr, pairs,
                         pair_count, d_im, d_s, workspace, stream, geom->x_tail, geom->y_tail, d_im_stride_b, d_im_stride_r,
                         d_s_stride_b, d_s_stride_t);
+}
+
+extern "C" int aladin_hinge_argmax_fused(const float* S, int64_t ldS, float margin, float* loss, float* dS, void* hinge_workspace,
+                                         const float* im, int64_t im_sb, int64_t im_sr, const int32_t* im_len, const float* s,
+                                         int64_t s_sb, int64_t s_st, const int32_t* s_len, const void* xm, const void* xe,
+                                         const void* y, const aladin_align_geom* geom, void* bwd_workspace, void* stream) {
+  if (!geom || !xm || !y) { aladin_set_error("hinge_argmax_fused: needs the packed operands and their geometry"); return ALADIN_ERR_ARG; }
+  if (geom->split) { aladin_set_error("hinge_argmax_fused: split-precision operands are forward-only (evaluation)"); return ALADIN_ERR_UNSUPPORTED; }
+  if (geom->Bi != geom->Bc) { aladin_set_error("hinge_argmax_fused: the hinge needs a square score matrix (%d x %d)", geom->Bi, geom->Bc); return ALADIN_ERR_ARG; }
+  const HingeArgs ha = {S, ldS, margin, loss, dS, hinge_workspace};
+  return align_bwd_impl(im, im_sb, im_sr, im_len, s, s_sb, s_st, s_len, geom->Bi, geom->Bc, geom->R, geom->T, geom->D, nullptr, 0,
+                        nullptr, xm, xe, y, geom, nullptr, nullptr, nullptr, nullptr, bwd_workspace, stream, geom->x_tail,
+                        geom->y_tail, 0, 0, 0, 0, BWD_HINGE_ARGMAX, &ha);
+}
+
+extern "C" int aladin_align_bwd_rows(const float* im, int64_t im_sb, int64_t im_sr, const int32_t* im_len, const float* s,
+                                     int64_t s_sb, int64_t s_st, const int32_t* s_len, const float* dS, int64_t ld_dS,
+                                     const float* gscale, const aladin_align_geom* geom, float* d_im, int64_t d_im_stride_b,
+                                     int64_t d_im_stride_r, float* d_s, int64_t d_s_stride_b, int64_t d_s_stride_t,
+                                     void* bwd_workspace, void* stream) {
+  if (!geom) { aladin_set_error("align_bwd_rows: null geometry"); return ALADIN_ERR_ARG; }
+  if (d_im_stride_b < 1 || d_im_stride_r < 1 || d_s_stride_b < 1 || d_s_stride_t < 1) { aladin_set_error("align_bwd_rows: bad output strides"); return ALADIN_ERR_ARG; }
+  return align_bwd_impl(im, im_sb, im_sr, im_len, s, s_sb, s_st, s_len, geom->Bi, geom->Bc, geom->R, geom->T, geom->D, dS, ld_dS,
+                        gscale, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, d_im, d_s, bwd_workspace, stream,
+                        geom->x_tail, geom->y_tail, d_im_stride_b, d_im_stride_r, d_s_stride_b, d_s_stride_t, BWD_ROWS, nullptr);
 }

@@ -266,10 +266,37 @@ class _AlignTriplet(torch.autograd.Function):
         if need:
             _check_backward_supported(im, s, 0, 2)
         S, packed = _align_forward(im, s, im_len_t, s_len_t)
+        geom = packed[0]
+        ctx.table_ws = None
+        if need and max_violation and geom.mtiles == 1 and geom.tp16 <= 4:
+            # hardest-negative hinge with the fp16 pair kernel's shapes (every training config): the backward's argmax
+            # table is computed HERE, in the kernel that also runs the hinge's element-wise pass (one launch less per
+            # step); it lives in its own workspace until backward() -- the shared scratch would not survive the heads
+            # that run in between
+            lib = _lib.load()
+            B = S.shape[0]
+            im_c, s_c = _rows_inner_contig(im), _rows_inner_contig(s)
+            loss = torch.empty((), dtype=torch.float32, device=S.device)
+            dS = torch.empty((B, B), dtype=torch.float32, device=S.device)
+            table_ws = torch.empty(lib.aladin_align_bwd_workspace_bytes(B, B, im.shape[1], s.shape[1], im.shape[2]),
+                                   dtype=torch.uint8, device=S.device)
+            hws = _workspace(lib.aladin_hinge_workspace_bytes(B), S.device)
+            sc = S if S.stride(1) == 1 else S.contiguous()
+            _lib.check(lib.aladin_hinge_argmax_fused(_ptr(sc), _ld(sc), float(margin), _ptr(loss), _ptr(dS), _ptr(hws),
+                                                     _ptr(im_c), im_c.stride(0), im_c.stride(1), _ptr(im_len_t),
+                                                     _ptr(s_c), s_c.stride(0), s_c.stride(1), _ptr(s_len_t),
+                                                     _ptr(packed[1]), _ptr(packed[2]), _ptr(packed[3]), C.byref(geom),
+                                                     _ptr(table_ws), _stream()), 'hinge_argmax_fused')
+            ctx.save_for_backward(im_c, s_c, im_len_t, s_len_t, packed[1], packed[2], packed[3], dS, table_ws)
+            ctx.geom = geom
+            ctx.pairs = None
+            ctx.table_ws = True
+            ctx.set_materialize_grads(False)
+            return loss, S
         loss, dS, pairs = _hinge_raw(S, margin, max_violation, need, want_pairs=True)
         if need:
             ctx.save_for_backward(im, s, im_len_t, s_len_t, packed[1], packed[2], packed[3], dS)
-            ctx.geom = packed[0]
+            ctx.geom = geom
             ctx.pairs = pairs
         ctx.set_materialize_grads(False)
         return loss, S
@@ -278,9 +305,22 @@ class _AlignTriplet(torch.autograd.Function):
     def backward(ctx, g_loss, g_scores):
         if g_loss is None and g_scores is None:
             return None, None, None, None, None, None
-        im, s, im_len_t, s_len_t, xm, xe, y, dS = ctx.saved_tensors
+        table_ws = None
+        if ctx.table_ws:
+            im, s, im_len_t, s_len_t, xm, xe, y, dS, table_ws = ctx.saved_tensors
+        else:
+            im, s, im_len_t, s_len_t, xm, xe, y, dS = ctx.saved_tensors
         packed = (ctx.geom, xm, xe, y)
-        if g_scores is None:
+        if g_scores is None and table_ws is not None:
+            # the argmax table is already there (forward): only the row kernel is left
+            g = g_loss.to(torch.float32).contiguous()
+            lib = _lib.load()
+            d_im, d_s = _grad_like(im), _grad_like(s)
+            _lib.check(lib.aladin_align_bwd_rows(_ptr(im), im.stride(0), im.stride(1), _ptr(im_len_t), _ptr(s), s.stride(0),
+                                                 s.stride(1), _ptr(s_len_t), _ptr(dS), dS.shape[1], _ptr(g), C.byref(ctx.geom),
+                                                 _ptr(d_im), d_im.stride(0), d_im.stride(1), _ptr(d_s), d_s.stride(0),
+                                                 d_s.stride(1), _ptr(table_ws), _stream()), 'align_bwd_rows')
+        elif g_scores is None:
             # the training path: only the loss is differentiated; dloss/dS (<= 3B non-zeros with the hardest-negative
             # hinge) never leaves the device and the upstream scalar goes to the kernels as a pointer
             g = g_loss.to(torch.float32).contiguous()

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define ALADIN_ABI_VERSION 5
+#define ALADIN_ABI_VERSION 6
 
 /* The library is built with -fvisibility=hidden: the entry points declared here are its ONLY exports. */
 #if defined(__GNUC__)
@@ -150,6 +150,28 @@ ALADIN_API int aladin_align_bwd_packed_strided(const float* im, int64_t im_strid
                                                const int32_t* pair_count, float* d_im, int64_t d_im_stride_b,
                                                int64_t d_im_stride_r, float* d_s, int64_t d_s_stride_b, int64_t d_s_stride_t,
                                                void* workspace, void* stream);
+
+/* The hardest-negative hinge (alad/loss.py:42-67, max_violation=True) and the backward's argmax table in TWO launches: the
+ * hinge's row / column statistics, then ONE kernel whose workgroups either recompute a non-zero pair of dloss/dS -- the pairs
+ * follow from the statistics: (q, q), (q, hardest caption of image q), (hardest image of caption q, q) -- or run the
+ * hinge's element-wise pass (loss, dense dloss/dS).  Replaces aladin_hinge_fused + the first two kernels of
+ * aladin_align_bwd_packed in the training step (one launch less; the element-wise pass hides under the pair work).
+ * S: the square score matrix of this (geom, xm, xe, y) problem; loss: 1 float; dS: (B, B) contiguous, fully written;
+ * hinge_workspace: aladin_hinge_workspace_bytes(B); bwd_workspace: aladin_align_bwd_workspace_bytes(...) -- it receives
+ * the argmax table and must stay untouched until aladin_align_bwd_rows consumed it.  Needs the fp16 pair kernel's
+ * shapes (geom->mtiles == 1, <= 64 padded words), else ALADIN_ERR_UNSUPPORTED.
+ * aladin_align_bwd_rows: the remaining kernel of the backward (autograd of alad/loss.py:80-125 given dS and the table),
+ * gradients in the caller's layout as in aladin_align_bwd_packed_strided. */
+ALADIN_API int aladin_hinge_argmax_fused(const float* S, int64_t ldS, float margin, float* loss, float* dS, void* hinge_workspace,
+                                         const float* im, int64_t im_stride_b, int64_t im_stride_r, const int32_t* im_len,
+                                         const float* s, int64_t s_stride_b, int64_t s_stride_t, const int32_t* s_len,
+                                         const void* xm, const void* xe, const void* y, const aladin_align_geom* geom,
+                                         void* bwd_workspace, void* stream);
+ALADIN_API int aladin_align_bwd_rows(const float* im, int64_t im_stride_b, int64_t im_stride_r, const int32_t* im_len,
+                                     const float* s, int64_t s_stride_b, int64_t s_stride_t, const int32_t* s_len,
+                                     const float* dS, int64_t ld_dS, const float* gscale, const aladin_align_geom* geom,
+                                     float* d_im, int64_t d_im_stride_b, int64_t d_im_stride_r, float* d_s,
+                                     int64_t d_s_stride_b, int64_t d_s_stride_t, void* bwd_workspace, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * 'sum' / 'mean' pooling (alad/loss.py:120-123): sum_r sum_w <im^,s^> = <sum_r im^, sum_w s^>.
