@@ -218,6 +218,43 @@ def _align_backward(im, s, im_len_t, s_len_t, dS, gscale=None, packed=None, pair
     return d_im, d_s
 
 
+def _hinge_argmax_fused(S, margin, im, s, im_len_t, s_len_t, packed, loss_out=None):
+    """Hardest-negative hinge of the square score matrix S AND the backward's argmax table in two launches
+    (aladin_hinge_argmax_fused): -> (loss, dS, im, s, table_ws), or None when the fp16 pair kernel does not cover the
+    shape (the caller then takes the list path).  im / s come back in the row layout the kernels were given; table_ws
+    holds the table until _align_backward_rows consumes it (its own buffer: the shared scratch would not survive the
+    other heads)."""
+    geom = packed[0]
+    if not (geom.mtiles == 1 and geom.tp16 <= 4 and geom.Bi == geom.Bc and not geom.split):
+        return None
+    lib = _lib.load()
+    B = S.shape[0]
+    im_c, s_c = _rows_inner_contig(im), _rows_inner_contig(s)
+    loss = loss_out if loss_out is not None else torch.empty((), dtype=torch.float32, device=S.device)
+    dS = torch.empty((B, B), dtype=torch.float32, device=S.device)
+    table_ws = torch.empty(lib.aladin_align_bwd_workspace_bytes(B, B, im.shape[1], s.shape[1], im.shape[2]),
+                           dtype=torch.uint8, device=S.device)
+    hws = _workspace(lib.aladin_hinge_workspace_bytes(B), S.device)
+    sc = S if S.stride(1) == 1 else S.contiguous()
+    _lib.check(lib.aladin_hinge_argmax_fused(_ptr(sc), _ld(sc), float(margin), _ptr(loss), _ptr(dS), _ptr(hws),
+                                             _ptr(im_c), im_c.stride(0), im_c.stride(1), _ptr(im_len_t),
+                                             _ptr(s_c), s_c.stride(0), s_c.stride(1), _ptr(s_len_t),
+                                             _ptr(packed[1]), _ptr(packed[2]), _ptr(packed[3]), C.byref(geom),
+                                             _ptr(table_ws), _stream()), 'hinge_argmax_fused')
+    return loss, dS, im_c, s_c, table_ws
+
+
+def _align_backward_rows(im, s, im_len_t, s_len_t, dS, gscale, geom, table_ws):
+    """The row kernel alone: the argmax table is already in table_ws (_hinge_argmax_fused)."""
+    lib = _lib.load()
+    d_im, d_s = _grad_like(im), _grad_like(s)
+    _lib.check(lib.aladin_align_bwd_rows(_ptr(im), im.stride(0), im.stride(1), _ptr(im_len_t), _ptr(s), s.stride(0),
+                                         s.stride(1), _ptr(s_len_t), _ptr(dS), dS.shape[1], _ptr(gscale), C.byref(geom),
+                                         _ptr(d_im), d_im.stride(0), d_im.stride(1), _ptr(d_s), d_s.stride(0),
+                                         d_s.stride(1), _ptr(table_ws), _stream()), 'align_bwd_rows')
+    return d_im, d_s
+
+
 class _AlignScores(torch.autograd.Function):
     @staticmethod
     def forward(ctx, im, s, im_len_t, s_len_t, x_tail, y_tail):
@@ -268,25 +305,11 @@ class _AlignTriplet(torch.autograd.Function):
         S, packed = _align_forward(im, s, im_len_t, s_len_t)
         geom = packed[0]
         ctx.table_ws = None
-        if need and max_violation and geom.mtiles == 1 and geom.tp16 <= 4:
+        fused = _hinge_argmax_fused(S, margin, im, s, im_len_t, s_len_t, packed) if need and max_violation else None
+        if fused is not None:
             # hardest-negative hinge with the fp16 pair kernel's shapes (every training config): the backward's argmax
-            # table is computed HERE, in the kernel that also runs the hinge's element-wise pass (one launch less per
-            # step); it lives in its own workspace until backward() -- the shared scratch would not survive the heads
-            # that run in between
-            lib = _lib.load()
-            B = S.shape[0]
-            im_c, s_c = _rows_inner_contig(im), _rows_inner_contig(s)
-            loss = torch.empty((), dtype=torch.float32, device=S.device)
-            dS = torch.empty((B, B), dtype=torch.float32, device=S.device)
-            table_ws = torch.empty(lib.aladin_align_bwd_workspace_bytes(B, B, im.shape[1], s.shape[1], im.shape[2]),
-                                   dtype=torch.uint8, device=S.device)
-            hws = _workspace(lib.aladin_hinge_workspace_bytes(B), S.device)
-            sc = S if S.stride(1) == 1 else S.contiguous()
-            _lib.check(lib.aladin_hinge_argmax_fused(_ptr(sc), _ld(sc), float(margin), _ptr(loss), _ptr(dS), _ptr(hws),
-                                                     _ptr(im_c), im_c.stride(0), im_c.stride(1), _ptr(im_len_t),
-                                                     _ptr(s_c), s_c.stride(0), s_c.stride(1), _ptr(s_len_t),
-                                                     _ptr(packed[1]), _ptr(packed[2]), _ptr(packed[3]), C.byref(geom),
-                                                     _ptr(table_ws), _stream()), 'hinge_argmax_fused')
+            # table is computed HERE, in the kernel that also runs the hinge's element-wise pass (one launch less per step)
+            loss, dS, im_c, s_c, table_ws = fused
             ctx.save_for_backward(im_c, s_c, im_len_t, s_len_t, packed[1], packed[2], packed[3], dS, table_ws)
             ctx.geom = geom
             ctx.pairs = None
@@ -314,12 +337,7 @@ class _AlignTriplet(torch.autograd.Function):
         if g_scores is None and table_ws is not None:
             # the argmax table is already there (forward): only the row kernel is left
             g = g_loss.to(torch.float32).contiguous()
-            lib = _lib.load()
-            d_im, d_s = _grad_like(im), _grad_like(s)
-            _lib.check(lib.aladin_align_bwd_rows(_ptr(im), im.stride(0), im.stride(1), _ptr(im_len_t), _ptr(s), s.stride(0),
-                                                 s.stride(1), _ptr(s_len_t), _ptr(dS), dS.shape[1], _ptr(g), C.byref(ctx.geom),
-                                                 _ptr(d_im), d_im.stride(0), d_im.stride(1), _ptr(d_s), d_s.stride(0),
-                                                 d_s.stride(1), _ptr(table_ws), _stream()), 'align_bwd_rows')
+            d_im, d_s = _align_backward_rows(im, s, im_len_t, s_len_t, dS, g, ctx.geom, table_ws)
         elif g_scores is None:
             # the training path: only the loss is differentiated; dloss/dS (<= 3B non-zeros with the hardest-negative
             # hinge) never leaves the device and the upstream scalar goes to the kernels as a pointer
@@ -825,13 +843,18 @@ class _BigHeads(torch.autograd.Function):
         dev = img_emb.device
         B = img_emb.shape[0]
         terms = torch.empty(3, dtype=torch.float32, device=dev)          # slots of absent heads are never read
-        S = packed = dS = pairs = None
+        S = packed = dS = pairs = table_ws = None
         if flags & (HEAD_ALIGN_HINGE | HEAD_LISTNET):
             if need_sets and flags & HEAD_ALIGN_HINGE:
                 _check_backward_supported(im, s, 0, 2)
             S, packed = _align_forward(im, s, im_len_t, s_len_t)
             if flags & HEAD_ALIGN_HINGE:
-                _, dS, pairs = _hinge_raw(S, margin, max_violation, need_sets, want_pairs=True, loss_out=terms[1:2])
+                fused = (_hinge_argmax_fused(S, margin, im, s, im_len_t, s_len_t, packed, loss_out=terms[1:2])
+                         if need_sets and max_violation else None)
+                if fused is not None:
+                    _, dS, im, s, table_ws = fused
+                else:
+                    _, dS, pairs = _hinge_raw(S, margin, max_violation, need_sets, want_pairs=True, loss_out=terms[1:2])
         a = b = M = dMh = dMl = None
         if flags & (HEAD_MATCH_HINGE | HEAD_LISTNET):
             a = img_emb if img_emb.stride(1) == 1 else img_emb.contiguous()
@@ -856,7 +879,7 @@ class _BigHeads(torch.autograd.Function):
         ctx.geom = packed[0] if packed is not None else None
         ctx.pairs = pairs
         pk = packed[1:] if packed is not None else (None, None, None)
-        ctx.save_for_backward(a, b, im, s, im_len_t, s_len_t, pk[0], pk[1], pk[2], dMh, dMl, dS)
+        ctx.save_for_backward(a, b, im, s, im_len_t, s_len_t, pk[0], pk[1], pk[2], dMh, dMl, dS, table_ws)
         ctx.set_materialize_grads(False)
         ctx.mark_non_differentiable(*[t for t in (terms, S, M) if t is not None])
         return total, terms, S, M
@@ -866,7 +889,7 @@ class _BigHeads(torch.autograd.Function):
         if g_total is None:
             return (None,) * 12
         lib = _lib.load()
-        a, b, im, s, im_len_t, s_len_t, xm, xe, y, dMh, dMl, dS = ctx.saved_tensors
+        a, b, im, s, im_len_t, s_len_t, xm, xe, y, dMh, dMl, dS, table_ws = ctx.saved_tensors
         w = ctx.weights
         g = g_total.to(torch.float32).contiguous()
         dev = g.device
@@ -887,7 +910,9 @@ class _BigHeads(torch.autograd.Function):
             if ctx.needs_input_grad[1]:
                 d_b = torch.empty((B, D), dtype=torch.float32, device=dev)
                 _sgemm(B, D, B, C_tot, 1, C_tot.stride(0), a, a.stride(0), a.stride(1), d_b)          # C.T @ img
-        if want_a:
+        if want_a and table_ws is not None:
+            d_im, d_s = _align_backward_rows(im, s, im_len_t, s_len_t, dS, scale, ctx.geom, table_ws)
+        elif want_a:
             d_im, d_s = _align_backward(im, s, im_len_t, s_len_t, dS, gscale=scale, packed=(ctx.geom, xm, xe, y), pairs=ctx.pairs)
         return d_a, d_b, d_im, d_s, None, None, None, None, None, None, None, None
 
