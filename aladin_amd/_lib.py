@@ -20,7 +20,7 @@ SYMBOLS = [
     'aladin_align_pack_captions', 'aladin_align_pack_both', 'aladin_align_scores', 'aladin_align_scores_ex',
     'aladin_align_bwd_workspace_bytes',
     'aladin_align_bwd', 'aladin_align_bwd_packed', 'aladin_align_bwd_packed_strided', 'aladin_hinge_workspace_bytes', 'aladin_hinge_fwd_bwd',
-    'aladin_hinge_fused', 'aladin_hinge_argmax_fused', 'aladin_align_bwd_rows',
+    'aladin_hinge_fused', 'aladin_hinge_argmax_fused', 'aladin_align_bwd_rows', 'aladin_heads_small_fwd_argmax',
     'aladin_listnet_workspace_bytes', 'aladin_listnet_fwd_bwd',
     'aladin_distill_workspace_bytes', 'aladin_distill_mse_fwd_bwd', 'aladin_distill_contrastive_fwd_bwd',
     'aladin_distill_ordinal_fwd_bwd', 'aladin_order_sim_fwd', 'aladin_order_sim_bwd', 'aladin_sgemm_strided',
@@ -69,6 +69,8 @@ def _declare(lib):
         'aladin_hinge_fwd_bwd': (C.c_int, [p, i64, i32, f32, i32, p, p, p, p]),
         'aladin_hinge_fused': (C.c_int, [p, i64, i32, f32, i32, p, p, p, p, p, p]),
         'aladin_hinge_argmax_fused': (C.c_int, [p, i64, f32, p, p, p, p, i64, i64, p, p, i64, i64, p, p, p, p, G, p, p]),
+        'aladin_heads_small_fwd_argmax': (C.c_int, [p, i64, p, i64, p, i64, i32, f32, i32, f32, f32, f32, f32, f32, p, p, p, p, p, p, p,
+                                                    p, i64, i64, p, p, i64, i64, p, p, p, p, G, p, p]),
         'aladin_align_bwd_rows': (C.c_int, [p, i64, i64, p, p, i64, i64, p, p, i64, p, G, p, i64, i64, p, i64, i64, p, p]),
         'aladin_listnet_workspace_bytes': (sz, [i32]),
         'aladin_listnet_fwd_bwd': (C.c_int, [p, i64, p, i64, i32, f32, f32, p, p, p, p]),

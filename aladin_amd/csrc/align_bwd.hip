@@ -23,6 +23,7 @@
 #include "../../include/aladin_hip.h"
 #include "gemm_core.hpp"
 #include "hinge_common.hpp"
+#include "small_heads_common.hpp"
 
 #define NO_GRAD 255
 
@@ -186,6 +187,8 @@ extern "C" __attribute__((visibility("default"))) int aladin_debug_read_pair_pro
 struct PairHinge {
   const float* S; int64_t ld; float margin; const float* val; const int* arg; float* loss; float* dS; int B; int n_pair_blocks;
 };
+// SRC == 2: the same merge for the small-batch loss heads (B <= 64): statistics from heads_small_stats_kernel
+//   (st[v][8..9] = value, arg of the alignment hinge), element-wise pass = heads_small_finish_body.
 template <int SRC>
 __global__ __launch_bounds__(256) void bwd_pair_argmax16_kernel(
     const half_t* __restrict__ xm, const half_t* __restrict__ xe, const half_t* __restrict__ y, int Dp, int rem,
@@ -193,7 +196,13 @@ __global__ __launch_bounds__(256) void bwd_pair_argmax16_kernel(
     const int32_t* __restrict__ im_len, const float* __restrict__ s, int64_t s_sb, int64_t s_st,
     const int32_t* __restrict__ s_len, int Bc, int Rq, int Tq, int D, const int* __restrict__ counter,
     const int* __restrict__ pairs, uint8_t* __restrict__ table, int tstride, int x_tail,
-    int y_tail, PairHinge hf) {
+    int y_tail, PairHinge hf, SmallFin sf) {
+  if constexpr (SRC == 2) {
+    if ((int)blockIdx.x >= hf.n_pair_blocks) {
+      heads_small_finish_body((int)blockIdx.x - hf.n_pair_blocks, (int)gridDim.x - hf.n_pair_blocks, sf);
+      return;
+    }
+  }
   if constexpr (SRC == 1) {
     if ((int)blockIdx.x >= hf.n_pair_blocks) {
       hinge_finish_body((int)blockIdx.x - hf.n_pair_blocks, (int)gridDim.x - hf.n_pair_blocks, hf.S, hf.ld, hf.B, hf.margin, 1,
@@ -217,8 +226,8 @@ __global__ __launch_bounds__(256) void bwd_pair_argmax16_kernel(
   const int h = lane >> 5, l5 = lane & 31;
   const int wm = wave >> 1, wn = wave & 1;
   PAIR_STAMP(0);
-  const int count = SRC == 1 ? 3 * hf.B : *counter;
-  const int stride = SRC == 1 ? hf.n_pair_blocks : (int)gridDim.x;
+  const int count = SRC != 0 ? 3 * hf.B : *counter;
+  const int stride = SRC != 0 ? hf.n_pair_blocks : (int)gridDim.x;
   // The pair list groups the pairs of one image (hinge_finish / bwd_compact emit row chunks), and blocks
   // are dealt round-robin over the 8 XCDs: give each XCD a CONTIGUOUS eighth of the list so that pairs
   // sharing an image panel meet in the same L2.
@@ -227,16 +236,18 @@ __global__ __launch_bounds__(256) void bwd_pair_argmax16_kernel(
     const int p = (b & 7) * per_xcd + (b >> 3);
     if (p >= count) continue;                          // uniform per workgroup
     int i, j;
-    if constexpr (SRC == 1) {
+    if constexpr (SRC != 0) {
       // sample q's three candidates are neighbours in p: (q, q) and (q, j*) share image q's panel in one L2
       const int q = p / 3, t = p - 3 * q, B = hf.B;
-      const float vr = hf.val[q], vc = hf.val[B + q];
+      auto row_val = [&](int v) { return SRC == 1 ? hf.val[v] : sf.st[(int64_t)v * SB_ST + 8]; };            // v in [0, 2B): rows, columns
+      auto row_arg = [&](int v) { return SRC == 1 ? hf.arg[v] : __float_as_int(sf.st[(int64_t)v * SB_ST + 9]); };
+      const float vr = row_val(q), vc = row_val(B + q);
       bool active;
       if (t == 0) { i = q; j = q; active = vr > 0.f || vc > 0.f; }
-      else if (t == 1) { i = q; j = hf.arg[q]; active = vr > 0.f; }
+      else if (t == 1) { i = q; j = row_arg(q); active = vr > 0.f; }
       else {
         i = q; j = q; active = vc > 0.f;
-        if (active) { i = hf.arg[B + q]; active = !(hf.val[i] > 0.f && hf.arg[i] == q); }   // else already listed as image i's row pair
+        if (active) { i = row_arg(B + q); active = !(row_val(i) > 0.f && row_arg(i) == q); }   // else already listed as image i's row pair
       }
       if (!active) continue;                           // uniform per workgroup
     } else {
@@ -616,7 +627,7 @@ __global__ __launch_bounds__(256) void bwd_rows_kernel(
 // phases of align_bwd_impl: everything (list or compaction -> pair argmax -> rows); the rows alone (the table is already in the
 // workspace); or hinge statistics + the merged [pair argmax | hinge finish] kernel (forward of the fused triplet node)
 enum { BWD_ALL = 0, BWD_ROWS = 1, BWD_HINGE_ARGMAX = 2 };
-struct HingeArgs { const float* S; int64_t ldS; float margin; float* loss; float* dS; void* workspace; };
+struct HingeArgs { const float* S; int64_t ldS; float margin; float* loss; float* dS; void* workspace; const SmallFin* small; };
 
 static int align_bwd_impl(const float* im, int64_t im_sb, int64_t im_sr, const int32_t* im_len, const float* s,
                           int64_t s_sb, int64_t s_st, const int32_t* s_len, int Bi, int Bc, int R, int T, int D,
@@ -627,6 +638,7 @@ static int align_bwd_impl(const float* im, int64_t im_sb, int64_t im_sr, const i
                           int phase = BWD_ALL, const HingeArgs* ha = nullptr) {
   if (phase == BWD_HINGE_ARGMAX) {                        // no gradients yet: the argmax table (and the hinge) only
     if (!ha || !ha->S || !ha->loss || !ha->dS || !ha->workspace || Bi != Bc || ha->ldS < Bc) { aladin_set_error("hinge_argmax: bad argument"); return ALADIN_ERR_ARG; }
+    if (ha->small && Bc > SB_MAX) { aladin_set_error("heads_small: B = %d > %d", Bc, SB_MAX); return ALADIN_ERR_UNSUPPORTED; }
     dS = ha->dS; ld_dS = Bc;
     static float dummy_target;                            // the gradient pointers are not touched in this phase
     d_im = d_s = &dummy_target;
@@ -659,6 +671,15 @@ static int align_bwd_impl(const float* im, int64_t im_sb, int64_t im_sr, const i
   int rc = ALADIN_OK;
   if (phase == BWD_HINGE_ARGMAX) {
     if (!packed) { aladin_set_error("hinge_argmax: needs the packed fp16 operands of a one-region-tile class (mtiles == 1, <= 64 padded words)"); return ALADIN_ERR_UNSUPPORTED; }
+    if (ha->small) {                                      // small-batch heads: their own statistics kernel ran already
+      int npb = (3 * Bc + 7) / 8 * 8;
+      const PairHinge hfs = {nullptr, 0, 0.f, nullptr, nullptr, nullptr, nullptr, Bc, npb};
+      hipLaunchKernelGGL(bwd_pair_argmax16_kernel<2>, dim3(npb + cdiv(Bc * Bc, 256)), dim3(256),
+                         (size_t)PAIR_STAGES * PairCfg::STAGE_BYTES, st, (const half_t*)xm, (const half_t*)xe, (const half_t*)y,
+                         g->Dp, g->rem, 16 * g->tp16, (int)g->xe_rows, (int)g->y_rows, im, im_sb, im_sr, im_len, s, s_sb, s_st,
+                         s_len, Bc, Rq, Tq, D, nullptr, nullptr, ws.table, tstride, x_tail, y_tail, hfs, *ha->small);
+      return aladin_check_launch("bwd_pair_argmax16_kernel<small heads>");
+    }
     rc = aladin_internal_hinge_stats(ha->S, ha->ldS, Bc, ha->margin, 1, ha->workspace, nullptr, st);
     if (rc) return rc;
     const float* val = (const float*)ha->workspace;
@@ -669,7 +690,7 @@ static int align_bwd_impl(const float* im, int64_t im_sb, int64_t im_sr, const i
     hipLaunchKernelGGL(bwd_pair_argmax16_kernel<1>, dim3(npb + nfin), dim3(256), (size_t)PAIR_STAGES * PairCfg::STAGE_BYTES, st,
                        (const half_t*)xm, (const half_t*)xe, (const half_t*)y, g->Dp, g->rem, 16 * g->tp16, (int)g->xe_rows,
                        (int)g->y_rows, im, im_sb, im_sr, im_len, s, s_sb, s_st, s_len, Bc, Rq, Tq, D, nullptr, nullptr,
-                       ws.table, tstride, x_tail, y_tail, hf);
+                       ws.table, tstride, x_tail, y_tail, hf, SmallFin{});
     return aladin_check_launch("bwd_pair_argmax16_kernel<hinge>");
   }
   if (phase == BWD_ROWS) {
@@ -690,7 +711,7 @@ static int align_bwd_impl(const float* im, int64_t im_sb, int64_t im_sr, const i
     hipLaunchKernelGGL(bwd_pair_argmax16_kernel<0>, dim3(pgrid), dim3(256), (size_t)PAIR_STAGES * PairCfg::STAGE_BYTES, st,
                        (const half_t*)xm, (const half_t*)xe, (const half_t*)y, g->Dp, g->rem, 16 * g->tp16, (int)g->xe_rows,
                        (int)g->y_rows, im, im_sb, im_sr, im_len, s, s_sb, s_st, s_len, Bc, Rq, Tq, D, ws.counter, ws.pairs,
-                       ws.table, tstride, x_tail, y_tail, PairHinge{});
+                       ws.table, tstride, x_tail, y_tail, PairHinge{}, SmallFin{});
     rc = aladin_check_launch("bwd_pair_argmax16_kernel");
   } else {
     hipLaunchKernelGGL(bwd_pair_argmax_kernel, dim3(pgrid), dim3(256), 0, st, im, im_sb, im_sr, im_len, s, s_sb, s_st,
@@ -756,7 +777,7 @@ extern "C" int aladin_hinge_argmax_fused(const float* S, int64_t ldS, float marg
   if (!geom || !xm || !y) { aladin_set_error("hinge_argmax_fused: needs the packed operands and their geometry"); return ALADIN_ERR_ARG; }
   if (geom->split) { aladin_set_error("hinge_argmax_fused: split-precision operands are forward-only (evaluation)"); return ALADIN_ERR_UNSUPPORTED; }
   if (geom->Bi != geom->Bc) { aladin_set_error("hinge_argmax_fused: the hinge needs a square score matrix (%d x %d)", geom->Bi, geom->Bc); return ALADIN_ERR_ARG; }
-  const HingeArgs ha = {S, ldS, margin, loss, dS, hinge_workspace};
+  const HingeArgs ha = {S, ldS, margin, loss, dS, hinge_workspace, nullptr};
   return align_bwd_impl(im, im_sb, im_sr, im_len, s, s_sb, s_st, s_len, geom->Bi, geom->Bc, geom->R, geom->T, geom->D, nullptr, 0,
                         nullptr, xm, xe, y, geom, nullptr, nullptr, nullptr, nullptr, bwd_workspace, stream, geom->x_tail,
                         geom->y_tail, 0, 0, 0, 0, BWD_HINGE_ARGMAX, &ha);
@@ -772,4 +793,30 @@ extern "C" int aladin_align_bwd_rows(const float* im, int64_t im_sb, int64_t im_
   return align_bwd_impl(im, im_sb, im_sr, im_len, s, s_sb, s_st, s_len, geom->Bi, geom->Bc, geom->R, geom->T, geom->D, dS, ld_dS,
                         gscale, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, d_im, d_s, bwd_workspace, stream,
                         geom->x_tail, geom->y_tail, d_im_stride_b, d_im_stride_r, d_s_stride_b, d_s_stride_t, BWD_ROWS, nullptr);
+}
+
+extern "C" int aladin_heads_small_fwd_argmax(const float* img, int64_t ld_img, const float* cap, int64_t ld_cap, const float* S,
+                                             int64_t ld_S, int D_emb, float margin, int flags, float temperature, float eps,
+                                             float w_match, float w_align, float w_dist, float* M, float* terms, float* total,
+                                             float* dM_hinge, float* dM_listnet, float* dS, void* heads_workspace,
+                                             const float* im, int64_t im_sb, int64_t im_sr, const int32_t* im_len, const float* s,
+                                             int64_t s_sb, int64_t s_st, const int32_t* s_len, const void* xm, const void* xe,
+                                             const void* y, const aladin_align_geom* geom, void* bwd_workspace, void* stream) {
+  if (!geom || !xm || !y) { aladin_set_error("heads_small_fwd_argmax: needs the packed operands and their geometry"); return ALADIN_ERR_ARG; }
+  if (geom->split) { aladin_set_error("heads_small_fwd_argmax: split-precision operands are forward-only (evaluation)"); return ALADIN_ERR_UNSUPPORTED; }
+  const int B = geom->Bi;
+  if (geom->Bi != geom->Bc || B > SB_MAX) { aladin_set_error("heads_small_fwd_argmax: square batches of at most %d (%d x %d)", SB_MAX, geom->Bi, geom->Bc); return ALADIN_ERR_UNSUPPORTED; }
+  if (!(flags & SB_ALIGN_HINGE) || !S || ld_S < B || !dS || !terms || !heads_workspace || D_emb < 1) { aladin_set_error("heads_small_fwd_argmax: the alignment hinge with its dS is what this entry point is for (flags=%d)", flags); return ALADIN_ERR_ARG; }
+  const bool need_m = (flags & (SB_MATCH_HINGE | SB_LISTNET)) != 0;
+  if (need_m && (!img || !cap || !M || ld_img < D_emb || ld_cap < D_emb)) { aladin_set_error("heads_small_fwd_argmax: missing operand for flags %d", flags); return ALADIN_ERR_ARG; }
+  float* st = (float*)heads_workspace;
+  int rc = aladin_internal_heads_small_stats(img, ld_img, cap, ld_cap, S, ld_S, B, D_emb, margin, 1, flags, temperature, eps, M, st,
+                                             nullptr, (hipStream_t)stream);
+  if (rc) return rc;
+  const SmallFin f = {M, S, ld_S, B, margin, 1, flags, temperature, eps, w_match, w_align, w_dist, st, terms, total, dM_hinge,
+                      dM_listnet, dS, nullptr, nullptr};
+  const HingeArgs ha = {S, ld_S, margin, terms, dS, heads_workspace, &f};
+  return align_bwd_impl(im, im_sb, im_sr, im_len, s, s_sb, s_st, s_len, geom->Bi, geom->Bc, geom->R, geom->T, geom->D, nullptr, 0,
+                        nullptr, xm, xe, y, geom, nullptr, nullptr, nullptr, nullptr, bwd_workspace, stream, geom->x_tail,
+                        geom->y_tail, 0, 0, 0, 0, BWD_HINGE_ARGMAX, &ha);
 }

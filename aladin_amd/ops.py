@@ -710,8 +710,12 @@ SMALL_BATCH_MAX = 64
 HEAD_MATCH_HINGE, HEAD_ALIGN_HINGE, HEAD_LISTNET = 1, 2, 4      # ALADIN_HEAD_* of include/aladin_hip.h
 
 
-def _heads_small_fwd(im, s, S, margin, max_violation, flags, temperature, eps, weights, want_grads, want_pairs):
-    """Launch aladin_heads_small_fwd -> dict of its outputs (see include/aladin_hip.h)."""
+def _heads_small_fwd(im, s, S, margin, max_violation, flags, temperature, eps, weights, want_grads, want_pairs, align=None):
+    """Launch aladin_heads_small_fwd -> dict of its outputs (see include/aladin_hip.h).
+    align = (im_set, s_seq, im_len_t, s_len_t, packed): with the hardest-negative alignment hinge and the fp16 pair
+    kernel's shapes the element-wise pass shares its launch with the backward's pair recompute
+    (aladin_heads_small_fwd_argmax); out['table_ws'] then holds the argmax table and out['sets'] the sets in the row
+    layout the kernels were given."""
     lib = _lib.load()
     B = (im if im is not None else S).shape[0]
     dev = (im if im is not None else S).device
@@ -723,7 +727,25 @@ def _heads_small_fwd(im, s, S, margin, max_violation, flags, temperature, eps, w
     out['dMh'] = torch.empty((B, B), **f32) if (want_grads and flags & HEAD_MATCH_HINGE) else None
     out['dMl'] = torch.empty((B, B), **f32) if (want_grads and flags & HEAD_LISTNET) else None
     out['dS'] = torch.empty((B, B), **f32) if (want_grads and flags & HEAD_ALIGN_HINGE) else None
-    out['pairs'] = None
+    out['pairs'] = out['table_ws'] = out['sets'] = None
+    if (align is not None and out['dS'] is not None and max_violation and align[4][0].mtiles == 1 and align[4][0].tp16 <= 4
+            and not align[4][0].split):
+        im_set, s_seq, im_len_t, s_len_t, packed = align
+        geom = packed[0]
+        im_c, s_c = _rows_inner_contig(im_set), _rows_inner_contig(s_seq)
+        out['table_ws'] = torch.empty(lib.aladin_align_bwd_workspace_bytes(B, B, im_set.shape[1], s_seq.shape[1], im_set.shape[2]),
+                                      dtype=torch.uint8, device=dev)
+        out['sets'] = (im_c, s_c)
+        ws = _workspace(lib.aladin_heads_small_workspace_bytes(B), dev)
+        _lib.check(lib.aladin_heads_small_fwd_argmax(_ptr(im), _ld(im) if im is not None else 0, _ptr(s), _ld(s) if s is not None else 0,
+                                                     _ptr(S), _ld(S), D, float(margin), int(flags), float(temperature), float(eps),
+                                                     float(weights[0]), float(weights[1]), float(weights[2]), _ptr(out['M']),
+                                                     _ptr(out['terms']), _ptr(out['total']), _ptr(out['dMh']), _ptr(out['dMl']),
+                                                     _ptr(out['dS']), _ptr(ws), _ptr(im_c), im_c.stride(0), im_c.stride(1),
+                                                     _ptr(im_len_t), _ptr(s_c), s_c.stride(0), s_c.stride(1), _ptr(s_len_t),
+                                                     _ptr(packed[1]), _ptr(packed[2]), _ptr(packed[3]), C.byref(geom),
+                                                     _ptr(out['table_ws']), _stream()), 'heads_small_fwd_argmax')
+        return out
     if want_pairs and out['dS'] is not None:
         out['pairs'] = (torch.empty(B * B, dtype=torch.int32, device=dev), torch.empty(1, dtype=torch.int32, device=dev))
     ws = _workspace(lib.aladin_heads_small_workspace_bytes(B), dev)
@@ -795,12 +817,15 @@ class _SmallHeads(torch.autograd.Function):
         if flags & (HEAD_MATCH_HINGE | HEAD_LISTNET):
             a = img_emb if img_emb.stride(1) == 1 else img_emb.contiguous()
             b = cap_emb if cap_emb.stride(1) == 1 else cap_emb.contiguous()
-        o = _heads_small_fwd(a, b, S, margin, max_violation, flags, temperature, eps, weights, need_sets or need_embs, True)
+        align = (im, s, im_len_t, s_len_t, packed) if (packed is not None and need_sets and flags & HEAD_ALIGN_HINGE) else None
+        o = _heads_small_fwd(a, b, S, margin, max_violation, flags, temperature, eps, weights, need_sets or need_embs, True, align)
+        if o['sets'] is not None:
+            im, s = o['sets']
         ctx.flags, ctx.weights = flags, weights
         ctx.geom = packed[0] if packed is not None else None
         ctx.pairs = o['pairs']
         pk = packed[1:] if packed is not None else (None, None, None)
-        ctx.save_for_backward(a, b, im, s, im_len_t, s_len_t, pk[0], pk[1], pk[2], o['dMh'], o['dMl'], o['dS'])
+        ctx.save_for_backward(a, b, im, s, im_len_t, s_len_t, pk[0], pk[1], pk[2], o['dMh'], o['dMl'], o['dS'], o['table_ws'])
         ctx.set_materialize_grads(False)
         terms = o['terms']
         ctx.mark_non_differentiable(*[t for t in (terms, S, o['M']) if t is not None])       # one call: it replaces the set
@@ -810,7 +835,7 @@ class _SmallHeads(torch.autograd.Function):
     def backward(ctx, g_total, _g_terms, _g_S, _g_M):
         if g_total is None:
             return (None,) * 12
-        a, b, im, s, im_len_t, s_len_t, xm, xe, y, dMh, dMl, dS = ctx.saved_tensors
+        a, b, im, s, im_len_t, s_len_t, xm, xe, y, dMh, dMl, dS, table_ws = ctx.saved_tensors
         flags, w = ctx.flags, ctx.weights
         g = g_total.to(torch.float32).contiguous()
         d_a = d_b = d_im = d_s = None
@@ -825,7 +850,10 @@ class _SmallHeads(torch.autograd.Function):
         elif scale is not None:
             scale = g * float(w[1])
         if dS is not None and any(ctx.needs_input_grad[2:4]):
-            d_im, d_s = _align_backward(im, s, im_len_t, s_len_t, dS, gscale=scale, packed=(ctx.geom, xm, xe, y), pairs=ctx.pairs)
+            if table_ws is not None:
+                d_im, d_s = _align_backward_rows(im, s, im_len_t, s_len_t, dS, scale, ctx.geom, table_ws)
+            else:
+                d_im, d_s = _align_backward(im, s, im_len_t, s_len_t, dS, gscale=scale, packed=(ctx.geom, xm, xe, y), pairs=ctx.pairs)
         return d_a, d_b, d_im, d_s, None, None, None, None, None, None, None, None
 
 

@@ -167,6 +167,18 @@ ALADIN_API int aladin_hinge_argmax_fused(const float* S, int64_t ldS, float marg
                                          const float* s, int64_t s_stride_b, int64_t s_stride_t, const int32_t* s_len,
                                          const void* xm, const void* xe, const void* y, const aladin_align_geom* geom,
                                          void* bwd_workspace, void* stream);
+/* The same merge for the small-batch loss heads (B <= 64; aladin_heads_small_fwd below): statistics launch + ONE kernel
+ * running the element-wise pass of all heads next to the pair recompute.  Hardest-negative hinge only (max_violation);
+ * flags must include ALADIN_HEAD_ALIGN_HINGE.  Arguments as aladin_heads_small_fwd (no pair list) followed by the
+ * backward's operands as in aladin_hinge_argmax_fused; D_emb is the width of the matching embeddings. */
+ALADIN_API int aladin_heads_small_fwd_argmax(const float* img, int64_t ld_img, const float* cap, int64_t ld_cap, const float* S,
+                                             int64_t ld_S, int D_emb, float margin, int flags, float temperature, float eps,
+                                             float w_match, float w_align, float w_dist, float* M, float* terms, float* total,
+                                             float* dM_hinge, float* dM_listnet, float* dS, void* heads_workspace,
+                                             const float* im, int64_t im_stride_b, int64_t im_stride_r, const int32_t* im_len,
+                                             const float* s, int64_t s_stride_b, int64_t s_stride_t, const int32_t* s_len,
+                                             const void* xm, const void* xe, const void* y, const aladin_align_geom* geom,
+                                             void* bwd_workspace, void* stream);
 ALADIN_API int aladin_align_bwd_rows(const float* im, int64_t im_stride_b, int64_t im_stride_r, const int32_t* im_len,
                                      const float* s, int64_t s_stride_b, int64_t s_stride_t, const int32_t* s_len,
                                      const float* dS, int64_t ld_dS, const float* gscale, const aladin_align_geom* geom,
