@@ -179,7 +179,7 @@ def main():
     args = parse()
     # before anything initialises the HIP runtime: the host driver only supports dmabuf IPC
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-    # HIP-runtime setting for graph replay: with "graph packet capture" on (this ROCm's default) the replay of the 7-kernel
+    # HIP-runtime setting for graph replay: with "graph packet capture" on (this ROCm's default) the replay of the (then) 7-kernel
     # step costs ~4 us more than with it off (0.2357 vs 0.2316 ms, alternated three times on one box,
     # profiles/r02_ab_experiments.txt).  Read once when the runtime starts; an exported value wins.
     os.environ.setdefault('DEBUG_CLR_GRAPH_PACKET_CAPTURE', '0')
@@ -243,7 +243,7 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         return float(tt.item())
 
-    # The step is 7 short launches; eager Python issue time (~0.22 ms) is close to the GPU time, so
+    # The step is 6 short launches; eager Python issue time (~0.22 ms) is close to the GPU time, so
     # the step is also captured once into a HIP graph (the C ABI neither allocates nor synchronises);
     # a trial below picks replay or eager issue.  Same kernels, same work; --eager / --graph force one.
     # Multi-GPU stays eager (collectives).
