@@ -186,6 +186,7 @@ extern "C" __attribute__((visibility("default"))) int aladin_debug_read_pair_pro
 //   runs under the pair workgroups.
 struct PairHinge {
   const float* S; int64_t ld; float margin; const float* val; const int* arg; float* loss; float* dS; int B; int n_pair_blocks;
+  float* dST;
 };
 // SRC == 2: the same merge for the small-batch loss heads (B <= 64): statistics from heads_small_stats_kernel
 //   (st[v][8..9] = value, arg of the alignment hinge), element-wise pass = heads_small_finish_body.
@@ -206,7 +207,7 @@ __global__ __launch_bounds__(256) void bwd_pair_argmax16_kernel(
   if constexpr (SRC == 1) {
     if ((int)blockIdx.x >= hf.n_pair_blocks) {
       hinge_finish_body((int)blockIdx.x - hf.n_pair_blocks, (int)gridDim.x - hf.n_pair_blocks, hf.S, hf.ld, hf.B, hf.margin, 1,
-                        hf.val, hf.arg, hf.loss, hf.dS, nullptr, nullptr);
+                        hf.val, hf.arg, hf.loss, hf.dS, nullptr, nullptr, hf.dST);
       return;
     }
   }
@@ -456,7 +457,7 @@ template <int NCH>
 __global__ __launch_bounds__(256) void bwd_rows_kernel(
     const float* __restrict__ im, int64_t im_sb, int64_t im_sr, const int32_t* __restrict__ im_len,
     const float* __restrict__ s, int64_t s_sb, int64_t s_st, const int32_t* __restrict__ s_len, int Bi, int Bc, int R,
-    int T, int D, const float* __restrict__ dS, int64_t ld, const float* __restrict__ gscale,
+    int T, int D, const float* __restrict__ dS, int64_t ld, const float* __restrict__ dST, const float* __restrict__ gscale,
     const uint8_t* __restrict__ table, int tstride, float* __restrict__ d_im, float* __restrict__ d_s, int x_tail,
     int y_tail, int64_t dim_sb, int64_t dim_sr, int64_t ds_sb, int64_t ds_st) {
   __shared__ int lst_p[4][ROWS_LIST];
@@ -503,7 +504,8 @@ __global__ __launch_bounds__(256) void bwd_rows_kernel(
         for (int q = 0; q < 4; ++q) {
           const int pl = p0 + 64 * q + lane;
           g4[q] = 0.f;
-          if (pl < nb) g4[q] = is_img ? dS[(int64_t)own_b * ld + pl] : dS[(int64_t)pl * ld + own_b];
+          // a caption row needs COLUMN own_b of dS: from the transposed copy when the fused hinge left one (coalesced)
+          if (pl < nb) g4[q] = is_img ? dS[(int64_t)own_b * ld + pl] : (dST ? dST[(int64_t)own_b * Bi + pl] : dS[(int64_t)pl * ld + own_b]);
         }
         bool full = false;
 #pragma unroll
@@ -673,11 +675,13 @@ static int align_bwd_impl(const float* im, int64_t im_sb, int64_t im_sr, const i
     if (!packed) { aladin_set_error("hinge_argmax: needs the packed fp16 operands of a one-region-tile class (mtiles == 1, <= 64 padded words)"); return ALADIN_ERR_UNSUPPORTED; }
     if (ha->small) {                                      // small-batch heads: their own statistics kernel ran already
       int npb = (3 * Bc + 7) / 8 * 8;
-      const PairHinge hfs = {nullptr, 0, 0.f, nullptr, nullptr, nullptr, nullptr, Bc, npb};
+      const PairHinge hfs = {nullptr, 0, 0.f, nullptr, nullptr, nullptr, nullptr, Bc, npb, nullptr};
+      SmallFin sfin = *ha->small;
+      sfin.dST = (float*)ws.pairs;                        // the list region is free in this mode: it carries dS^T
       hipLaunchKernelGGL(bwd_pair_argmax16_kernel<2>, dim3(npb + cdiv(Bc * Bc, 256)), dim3(256),
                          (size_t)PAIR_STAGES * PairCfg::STAGE_BYTES, st, (const half_t*)xm, (const half_t*)xe, (const half_t*)y,
                          g->Dp, g->rem, 16 * g->tp16, (int)g->xe_rows, (int)g->y_rows, im, im_sb, im_sr, im_len, s, s_sb, s_st,
-                         s_len, Bc, Rq, Tq, D, nullptr, nullptr, ws.table, tstride, x_tail, y_tail, hfs, *ha->small);
+                         s_len, Bc, Rq, Tq, D, nullptr, nullptr, ws.table, tstride, x_tail, y_tail, hfs, sfin);
       return aladin_check_launch("bwd_pair_argmax16_kernel<small heads>");
     }
     rc = aladin_internal_hinge_stats(ha->S, ha->ldS, Bc, ha->margin, 1, ha->workspace, nullptr, st);
@@ -686,7 +690,7 @@ static int align_bwd_impl(const float* im, int64_t im_sb, int64_t im_sr, const i
     const int* arg = (const int*)(val + 2 * (size_t)Bc);
     int npb = (3 * Bc + 7) / 8 * 8; if (npb > 2048) npb = 2048;
     const int nfin = Bc < 1024 ? Bc : 1024;
-    const PairHinge hf = {ha->S, ha->ldS, ha->margin, val, arg, ha->loss, ha->dS, Bc, npb};
+    const PairHinge hf = {ha->S, ha->ldS, ha->margin, val, arg, ha->loss, ha->dS, Bc, npb, (float*)ws.pairs};
     hipLaunchKernelGGL(bwd_pair_argmax16_kernel<1>, dim3(npb + nfin), dim3(256), (size_t)PAIR_STAGES * PairCfg::STAGE_BYTES, st,
                        (const half_t*)xm, (const half_t*)xe, (const half_t*)y, g->Dp, g->rem, 16 * g->tp16, (int)g->xe_rows,
                        (int)g->y_rows, im, im_sb, im_sr, im_len, s, s_sb, s_st, s_len, Bc, Rq, Tq, D, nullptr, nullptr,
@@ -724,7 +728,7 @@ static int align_bwd_impl(const float* im, int64_t im_sb, int64_t im_sr, const i
   const int nch = (D + 255) / 256;
 #define LAUNCH_ROWS(N)                                                                                                  \
   hipLaunchKernelGGL(bwd_rows_kernel<N>, dim3(rgrid), dim3(256), 0, st, im, im_sb, im_sr, im_len, s, s_sb, s_st, s_len, \
-                     Bi, Bc, R, T, D, dS, ld_dS, gscale, ws.table, tstride, d_im, d_s, x_tail, y_tail, dim_sb, dim_sr, ds_sb, ds_st)
+                     Bi, Bc, R, T, D, dS, ld_dS, phase == BWD_ROWS ? (const float*)ws.pairs : (const float*)nullptr, gscale, ws.table, tstride, d_im, d_s, x_tail, y_tail, dim_sb, dim_sr, ds_sb, ds_st)
   switch (nch) {
     case 1: LAUNCH_ROWS(1); break;
     case 2: LAUNCH_ROWS(2); break;
@@ -814,7 +818,7 @@ extern "C" int aladin_heads_small_fwd_argmax(const float* img, int64_t ld_img, c
                                              nullptr, (hipStream_t)stream);
   if (rc) return rc;
   const SmallFin f = {M, S, ld_S, B, margin, 1, flags, temperature, eps, w_match, w_align, w_dist, st, terms, total, dM_hinge,
-                      dM_listnet, dS, nullptr, nullptr};
+                      dM_listnet, dS, nullptr, nullptr, nullptr};
   const HingeArgs ha = {S, ld_S, margin, terms, dS, heads_workspace, &f};
   return align_bwd_impl(im, im_sb, im_sr, im_len, s, s_sb, s_st, s_len, geom->Bi, geom->Bc, geom->R, geom->T, geom->D, nullptr, 0,
                         nullptr, xm, xe, y, geom, nullptr, nullptr, nullptr, nullptr, bwd_workspace, stream, geom->x_tail,

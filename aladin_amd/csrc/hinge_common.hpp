@@ -21,7 +21,7 @@ __device__ __forceinline__ void hinge_finish_body(int vblock, int nblocks, const
                                                   float margin, int max_violation, const float* __restrict__ val,
                                                   const int* __restrict__ arg, float* __restrict__ loss,
                                                   float* __restrict__ dS, int* __restrict__ pairs,
-                                                  int* __restrict__ pair_count) {
+                                                  int* __restrict__ pair_count, float* __restrict__ dST = nullptr) {
   __shared__ float red[4];
   if (vblock == 0) {
     float rs = 0.f, cs = 0.f;                             // rows first, then columns, fixed order
@@ -51,6 +51,7 @@ __device__ __forceinline__ void hinge_finish_body(int vblock, int nblocks, const
           }
         }
         if (dS) dS[(int64_t)i * B + j] = g;
+        if (dST) dST[(int64_t)j * B + i] = g;              // transposed copy: the row kernel's caption rows read it coalesced
       }
       if (pairs) {                                        // list of non-zero pairs for the alignment backward
         // ONE atomic per workgroup and 256 columns (the four waves' counts meet in LDS): every workgroup hits the

@@ -205,7 +205,7 @@ extern "C" int aladin_heads_small_fwd(const float* img, int64_t ld_img, const fl
                                              M, st, pairs ? pair_count : nullptr, s);
   if (rc) return rc;
   const SmallFin f = {M, S, ld_S, B, margin, max_violation, flags, temperature, eps, w_match, w_align, w_dist, st, terms, total,
-                      dM_hinge, dM_listnet, dS, pairs, pair_count};
+                      dM_hinge, dM_listnet, dS, pairs, pair_count, nullptr};
   hipLaunchKernelGGL(heads_small_finish_kernel, dim3(cdiv(B * B, 256)), dim3(256), 0, s, f);
   return aladin_check_launch("heads_small_finish_kernel");
 }

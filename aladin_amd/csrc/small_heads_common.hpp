@@ -13,7 +13,7 @@
 struct SmallFin {                      // arguments of the element-wise pass (heads_small_finish)
   const float* M; const float* S; int64_t ld_s; int B; float margin; int max_violation; int flags; float tau; float eps;
   float w_match, w_align, w_dist; const float* st; float* terms; float* total; float* dM_hinge; float* dM_listnet; float* dS;
-  int* pairs; int* pair_count;
+  int* pairs; int* pair_count; float* dST;
 };
 
 __device__ __forceinline__ float hinge_grad(const float* st, int off, const float* X, int64_t ld, int B, int i, int j, float margin,
@@ -80,6 +80,7 @@ __device__ __forceinline__ void heads_small_finish_body(int vblock, int nblocks,
     if ((flags & SB_ALIGN_HINGE) && (dS || pairs)) {
       const float g = in ? hinge_grad(st, 8, S, ld_s, B, i, j, margin, max_violation) : 0.f;
       if (in && dS) dS[e] = g;
+      if (in && f.dST) f.dST[(int64_t)j * B + i] = g;
       if (pairs) {                                                    // the non-zero pairs, for the alignment backward
         const unsigned long long mask = __ballot(g != 0.f);
         if (mask) {

@@ -161,7 +161,8 @@ ALADIN_API int aladin_align_bwd_packed_strided(const float* im, int64_t im_strid
  * the argmax table and must stay untouched until aladin_align_bwd_rows consumed it.  Needs the fp16 pair kernel's
  * shapes (geom->mtiles == 1, <= 64 padded words), else ALADIN_ERR_UNSUPPORTED.
  * aladin_align_bwd_rows: the remaining kernel of the backward (autograd of alad/loss.py:80-125 given dS and the table),
- * gradients in the caller's layout as in aladin_align_bwd_packed_strided. */
+ * gradients in the caller's layout as in aladin_align_bwd_packed_strided.  dS must be the matrix the fused call wrote: the
+ * workspace also carries its transpose (the caption rows read their column of dS from it, coalesced). */
 ALADIN_API int aladin_hinge_argmax_fused(const float* S, int64_t ldS, float margin, float* loss, float* dS, void* hinge_workspace,
                                          const float* im, int64_t im_stride_b, int64_t im_stride_r, const int32_t* im_len,
                                          const float* s, int64_t s_stride_b, int64_t s_stride_t, const int32_t* s_len,
