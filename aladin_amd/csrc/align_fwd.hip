@@ -118,15 +118,25 @@ extern "C" int aladin_align_geometry_mode(int Bi, int Bc, int R, int T, int D, i
 //      max and sum commute with it exactly) and are scaled back after the score kernel.
 #define ALADIN_SPLIT_SCALE 16384.0f
 #define ALADIN_SPLIT_UNSCALE (1.0f / (16384.0f * 16384.0f))
+// len_ptr != nullptr: the row only counts if pos < clamp(*len_ptr - 1 - tail, 0, cap) (the masks of alad/loss.py:103-116);
+// the fast path issues the row's loads BEFORE it knows (the row exists in memory either way), so that the length and the
+// row arrive together instead of one memory latency after the other.
 __device__ __forceinline__ void pack_row(const float* __restrict__ src, half_t* __restrict__ dst, int D, int Dp,
-                                         int lane, bool vec4, int seg = 0) {
+                                         int lane, bool vec4, int seg = 0, const int32_t* __restrict__ len_ptr = nullptr,
+                                         int pos = 0, int tail = 0, int cap = 0) {
   const int width = seg ? 3 * Dp : Dp;
+  const bool fast = vec4 && !seg && D <= 1024;
+  if (src != nullptr && len_ptr != nullptr && !fast) {
+    int L = *len_ptr - 1 - tail;
+    L = L < 0 ? 0 : (L > cap ? cap : L);
+    if (pos >= L) src = nullptr;
+  }
   // src == nullptr -> zero row
   if (src == nullptr) {
     for (int c = lane * 8; c < width; c += 64 * 8) *reinterpret_cast<half8*>(dst + c) = half8{0, 0, 0, 0, 0, 0, 0, 0};
     return;
   }
-  if (vec4 && !seg && D <= 1024) {
+  if (fast) {
     // the whole row in registers (<= 4 float4 per lane): one read of the source, the loads of a row all in flight at once
     float4 v[4];
     float ss = 0.f;
@@ -134,6 +144,14 @@ __device__ __forceinline__ void pack_row(const float* __restrict__ src, half_t* 
     for (int k = 0; k < 4; ++k) {
       const int c = lane * 4 + 256 * k;
       v[k] = c < D ? *reinterpret_cast<const float4*>(src + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (len_ptr != nullptr) {
+      int L = *len_ptr - 1 - tail;
+      L = L < 0 ? 0 : (L > cap ? cap : L);
+      if (pos >= L) {                                   // masked after all: a zero row
+        for (int c = lane * 8; c < width; c += 64 * 8) *reinterpret_cast<half8*>(dst + c) = half8{0, 0, 0, 0, 0, 0, 0, 0};
+        return;
+      }
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) ss = sumsq4(ss, v[k]);
@@ -244,6 +262,8 @@ __global__ __launch_bounds__(256) void pack_both_kernel(const float* __restrict_
   const int64_t d = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (d >= total_rows) return;
   const float* src = nullptr;
+  const int32_t* len_ptr = nullptr;
+  int pos = 0, tail = 0, cap = 0;
   half_t* dst;
   bool vec;
   int seg = 0;
@@ -261,25 +281,17 @@ __global__ __launch_bounds__(256) void pack_both_kernel(const float* __restrict_
       rho = 32 * mtiles + (int)((d - xm_rows) % rem);
       dst = xe + (d - xm_rows) * Dp;
     }
-    if (i < Bi) {
-      int Li = im_len[i] - 1 - x_tail;
-      Li = Li < 0 ? 0 : (Li > Rq ? Rq : Li);
-      if (rho < Li) src = im + i * isb + (int64_t)(rho + 1) * isr;
-    }
+    if (i < Bi && rho < Rq) { src = im + i * isb + (int64_t)(rho + 1) * isr; len_ptr = im_len + i; pos = rho; tail = x_tail; cap = Rq; }
     vec = vec_i != 0;
   } else {
     const int64_t q = d - img_rows;
     const int j = (int)(q / tpad), w = (int)(q % tpad);
-    if (j < Bc) {
-      int Lj = s_len[j] - 1 - y_tail;
-      Lj = Lj < 0 ? 0 : (Lj > Tq ? Tq : Lj);
-      if (w < Lj) src = s + j * ssb + (int64_t)(w + 1) * sst;
-    }
+    if (j < Bc && w < Tq) { src = s + j * ssb + (int64_t)(w + 1) * sst; len_ptr = s_len + j; pos = w; tail = y_tail; cap = Tq; }
     dst = y + q * Dp;
     vec = vec_s != 0;
     seg = split ? 2 : 0;
   }
-  pack_row(src, dst, D, split ? Dp / 3 : Dp, lane, vec, seg);
+  pack_row(src, dst, D, split ? Dp / 3 : Dp, lane, vec, seg, len_ptr, pos, tail, cap);
 }
 
 static int is_vec4_ok(const void* p, int64_t s0, int64_t s1, int D) {
