@@ -907,6 +907,28 @@ def test_large_batch_equals_its_blocks():
             assert torch.equal(S[i0:i0 + blk, j0:j0 + blk], part), (i0, j0)
 
 
+def test_fused_hinge_argmax_equals_the_list_path():
+    """The training step derives the backward's pairs from the hinge statistics and runs the hinge's element-wise pass in
+    the pair kernel's launch (aladin_hinge_argmax_fused + aladin_align_bwd_rows); the list-driven form (aladin_hinge_fused
+    -> pair list -> aladin_align_bwd_packed_strided) must give the same loss, dS and gradients bit for bit -- including
+    when a row's and a column's hardest negative are the same pair, inactive terms and ragged lengths."""
+    from aladin_amd import ops, synth
+    for B, seed, noise in ((40, 11, 1.0), (96, 12, 3.0), (256, 13, 1.0)):
+        im, s, il, sl = synth.structured_alignment_batch(B, 34, 50, 768, seed=seed, noise=noise, ragged=True)
+        a, b = T(im).requires_grad_(True), T(s).requires_grad_(True)
+        loss, S = ops.alignment_triplet_loss(a, b, il, sl, 0.2, True)
+        loss.backward()
+        ilt, slt = ops.lengths_tensor(il, a.device), ops.lengths_tensor(sl, a.device)
+        with torch.no_grad():
+            S2, packed = ops._align_forward(a.detach(), b.detach(), ilt, slt)
+            loss2, dS2, pairs = ops._hinge_raw(S2, 0.2, True, True, want_pairs=True)
+            one = torch.ones((), device=a.device)
+            d_im, d_s = ops._align_backward(a.detach(), b.detach(), ilt, slt, dS2, gscale=one, packed=packed, pairs=pairs)
+        assert torch.equal(S, S2) and float(loss) == float(loss2), (B, float(loss), float(loss2))
+        assert torch.equal(a.grad, d_im) and torch.equal(b.grad, d_s), B
+        assert int(pairs[1].item()) <= 3 * B
+
+
 def test_small_grid_score_variant_is_bit_identical():
     """Grids of at most 64 of the 256 x 384 tiles (B <= 64 at the headline shape) run the two-wave 128 x 192 /
     three-stage variant of the score kernel, larger ones the eight-wave 128 x 96-wave-tile kernel: same MFMA shape, K
