@@ -4,7 +4,9 @@
             trimmed / padded sets, tensors and packed stores (bit-equal to each other);
   heads     the three-launch small-batch loss heads (ops.small_batch_loss_heads) vs the separate differentiable pieces;
   topk      aladin_topk vs a numpy stable argsort, both orientations;
-  sgemm     the split-K fp32 MFMA GEMM vs float64.
+  sgemm     the split-K fp32 MFMA GEMM vs float64;
+  fused     the fused hinge + argmax training path (pairs from the hinge statistics, aladin_hinge_argmax_fused /
+            aladin_align_bwd_rows) vs the list-driven path and vs the oracle's gradients, any B, margin and raggedness.
 usage: tests/fuzz/fuzz_round2.py [seconds] [seed]"""
 import os
 import sys
@@ -26,10 +28,10 @@ rng = np.random.RandomState(seed)
 dev = torch.device('cuda:0')
 T = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
 t0 = time.time()
-counts = {'split': 0, 'heads': 0, 'topk': 0, 'sgemm': 0}
+counts = {'split': 0, 'heads': 0, 'topk': 0, 'sgemm': 0, 'fused': 0}
 worst_split = 0.0
 while time.time() - t0 < budget:
-    kind = ['split', 'split', 'heads', 'topk', 'sgemm'][int(rng.randint(0, 5))]
+    kind = ['split', 'split', 'heads', 'topk', 'sgemm', 'fused'][int(rng.randint(0, 6))]
     case_seed = int(rng.randint(1, 1 << 30))
     if kind == 'split':
         Bi, Bc = int(rng.randint(1, 30)), int(rng.randint(1, 30))
@@ -96,6 +98,34 @@ while time.time() - t0 < budget:
             else:
                 sc_ = max(1e-12, float(b.grad.abs().max()))
                 assert float((a.grad - b.grad).abs().max()) <= 2e-6 * sc_ + 1e-5 * float(b.grad.abs().mean()), tag
+    elif kind == 'fused':
+        B = int(rng.choice([1, 2, 3, 5, 8, 17, 31, 32, 33, 64, 65, 70, 100]))
+        R, Tn = int(rng.choice([3, 9, 20, 33, 34])), int(rng.choice([5, 12, 36, 50, 66]))
+        D = int(rng.choice([64, 128, 768]))
+        margin = float(rng.choice([0.0, 0.05, 0.2, 1.0, 50.0]))
+        # (noise >= 1: with less the regions of an image are nearly parallel and which of them is the fp32 argmax is a matter
+        #  of summation order -- the reference's own autograd is ambiguous there)
+        im, s, il, sl = synth.structured_alignment_batch(B, R, Tn, D, seed=case_seed, noise=float(rng.choice([1.0, 3.0])), ragged=True)
+        if rng.rand() < 0.3 and B > 2:
+            im[1] = im[0]; s[1] = s[0]; il[1] = il[0]; sl[1] = sl[0]      # duplicated samples: exact ties in S
+        a, b = T(im).requires_grad_(True), T(s).requires_grad_(True)
+        loss, S = ops.alignment_triplet_loss(a, b, il, sl, margin, True)
+        loss.backward()
+        ilt, slt = ops.lengths_tensor(il, dev), ops.lengths_tensor(sl, dev)
+        with torch.no_grad():
+            S2, packed = ops._align_forward(a.detach(), b.detach(), ilt, slt)
+            loss2, dS2, pairs = ops._hinge_raw(S2, margin, True, True, want_pairs=True)
+            d_im, d_s = ops._align_backward(a.detach(), b.detach(), ilt, slt, dS2, gscale=torch.ones((), device=dev), packed=packed, pairs=pairs)
+        tag = 'fused B=%d R=%d T=%d D=%d margin=%g seed=%d' % (B, R, Tn, D, margin, case_seed)
+        assert torch.equal(S, S2) and float(loss) == float(loss2), tag
+        assert torch.equal(a.grad, d_im) and torch.equal(b.grad, d_s), tag
+        S_np = S.detach().cpu().numpy()
+        _, dS_o = O.hinge_loss(S_np, margin, True, return_grad=True)
+        assert np.array_equal(dS_o, dS2.cpu().numpy()), tag
+        gi, gs = O.alignment_scores_backward(im, s, il, sl, dS_o)
+        for got, want in ((a.grad.cpu().numpy(), gi), (b.grad.cpu().numpy(), gs)):
+            sc_ = max(1e-3, float(np.abs(want).max()))     # (duplicated samples cancel exactly: only rounding noise is left)
+            assert float(np.abs(got - want).max()) <= 1e-3 * sc_, tag
     elif kind == 'topk':
         n_q, n_c, k = int(rng.randint(1, 60)), int(rng.randint(1, 3000)), int(rng.choice([1, 5, 50, 64]))
         M = rng.randn(n_q, n_c).astype(np.float32)
