@@ -548,17 +548,20 @@ __global__ __launch_bounds__(256) void bwd_rows_kernel(
         unsigned long long hit_lo = 0, hit_hi = 0;                  // words 0..63 / 64..127
         if (lane < cnt) {
           const uint4* trow = reinterpret_cast<const uint4*>(table + ((int64_t)own_b * Bc + my_p) * tstride);
+          // branch-free byte search: x = word ^ (idx in every byte) has a zero byte where the table entry equals idx;
+          // z flags exactly the zero bytes with 0x80; the multiply gathers the four flags into one nibble
+          const unsigned idx4 = (unsigned)idx * 0x01010101u;
           for (int q = 0; q < tstride / 16; ++q) {
             const uint4 t4 = trow[q];
             const unsigned wds[4] = {t4.x, t4.y, t4.z, t4.w};
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
-#pragma unroll
-              for (int b = 0; b < 4; ++b)
-                if (((wds[u] >> (8 * b)) & 0xffu) == (unsigned)idx) {
-                  const int wpos = q * 16 + u * 4 + b;
-                  if (wpos < 64) hit_lo |= 1ull << wpos; else hit_hi |= 1ull << (wpos - 64);
-                }
+            for (int u = 0; u < 4; ++u) {
+              const unsigned x = wds[u] ^ idx4;
+              const unsigned z = ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x | 0x7F7F7F7Fu);
+              const unsigned long long nib = (((z >> 7) * 0x01020408u) >> 24) & 0xFu;
+              const int wpos = q * 16 + u * 4;
+              if (wpos < 64) hit_lo |= nib << wpos; else hit_hi |= nib << (wpos - 64);
+            }
           }
         }
         unsigned long long live = __ballot((hit_lo | hit_hi) != 0);
