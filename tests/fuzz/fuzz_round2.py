@@ -125,7 +125,23 @@ while time.time() - t0 < budget:
         gi, gs = O.alignment_scores_backward(im, s, il, sl, dS_o)
         for got, want in ((a.grad.cpu().numpy(), gi), (b.grad.cpu().numpy(), gs)):
             sc_ = max(1e-3, float(np.abs(want).max()))     # (duplicated samples cancel exactly: only rounding noise is left)
-            assert float(np.abs(got - want).max()) <= 1e-3 * sc_, tag
+            if float(np.abs(got - want).max()) > 1e-3 * sc_:
+                # a whole row moves when an argmax flips; legitimate only if some differentiated (pair, word) has its two
+                # best regions closer than fp32 can resolve (the kernel's exact fp32 dot and numpy sum in different orders)
+                gap = np.inf
+                for i_, j_ in zip(*np.nonzero(dS_o)):
+                    Li_, Lj_ = il[i_] - 1, sl[j_] - 3
+                    if Li_ < 2 or Lj_ < 1:
+                        continue
+                    x64, y64 = im[i_, 1:1 + Li_].astype(np.float64), s[j_, 1:1 + Lj_].astype(np.float64)
+                    A64 = (x64 / np.linalg.norm(x64, axis=1, keepdims=True)) @ (y64 / np.linalg.norm(y64, axis=1, keepdims=True)).T
+                    top = np.sort(A64, axis=0)[-2:]
+                    gap = min(gap, float((top[1] - top[0]).min()))
+                    if Li_ < R - 1:
+                        gap = min(gap, float(np.abs(top[1]).min()))            # the zero fill competes too
+                assert gap < 5e-7, '%s: gradient mismatch %.3e with no fp32-unresolvable argmax (smallest top-2 gap %.3e)' % (
+                    tag, float(np.abs(got - want).max()), gap)
+                counts['near_ties'] = counts.get('near_ties', 0) + 1
     elif kind == 'topk':
         n_q, n_c, k = int(rng.randint(1, 60)), int(rng.randint(1, 3000)), int(rng.choice([1, 5, 50, 64]))
         M = rng.randn(n_q, n_c).astype(np.float32)
