@@ -645,17 +645,15 @@ static int align_bwd_impl(const float* im, int64_t im_sb, int64_t im_sr, const i
     if (!ha || !ha->S || !ha->loss || !ha->dS || !ha->workspace || Bi != Bc || ha->ldS < Bc) { aladin_set_error("hinge_argmax: bad argument"); return ALADIN_ERR_ARG; }
     if (ha->small && Bc > SB_MAX) { aladin_set_error("heads_small: B = %d > %d", Bc, SB_MAX); return ALADIN_ERR_UNSUPPORTED; }
     dS = ha->dS; ld_dS = Bc;
-    static float dummy_target;                            // the gradient pointers are not touched in this phase
-    d_im = d_s = &dummy_target;
-    dim_sb = dim_sr = ds_sb = ds_st = 4;
   }
+  const bool wants_grads = phase != BWD_HINGE_ARGMAX;     // that phase only fills the argmax table: no gradient buffers yet
   if (dim_sb == 0 && dim_sr == 0) { dim_sb = (int64_t)R * D; dim_sr = D; }          // contiguous (Bi, R, D) / (Bc, T, D) outputs
   if (ds_sb == 0 && ds_st == 0) { ds_sb = (int64_t)T * D; ds_st = D; }
-  if (phase != BWD_HINGE_ARGMAX && (dim_sb % 4 || dim_sr % 4 || ds_sb % 4 || ds_st % 4 || ((uintptr_t)d_im & 15) || ((uintptr_t)d_s & 15))) {
+  if (wants_grads && (dim_sb % 4 || dim_sr % 4 || ds_sb % 4 || ds_st % 4 || ((uintptr_t)d_im & 15) || ((uintptr_t)d_s & 15))) {
     aladin_set_error("align_bwd: gradient rows must be 16-byte aligned (strides %lld %lld %lld %lld)", (long long)dim_sb, (long long)dim_sr, (long long)ds_sb, (long long)ds_st);
     return ALADIN_ERR_ARG;
   }
-  if (!im || !s || !im_len || !s_len || !dS || !d_im || !d_s || !workspace) { aladin_set_error("align_bwd: null argument"); return ALADIN_ERR_ARG; }
+  if (!im || !s || !im_len || !s_len || !dS || (wants_grads && (!d_im || !d_s)) || !workspace) { aladin_set_error("align_bwd: null argument"); return ALADIN_ERR_ARG; }
   if (Bi < 1 || Bc < 1 || R < 2 + x_tail || T < 2 + y_tail || D < 1 || ld_dS < Bc) { aladin_set_error("align_bwd: bad sizes"); return ALADIN_ERR_ARG; }
   const int Rq = R - 1 - x_tail;
   if (Rq > PA_MAXR - 2 || Rq >= NO_GRAD || T - 1 - y_tail > PA_MAXT) { aladin_set_error("align_bwd: at most %d regions / %d words", PA_MAXR - 2, PA_MAXT); return ALADIN_ERR_UNSUPPORTED; }
