@@ -293,15 +293,22 @@ __global__ __launch_bounds__(256) void bwd_pair_argmax16_kernel(
     const bool wvalid = wd >= 0 && wd < Lj && Li > 0;
     float b1 = -INFINITY, b2 = -INFINITY;
     int a1 = 255;
+    // region index of accumulator register r of this lane (255: not a region of this pair), branch-free: written with
+    // if / else the compiler built 66 exec-mask branches and parked b1 / b2 in AccVGPRs (1.6 us for this loop)
+    auto region_of = [&](int r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+      const int d = row - eo;
+      const int side = ((unsigned)d < (unsigned)rem) ? 32 + d : 255;
+      return wm == 0 ? row : side;
+    };
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-      const int reg = wm == 0 ? row : ((row >= eo && row < eo + rem) ? 32 + row - eo : 255);
-      const float v = acc[0][0][r];
-      if (reg < Li) {
-        if (v > b1) { b2 = b1; b1 = v; a1 = reg; }
-        else if (v > b2) b2 = v;
-      }
+      const int reg = region_of(r);
+      const float v = reg < Li ? acc[0][0][r] : -INFINITY;         // a masked region never wins (-inf > -inf is false)
+      const bool first = v > b1;
+      b2 = first ? b1 : (v > b2 ? v : b2);
+      a1 = first ? reg : a1;
+      b1 = first ? v : b1;
     }
 #define TOP2_MERGE(ob1, oa1, ob2)                                                              \
     do {                                                                                       \
@@ -328,15 +335,14 @@ __global__ __launch_bounds__(256) void bwd_pair_argmax16_kernel(
         word_res[wd] = (Li < Rq && b1 <= 0.f) ? NO_GRAD : (uint8_t)a1;
       }
       if (amb) {
+        unsigned close = 0;                                // which of this lane's 16 regions are within the margin of the best
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-          const int reg = wm == 0 ? row : ((row >= eo && row < eo + rem) ? 32 + row - eo : 255);
-          if (reg < Li && acc[0][0][r] > b1 - AMBIG_MARGIN) {
-            const int slot = atomicAdd(&ncand, 1);           // < 64 * 64 = CAND_MAX by construction
-            cand_w[slot] = (uint8_t)wd;
-            cand_r[slot] = (uint8_t)reg;
-          }
+        for (int r = 0; r < 16; ++r) close |= (unsigned)(region_of(r) < Li && acc[0][0][r] > b1 - AMBIG_MARGIN) << r;
+        while (close) {                                    // a handful per pair
+          const int r = __ffs((int)close) - 1; close &= close - 1;
+          const int slot = atomicAdd(&ncand, 1);           // < 64 * 64 = CAND_MAX by construction
+          cand_w[slot] = (uint8_t)wd;
+          cand_r[slot] = (uint8_t)region_of(r);
         }
       }
     }
