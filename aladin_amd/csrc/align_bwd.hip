@@ -215,14 +215,16 @@ __global__ __launch_bounds__(256) void bwd_pair_argmax16_kernel(
   extern __shared__ __attribute__((aligned(16))) char pair_smem[];
   // The candidate list of the exact phase lives in the ring, which is dead once every wave has left the K loop (the
   // barrier of the top-2 merge): 64 x 64 entries, one per accumulator element, so it cannot overflow.
-  float* cand_val = reinterpret_cast<float*>(pair_smem);
-  uint8_t* cand_w = reinterpret_cast<uint8_t*>(pair_smem) + 4 * CAND_MAX;
+  uint8_t* cand_w = reinterpret_cast<uint8_t*>(pair_smem);
   uint8_t* cand_r = cand_w + CAND_MAX;
-  static_assert(6 * CAND_MAX <= PAIR_STAGES * PairCfg::STAGE_BYTES, "candidate list must fit in the ring");
+  static_assert(2 * CAND_MAX <= PAIR_STAGES * PairCfg::STAGE_BYTES, "candidate list must fit in the ring");
   __shared__ float top_b1[2][64], top_b2[2][64];
   __shared__ int top_a1[2][64];
   __shared__ int ncand;
   __shared__ uint8_t word_amb[64], word_res[64];
+  // exact decision per ambiguous word: max over its candidates of (order-preserving bits of the fp32 cosine, 255 - region):
+  // larger value first, then the lower region -- one 64-bit LDS max per candidate, order-independent
+  __shared__ unsigned long long word_key[64];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int h = lane >> 5, l5 = lane & 31;
   const int wm = wave >> 1, wn = wave & 1;
@@ -259,7 +261,7 @@ __global__ __launch_bounds__(256) void bwd_pair_argmax16_kernel(
     __syncthreads();                                   // everyone is done with the previous pair's blk
     if (Li + Lj >= 0) PAIR_STAMP(1);
     if (threadIdx.x == 0) ncand = 0;
-    if (threadIdx.x < 64) { word_amb[threadIdx.x] = 0; word_res[threadIdx.x] = NO_GRAD; }
+    if (threadIdx.x < 64) { word_amb[threadIdx.x] = 0; word_res[threadIdx.x] = NO_GRAD; word_key[threadIdx.x] = 0ull; }
     // operand panels: rows [0,32) = the image's 32 main regions, rows [32,64) = 32 consecutive rows
     // of the extra-region operand containing image i's rem rows at offset eo; 64 caption-word rows
     // starting at by (the caption's words sit at column offset co)
@@ -375,7 +377,11 @@ __global__ __launch_bounds__(256) void bwd_pair_argmax16_kernel(
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const float xy = wave_sum(sxy[q]), xx = wave_sum(sxx[q]);
-        if (lane == 0 && e0 + q < nc) cand_val[e0 + q] = xy / fmaxf(sqrtf(xx), 1e-12f);
+        if (lane == 0 && e0 + q < nc) {
+          unsigned u = __float_as_uint(xy / fmaxf(sqrtf(xx), 1e-12f));
+          u ^= (u >> 31) ? 0xFFFFFFFFu : 0x80000000u;                       // order-preserving map float -> uint
+          atomicMax(&word_key[cand_w[e0 + q]], ((unsigned long long)u << 32) | (unsigned long long)(255 - cand_r[e0 + q]));
+        }
       }
     }
     __syncthreads();
@@ -388,14 +394,11 @@ __global__ __launch_bounds__(256) void bwd_pair_argmax16_kernel(
     if (w < 64) {
       res = word_res[w];
       if (word_amb[w]) {
-        float best = -INFINITY;
-        int arg = 0;
-        for (int e = 0; e < nc; ++e)
-          if (cand_w[e] == (uint8_t)w) {
-            const float v = cand_val[e];
-            const int r = cand_r[e];
-            if (v > best || (v == best && r < arg)) { best = v; arg = r; }
-          }
+        const unsigned long long key = word_key[w];                        // an ambiguous word lists at least its winner
+        unsigned u = (unsigned)(key >> 32);
+        u ^= (u >> 31) ? 0x80000000u : 0xFFFFFFFFu;
+        const float best = __uint_as_float(u);
+        const int arg = 255 - (int)(key & 0xFFull);
         res = (Li < Rq && best <= 0.f) ? NO_GRAD : (uint8_t)arg;
       }
     }
