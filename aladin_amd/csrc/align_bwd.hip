@@ -426,12 +426,13 @@ struct RowAcc {
   }
 };
 
-template <int NCH>
+// FULL: D == 256 NCH (D = 768, 512, 256, 1024): every lane's columns exist and the loads need no per-chunk exec-mask branch
+template <int NCH, bool FULL>
 __device__ __forceinline__ void load_row(const float* __restrict__ p, int D, int lane, float4 (&v)[NCH]) {
 #pragma unroll
   for (int c = 0; c < NCH; ++c) {
     const int col = lane * 4 + 256 * c;
-    v[c] = (col < D) ? *reinterpret_cast<const float4*>(p + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+    v[c] = (FULL || col < D) ? *reinterpret_cast<const float4*>(p + col) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
 }
 template <int NCH>
@@ -448,13 +449,13 @@ __device__ __forceinline__ void axpy_row(float f, const float4 (&v)[NCH], RowAcc
 }
 
 // gather one or two partner rows (r1 == nullptr: one); both loads are issued before either is used
-template <int NCH>
+template <int NCH, bool FULL>
 __device__ __forceinline__ void gather2(const float* __restrict__ r0, float g0, const float* __restrict__ r1, float g1, int D,
                                         int lane, RowAcc<NCH>& acc) {
   float4 v0[NCH], v1[NCH];
-  load_row<NCH>(r0, D, lane, v0);
+  load_row<NCH, FULL>(r0, D, lane, v0);
   if (r1 != nullptr) {                                   // wave-uniform
-    load_row<NCH>(r1, D, lane, v1);
+    load_row<NCH, FULL>(r1, D, lane, v1);
     const float n1 = wave_sum(row_sumsq<NCH>(v1));
     axpy_row<NCH>(g1 / fmaxf(sqrtf(n1), 1e-12f), v1, acc);
   }
@@ -462,7 +463,7 @@ __device__ __forceinline__ void gather2(const float* __restrict__ r0, float g0, 
   axpy_row<NCH>(g0 / fmaxf(sqrtf(n0), 1e-12f), v0, acc);
 }
 
-template <int NCH>
+template <int NCH, bool FULL>
 __global__ __launch_bounds__(256) void bwd_rows_kernel(
     const float* __restrict__ im, int64_t im_sb, int64_t im_sr, const int32_t* __restrict__ im_len,
     const float* __restrict__ s, int64_t s_sb, int64_t s_st, const int32_t* __restrict__ s_len, int Bi, int Bc, int R,
@@ -499,7 +500,7 @@ __global__ __launch_bounds__(256) void bwd_rows_kernel(
   float4 xv[NCH];
 
   if (idx >= 0 && idx < L) {
-    load_row<NCH>(xrow, D, lane, xv);                               // (a) own row, needed last
+    load_row<NCH, FULL>(xrow, D, lane, xv);                               // (a) own row, needed last
     const float gs = gscale ? *gscale : 1.f;
     const int nb = is_img ? Bc : Bi;                                // partners
     int* lp = lst_p[wave];
@@ -549,7 +550,7 @@ __global__ __launch_bounds__(256) void bwd_rows_kernel(
           const float g_1 = k1 < 0 ? 0.f : lane_bcast(my_g, kk1);
           const float* x0 = im + p_0 * im_sb + (int64_t)(r_0 + 1) * im_sr;
           const float* x1 = k1 < 0 ? nullptr : im + p_1 * im_sb + (int64_t)(r_1 + 1) * im_sr;
-          gather2<NCH>(x0, g_0, x1, g_1, D, lane, acc);
+          gather2<NCH, FULL>(x0, g_0, x1, g_1, D, lane, acc);
           any = true;
         }
       } else {
@@ -589,7 +590,7 @@ __global__ __launch_bounds__(256) void bwd_rows_kernel(
               const int wb = __ffsll((long long)bits) - 1 + 64 * part; bits &= bits - 1;
               if (pend_p < 0) { pend_p = pk; pend_w = wb; pend_g = gk; }
               else {
-                gather2<NCH>(s + pend_p * s_sb + (int64_t)(pend_w + 1) * s_st, pend_g,
+                gather2<NCH, FULL>(s + pend_p * s_sb + (int64_t)(pend_w + 1) * s_st, pend_g,
                              s + pk * s_sb + (int64_t)(wb + 1) * s_st, gk, D, lane, acc);
                 pend_p = -1;
                 any = true;
@@ -598,7 +599,7 @@ __global__ __launch_bounds__(256) void bwd_rows_kernel(
           }
         }
         if (pend_p >= 0) {
-          gather2<NCH>(s + pend_p * s_sb + (int64_t)(pend_w + 1) * s_st, pend_g, nullptr, 0.f, D, lane, acc);
+          gather2<NCH, FULL>(s + pend_p * s_sb + (int64_t)(pend_w + 1) * s_st, pend_g, nullptr, 0.f, D, lane, acc);
           any = true;
         }
       }
@@ -609,7 +610,7 @@ __global__ __launch_bounds__(256) void bwd_rows_kernel(
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
       const int col = lane * 4 + 256 * c;
-      if (col < D) *reinterpret_cast<float4*>(out + col) = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (FULL || col < D) *reinterpret_cast<float4*>(out + col) = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     return;
   }
@@ -627,7 +628,7 @@ __global__ __launch_bounds__(256) void bwd_rows_kernel(
 #pragma unroll
   for (int c = 0; c < NCH; ++c) {
     const int col = lane * 4 + 256 * c;
-    if (col < D) {
+    if (FULL || col < D) {
       float4 o;
       o.x = (acc.a[c].x - xv[c].x * proj) * inv;
       o.y = (acc.a[c].y - xv[c].y * proj) * inv;
@@ -736,9 +737,10 @@ static int align_bwd_impl(const float* im, int64_t im_sb, int64_t im_sr, const i
   const int64_t rows = (int64_t)Bi * R + (int64_t)Bc * T;
   const unsigned rgrid = (unsigned)((rows + 3) / 4);
   const int nch = (D + 255) / 256;
-#define LAUNCH_ROWS(N)                                                                                                  \
-  hipLaunchKernelGGL(bwd_rows_kernel<N>, dim3(rgrid), dim3(256), 0, st, im, im_sb, im_sr, im_len, s, s_sb, s_st, s_len, \
+#define LAUNCH_ROWS_F(N, F)                                                                                             \
+  hipLaunchKernelGGL((bwd_rows_kernel<N, F>), dim3(rgrid), dim3(256), 0, st, im, im_sb, im_sr, im_len, s, s_sb, s_st, s_len, \
                      Bi, Bc, R, T, D, dS, ld_dS, phase == BWD_ROWS ? (const float*)ws.pairs : (const float*)nullptr, gscale, ws.table, tstride, d_im, d_s, x_tail, y_tail, dim_sb, dim_sr, ds_sb, ds_st)
+#define LAUNCH_ROWS(N) do { if (D == 256 * (N)) LAUNCH_ROWS_F(N, true); else LAUNCH_ROWS_F(N, false); } while (0)
   switch (nch) {
     case 1: LAUNCH_ROWS(1); break;
     case 2: LAUNCH_ROWS(2); break;
@@ -746,6 +748,7 @@ static int align_bwd_impl(const float* im, int64_t im_sb, int64_t im_sr, const i
     default: LAUNCH_ROWS(4); break;
   }
 #undef LAUNCH_ROWS
+#undef LAUNCH_ROWS_F
   return aladin_check_launch("bwd_rows_kernel");
 }
 
