@@ -8,8 +8,8 @@ D=768 (BASELINE.json configs[1]; configs[3] when --gpus > 1: images all-gathered
 rank scores the (N*256 x 256) caption block, hinge on the global matrix).
 Inputs are resident in HBM before the timed region.  value = (N*256)^2 pairs / step time.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
-    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py [--gpus N] [--steps K] [--warmup W]      # N > 1: starts its own N ranks as child processes
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   # or is started as one of them
 
 Timing protocol (so that a short driver run and a long builder run report the same number):
   1. clock-settling pre-roll: the step is replayed for --preroll-s seconds (default 1.0) whatever --warmup says
@@ -179,6 +179,12 @@ def main():
     args = parse()
     # before anything initialises the HIP runtime: the host driver only supports dmabuf IPC
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    # `python bench.py --gpus N` outside torch.distributed.run: start the N ranks as CHILDREN (before torch or the
+    # HIP runtime exist in this process), relay their output with the JSON line last, exit with their return code
+    from aladin_amd import launch
+    if launch.needs_self_launch(args.gpus):
+        rc, _ = launch.run_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus)
+        raise SystemExit(rc)
     # HIP-runtime setting for graph replay: with "graph packet capture" on (this ROCm's default) the replay of the (then) 7-kernel
     # step costs ~4 us more than with it off (0.2357 vs 0.2316 ms, alternated three times on one box,
     # profiles/r02_ab_experiments.txt).  Read once when the runtime starts; an exported value wins.
@@ -188,9 +194,8 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit('bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d'
-                             % (args.gpus, args.gpus))
+        raise SystemExit('bench.py --gpus %d runs as rank %d of a world of %d: --gpus must equal the number of ranks started'
+                         % (args.gpus, rank, world))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X (no GPU visible); there is no CPU fallback')
     torch.cuda.set_device(local_rank)
@@ -371,6 +376,8 @@ def main():
                           'ms_per_step_min': round(min(region_ms), 4), 'ms_per_step_max': round(max(region_ms), 4)},
                'step_tflops_algorithmic': round(value * FLOPS_PER_PAIR / 1e12, 2)}
         if sharded:
+            cfg['collectives'] = {'backend': dist.get_backend(), 'ranks': dist.get_world_size(),
+                                  'launcher': 'self (aladin_amd.launch)' if os.environ.get('ALADIN_SELF_LAUNCHED') else 'external'}
             cfg['bwd_exchange'] = exchange[0]
             cfg['bwd_exchange_tuning_ms'] = {k: (round(v, 4) if v != float('inf') else None) for k, v in tuned.items()}
             cfg['phases_ms'] = phases          # rank 0's device timeline of one step (10-step mean), see PhaseRecorder

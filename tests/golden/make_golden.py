@@ -29,7 +29,7 @@ import alad.loss as ref_loss                      # noqa: E402
 import alad.recall_auxiliary as ref_recall        # noqa: E402
 import alad.evaluation as ref_eval                # noqa: E402
 
-torch.set_num_threads(8)
+torch.set_num_threads(int(os.environ.get("GOLDEN_THREADS", "8")))
 
 
 def t(x):
@@ -159,9 +159,16 @@ def gen_eval():
 
 
 COCO1K = dict(n_img=1000, D=64, seed=71, base_weight=0.36, img_len_range=(20, 60), cap_len_range=(8, 26), n_full=8)
+# the same grid at the HEADLINE feature width (north_star's Recall@1 claim is for D=768 features): base_weight chosen so that
+# recall stays non-degenerate at this width (the noise cosine shrinks with 1/sqrt(D)); ~15 min per direction on 8 cores
+COCO1K_D768 = dict(n_img=1000, D=768, seed=73, base_weight=0.16, img_len_range=(20, 60), cap_len_range=(8, 26), n_full=8)
 
 
-def gen_eval_coco1k():
+def gen_eval_coco1k_d768():
+    gen_eval_coco1k('eval_coco1k_d768', COCO1K_D768)
+
+
+def gen_eval_coco1k(name='eval_coco1k', cfg=None):
     """COCO-1k sized alignment-head retrieval (1000 images x 5000 captions, sets padded to 71 positions as
     encode_data leaves them) through the reference's own i2t / t2i loops with its alignment_sim_fn closure
     (alad/evaluation.py:158-327, train.py:493-509: cap_batches=5, im_batches=1).  Besides ranks / top
@@ -169,7 +176,7 @@ def gen_eval_coco1k():
     the reference's OWN fp32 scores: queries whose gap is at the level of fp32 rounding are the ones
     whose rank the reference itself does not resolve (a different summation order moves them)."""
     import time
-    kw = dict(COCO1K)
+    kw = dict(cfg or COCO1K)
     n_img, D, seed = kw.pop('n_img'), kw.pop('D'), kw.pop('seed')
     images, captions, img_len, cap_len = synth.eval_sets(n_img, D, seed, **kw)
     out = dict(n_img=n_img, D=D, seed=seed, images_checksum=synth.checksum(images), captions_checksum=synth.checksum(captions),
@@ -243,7 +250,7 @@ def gen_eval_coco1k():
     out['S_diag'] = S_i2t[cols // 5, cols].copy()
     print('gaps below 1e-5: i2t %d, t2i %d; below 1e-6: %d, %d' % ((gap_i2t < 1e-5).sum(), (gap_t2i < 1e-5).sum(),
                                                                     (gap_i2t < 1e-6).sum(), (gap_t2i < 1e-6).sum()))
-    save('eval_coco1k', **out)
+    save(name, **out)
 
 
 # --------------------------------------------------------------------- matching / distillation
@@ -506,6 +513,7 @@ if __name__ == '__main__':
     gen_alignment()
     gen_eval()
     gen_eval_coco1k()
+    gen_eval_coco1k_d768()
     gen_eval_pipeline()
     gen_matching()
     gen_distill()

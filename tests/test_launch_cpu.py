@@ -1,0 +1,81 @@
+"""CPU tier: `bench.py --gpus N` starts its own ranks (aladin_amd/launch.py).  The reference has no launcher
+(single process, alad/train.py:251-255); BASELINE configs[3] needs one.  A stub rank body under gloo checks what the
+launcher owes the driver: N ranks with the torch.distributed.run environment on 127.0.0.1, the JSON line LAST on
+stdout, the children's failure as a non-zero return code, no launch when already inside a rank."""
+import io
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+STUB = os.path.join(ROOT, 'tests', 'helpers', 'launch_stub.py')
+
+
+def _run(argv, nproc, **kw):
+    from aladin_amd import launch
+    out, err = io.StringIO(), io.StringIO()
+    env = dict(os.environ, OMP_NUM_THREADS='1')
+    rc, line = launch.run_ranks(STUB, argv, nproc, env=env, out=out, err=err, **kw)
+    return rc, line, out.getvalue(), err.getvalue()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize('nproc', [2, 3])
+def test_launcher_starts_n_ranks_and_keeps_the_result_line_last(nproc):
+    rc, line, out, err = _run(['--gpus', str(nproc)], nproc)
+    assert rc == 0, err
+    lines = [l for l in out.splitlines() if l.strip()]
+    assert lines[-1] == line                                           # the driver reads the last line
+    res = json.loads(line)
+    assert res['n_gpus'] == nproc and res['asked'] == nproc
+    assert res['local_ranks_plus_1'] == list(range(1, nproc + 1))      # every rank took part, LOCAL_RANK = rank on one node
+    assert res['master'][0] == '127.0.0.1' and int(res['master'][1]) > 0
+    assert res['self_launched'] == '1'
+    assert 'banner: not the result line' in out and out.count('late noise') == nproc      # nothing swallowed
+    assert '{"looks": "like json but is followed by the real line"}' in lines[:-1]
+
+
+@pytest.mark.timeout(300)
+def test_a_failing_rank_fails_the_launch():
+    rc, line, out, err = _run(['--gpus', '2', '--fail-rank', '1'], 2)
+    assert rc != 0
+    assert 'failing on purpose' in err
+
+
+@pytest.mark.timeout(300)
+def test_success_without_a_result_line_is_an_error():
+    rc, line, out, err = _run(['--gpus', '2', '--no-result'], 2)
+    assert rc == 1 and line is None and 'without printing a result line' in err
+
+
+@pytest.mark.timeout(300)
+def test_timeout_ends_the_ranks():
+    rc, line, out, err = _run(['--gpus', '2', '--hang'], 2, timeout=20)
+    assert rc == 124 and line is None
+
+
+def test_no_self_launch_inside_a_rank_or_for_one_gpu():
+    from aladin_amd import launch
+    assert launch.needs_self_launch(8, {})
+    assert not launch.needs_self_launch(1, {})
+    assert not launch.needs_self_launch(8, {'WORLD_SIZE': '8', 'RANK': '3', 'LOCAL_RANK': '3'})
+    cmd = launch.rank_command('bench.py', ['--gpus', '8', '--steps', '5'], 8, 29999, python='python3')
+    assert cmd == ['python3', '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '8', '--master-addr', '127.0.0.1',
+                   '--master-port', '29999', 'bench.py', '--gpus', '8', '--steps', '5']
+
+
+@pytest.mark.timeout(300)
+def test_bench_gpus_2_launches_its_ranks_here_and_reports_their_failure():
+    """No GPU in this container: both ranks of `python bench.py --gpus 2` must START (the old bench refused to) and fail
+    with bench's own 'needs an MI355X' message; the launcher hands their failure on."""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0'],
+                       capture_output=True, text=True, timeout=280, env=dict(os.environ, OMP_NUM_THREADS='1'))
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip('GPU box: covered by the gpu tier')
+    assert p.returncode != 0
+    assert 'needs an MI355X' in p.stderr and 'must be launched with' not in p.stderr
