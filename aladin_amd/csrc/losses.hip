@@ -212,9 +212,10 @@ extern "C" int aladin_listnet_fwd_bwd(const float* teacher, int64_t ld_t, const 
 // ------------------------------------------------------------------------------------------------
 __global__ void loss_total_kernel(const float* a, float wa, const float* b, float wb, const float* c, float wc, float* total) {
   float acc = 0.f;
-  if (a) acc = __fadd_rn(acc, __fmul_rn(*a, wa));
-  if (b) acc = __fadd_rn(acc, __fmul_rn(*b, wb));
-  if (c) acc = __fadd_rn(acc, __fmul_rn(*c, wc));
+  // a zero weight drops the term (logged-only, alad_model.py:442-444): 0 * NaN must not reach the total
+  if (a && wa != 0.f) acc = __fadd_rn(acc, __fmul_rn(*a, wa));
+  if (b && wb != 0.f) acc = __fadd_rn(acc, __fmul_rn(*b, wb));
+  if (c && wc != 0.f) acc = __fadd_rn(acc, __fmul_rn(*c, wc));
   *total = acc;
 }
 
@@ -226,8 +227,8 @@ __global__ __launch_bounds__(256) void grad_combine_kernel(int64_t n, const floa
   if (!out) return;
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
     float v = 0.f;
-    if (A) v += gv * wa * A[e];
-    if (Bm) v += gv * wb * Bm[e];
+    if (A && wa != 0.f) v += gv * wa * A[e];
+    if (Bm && wb != 0.f) v += gv * wb * Bm[e];
     out[e] = v;
   }
 }

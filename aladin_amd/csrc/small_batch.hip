@@ -144,8 +144,8 @@ __global__ __launch_bounds__(256) void heads_small_bwd_kernel(
     const int p = threadIdx.x;
     const int i = img_row ? q : p, j = img_row ? p : q;
     float c = 0.f;
-    if (dM_hinge && g_hinge) c += *g_hinge * w_hinge * dM_hinge[i * B + j];
-    if (dM_listnet && g_listnet) c += *g_listnet * w_listnet * dM_listnet[i * B + j];
+    if (dM_hinge && g_hinge && w_hinge != 0.f) c += *g_hinge * w_hinge * dM_hinge[i * B + j];
+    if (dM_listnet && g_listnet && w_listnet != 0.f) c += *g_listnet * w_listnet * dM_listnet[i * B + j];
     if (g_M) c += g_M[(int64_t)i * ld_g + j];
     coef[p] = c;
   }

@@ -55,9 +55,11 @@ __device__ __forceinline__ void heads_small_finish_body(int vblock, int nblocks,
       terms[0] = t_m; terms[1] = t_a; terms[2] = t_d;
       if (total) {                                                    // alad_model.py:450-453, in the reference's key order
         float acc = 0.f;                                              // separate multiply and add, as the eager sum rounds
-        if (flags & SB_MATCH_HINGE) acc = __fadd_rn(acc, __fmul_rn(t_m, w_match));
-        if (flags & SB_ALIGN_HINGE) acc = __fadd_rn(acc, __fmul_rn(t_a, w_align));
-        if (flags & SB_LISTNET) acc = __fadd_rn(acc, __fmul_rn(t_d, w_dist));
+        // a zero weight means "computed for logging only" (the reference pops the distillation term before distill_epoch,
+        // alad_model.py:442-444): the term must not reach the total, or 0 * inf / 0 * NaN would poison it
+        if ((flags & SB_MATCH_HINGE) && w_match != 0.f) acc = __fadd_rn(acc, __fmul_rn(t_m, w_match));
+        if ((flags & SB_ALIGN_HINGE) && w_align != 0.f) acc = __fadd_rn(acc, __fmul_rn(t_a, w_align));
+        if ((flags & SB_LISTNET) && w_dist != 0.f) acc = __fadd_rn(acc, __fmul_rn(t_d, w_dist));
         *total = acc;
       }
     }

@@ -71,6 +71,7 @@ def encode_data(model, data_loader, log_step=10, logging=print, max_len=71):
     device->host copy (:124-128) and the per-query host->device copies of i2t / t2i
     (:179,202,267,291) disappear, and compute_sim_matrix() consumes the buffers in place."""
     import time
+    clear_eval_cache()                               # a new embedding store is coming: the last grid is stale
     batch_time = AverageMeter()
     val_logger = LogCollector()
     model.eval()
@@ -112,6 +113,7 @@ def encode_data_packed(model, data_loader, log_step=10, logging=print, precision
     rank-exact alignment retrieval, fp16 hi/lo pair per value) or 'fp16' (half the bytes, ~1e-4 score error)."""
     import time
     from .store import PackedSetStore
+    clear_eval_cache()
     batch_time = AverageMeter()
     val_logger = LogCollector()
     model.eval()
@@ -256,36 +258,64 @@ def recall_1k_5fold_test(img_embs, cap_embs, tot_lengths=None, model=None, verbo
 
 # The score grid of the last i2t / t2i call: validate() / test() call the two back to back on the same
 # embeddings (reference train.py:504-509, test.py:271-276), so the second call re-uses the first one's grid.
-# Keyed on the identity AND version counter of the inputs (an in-place update invalidates it).
-_GRID_MEMO = {'key': None, 'sim': None}
+# A hit needs the SAME input objects, still alive (weak references compared with `is`: an address alone says
+# nothing -- the caching allocator hands the next validation's buffers the block the previous ones freed, with
+# the same shape and the same number of in-place fills), unchanged (tensor version counter / store row count).
+# The memo never keeps its inputs alive, and encode_data / encode_data_packed drop it before they start.
+_GRID_MEMO = {'key': None, 'refs': None, 'sim': None}
 
 
 def clear_eval_cache():
     """Drop the memoised score grid (it holds N_img x N_cap floats on the device: 500 MB at COCO-5k)."""
-    _GRID_MEMO['key'] = _GRID_MEMO['sim'] = None
+    _GRID_MEMO['key'] = _GRID_MEMO['refs'] = _GRID_MEMO['sim'] = None
 
 
 def _memo_key(images, captions, img_lenghts, cap_lenghts, measure, sim_function):
+    """-> (key, objects the key is only valid for) or (None, None) when an input cannot be tracked (then nothing
+    is memoised)."""
+    import weakref
+    objs = []
+
     def ident(x):
         if isinstance(x, torch.Tensor):
-            return ('t', x.data_ptr(), tuple(x.shape), x._version, str(x.device))
+            objs.append(x)
+            return ('t', x.data_ptr(), tuple(x.shape), tuple(x.stride()), x._version, str(x.device))
         if _is_store(x):
             st = getattr(x, 'store', x)
-            return ('s', id(st), st.n_rows, len(st), hash(tuple(getattr(x, 'ids', ()))), len(x))
-        return ('o', id(x))
-    fn = sim_function if (sim_function is None or isinstance(sim_function, str)) else id(sim_function)
-    return (ident(images), ident(captions), hash(tuple(int(v) for v in img_lenghts)) if img_lenghts is not None else None,
-            hash(tuple(int(v) for v in cap_lenghts)) if cap_lenghts is not None else None, measure, fn, ops._EVAL_PRECISION[0])
+            objs.extend([x, st])
+            return ('s', st.n_rows, len(st), hash(tuple(getattr(x, 'ids', ()))), len(x))
+        if isinstance(x, np.ndarray):
+            return None                              # no version counter: an in-place refill would go unnoticed
+        return None
+    ki, kc = ident(images), ident(captions)
+    if ki is None or kc is None:
+        return None, None
+    if sim_function is None or isinstance(sim_function, str):
+        fn = sim_function
+    else:
+        objs.append(sim_function)
+        fn = 'callable'
+    try:
+        refs = [weakref.ref(o) for o in objs]
+    except TypeError:                                # e.g. a bound method: a new object per access, not trackable
+        return None, None
+    key = (ki, kc, tuple(int(v) for v in img_lenghts) if img_lenghts is not None else None,
+           tuple(int(v) for v in cap_lenghts) if cap_lenghts is not None else None, measure, fn, ops._EVAL_PRECISION[0])
+    return key, (refs, objs)
 
 
 def _eval_scores(images, captions, img_lenghts, cap_lenghts, measure, sim_function):
     """(n_img, n_cap) scores of the de-duplicated images (rows 0::5, alad/evaluation.py:171,252) against every
     caption -- ONE grid instead of the reference's per-query loops."""
-    key = _memo_key(images, captions, img_lenghts, cap_lenghts, measure, sim_function)
-    if _GRID_MEMO['key'] == key:
+    key, tracked = _memo_key(images, captions, img_lenghts, cap_lenghts, measure, sim_function)
+    if key is not None and _GRID_MEMO['key'] == key and _GRID_MEMO['refs'] is not None \
+            and len(_GRID_MEMO['refs']) == len(tracked[1]) \
+            and all(r() is o for r, o in zip(_GRID_MEMO['refs'], tracked[1])):
         return _GRID_MEMO['sim']
+    clear_eval_cache()                               # release the old grid before the new one is allocated
     sim = _eval_scores_uncached(images, captions, img_lenghts, cap_lenghts, measure, sim_function)
-    _GRID_MEMO['key'], _GRID_MEMO['sim'] = key, sim
+    if key is not None:
+        _GRID_MEMO['key'], _GRID_MEMO['refs'], _GRID_MEMO['sim'] = key, tracked[0], sim
     return sim
 
 

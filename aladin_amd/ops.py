@@ -160,9 +160,9 @@ def _check_backward_supported(im, s, x_tail, y_tail):
     if D % 4 != 0 or D > 1024:
         raise ValueError('aladin_amd: differentiable alignment scores need D %% 4 == 0 and D <= 1024 (got D=%d); '
                          'score under torch.no_grad() or pad the feature axis' % D)
-    if R - 1 - x_tail > 126 or T - 1 - y_tail > 96:
-        raise ValueError('aladin_amd: differentiable alignment scores support at most 126 scored positions on the '
-                         'max side and 96 on the sum side (got %d, %d)' % (R - 1 - x_tail, T - 1 - y_tail))
+    if R - 1 - x_tail > 96 or T - 1 - y_tail > 96:          # = the packed geometry's own limits (aladin_align_geometry_mode)
+        raise ValueError('aladin_amd: alignment scores support at most 96 scored positions per set '
+                         '(got %d on the max side, %d on the sum side)' % (R - 1 - x_tail, T - 1 - y_tail))
 
 
 def _align_forward(im, s, im_len_t, s_len_t, x_tail=0, y_tail=2, precision=None):
@@ -724,8 +724,10 @@ def _heads_small_fwd(im, s, S, margin, max_violation, flags, temperature, eps, w
            'terms': torch.empty(3, dtype=torch.float32, device=dev),             # [matching, alignment, listnet]
            'total': torch.empty((), dtype=torch.float32, device=dev)}
     f32 = dict(dtype=torch.float32, device=dev)
-    out['dMh'] = torch.empty((B, B), **f32) if (want_grads and flags & HEAD_MATCH_HINGE) else None
-    out['dMl'] = torch.empty((B, B), **f32) if (want_grads and flags & HEAD_LISTNET) else None
+    # a head with weight 0 is computed for its logged value only (the distillation term before distill_epoch,
+    # alad_model.py:442-444): no gradient matrix is produced for it, and the kernels keep it out of the total
+    out['dMh'] = torch.empty((B, B), **f32) if (want_grads and flags & HEAD_MATCH_HINGE and weights[0] != 0) else None
+    out['dMl'] = torch.empty((B, B), **f32) if (want_grads and flags & HEAD_LISTNET and weights[2] != 0) else None
     out['dS'] = torch.empty((B, B), **f32) if (want_grads and flags & HEAD_ALIGN_HINGE) else None
     out['pairs'] = out['table_ws'] = out['sets'] = None
     if (align is not None and out['dS'] is not None and max_violation and align[4][0].mtiles == 1 and align[4][0].tp16 <= 4
@@ -772,8 +774,6 @@ class _SmallMatchDistill(torch.autograd.Function):
             t = teacher if teacher.stride(1) == 1 else teacher.contiguous()
         flags = (HEAD_MATCH_HINGE if want_hinge else 0) | (HEAD_LISTNET if t is not None else 0)
         need = any(ctx.needs_input_grad[:2])
-        if not flags:                                         # scores only
-            return im.new_zeros(()), im.new_zeros(()), _DotScores.apply(im, s)
         o = _heads_small_fwd(im, s, t, margin, max_violation, flags, temperature, eps, (1.0, 1.0, 1.0), need, False)
         ctx.save_for_backward(im, s, o['dMh'], o['dMl'])
         ctx.set_materialize_grads(False)
@@ -892,7 +892,7 @@ class _BigHeads(torch.autograd.Function):
             if flags & HEAD_MATCH_HINGE:
                 _, dMh, _ = _hinge_raw(M, margin, max_violation, need_embs, loss_out=terms[0:1])
             if flags & HEAD_LISTNET:
-                dMl = torch.empty((B, B), dtype=torch.float32, device=dev) if need_embs else None
+                dMl = torch.empty((B, B), dtype=torch.float32, device=dev) if (need_embs and weights[2] != 0) else None
                 ws = _workspace(lib.aladin_listnet_workspace_bytes(B), dev)
                 _lib.check(lib.aladin_listnet_fwd_bwd(_ptr(S), _ld(S), _ptr(M), _ld(M), B, float(temperature), float(eps),
                                                       C.c_void_p(terms.data_ptr() + 8), _ptr(dMl), _ptr(ws), _stream()),
@@ -983,6 +983,8 @@ def small_batch_match_distill(im, s, teacher, margin, max_violation, want_hinge=
         if tuple(teacher.shape) != (im.shape[0], im.shape[0]):
             raise ValueError('aladin_amd: teacher scores must be (B, B)')
         teacher = teacher.detach()
+    if not want_hinge and teacher is None:                    # scores only: the plain differentiable dot-product node
+        return im.new_zeros(()), im.new_zeros(()), dot_scores(im, s)
     return _SmallMatchDistill.apply(im, s, teacher, margin, max_violation, want_hinge, temperature, eps)
 
 

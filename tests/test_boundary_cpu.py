@@ -215,3 +215,65 @@ def test_encode_data_store_layout():
     assert torch.all(img[:, 0, :] == 7.0) and torch.all(cap[:, 0, :] == -7.0)
     assert torch.equal(img[2:4, 1:9, :], batches[1][0][0][:, 1:9, :8]) and torch.all(img[:, 9:, :] == 0)
     assert torch.equal(cap[4:6, 1:6, :], batches[2][1][0][:, 1:6, :8]) and torch.all(cap[:, 6:, :] == 0)
+
+
+# ------------------------------------------------------------------------------------------------
+# The i2t / t2i score-grid memo (aladin_amd/evaluation.py): a hit needs the same LIVE input objects.
+# ------------------------------------------------------------------------------------------------
+def test_eval_grid_memo_is_keyed_on_live_objects_not_addresses(monkeypatch):
+    """Two validations in one process: encode_data returns fresh buffers of the same shape, filled by the same number of
+    in-place writes, and the allocator hands them the block the previous ones freed.  The second validation must NOT be
+    served the first one's grid (reference alad/evaluation.py:158-327 recomputes every call; train.py:504-509 calls
+    i2t then t2i on the same embeddings, which is the one reuse the memo exists for)."""
+    import gc
+    import weakref
+    import torch
+    from aladin_amd import evaluation as E
+    calls = []
+
+    def fake_scores(images, captions, il, cl, measure, fn):
+        calls.append(float(images.sum()))
+        return torch.full((len(images) // 5, len(captions)), float(images.sum()))
+    monkeypatch.setattr(E, '_eval_scores_uncached', fake_scores)
+    E.clear_eval_cache()
+
+    def buffers(fill):
+        a, b = torch.zeros((10, 7, 4)), torch.zeros((10, 7, 4))
+        a[:, :3] = fill                                  # same number of in-place fills whatever the content
+        b[:, :3] = -fill
+        return a, b
+    il, cl = [5] * 10, [6] * 10
+    a, b = buffers(1.0)
+    key_before = E._memo_key(a, b, il, cl, 'dot', None)[0]
+    s1 = E._eval_scores(a, b, il, cl, 'dot', None)
+    s2 = E._eval_scores(a, b, il, cl, 'dot', None)          # i2t then t2i: one grid
+    assert len(calls) == 1 and s1 is s2
+    wa = weakref.ref(a)
+    del a, b, s1, s2
+    gc.collect()
+    assert wa() is None, 'the memo must not keep the embedding buffers alive'
+    a, b = buffers(2.0)                                  # the next validation: same shapes, versions, very likely same addresses
+    assert E._memo_key(a, b, il, cl, 'dot', None)[0][0][2:] == key_before[0][2:]      # indistinguishable by shape / version
+    s3 = E._eval_scores(a, b, il, cl, 'dot', None)
+    assert len(calls) == 2 and float(s3[0, 0]) == calls[1] != calls[0]
+    a[0, 0, 0] += 1.0                                    # in-place update: version counter moves
+    E._eval_scores(a, b, il, cl, 'dot', None)
+    assert len(calls) == 3
+    E._eval_scores(a, b, il, [7] * 10, 'dot', None)      # other lengths
+    assert len(calls) == 4
+
+    class Crit:
+        def sim(self, *args):
+            return None
+    c = Crit()
+    E._eval_scores(a, b, il, cl, 'dot', c.sim)            # a bound method is a new object per access: never memoised
+    E._eval_scores(a, b, il, cl, 'dot', c.sim)
+    assert len(calls) == 6
+    fn = lambda *args: None                              # noqa: E731  a plain function object is tracked
+    E._eval_scores(a, b, il, cl, 'dot', fn)
+    E._eval_scores(a, b, il, cl, 'dot', fn)
+    assert len(calls) == 7
+    E._eval_scores(a.numpy(), b.numpy(), il, cl, 'dot', None)     # numpy inputs have no version counter: not memoised
+    E._eval_scores(a.numpy(), b.numpy(), il, cl, 'dot', None)
+    assert len(calls) == 9
+    E.clear_eval_cache()

@@ -42,13 +42,23 @@ def eval_precision(request):
     E.clear_eval_cache()
 
 
-def assert_scores_close(S, ref, rtol=RTOL, atol_rel=5e-4, scale='mean'):
-    """|S - ref| <= rtol*|ref| + atol_rel*scale, scale = mean (or max) |ref|: elements that happen
-    to be near zero are judged against the magnitude of the score matrix."""
+SCORE_ERR_LOG = []          # (test id, worst |S - ref| / (rtol |ref| + atol)) per call; conftest writes it out on the GPU box
+
+
+def assert_scores_close(S, ref, rtol=RTOL, atol_rel=1e-4, scale='mean'):
+    """|S - ref| <= rtol*|ref| + atol_rel*scale, scale = mean (or max) |ref|.  north_star's tolerance is 1e-3
+    relative; the absolute term (a TENTH of that, of the matrix's typical magnitude) only covers elements that
+    cancel to ~0, for which a relative bound is meaningless.  fp16 operands measure ~1e-4 relative."""
+    import os
     S = np.asarray(S, np.float64)
     ref = np.asarray(ref, np.float64)
     mag = np.abs(ref).max() if scale == 'max' else np.abs(ref).mean()
-    np.testing.assert_allclose(S, ref, rtol=rtol, atol=atol_rel * max(1e-6, mag))
+    atol = atol_rel * max(1e-6, mag)
+    if S.shape == ref.shape and S.size:
+        worst = float((np.abs(S - ref) / (rtol * np.abs(ref) + atol)).max())
+        rel = float((np.abs(S - ref) / np.maximum(np.abs(ref), 1e-3 * max(1e-6, mag))).max())
+        SCORE_ERR_LOG.append((os.environ.get('PYTEST_CURRENT_TEST', '?'), round(worst, 4), float('%.3g' % rel)))
+    np.testing.assert_allclose(S, ref, rtol=rtol, atol=atol)
 
 
 def test_extension_is_loaded():
@@ -868,6 +878,33 @@ def test_b256_scores_vs_oracle_and_properties():
     S2 = ops.alignment_scores(T(im3), T(s3), il2, sl2)
     assert torch.equal(S1, S2)
     assert_scores_close(S1.cpu().numpy(), O.alignment_scores(im2, s2, il2, sl2))
+
+
+@pytest.mark.parametrize('ragged', [True, False])
+def test_b256_triplet_step_gradients_vs_oracle(ragged):
+    """BASELINE configs[1] size: loss AND gradient VALUES of the B = 256 triplet step against the oracle (float64
+    closed form of the autograd of alad/loss.py:79-159, chained on the HIP S like the shape sweep).  The hinge
+    leaves <= 3B non-zero pairs, so the oracle's per-pair loop finishes in seconds."""
+    from aladin_amd import synth
+    from aladin_amd.loss import AlignmentContrastiveLoss
+    B = 256
+    if ragged:
+        im, s, il, sl = synth.structured_alignment_batch(B, 34, 50, 768, seed=77, noise=3.0, ragged=True)
+    else:
+        im, s, il, sl = synth.alignment_batch(B, 34, 50, 768, seed=1234, ragged=False)       # the bench batch
+    a, b = T(im).requires_grad_(True), T(s).requires_grad_(True)
+    crit = AlignmentContrastiveLoss(margin=0.2, measure='dot', max_violation=True, aggregation='MrSw')
+    loss, S = crit(a, b, il, sl, return_similarity_mat=True)
+    loss.backward()
+    S_np = S.detach().cpu().numpy()
+    assert_scores_close(S_np, O.alignment_scores(im, s, il, sl))
+    ref_loss, dS = O.hinge_loss(S_np, 0.2, True, return_grad=True)
+    np.testing.assert_allclose(loss.item(), ref_loss, rtol=1e-5)
+    assert 0 < (dS != 0).sum() <= 3 * B
+    dim, ds = O.alignment_scores_backward(im, s, il, sl, dS)
+    for got, ref in ((a.grad, dim), (b.grad, ds)):
+        scale = max(1e-9, float(np.abs(ref).max()))
+        np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=1e-3, atol=2e-5 * scale)
 
 
 def test_b256_triplet_step_gradient_sparsity():
