@@ -17,8 +17,11 @@ from .loss import AlignmentContrastiveLoss, ContrastiveLoss, DistillationLoss, d
 
 
 class ALADModel(nn.Module):
-    def __init__(self, config, oscar_checkpoint=None, encoder=None, backbone=None):
-        """encoder: any module with the 7-tuple contract of JointTextImageTransformerEncoder; or backbone: the
+    def __init__(self, config, oscar_checkpoint=None, encoder=None, backbone=None, shard_group=False):
+        """shard_group: False = single device (the reference, alad/train.py:251-255); None or a torch.distributed group =
+        one process per GPU, the loss heads run on the GLOBAL batch (all ranks' samples) with the score matrices sharded
+        by caption block (aladin_amd.distributed.sharded_loss_heads; BASELINE configs[3] for the shipped YAMLs).
+        encoder: any module with the 7-tuple contract of JointTextImageTransformerEncoder; or backbone: the
         VinVL/Oscar model (anything with the `.bert(...)` call of alad_model.py:129,139), around which
         aladin_amd.encoder.JointTextImageTransformerEncoder -- matching head included -- is built here as
         the reference does at :259."""
@@ -53,6 +56,7 @@ class ALADModel(nn.Module):
         self.config = config
         self.logger = None
         self.pending_log = None
+        self.shard_group = shard_group
 
     def forward_emb(self, example_imgs, example_txts):
         """reference alad_model.py:325-348 (host->device copies + encoder call)."""
@@ -171,6 +175,9 @@ class ALADModel(nn.Module):
         For the shipped configurations the whole thing is ONE autograd node (no element-wise glue; three head launches at
         bs <= 64): the terms of `loss_dict` are then detached values for logging, `loss` carries the graph.
         Otherwise it is forward_loss followed by weighted_total."""
+        if self.shard_group is not False:
+            return self._sharded_loss_total(img_emb, cap_emb, img_emb_set, cap_emb_seq, img_lengths, cap_lengths, epoch,
+                                            distill_epoch, log)
         if not self._fused_heads_ok(img_emb):
             d = self.forward_loss(img_emb, cap_emb, img_emb_set, cap_emb_seq, img_lengths, cap_lengths, reg_loss, log=log)
             return self.weighted_total(d, epoch, distill_epoch), d
@@ -190,6 +197,33 @@ class ALADModel(nn.Module):
         if log:
             self.flush_log()
         return total, {k: terms[idx[k]] for k in heads}
+
+    def _sharded_loss_total(self, img_emb, cap_emb, img_emb_set, cap_emb_seq, img_lengths, cap_lengths, epoch, distill_epoch,
+                            log=True):
+        """forward_loss_total on the global batch of all ranks (self.shard_group): the same terms, gating, weights and
+        logger keys as the single-device path on the concatenated batch; logged with n = the GLOBAL batch size."""
+        from . import distributed as AD
+        import torch.distributed as dist
+        if not self._fused_heads_ok(img_emb):
+            raise NotImplementedError('aladin_amd: the sharded step covers the shipped configurations (dot measure, MrSw, '
+                                      'listnet, fixed loss weights); got %r' % (self.config['training'],))
+        wants_matching = 'matching' in self.config['training']['loss-type']
+        logged_heads = [k for k in ('matching', 'alignment', 'distillation')
+                        if (k in self.losses_types) and (k != 'matching' or wants_matching)]
+        heads = list(logged_heads)
+        if epoch < distill_epoch and len(heads) > 1 and 'distillation' in heads:       # :442-444
+            heads.remove('distillation')
+        mc = self.matching_criterion
+        total, terms, _, _ = AD.sharded_loss_heads(
+            img_emb, cap_emb, img_emb_set.permute(1, 0, 2), cap_emb_seq.permute(1, 0, 2), img_lengths, cap_lengths,
+            mc.margin, mc.max_violation, logged_heads, {k: (self.losses_weights[k] if k in heads else 0.0) for k in logged_heads},
+            group=self.shard_group)
+        n = img_emb.size(0) * dist.get_world_size(self.shard_group)
+        names = {'matching': 'matching_loss', 'alignment': 'alignment_loss', 'distillation': 'distillation_loss'}
+        self.pending_log = [(names[k], terms[k], n) for k in logged_heads]
+        if log:
+            self.flush_log()
+        return total, {k: terms[k] for k in heads}
 
     def forward(self, example_imgs, example_txts, epoch=0, distill_epoch=2):
         """reference alad_model.py:430-454."""

@@ -362,3 +362,71 @@ def sharded_alignment_loss_fast(im_set, s_seq, im_len, s_len, margin=0.2, max_vi
     from . import ops
     im_len_t, s_len_t = ops._check_sets(im_set, s_seq, im_len, s_len)
     return _ShardedTriplet.apply(im_set, s_seq, im_len_t, s_len_t, margin, max_violation, group, exchange)
+
+
+# ------------------------------------------------------------------------------------------------
+# All loss heads of a training step on the GLOBAL batch (reference alad/alad_model.py:371-454 on the
+# concatenation of every rank's samples): the shipped distillation configs across the GPUs of a node.
+# ------------------------------------------------------------------------------------------------
+def sharded_loss_heads(img_emb, cap_emb, im_set, s_seq, im_len, s_len, margin, max_violation, heads, weights,
+                       group=None, exchange='auto', temperature=6.0, eps=1e-10,
+                       align_fn=None, dot_fn=None, hinge_fn=None, listnet_fn=None):
+    """Matching hinge, alignment hinge and ListNet distillation of the global batch, every rank passing its local
+    (B, D) global embeddings and (B, R, D) / (B, T, D) sets -> (total, terms, S_full, M_full):
+
+        total   sum_k w_k L_k over `heads` with a non-zero weight (alad_model.py:450-453), replicated on every rank
+        terms   dict head -> loss value (detached; a head in `heads` with weight 0 is computed for logging only,
+                like the distillation term before distill_epoch, :442-444)
+        S_full  (W*B, W*B) alignment scores (the detached teacher, alad/loss.py:370) or None
+        M_full  (W*B, W*B) matching scores or None
+
+    Sharding = caption blocks, as for the alignment triplet (module docstring): rank r owns column block r of BOTH
+    score matrices.  The image-side operands are all-gathered (packed fp16 sets for S, the (B, D) fp32 global
+    embeddings for M), each rank computes its (W*B x B) blocks, the blocks are all-gathered (2 x 2 MB per rank at
+    B=256, W=8) and the heads run on the replicated matrices -- the row-wise softmaxes / maxima of alad/loss.py:
+    431-445 and :60-67 need every caption block.  Backward: a rank keeps its own column block of dL/dM and dL/dS;
+    d(cap_emb), d(s_seq) are local, d(img_emb) is a reduce-scatter of (W*B, D), d(im_set) the alignment exchange.
+    Same gradient convention as sharded_alignment_loss_fast (the loss is the global loss on every rank).
+    The *_fn hooks default to the HIP ops; the CPU tests inject the oracle."""
+    heads = list(heads)
+    unknown = set(heads) - {'matching', 'alignment', 'distillation'}
+    if unknown or not heads:
+        raise ValueError('aladin_amd.distributed: heads must be a non-empty subset of matching / alignment / distillation')
+    from . import ops
+    dot_fn = dot_fn or ops.dot_scores
+    hinge_fn = hinge_fn or ops.hinge_loss
+    listnet_fn = listnet_fn or (lambda t, m: ops.listnet_loss(t, m, temperature, eps))
+    w = {k: float(weights.get(k, 0.0)) for k in heads}
+    terms, S_full, M_full = {}, None, None
+    total = None
+
+    def add(k, value):
+        nonlocal total
+        terms[k] = value.detach()
+        if w[k] != 0.0:
+            total = value * w[k] if total is None else total + value * w[k]
+
+    if 'alignment' in heads or 'distillation' in heads:
+        if align_fn is None:
+            def align_fn(a, b, al, bl):
+                return sharded_alignment_loss_fast(a, b, al, bl, margin, max_violation, group=group, exchange=exchange)
+        live = 'alignment' in heads and w['alignment'] != 0.0
+        if live:
+            a_loss, S_full = align_fn(im_set, s_seq, im_len, s_len)
+        else:                                        # teacher only (or logged only): no backward through the sets
+            with torch.no_grad():
+                a_loss, S_full = align_fn(im_set.detach(), s_seq.detach(), im_len, s_len)
+        S_full = S_full.detach()
+    if 'matching' in heads or 'distillation' in heads:
+        img_all = _AllGatherRows.apply(img_emb, group)                      # (W*B, D)
+        M_full = _GatherColumnBlocks.apply(dot_fn(img_all, cap_emb), group)  # (W*B, W*B), differentiable
+    # the reference's key order: matching, alignment, distillation (alad_model.py:380-408)
+    if 'matching' in heads:
+        add('matching', hinge_fn(M_full, margin, max_violation))
+    if 'alignment' in heads:
+        add('alignment', a_loss)
+    if 'distillation' in heads:
+        add('distillation', listnet_fn(S_full, M_full))
+    if total is None:
+        raise ValueError('aladin_amd.distributed: every selected head has weight 0')
+    return total, terms, S_full, (M_full.detach() if M_full is not None else None)

@@ -127,3 +127,130 @@ def test_sparse_image_exchange_world3():
                 used = np.nonzero((dS[r * B:(r + 1) * B, b * B:(b + 1) * B] != 0).any(axis=1))[0]
                 want[used] += _contribution(used + r * B, b, R, D)
             np.testing.assert_allclose(d_local, want, rtol=1e-6)
+
+
+# ------------------------------------------------------------------------------------------------
+# sharded_loss_heads: matching hinge + alignment hinge + ListNet of the GLOBAL batch (the shipped distillation YAMLs
+# across ranks, reference alad/alad_model.py:371-454 on the concatenated batch), gloo, world_size 2
+# ------------------------------------------------------------------------------------------------
+def _torch_listnet(teacher, student, temperature=6.0, eps=1e-10):
+    """alad/loss.py:427-445 as written, in torch (autograd for the test); checked against the pinned numpy oracle below."""
+    t = teacher.detach()
+    loss = 0
+    for dim in (1, 0):
+        p = torch.softmax(t, dim=dim)
+        q = torch.softmax(temperature * student, dim=dim) + eps
+        loss = loss + torch.mean(-torch.sum(p * torch.log(q), dim=dim))
+    return loss
+
+
+HEADS_CASES = [
+    (['matching', 'alignment', 'distillation'], {'matching': 0.1, 'alignment': 1.0, 'distillation': 1.0}),
+    (['alignment', 'distillation'], {'alignment': 1.0, 'distillation': 1.0}),                 # alad-alignment-and-matching-distill.yaml
+    (['alignment', 'distillation'], {'alignment': 1.0, 'distillation': 0.0}),                 # the same before distill_epoch
+    (['matching'], {'matching': 1.0}),
+]
+
+
+def _heads_inputs(world, B, R, T, D):
+    from aladin_amd import synth
+    im, s, il, sl = synth.structured_alignment_batch(B * world, R, T, D, seed=654, noise=3.0, ragged=True)
+    ie, ce = synth.global_embeddings(B * world, D, seed=655, noise=3.0)
+    return im, s, il, sl, ie, ce
+
+
+def _heads_total(ie, ce, im, s, il, sl, heads, w, align_fn):
+    """Single-process statement with the same building blocks."""
+    import faithful_torch as FT
+    total, terms = 0, {}
+    S = None
+    if 'alignment' in heads or 'distillation' in heads:
+        a_loss, S = align_fn(im, s, il, sl)
+    M = ie @ ce.t()
+    if 'matching' in heads:
+        terms['matching'] = FT.hinge_faithful(M, 0.2, True)
+    if 'alignment' in heads:
+        terms['alignment'] = a_loss
+    if 'distillation' in heads:
+        terms['distillation'] = _torch_listnet(S, M)
+    for k in heads:
+        if w[k] != 0:
+            total = total + w[k] * terms[k]
+    return total, terms
+
+
+def _heads_worker(rank, world, port, ret):
+    for p in (ROOT, os.path.join(ROOT, 'oracle')):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as dist
+    import faithful_torch as FT
+    from aladin_amd.distributed import sharded_alignment_loss, sharded_loss_heads
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    B, R, T, D = 4, 12, 15, 32
+    im, s, il, sl, ie, ce = _heads_inputs(world, B, R, T, D)
+    sl_ = slice(rank * B, (rank + 1) * B)
+
+    def align_fn(a, b, al, bl):
+        return sharded_alignment_loss(
+            a, b, al, bl, 0.2, True,
+            scores_fn=lambda x, y, xl, yl: FT.alignment_scores_faithful(x, y, [int(v) for v in xl], [int(v) for v in yl]),
+            hinge_fn=FT.hinge_faithful)
+    out = []
+    for heads, w in HEADS_CASES:
+        leaves = [torch.from_numpy(x[sl_].copy()).requires_grad_(True) for x in (ie, ce, im, s)]
+        total, terms, S_full, M_full = sharded_loss_heads(
+            leaves[0], leaves[1], leaves[2], leaves[3], il[sl_], sl[sl_], 0.2, True, heads, w,
+            align_fn=align_fn, dot_fn=lambda a, b: a @ b.t(), hinge_fn=FT.hinge_faithful, listnet_fn=_torch_listnet)
+        total.backward()
+        out.append((total.item(), {k: v.item() for k, v in terms.items()},
+                    None if S_full is None else S_full.numpy(), None if M_full is None else M_full.numpy(),
+                    [None if t.grad is None else t.grad.numpy() for t in leaves]))
+    ret[rank] = out
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_sharded_loss_heads_equal_the_single_process_step():
+    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    import alad_oracle as O
+    import faithful_torch as FT
+    world, B, R, T, D = 2, 4, 12, 15, 32
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 33500 + (os.getpid() % 2000)
+    mp.spawn(_heads_worker, args=(world, port, ret), nprocs=world, join=True)
+    im, s, il, sl, ie, ce = _heads_inputs(world, B, R, T, D)
+
+    def align_fn(a, b, al, bl):
+        S = FT.alignment_scores_faithful(a, b, al, bl)
+        return FT.hinge_faithful(S, 0.2, True), S
+    for case, (heads, w) in enumerate(HEADS_CASES):
+        leaves = [torch.from_numpy(x.copy()).requires_grad_(True) for x in (ie, ce, im, s)]
+        total, terms = _heads_total(leaves[0], leaves[1], leaves[2], leaves[3], il, sl, heads, w, align_fn)
+        total.backward()
+        # the torch building blocks against the pinned numpy oracle (reference alad_model.py:371-428 on the whole batch)
+        ref = O.forward_loss(ie, ce, im.transpose(1, 0, 2), s.transpose(1, 0, 2), il, sl, 'alignment-distillation-matching')
+        for k in heads:
+            np.testing.assert_allclose(terms[k].item(), float(ref[k]), rtol=2e-5)
+        for r in range(world):
+            tot_r, terms_r, S_r, M_r, grads_r = ret[r][case]
+            np.testing.assert_allclose(tot_r, total.item(), rtol=1e-6)
+            assert list(terms_r) == [k for k in ('matching', 'alignment', 'distillation') if k in heads]      # the reference's key order
+            for k in heads:
+                np.testing.assert_allclose(terms_r[k], terms[k].item(), rtol=1e-6)
+            if 'matching' in heads or 'distillation' in heads:
+                np.testing.assert_allclose(M_r, O.dot_scores(ie, ce), rtol=1e-5, atol=1e-6)
+            if 'alignment' in heads or 'distillation' in heads:
+                np.testing.assert_allclose(S_r, O.alignment_scores(im, s, il, sl), rtol=1e-5, atol=1e-5)
+            for got, leaf in zip(grads_r, leaves):
+                if leaf.grad is None:
+                    assert got is None or not np.any(got)
+                    continue
+                want = leaf.grad.numpy()[r * B:(r + 1) * B]
+                assert got is not None
+                np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-7)

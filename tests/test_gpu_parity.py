@@ -45,19 +45,24 @@ def eval_precision(request):
 SCORE_ERR_LOG = []          # (test id, worst |S - ref| / (rtol |ref| + atol)) per call; conftest writes it out on the GPU box
 
 
-def assert_scores_close(S, ref, rtol=RTOL, atol_rel=1e-4, scale='mean'):
-    """|S - ref| <= rtol*|ref| + atol_rel*scale, scale = mean (or max) |ref|.  north_star's tolerance is 1e-3
-    relative; the absolute term (a TENTH of that, of the matrix's typical magnitude) only covers elements that
-    cancel to ~0, for which a relative bound is meaningless.  fp16 operands measure ~1e-4 relative."""
+def assert_scores_close(S, ref, rtol=RTOL, atol_rel=3e-4, scale='max'):
+    """|S - ref| <= rtol*|ref| + atol_rel*scale, scale = max (or mean) |ref|.  north_star's tolerance is 1e-3
+    relative.  A score is a SUM of signed cosines, each carrying an absolute error of ~1e-4 from the fp16 rounding of
+    its operands whatever the sum comes to, so an element that cancels to ~0 cannot be held to a relative bound: the
+    absolute term judges it against the matrix's largest score."""
     import os
     S = np.asarray(S, np.float64)
     ref = np.asarray(ref, np.float64)
     mag = np.abs(ref).max() if scale == 'max' else np.abs(ref).mean()
     atol = atol_rel * max(1e-6, mag)
     if S.shape == ref.shape and S.size:
-        worst = float((np.abs(S - ref) / (rtol * np.abs(ref) + atol)).max())
-        rel = float((np.abs(S - ref) / np.maximum(np.abs(ref), 1e-3 * max(1e-6, mag))).max())
-        SCORE_ERR_LOG.append((os.environ.get('PYTEST_CURRENT_TEST', '?'), round(worst, 4), float('%.3g' % rel)))
+        err = np.abs(S - ref)
+        SCORE_ERR_LOG.append((os.environ.get('PYTEST_CURRENT_TEST', '?'), {
+            'frac_of_tol': round(float((err / (rtol * np.abs(ref) + atol)).max()), 4),
+            'max_abs_err': float('%.3g' % err.max()), 'max_abs_ref': float('%.3g' % np.abs(ref).max()),
+            'mean_abs_ref': float('%.3g' % np.abs(ref).mean()),
+            'max_err_over_max_ref': float('%.3g' % (err.max() / max(1e-30, np.abs(ref).max()))),
+            'max_rel_err_where_ref_ge_tenth_of_max': float('%.3g' % (err / np.maximum(np.abs(ref), 1e-30))[np.abs(ref) >= 0.1 * np.abs(ref).max()].max())}))
     np.testing.assert_allclose(S, ref, rtol=rtol, atol=atol)
 
 
@@ -1151,7 +1156,7 @@ def test_alignment_scores_shape_sweep(shape, eval_precision):
     else:
         # tiny D (8..40): few, large vector components, so the fp16 operand rounding (2^-11 relative per
         # component) is not averaged down as at D=768; still within 1e-3 of the score magnitude
-        assert_scores_close(S, ref, rtol=1e-3, atol_rel=1e-3, scale='max')
+        assert_scores_close(S, ref)
 
 
 @pytest.mark.parametrize('R', [35, 36, 37, 38, 39, 40, 41, 66])
@@ -1165,7 +1170,7 @@ def test_leftover_regions_as_side_rows(R):
     il[0], il[1], il[2] = R, R - 1, 33                     # full length, one short of it, exactly the main tile
     a, b = T(im).requires_grad_(True), T(s).requires_grad_(True)
     S = ops.alignment_scores(a, b, il, sl)
-    assert_scores_close(S.detach().cpu().numpy(), O.alignment_scores(im, s, il, sl), scale='max')
+    assert_scores_close(S.detach().cpu().numpy(), O.alignment_scores(im, s, il, sl))
     w = np.random.default_rng(R).standard_normal((Bi, Bc)).astype(np.float32)
     w *= np.random.default_rng(R + 1).random((Bi, Bc)) < 0.25
     (S * T(w)).sum().backward()
@@ -1406,6 +1411,65 @@ def test_sharded_fast_path_under_rccl_world1():
         np.testing.assert_allclose(b3.grad.cpu().numpy(), b2.grad.cpu().numpy(), rtol=1e-5, atol=1e-6 * scale)
         with pytest.raises(ValueError):
             sharded_alignment_loss_fast(T(im[:10]), T(s[:10]), il[:10], sl[:10])
+    finally:
+        if created:
+            dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('loss_type,weights', [('alignment-distillation', [1, 1]), ('alignment-distillation-matching', [1, 1, 0.1]),
+                                               ('matching', [1]), ('alignment', [1])])
+def test_sharded_model_step_under_rccl_world1(loss_type, weights, eval_precision):
+    """ALADModel(shard_group=None): forward_loss_total over aladin_amd.distributed.sharded_loss_heads on the real backend
+    (RCCL, one rank: every collective and autograd wrapper runs on the device) must give the single-device model's
+    terms, total, logger entries and gradients -- for the shipped distillation YAML's loss types, before and after
+    distill_epoch, at the YAML's bs 32 and at bs 64 (the cross-rank logic is covered under gloo, world 2, in
+    tests/test_distributed_cpu.py)."""
+    if eval_precision != 'fp16':
+        pytest.skip('differentiable path only; run once')
+    import os
+    import torch.distributed as dist
+    from aladin_amd import synth
+    from aladin_amd.alad_model import ALADModel
+    from aladin_amd.evaluation import LogCollector
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29613')
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev())
+        created = True
+    try:
+        config = {'training': {'loss-type': loss_type, 'loss-weights': weights, 'margin': 0.2, 'measure': 'dot',
+                               'max-violation': True, 'alignment-mode': 'MrSw', 'distillation-mode': 'listnet'}}
+        for B in (64, 128):                             # the fast sharded path needs a per-rank batch of whole 64-row groups
+            im, s, il, sl = synth.structured_alignment_batch(B, 34, 50, 768, seed=900 + B, noise=3.0, ragged=True)
+            ie, ce = synth.global_embeddings(B, 768, seed=901 + B, noise=3.0)
+            for epoch in (0, 5):
+                res = []
+                for shard in (False, None):
+                    m = ALADModel(config, shard_group=shard)
+                    m.logger = LogCollector()
+                    leaves = [T(x).requires_grad_(True) for x in (ie, ce, im, s)]
+                    sets = (leaves[0], leaves[1], leaves[2].permute(1, 0, 2), leaves[3].permute(1, 0, 2), il, sl, 0)
+                    m.forward_emb = lambda a, b, _s=sets: _s
+                    loss, d = m.forward(None, None, epoch=epoch, distill_epoch=2)
+                    loss.backward()
+                    res.append((loss.detach(), d, m.logger, leaves))
+                (l0, d0, g0, x0), (l1, d1, g1, x1) = res
+                assert list(d0.keys()) == list(d1.keys())
+                np.testing.assert_allclose(float(l1), float(l0), rtol=1e-6)
+                for k in d0:
+                    np.testing.assert_allclose(float(d1[k]), float(d0[k]), rtol=1e-6)
+                assert list(g0.meters.keys()) == list(g1.meters.keys())
+                for k in g0.meters:
+                    np.testing.assert_allclose(g1.meters[k].val, g0.meters[k].val, rtol=1e-6)
+                    assert g1.meters[k].count == g0.meters[k].count              # world 1: global batch == local batch
+                for a, b in zip(x0, x1):
+                    if a.grad is None:
+                        assert b.grad is None or not bool(b.grad.any())
+                        continue
+                    scale = float(a.grad.abs().max())
+                    np.testing.assert_allclose(b.grad.cpu().numpy(), a.grad.cpu().numpy(), rtol=1e-5, atol=1e-6 * scale)
     finally:
         if created:
             dist.destroy_process_group()
@@ -1669,7 +1733,7 @@ def test_degenerate_lengths_and_zero_vectors():
     S_np = S.detach().cpu().numpy()
     assert np.isfinite(S_np).all()
     assert np.all(S_np[:, 0] == 0) and np.all(S_np[0, :] == 0)
-    assert_scores_close(S_np, ref, atol_rel=1e-3, scale='max')
+    assert_scores_close(S_np, ref)
     loss = ops.hinge_loss(S, 0.2, True)
     loss.backward()
     ga, gb = a.grad.cpu().numpy(), b.grad.cpu().numpy()
@@ -1698,7 +1762,7 @@ def test_backward_exact_ties_and_full_candidate_list():
     a, b = T(im).requires_grad_(True), T(s).requires_grad_(True)
     S = ops.alignment_scores(a, b, il, sl)
     S_np = S.detach().cpu().numpy()
-    assert_scores_close(S_np, O.alignment_scores(im, s, il, sl), atol_rel=1e-3, scale='max')
+    assert_scores_close(S_np, O.alignment_scores(im, s, il, sl))
     dS = np.zeros((B, B), dtype=np.float32)
     dS[0, 0], dS[0, 3], dS[1, 1], dS[1, 4], dS[2, 2], dS[3, 0], dS[4, 5] = 1.0, -0.5, 1.0, 0.25, -1.0, 0.75, 2.0
     (S * T(dS)).sum().backward()
