@@ -26,9 +26,9 @@ class ALADModel(nn.Module):
         aladin_amd.encoder.JointTextImageTransformerEncoder -- matching head included -- is built here as
         the reference does at :259."""
         super().__init__()
-        if encoder is None and backbone is not None:
+        if encoder is None and (backbone is not None or oscar_checkpoint is not None):
             from .encoder import JointTextImageTransformerEncoder
-            encoder = JointTextImageTransformerEncoder(config, backbone)
+            encoder = JointTextImageTransformerEncoder(config, backbone, oscar_checkpoint)     # :259
         self.img_txt_enc = encoder                                   # alad_model.py:259 (injected here)
         training = config['training']
         self.losses_types = training['loss-type'].split('-')          # :265

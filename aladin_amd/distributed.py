@@ -193,13 +193,39 @@ def rank_backward_block(im_all, il_all_t, s_local, s_len_t, dS_full, rank, g_glo
                                packed=(g_glob, xm_all, xe_all, y))
 
 
+class _PinnedPool:
+    """A few pinned host buffers handed out in rotation for asynchronous device->host copies: a buffer comes back
+    only after the copy last issued into it has completed (event), so a plan that is never resolved cannot be
+    overwritten mid-copy and no step allocates pinned memory."""
+
+    def __init__(self, n=8):
+        self.slots, self.n, self.k = {}, n, 0
+
+    def get(self, numel):
+        key = (self.k % self.n, int(numel))
+        self.k += 1
+        buf, ev = self.slots.get(key, (None, None))
+        if buf is None:
+            buf, ev = torch.empty(int(numel), dtype=torch.int64).pin_memory(), torch.cuda.Event()
+            self.slots[key] = (buf, ev)
+        else:
+            ev.synchronize()
+        return buf, ev
+
+
+_PINNED = _PinnedPool()
+
+
 class SparseImageExchange:
     """Pair-driven exchange of image sets for the backward of a SPARSE dS (max_violation hinge).
 
     dS_full is replicated (the hinge runs on the gathered score matrix on every rank), so every rank
     derives the whole send/receive plan from it without talking: caption block b needs image i iff
-    dS_full[i, block b] has a non-zero.  One device->host copy (the W x W count matrix, needed for the
-    all-to-all split sizes) is the only synchronisation.
+    dS_full[i, block b] has a non-zero.  The split sizes of the variable-length all-to-all have to be known on
+    the HOST: the (W x W) count matrix leaves the device by an asynchronous copy issued when the plan is built (in
+    the forward) and is waited for only when the exchange is first used (fetch(), in the backward) -- the forward
+    itself never blocks the host.  (A fixed-capacity, sync-free all-to-all cannot be both exact and smaller than
+    the dense form: the only bound on what a caption block needs from one peer is that peer's whole batch.)
 
         fetch(im_local)        -> (n_need, R, D) fp32 sets of the images this rank's captions pair with,
                                   in ascending global index order (self.need_idx)
@@ -215,14 +241,39 @@ class SparseImageExchange:
         W, r = _world(group)
         self.W, self.r, self.B = W, r, B
         nz = (dS_full.view(W * B, W, B) != 0).any(dim=2).t().contiguous()          # nz[b, i]
-        counts = nz.view(W, W, B).sum(dim=2).cpu().tolist()                        # counts[b][a]; the one sync
+        counts = nz.view(W, W, B).sum(dim=2).reshape(-1)                           # counts[b * W + a]
+        self._event = None
+        if counts.is_cuda:
+            self._counts, self._event = _PINNED.get(W * W)
+            self._counts.copy_(counts, non_blocking=True)
+            self._event.record()
+        else:
+            self._counts = counts
+        # ascending indices of the True entries without a sync: stable sort of the negated mask, cut at resolve time
+        self._need_order = torch.argsort((~nz[r]).to(torch.uint8), stable=True)
+        mine = nz[:, r * B:(r + 1) * B].reshape(-1)                                # dest-major, local image minor
+        self._send_order = torch.argsort((~mine).to(torch.uint8), stable=True)
+        self._resolved = False
+
+    def _resolve(self):
+        """The one host wait of the exchange (first use)."""
+        if self._resolved:
+            return
+        if self._event is not None:
+            self._event.synchronize()
+        W, r, B = self.W, self.r, self.B
+        counts = self._counts.view(W, W).tolist()                                  # counts[b][a]
+        self._counts = None
         self.recv_splits = [int(counts[r][a]) for a in range(W)]
         self.send_splits = [int(counts[b][r]) for b in range(W)]
-        n_recv, n_send = sum(self.recv_splits), sum(self.send_splits)
-        # ascending indices of the True entries without another sync: stable sort of the negated mask
-        self.need_idx = torch.argsort((~nz[r]).to(torch.uint8), stable=True)[:n_recv]
-        mine = nz[:, r * B:(r + 1) * B].reshape(-1)                                # dest-major, local image minor
-        self.send_rows = torch.argsort((~mine).to(torch.uint8), stable=True)[:n_send] % B
+        self._need_idx = self._need_order[:sum(self.recv_splits)]
+        self.send_rows = self._send_order[:sum(self.send_splits)] % B
+        self._resolved = True
+
+    @property
+    def need_idx(self):
+        self._resolve()
+        return self._need_idx
 
     def _all_to_all(self, send, out_splits, in_splits):
         out = torch.empty((sum(out_splits),) + tuple(send.shape[1:]), dtype=send.dtype, device=send.device)
@@ -231,9 +282,11 @@ class SparseImageExchange:
         return out
 
     def fetch(self, im_local):
+        self._resolve()
         return self._all_to_all(im_local.index_select(0, self.send_rows), self.recv_splits, self.send_splits)
 
     def give_back(self, d_im_need, shape):
+        self._resolve()
         back = self._all_to_all(d_im_need, self.send_splits, self.recv_splits)
         d_im = torch.zeros(shape, dtype=d_im_need.dtype, device=d_im_need.device)
         off = 0
@@ -302,12 +355,12 @@ class _ShardedTriplet(torch.autograd.Function):
         _mark('hinge')
         ctx.exchange = None
         if need and sparse:
+            # the plan only: its split sizes travel to the host asynchronously and are first needed by the fetch, which
+            # runs in the backward -- the forward never blocks the host
             ex = SparseImageExchange(dS_full, B, group)
-            im_need = ex.fetch(im_c)
-            _mark('sparse_plan+fetch')
-            dS_need = dS_full.index_select(0, ex.need_idx)[:, r * B:(r + 1) * B].contiguous()
-            ctx.save_for_backward(im_need, il_all.index_select(0, ex.need_idx), s, s_len_t, dS_need)
-            ctx.exchange, ctx.im_shape = ex, tuple(im.shape)
+            _mark('sparse_plan')
+            ctx.save_for_backward(im_c, il_all, s, s_len_t, dS_full)
+            ctx.exchange, ctx.im_shape, ctx.rank = ex, tuple(im.shape), r
         elif need:
             ctx.save_for_backward(im_all, il_all, s, s_len_t, dS_full, xm_all, xe_all, y)
             ctx.g_glob, ctx.group = g_glob, group
@@ -321,9 +374,14 @@ class _ShardedTriplet(torch.autograd.Function):
             return (None,) * 8
         if ctx.exchange is not None:
             from . import ops
-            im_need, il_need, s, s_len_t, dS_need = ctx.saved_tensors
+            im_c, il_all, s, s_len_t, dS_full = ctx.saved_tensors
             gscale = g_loss.to(torch.float32).contiguous()
             _mark('bwd_start')
+            ex, r, B = ctx.exchange, ctx.rank, s.shape[0]
+            im_need = ex.fetch(im_c)                              # waits for the plan's split sizes (the one host sync)
+            il_need = il_all.index_select(0, ex.need_idx)
+            dS_need = dS_full.index_select(0, ex.need_idx)[:, r * B:(r + 1) * B].contiguous()
+            _mark('bwd_sparse_fetch')
             if im_need.shape[0]:
                 d_im_need, d_s = ops._align_backward(im_need, s, il_need, s_len_t, dS_need, gscale=gscale)
             else:                                  # no violation anywhere in this caption block

@@ -9,15 +9,17 @@
                                           sets are F.normalize'd and globals l2norm'd (:237-241)
     slot0_transformer                  the head evaluated for what the model consumes -- output row 0 only
 
-The VinVL / Oscar BERT itself (`oscar/modeling/modeling_bert.py:150-279` over the un-vendored
-`transformers@067923d`) stays out of scope: it is INJECTED as `backbone`, any module with the
+The VinVL / Oscar BERT (`oscar/modeling/modeling_bert.py:150-279`) is aladin_amd/backbone.py; it -- or any module with the
 `.bert(input_ids=, attention_mask=, token_type_ids=, img_feats=) -> (sequence_output, ...)` call the reference
-makes (alad_model.py:129,139) ("parity unpinned" for the backbone; tests/standins.py holds a random-init
-substitute with that call surface for the shape-level tests).
+makes (alad_model.py:129,139) -- is handed in as `backbone`, or built from a VinVL checkpoint directory
+(`oscar_checkpoint`, as the reference does at :40-43).
 
 This module is host code on PyTorch-ROCm (north_star: "host code stays Python on PyTorch-ROCm for the
-backbone"); parameter names equal the reference's, so `img_txt_enc.final_projection_net.*` entries of a
-reference checkpoint load unchanged.  Only `l2norm` runs in this package's HIP kernels.
+backbone").  Parameter names equal the reference's and the two projections the reference constructs but never calls
+for these configurations (`img_proj`, `cap_proj`, :55-56) are kept, so the `img_txt_enc.*` entries of a reference
+ALADIN checkpoint (train.py:329-337) load with strict=True: oscar_model.bert.*, oscar_model.classifier.*, img_proj.*,
+cap_proj.*, final_projection_net.* (the 'first' aggregators of the shipped YAMLs hold no parameters).
+Only `l2norm` runs in this package's HIP kernels.
 """
 import torch
 from torch import nn
@@ -84,9 +86,18 @@ class JointTextImageTransformerEncoder(nn.Module):
         examples_imgs = (input_ids, attention_mask, token_type_ids, img_feats, <unused>, feat_len)
     and returns (img_glob (B,D), cap_glob (B,D), img_set (R,B,D), cap_seq (T,B,D), feat_len, cap_len, reg_loss)."""
 
-    def __init__(self, config, backbone):
+    def __init__(self, config, backbone=None, oscar_checkpoint=None):
         super().__init__()
         m = config['model']
+        if backbone is None:
+            if oscar_checkpoint is None:
+                raise ValueError('aladin_amd.encoder: pass a backbone module or the VinVL checkpoint directory')
+            from .backbone import BertConfig, ImageBertForSequenceClassification
+            bert_config = BertConfig.from_pretrained(oscar_checkpoint)                  # alad_model.py:40-43
+            # the reference switches output_attentions / output_hidden_states on here (:41-42) and reads the extra
+            # outputs only under depth aggregation, which the supported configurations do not use: left off, so that
+            # attention runs as one fused kernel per layer
+            backbone = ImageBertForSequenceClassification.from_pretrained(oscar_checkpoint, config=bert_config)
         if m.get('teran-layers', 0) != 0 or m.get('post-layers', 0) != 0 or m.get('depth-aggregation-alignment') \
                 or m.get('depth-aggregation-matching') or m.get('depth-aggregation'):
             raise NotImplementedError('aladin_amd: only the model section of the shipped configs is provided '
@@ -95,6 +106,9 @@ class JointTextImageTransformerEncoder(nn.Module):
         self.freeze_teran = m.get('freeze-teran', False)
         embed_size = m['embed-size']
         self.embed_size = embed_size
+        hidden_size = 768                                             # :54 (hard-wired in the reference)
+        self.img_proj = nn.Linear(hidden_size, embed_size)           # :55-56: constructed, never called (kept for its keys)
+        self.cap_proj = nn.Linear(hidden_size, embed_size)
         layer = nn.TransformerEncoderLayer(d_model=embed_size, nhead=4, dim_feedforward=embed_size, dropout=m['dropout'])
         self.final_projection_net = nn.TransformerEncoder(layer, num_layers=m['tern-layers'], enable_nested_tensor=False)      # :104-108
         self.l1_regularization = 'regularizehidden' in config['training']['loss-type']

@@ -24,7 +24,7 @@ import torch
 
 
 class _Entry:
-    __slots__ = ('graph', 'inputs', 'lens', 'lens_host', 'loss', 'terms', 'grads', 'logged')
+    __slots__ = ('graph', 'inputs', 'lens', 'lens_host', 'lens_event', 'loss', 'terms', 'grads', 'logged', 'generation')
 
 
 class _Replay(torch.autograd.Function):
@@ -33,12 +33,18 @@ class _Replay(torch.autograd.Function):
         for dst, src in zip(entry.inputs, embs):
             dst.copy_(src)                                   # also lays permuted (S,B,D)<->(B,S,D) views out as captured
         entry.graph.replay()
-        ctx.entry = entry
+        entry.generation += 1                                # the static gradient buffers now belong to THIS replay
+        ctx.entry, ctx.generation = entry, entry.generation
         return entry.loss.clone()
 
     @staticmethod
     def backward(ctx, g):
-        # the replay already differentiated the captured loss w.r.t. its static inputs; consumed before the next replay
+        # the replay already differentiated the captured loss w.r.t. its static inputs; they live in the graph's static
+        # buffers, which the next replay of the same batch shape overwrites
+        if ctx.generation != ctx.entry.generation:
+            raise RuntimeError('aladin_amd.graphs: backward() of a GraphedLossStep result after a later step of the same batch '
+                               'shape was run -- the captured graph keeps ONE set of gradient buffers per shape; call '
+                               'backward() before the next step (or use ALADModel.forward for overlapping steps)')
         live = [t for t in ctx.entry.grads if t is not None]               # an input no active term depends on has none
         scaled = iter(torch._foreach_mul(live, g.to(torch.float32)) if live else [])
         return (None,) + tuple(next(scaled) if t is not None else None for t in ctx.entry.grads)
@@ -63,6 +69,8 @@ class GraphedLossStep:
     def _capture(self, key, embs):
         B, R, T, D, before, dev = key
         e = _Entry()
+        e.generation = 0
+        e.lens_event = None
         e.lens_host = (torch.empty(B, dtype=torch.int32).pin_memory(), torch.empty(B, dtype=torch.int32).pin_memory())
         cur = torch.cuda.current_stream()
         side = torch.cuda.Stream()
@@ -101,9 +109,16 @@ class GraphedLossStep:
                 self._cache.popitem(last=False)
         else:
             self._cache.move_to_end(key)
+        if e.lens_event is not None:
+            # the pinned staging buffers are reused: the previous step's asynchronous host->device copies must have been
+            # EXECUTED before they are rewritten (with logger None nothing else makes the host wait for the device)
+            e.lens_event.synchronize()
         for host, dst, src in zip(e.lens_host, e.lens, (img_lengths, cap_lengths)):
             host.copy_(torch.as_tensor([int(v) for v in src], dtype=torch.int32))
             dst.copy_(host, non_blocking=True)
+        if e.lens_event is None:
+            e.lens_event = torch.cuda.Event()
+        e.lens_event.record()
         loss = _Replay.apply(e, *embs)
         m = self.model
         m.pending_log = e.logged

@@ -166,7 +166,7 @@ def module_parameters(named_shapes, seed, scale=0.03):
     out = {}
     for k, (name, shape) in enumerate(named_shapes):
         z = normal(tuple(shape), seed + 131 * k)
-        if name.endswith('weight') and 'norm' in name.split('.')[-2]:
+        if name.endswith('weight') and 'norm' in name.split('.')[-2].lower():
             out[name] = (1.0 + 0.1 * z).astype(np.float32)
         elif name.endswith('bias'):
             out[name] = (scale / 3.0 * z).astype(np.float32)

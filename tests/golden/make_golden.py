@@ -478,6 +478,100 @@ def gen_matching_head():
     save('matching_head', **out)
 
 
+
+# ------------------------------------------------------------------ VinVL / Oscar backbone (last piece)
+BACKBONE_CFG = dict(vocab_size=120, hidden_size=64, num_hidden_layers=3, num_attention_heads=4, intermediate_size=160,
+                    hidden_act='gelu', hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1, max_position_embeddings=48,
+                    type_vocab_size=2, initializer_range=0.02, layer_norm_eps=1e-12, img_feature_dim=22,
+                    img_feature_type='faster_r-cnn', use_img_layernorm=1, img_layer_norm_eps=1e-12, num_labels=2, loss_type='sfmx')
+
+
+from backbone_inputs import backbone_inputs            # noqa: E402  (tests/golden/backbone_inputs.py, shared with the tests)
+
+
+def gen_backbone():
+    """The reference's OWN BertImgModel (oscar/modeling/modeling_bert.py:150-279: image embedding + LayerNorm, concatenation,
+    extended mask, CaptionBertEncoder loop, CaptionBertSelfAttention arithmetic, pooler hand-off) run over
+    tests/golden/hf_bert_layers.py standing in for the un-vendored `transformers.pytorch_transformers` layers; plus, as an
+    independent check of those layers, the installed transformers' BertModel on the text-only input with the same weights."""
+    import importlib.util
+    saved = {k: sys.modules.get(k) for k in ('transformers.pytorch_transformers', 'transformers.pytorch_transformers.modeling_bert',
+                                             'oscar.modeling.modeling_bert', 'oscar.modeling.modeling_utils', 'oscar.utils.cbs')}
+    import transformers as _tf
+    spec = importlib.util.spec_from_file_location('transformers.pytorch_transformers.modeling_bert', os.path.join(HERE, 'hf_bert_layers.py'))
+    layers = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(layers)
+    pkg = types.ModuleType('transformers.pytorch_transformers')
+    pkg.modeling_bert = layers
+    mu = types.ModuleType('oscar.modeling.modeling_utils')
+    mu.CaptionPreTrainedModel = type('CaptionPreTrainedModel', (layers.BertPreTrainedModel,), {})
+    mu.ImgPreTrainedModel = type('ImgPreTrainedModel', (layers.BertPreTrainedModel,), {})
+    cbs = types.ModuleType('oscar.utils.cbs')
+    cbs.ConstrainedBeamSearch = cbs.select_best_beam_with_constraints = None
+    try:
+        sys.modules.update({'transformers.pytorch_transformers': pkg, 'transformers.pytorch_transformers.modeling_bert': layers,
+                            'oscar.modeling.modeling_utils': mu, 'oscar.utils.cbs': cbs})
+        sys.modules.pop('oscar.modeling.modeling_bert', None)
+        import oscar, oscar.modeling                                   # noqa: F401,E401
+        import importlib
+        ref_mb = importlib.import_module('oscar.modeling.modeling_bert')
+        assert ref_mb.__file__.startswith('/root/reference/')
+        seed = 1301
+        cfg = layers.BertConfig(output_attentions=True, output_hidden_states=True, **BACKBONE_CFG)   # as alad_model.py:41-42 sets them
+        torch.manual_seed(0)
+        ref = ref_mb.BertImgModel(cfg).eval()
+        named = [(n, tuple(p.shape)) for n, p in ref.named_parameters()]
+        vals = synth.module_parameters(named, seed, scale=0.08)
+        with torch.no_grad():
+            for n, p in ref.named_parameters():
+                p.copy_(t(vals[n]))
+        ids, tmask, fmask, types_, feats = backbone_inputs(seed + 50)
+        out = dict(seed=seed, cfg_json=np.array(__import__('json').dumps(BACKBONE_CFG)), param_names=np.array([n for n, _ in named]),
+                   ids_checksum=synth.checksum(ids), feats_checksum=synth.checksum(feats))
+        # text-only pass (alad_model.py:124-131) and tags + regions pass (:133-140)
+        o_txt = ref(t(ids), token_type_ids=t(types_), attention_mask=t(tmask), img_feats=None)
+        f = t(feats).requires_grad_(True)
+        o_img = ref(t(ids), token_type_ids=t(types_), attention_mask=t(fmask), img_feats=f)
+        w = synth.normal(tuple(o_img[0].shape), seed + 60)
+        ref.zero_grad()
+        (o_img[0] * t(w)).sum().add(o_img[1].sum()).backward()
+        out.update(txt_seq=o_txt[0].detach().numpy(), txt_pooled=o_txt[1].detach().numpy(),
+                   img_seq=o_img[0].detach().numpy(), img_pooled=o_img[1].detach().numpy(),
+                   img_hidden_1=o_img[2][1].detach().numpy(), n_hidden=len(o_img[2]),
+                   img_att_last=o_img[3][-1].detach().numpy(), n_att=len(o_img[3]),
+                   d_feats=f.grad.numpy(), d_img_embedding_weight=ref.img_embedding.weight.grad.numpy(),
+                   d_word_embeddings_abs=float(ref.embeddings.word_embeddings.weight.grad.abs().sum()),
+                   d_q0=ref.encoder.layer[0].attention.self.query.weight.grad.numpy())
+        # independent check of the restated layers: today's transformers BertModel, same weights, text-only path
+        from transformers.models.bert.modeling_bert import BertModel as HFBert, BertConfig as HFConfig
+        hc = HFConfig(**{k: v for k, v in BACKBONE_CFG.items() if not k.startswith('img_') and k not in ('use_img_layernorm', 'loss_type')})
+        try:
+            hc._attn_implementation = 'eager'
+        except Exception:
+            pass
+        hf = HFBert(hc, add_pooling_layer=True).eval()
+        sd = {k: v for k, v in ref.state_dict().items() if not k.startswith('img_embedding') and k not in ('LayerNorm.weight', 'LayerNorm.bias')}
+        missing = hf.load_state_dict(sd, strict=False)
+        assert not [k for k in missing.unexpected_keys], missing
+        assert all('position_ids' in k or 'token_type_ids' in k for k in missing.missing_keys), missing
+        with torch.no_grad():
+            ho = hf(input_ids=t(ids), attention_mask=t(tmask), token_type_ids=t(types_))
+        d = (ho.last_hidden_state - o_txt[0]).abs().max().item()
+        # the additive masks differ (-10000 in the reference, dtype-min in today's HF): identical on attended positions
+        print('text-only path vs installed transformers %s BertModel: max |diff| %.3g (pooled %.3g)'
+              % (_tf.__version__, d, (ho.pooler_output - o_txt[1]).abs().max().item()))
+        assert d < 5e-5
+        out['hf_version'] = np.array(_tf.__version__)
+        out['hf_txt_seq_maxdiff'] = d
+        save('backbone_bertimg', **out)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+
+
 # --------------------------------------------------------------------------------------- recall
 def gen_recall():
     for name, n_img, D, seed, sigma in (('recall_n500', 100, 64, 61, 3.5),
@@ -520,5 +614,6 @@ if __name__ == '__main__':
     gen_order_sim()
     gen_model()
     gen_matching_head()
+    gen_backbone()
     gen_recall()
     gen_recall_5fold()

@@ -1465,14 +1465,35 @@ def test_sharded_model_step_under_rccl_world1(loss_type, weights, eval_precision
                     np.testing.assert_allclose(g1.meters[k].val, g0.meters[k].val, rtol=1e-6)
                     assert g1.meters[k].count == g0.meters[k].count              # world 1: global batch == local batch
                 for a, b in zip(x0, x1):
-                    if a.grad is None:
-                        assert b.grad is None or not bool(b.grad.any())
+                    if a.grad is None or b.grad is None:          # no active term depends on this input: None or zeros
+                        assert all(t.grad is None or not bool(t.grad.any()) for t in (a, b))
                         continue
                     scale = float(a.grad.abs().max())
                     np.testing.assert_allclose(b.grad.cpu().numpy(), a.grad.cpu().numpy(), rtol=1e-5, atol=1e-6 * scale)
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def test_backbone_on_the_gpu_matches_the_reference_golden(eval_precision):
+    """aladin_amd/backbone.py on PyTorch-ROCm against the outputs the reference's own BertImgModel.forward produced
+    (tests/golden/backbone_bertimg.npz; the CPU tier runs the same comparison plus gradients): fused-SDPA and explicit
+    attention paths, text-only and tags + regions passes."""
+    if eval_precision != 'fp16':
+        pytest.skip('no alignment scores involved; run once')
+    from test_backbone_cpu import backbone_case
+    for explicit in (False, True):
+        g, model, (ids, tmask, fmask, types_, feats) = backbone_case(device=dev(), output_attentions=explicit,
+                                                                     output_hidden_states=explicit)
+        with torch.no_grad():
+            o_txt = model(ids, token_type_ids=types_, attention_mask=tmask, img_feats=None)
+            o_img = model(ids, token_type_ids=types_, attention_mask=fmask, img_feats=feats)
+        tol = dict(rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(o_txt[0].cpu().numpy(), g['txt_seq'], **tol)
+        np.testing.assert_allclose(o_img[0].cpu().numpy(), g['img_seq'], **tol)
+        np.testing.assert_allclose(o_img[1].cpu().numpy(), g['img_pooled'], **tol)
+        if explicit:
+            np.testing.assert_allclose(o_img[3][-1].cpu().numpy(), g['img_att_last'], **tol)
 
 
 def test_matching_head_and_encoder_handoff_vs_reference(eval_precision):
@@ -1507,13 +1528,15 @@ def test_matching_head_and_encoder_handoff_vs_reference(eval_precision):
 
 def test_config4_shape_level_step_with_the_real_head(eval_precision):
     """BASELINE configs[4] as far as it goes offline: alad-alignment-and-matching-distill.yaml's sections (values
-    copied from the YAML: they are configuration data), batch size 32, a random-init stand-in for the VinVL BERT,
-    the REAL matching head and the HIP alignment / distillation heads: forward + backward of ALADModel.forward,
-    gradients reach the head and the backbone; epoch gating of the distillation term as in the reference."""
+    copied from the YAML: they are configuration data), batch size 32, the VinVL-base BertImgModel of
+    aladin_amd/backbone.py at its real size (12 layers, 768 wide, 2054-d region features) with RANDOM weights (the
+    checkpoint cannot be downloaded here), the matching head and the HIP alignment / distillation heads: forward +
+    backward of ALADModel.forward, gradients reach the head and the backbone; epoch gating of the distillation term as
+    in the reference; evaluation hand-off through encode_data."""
     if eval_precision != 'fp16':
         pytest.skip('training step; run once')
     from aladin_amd.alad_model import ALADModel
-    from standins import StandInBackbone
+    from aladin_amd.backbone import BertConfig, ImageBertForSequenceClassification
     from aladin_amd.evaluation import LogCollector
     config = {'dataset': {'name': 'coco'},
               'model': {'name': 'teran', 'embed-size': 768, 'text-aggregation': 'first', 'image-aggregation': 'first',
@@ -1524,7 +1547,8 @@ def test_config4_shape_level_step_with_the_real_head(eval_precision):
                            'loss-weights': [1, 1], 'alignment-mode': 'MrSw', 'distillation-mode': 'listnet',
                            'activate_distillation_after': 0, 'measure': 'dot', 'margin': 0.2, 'bs': 32}}
     torch.manual_seed(0)
-    model = ALADModel(config, backbone=StandInBackbone(hidden=768, feat_dim=2054, vocab=3000)).to(dev())
+    backbone = ImageBertForSequenceClassification(BertConfig(vocab_size=3000))       # VinVL base shapes otherwise
+    model = ALADModel(config, backbone=backbone).to(dev())
     model.logger = LogCollector()
     model.train()
     bs, n_tok, n_reg = 32, 35, 50
@@ -1532,16 +1556,24 @@ def test_config4_shape_level_step_with_the_real_head(eval_precision):
     cap_len = [int(v) for v in rng.integers(6, n_tok + 1, bs)]
     feat_len = [int(v) for v in rng.integers(10, n_reg + 1, bs)]
     cap_len[0], feat_len[1] = n_tok, n_reg
-    ids = torch.from_numpy(rng.integers(0, 3000, (bs, n_tok))).to(dev())
+    ids = torch.from_numpy(rng.integers(1, 3000, (bs, n_tok))).to(dev())
     feats = torch.from_numpy(rng.standard_normal((bs, n_reg, 2054)).astype(np.float32)).to(dev())
-    examples_txts = (ids, None, None, None, cap_len)
-    examples_imgs = (ids, None, None, feats, None, feat_len)
+    # the collated tuples of alad/dataset.py: (input_ids, attention_mask, token_type_ids, [img_feats,] ..., lengths)
+    tmask = (torch.arange(n_tok)[None, :] < torch.tensor(cap_len)[:, None]).long().to(dev())
+    rmask = (torch.arange(n_reg)[None, :] < torch.tensor(feat_len)[:, None]).long().to(dev())
+    types = torch.zeros_like(ids)
+    examples_txts = (ids * tmask, tmask, types, None, cap_len)
+    examples_imgs = (ids * tmask, torch.cat([tmask, rmask], 1), types, feats * rmask[:, :, None], None, feat_len)
     loss, d = model(examples_imgs, examples_txts, epoch=3, distill_epoch=2)
     assert list(d.keys()) == ['alignment', 'distillation'] and torch.isfinite(loss)
     loss.backward()
     head = model.img_txt_enc.final_projection_net
     assert all(p.grad is not None and torch.isfinite(p.grad).all() and float(p.grad.abs().sum()) > 0 for p in head.parameters())
-    assert float(model.img_txt_enc.oscar_model.word.weight.grad.abs().sum()) > 0
+    bert = model.img_txt_enc.oscar_model.bert
+    for p in (bert.embeddings.word_embeddings.weight, bert.img_embedding.weight, bert.encoder.layer[0].attention.self.query.weight,
+              bert.encoder.layer[11].output.dense.weight):
+        assert p.grad is not None and torch.isfinite(p.grad).all() and float(p.grad.abs().sum()) > 0
+    assert bert.pooler.dense.weight.grad is None                      # ALADIN never reads the pooled output
     assert list(model.logger.meters.keys()) == ['Eit', 'alignment_loss', 'distillation_loss']
     loss0, d0 = model(examples_imgs, examples_txts, epoch=0, distill_epoch=2)        # distillation popped before distill_epoch (:442-444)
     assert list(d0.keys()) == ['alignment']
