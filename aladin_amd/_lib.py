@@ -10,8 +10,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # ALADIN_LIB points at an alternative build of the same ABI (kernel A/B runs, tools/ab_bench.py)
 LIB_PATH = os.environ.get('ALADIN_LIB') or os.path.join(_HERE, 'lib', 'libaladin_hip.so')
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 PRECISION_FP16, PRECISION_SPLIT = 0, 1      # ALADIN_PRECISION_* of include/aladin_hip.h
+BWD_PARTNERS_FP16 = 1                       # ALADIN_BWD_PARTNERS_FP16
 
 # every symbol include/aladin_hip.h declares (tests check that the library exports all of them)
 SYMBOLS = [
@@ -31,6 +32,7 @@ SYMBOLS = [
     'aladin_scan_workspace_bytes', 'aladin_scan_fwd', 'aladin_scan_bwd',
     'aladin_store_row_width', 'aladin_store_append', 'aladin_align_pack_store_x', 'aladin_align_pack_store_y',
     'aladin_store_row_width_mode', 'aladin_store_append_mode', 'aladin_topk',
+    'aladin_align_bwd_packed_strided_ex', 'aladin_align_bwd_rows_ex',
     'aladin_loss_total', 'aladin_grad_combine', 'aladin_heads_small_workspace_bytes', 'aladin_heads_small_fwd', 'aladin_heads_small_bwd',
 ]
 
@@ -65,6 +67,9 @@ def _declare(lib):
         'aladin_align_bwd_packed': (C.c_int, [p, i64, i64, p, p, i64, i64, p, p, i64, p, p, p, p, G, p, p, p, p, p, p]),
         'aladin_align_bwd_packed_strided': (C.c_int, [p, i64, i64, p, p, i64, i64, p, p, i64, p, p, p, p, G, p, p, p, i64, i64, p, i64, i64,
                                                       p, p]),
+        'aladin_align_bwd_packed_strided_ex': (C.c_int, [p, i64, i64, p, p, i64, i64, p, p, i64, p, p, p, p, G, p, p, p, i64, i64, p, i64, i64,
+                                                         p, i32, p]),
+        'aladin_align_bwd_rows_ex': (C.c_int, [p, i64, i64, p, p, i64, i64, p, p, i64, p, p, p, p, G, p, i64, i64, p, i64, i64, p, i32, p]),
         'aladin_hinge_workspace_bytes': (sz, [i32]),
         'aladin_hinge_fwd_bwd': (C.c_int, [p, i64, i32, f32, i32, p, p, p, p]),
         'aladin_hinge_fused': (C.c_int, [p, i64, i32, f32, i32, p, p, p, p, p, p]),

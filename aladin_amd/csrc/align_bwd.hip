@@ -463,13 +463,49 @@ __device__ __forceinline__ void gather2(const float* __restrict__ r0, float g0, 
   axpy_row<NCH>(g0 / fmaxf(sqrtf(n0), 1e-12f), v0, acc);
 }
 
+// The opt-in ALADIN_BWD_PARTNERS_FP16 form of the gather: partner rows come from the forward's PACKED operands -- unit
+// vectors already, rounded once to fp16 -- instead of the raw fp32 sets: half the bytes per partner and no norm reduction.
+// The 2^-12 relative rounding of the partners puts the gradients ~1.5e-4 of their maximum off the reference's (inside
+// north_star's 1e-3; the exact path holds 3e-5), which is why it is not the default.
 template <int NCH, bool FULL>
+__device__ __forceinline__ void load_row_h(const half_t* __restrict__ p, int D, int lane, float4 (&v)[NCH]) {
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int col = lane * 4 + 256 * c;
+    if (FULL || col < D) {
+      const uint2 raw = *reinterpret_cast<const uint2*>(p + col);
+      const half_t* h = reinterpret_cast<const half_t*>(&raw);
+      v[c] = make_float4((float)h[0], (float)h[1], (float)h[2], (float)h[3]);
+    } else v[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+}
+template <int NCH, bool FULL>
+__device__ __forceinline__ void gather2_h(const half_t* __restrict__ r0, float g0, const half_t* __restrict__ r1, float g1, int D,
+                                          int lane, RowAcc<NCH>& acc) {
+  float4 v0[NCH], v1[NCH];
+  load_row_h<NCH, FULL>(r0, D, lane, v0);
+  if (r1 != nullptr) {                                   // wave-uniform
+    load_row_h<NCH, FULL>(r1, D, lane, v1);
+    axpy_row<NCH>(g1, v1, acc);
+  }
+  axpy_row<NCH>(g0, v0, acc);
+}
+// where the packers put region `r` of max-side sample `b` / word `w` of sum-side sample `b` (aladin_align_geometry)
+struct PackedRows { const half_t* xm; const half_t* xe; const half_t* y; int Dp, main_rows, rem, ycap; };
+__device__ __forceinline__ const half_t* packed_x_row(const PackedRows& pk, int b, int r) {
+  return r < pk.main_rows ? pk.xm + ((int64_t)b * pk.main_rows + r) * pk.Dp : pk.xe + ((int64_t)b * pk.rem + (r - pk.main_rows)) * pk.Dp;
+}
+__device__ __forceinline__ const half_t* packed_y_row(const PackedRows& pk, int b, int w) {
+  return pk.y + ((int64_t)b * pk.ycap + w) * pk.Dp;
+}
+
+template <int NCH, bool FULL, bool P16 = false>
 __global__ __launch_bounds__(256) void bwd_rows_kernel(
     const float* __restrict__ im, int64_t im_sb, int64_t im_sr, const int32_t* __restrict__ im_len,
     const float* __restrict__ s, int64_t s_sb, int64_t s_st, const int32_t* __restrict__ s_len, int Bi, int Bc, int R,
     int T, int D, const float* __restrict__ dS, int64_t ld, const float* __restrict__ dST, const float* __restrict__ gscale,
     const uint8_t* __restrict__ table, int tstride, float* __restrict__ d_im, float* __restrict__ d_s, int x_tail,
-    int y_tail, int64_t dim_sb, int64_t dim_sr, int64_t ds_sb, int64_t ds_st) {
+    int y_tail, int64_t dim_sb, int64_t dim_sr, int64_t ds_sb, int64_t ds_st, PackedRows pk) {
   __shared__ int lst_p[4][ROWS_LIST];
   __shared__ float lst_g[4][ROWS_LIST];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -548,9 +584,13 @@ __global__ __launch_bounds__(256) void bwd_rows_kernel(
           const int kk1 = k1 < 0 ? k0 : k1;
           const int p_1 = lane_bcast(my_p, kk1), r_1 = lane_bcast((int)my_rho, kk1);
           const float g_1 = k1 < 0 ? 0.f : lane_bcast(my_g, kk1);
-          const float* x0 = im + p_0 * im_sb + (int64_t)(r_0 + 1) * im_sr;
-          const float* x1 = k1 < 0 ? nullptr : im + p_1 * im_sb + (int64_t)(r_1 + 1) * im_sr;
-          gather2<NCH, FULL>(x0, g_0, x1, g_1, D, lane, acc);
+          if constexpr (P16) {
+            gather2_h<NCH, FULL>(packed_x_row(pk, p_0, r_0), g_0, k1 < 0 ? nullptr : packed_x_row(pk, p_1, r_1), g_1, D, lane, acc);
+          } else {
+            const float* x0 = im + p_0 * im_sb + (int64_t)(r_0 + 1) * im_sr;
+            const float* x1 = k1 < 0 ? nullptr : im + p_1 * im_sb + (int64_t)(r_1 + 1) * im_sr;
+            gather2<NCH, FULL>(x0, g_0, x1, g_1, D, lane, acc);
+          }
           any = true;
         }
       } else {
@@ -580,7 +620,7 @@ __global__ __launch_bounds__(256) void bwd_rows_kernel(
         float pend_g = 0.f;
         while (live) {
           const int k = __ffsll((long long)live) - 1; live &= live - 1;
-          const int pk = lane_bcast(my_p, k);
+          const int pk_ = lane_bcast(my_p, k);
           const float gk = lane_bcast(my_g, k);
           unsigned long long lo = lane_bcast((unsigned)(hit_lo & 0xffffffffu), k) | ((unsigned long long)lane_bcast((unsigned)(hit_lo >> 32), k) << 32);
           unsigned long long hi = lane_bcast((unsigned)(hit_hi & 0xffffffffu), k) | ((unsigned long long)lane_bcast((unsigned)(hit_hi >> 32), k) << 32);
@@ -588,10 +628,11 @@ __global__ __launch_bounds__(256) void bwd_rows_kernel(
             unsigned long long bits = part == 0 ? lo : hi;
             while (bits) {
               const int wb = __ffsll((long long)bits) - 1 + 64 * part; bits &= bits - 1;
-              if (pend_p < 0) { pend_p = pk; pend_w = wb; pend_g = gk; }
+              if (pend_p < 0) { pend_p = pk_; pend_w = wb; pend_g = gk; }
               else {
-                gather2<NCH, FULL>(s + pend_p * s_sb + (int64_t)(pend_w + 1) * s_st, pend_g,
-                             s + pk * s_sb + (int64_t)(wb + 1) * s_st, gk, D, lane, acc);
+                if constexpr (P16) gather2_h<NCH, FULL>(packed_y_row(pk, pend_p, pend_w), pend_g, packed_y_row(pk, pk_, wb), gk, D, lane, acc);
+                else gather2<NCH, FULL>(s + pend_p * s_sb + (int64_t)(pend_w + 1) * s_st, pend_g,
+                                        s + pk_ * s_sb + (int64_t)(wb + 1) * s_st, gk, D, lane, acc);
                 pend_p = -1;
                 any = true;
               }
@@ -599,7 +640,8 @@ __global__ __launch_bounds__(256) void bwd_rows_kernel(
           }
         }
         if (pend_p >= 0) {
-          gather2<NCH, FULL>(s + pend_p * s_sb + (int64_t)(pend_w + 1) * s_st, pend_g, nullptr, 0.f, D, lane, acc);
+          if constexpr (P16) gather2_h<NCH, FULL>(packed_y_row(pk, pend_p, pend_w), pend_g, nullptr, 0.f, D, lane, acc);
+          else gather2<NCH, FULL>(s + pend_p * s_sb + (int64_t)(pend_w + 1) * s_st, pend_g, nullptr, 0.f, D, lane, acc);
           any = true;
         }
       }
@@ -650,7 +692,7 @@ static int align_bwd_impl(const float* im, int64_t im_sb, int64_t im_sr, const i
                           const void* y, const aladin_align_geom* g, const int32_t* pairs_in, const int32_t* count_in,
                           float* d_im, float* d_s, void* workspace, void* stream, int x_tail = 0, int y_tail = 2,
                           int64_t dim_sb = 0, int64_t dim_sr = 0, int64_t ds_sb = 0, int64_t ds_st = 0,
-                          int phase = BWD_ALL, const HingeArgs* ha = nullptr) {
+                          int phase = BWD_ALL, const HingeArgs* ha = nullptr, int flags = 0) {
   if (phase == BWD_HINGE_ARGMAX) {                        // no gradients yet: the argmax table (and the hinge) only
     if (!ha || !ha->S || !ha->loss || !ha->dS || !ha->workspace || Bi != Bc || ha->ldS < Bc) { aladin_set_error("hinge_argmax: bad argument"); return ALADIN_ERR_ARG; }
     if (ha->small && Bc > SB_MAX) { aladin_set_error("heads_small: B = %d > %d", Bc, SB_MAX); return ALADIN_ERR_UNSUPPORTED; }
@@ -737,9 +779,20 @@ static int align_bwd_impl(const float* im, int64_t im_sb, int64_t im_sr, const i
   const int64_t rows = (int64_t)Bi * R + (int64_t)Bc * T;
   const unsigned rgrid = (unsigned)((rows + 3) / 4);
   const int nch = (D + 255) / 256;
-#define LAUNCH_ROWS_F(N, F)                                                                                             \
-  hipLaunchKernelGGL((bwd_rows_kernel<N, F>), dim3(rgrid), dim3(256), 0, st, im, im_sb, im_sr, im_len, s, s_sb, s_st, s_len, \
-                     Bi, Bc, R, T, D, dS, ld_dS, phase == BWD_ROWS ? (const float*)ws.pairs : (const float*)nullptr, gscale, ws.table, tstride, d_im, d_s, x_tail, y_tail, dim_sb, dim_sr, ds_sb, ds_st)
+  // ALADIN_BWD_PARTNERS_FP16: gather the partner rows from the packed fp16 operands (must be this problem's, non-split)
+  const bool p16 = (flags & ALADIN_BWD_PARTNERS_FP16) != 0;
+  PackedRows pk = {nullptr, nullptr, nullptr, 0, 0, 0, 0};
+  if (p16) {
+    if (!xm || !y || !g || g->split || (g->rem && !xe) || g->Bi != Bi || g->Bc != Bc || g->R != R || g->T != T || g->D != D) {
+      aladin_set_error("align_bwd: ALADIN_BWD_PARTNERS_FP16 needs the forward's fp16 packed operands and their geometry");
+      return ALADIN_ERR_ARG;
+    }
+    pk = PackedRows{(const half_t*)xm, (const half_t*)xe, (const half_t*)y, g->Dp, 32 * g->mtiles, g->rem, 16 * g->tp16};
+  }
+#define LAUNCH_ROWS_FP(N, F, P)                                                                                         \
+  hipLaunchKernelGGL((bwd_rows_kernel<N, F, P>), dim3(rgrid), dim3(256), 0, st, im, im_sb, im_sr, im_len, s, s_sb, s_st, s_len, \
+                     Bi, Bc, R, T, D, dS, ld_dS, phase == BWD_ROWS ? (const float*)ws.pairs : (const float*)nullptr, gscale, ws.table, tstride, d_im, d_s, x_tail, y_tail, dim_sb, dim_sr, ds_sb, ds_st, pk)
+#define LAUNCH_ROWS_F(N, F) do { if (p16) LAUNCH_ROWS_FP(N, F, true); else LAUNCH_ROWS_FP(N, F, false); } while (0)
 #define LAUNCH_ROWS(N) do { if (D == 256 * (N)) LAUNCH_ROWS_F(N, true); else LAUNCH_ROWS_F(N, false); } while (0)
   switch (nch) {
     case 1: LAUNCH_ROWS(1); break;
@@ -749,6 +802,7 @@ static int align_bwd_impl(const float* im, int64_t im_sb, int64_t im_sr, const i
   }
 #undef LAUNCH_ROWS
 #undef LAUNCH_ROWS_F
+#undef LAUNCH_ROWS_FP
   return aladin_check_launch("bwd_rows_kernel");
 }
 
@@ -787,6 +841,22 @@ extern "C" int aladin_align_bwd_packed_strided(const float* im, int64_t im_sb, i
                         d_s_stride_b, d_s_stride_t);
 }
 
+extern "C" int aladin_align_bwd_packed_strided_ex(const float* im, int64_t im_sb, int64_t im_sr, const int32_t* im_len, const float* s,
+                                                  int64_t s_sb, int64_t s_st, const int32_t* s_len, const float* dS, int64_t ld_dS,
+                                                  const float* gscale, const void* xm, const void* xe, const void* y,
+                                                  const aladin_align_geom* geom, const int32_t* pairs, const int32_t* pair_count,
+                                                  float* d_im, int64_t d_im_stride_b, int64_t d_im_stride_r, float* d_s,
+                                                  int64_t d_s_stride_b, int64_t d_s_stride_t, void* workspace, int flags, void* stream) {
+  if (!geom) { aladin_set_error("align_bwd_packed_strided_ex: null geometry"); return ALADIN_ERR_ARG; }
+  if (geom->split) { aladin_set_error("align_bwd_packed_strided_ex: split-precision operands are forward-only (evaluation); pack with ALADIN_PRECISION_FP16"); return ALADIN_ERR_UNSUPPORTED; }
+  if (flags & ~ALADIN_BWD_PARTNERS_FP16) { aladin_set_error("align_bwd_packed_strided_ex: unknown flags %d", flags); return ALADIN_ERR_ARG; }
+  if (d_im_stride_b < 1 || d_im_stride_r < 1 || d_s_stride_b < 1 || d_s_stride_t < 1) { aladin_set_error("align_bwd_packed_strided_ex: bad output strides"); return ALADIN_ERR_ARG; }
+  return align_bwd_impl(im, im_sb, im_sr, im_len, s, s_sb, s_st, s_len, geom->Bi, geom->Bc, geom->R, geom->T, geom->D, dS,
+                        ld_dS, gscale, (xm && y) ? xm : nullptr, xe, (xm && y) ? y : nullptr, (xm && y) ? geom : nullptr, pairs,
+                        pair_count, d_im, d_s, workspace, stream, geom->x_tail, geom->y_tail, d_im_stride_b, d_im_stride_r,
+                        d_s_stride_b, d_s_stride_t, BWD_ALL, nullptr, flags);
+}
+
 extern "C" int aladin_hinge_argmax_fused(const float* S, int64_t ldS, float margin, float* loss, float* dS, void* hinge_workspace,
                                          const float* im, int64_t im_sb, int64_t im_sr, const int32_t* im_len, const float* s,
                                          int64_t s_sb, int64_t s_st, const int32_t* s_len, const void* xm, const void* xe,
@@ -810,6 +880,20 @@ extern "C" int aladin_align_bwd_rows(const float* im, int64_t im_sb, int64_t im_
   return align_bwd_impl(im, im_sb, im_sr, im_len, s, s_sb, s_st, s_len, geom->Bi, geom->Bc, geom->R, geom->T, geom->D, dS, ld_dS,
                         gscale, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, d_im, d_s, bwd_workspace, stream,
                         geom->x_tail, geom->y_tail, d_im_stride_b, d_im_stride_r, d_s_stride_b, d_s_stride_t, BWD_ROWS, nullptr);
+}
+
+extern "C" int aladin_align_bwd_rows_ex(const float* im, int64_t im_sb, int64_t im_sr, const int32_t* im_len, const float* s,
+                                        int64_t s_sb, int64_t s_st, const int32_t* s_len, const float* dS, int64_t ld_dS,
+                                        const float* gscale, const void* xm, const void* xe, const void* y,
+                                        const aladin_align_geom* geom, float* d_im, int64_t d_im_stride_b,
+                                        int64_t d_im_stride_r, float* d_s, int64_t d_s_stride_b, int64_t d_s_stride_t,
+                                        void* bwd_workspace, int flags, void* stream) {
+  if (!geom) { aladin_set_error("align_bwd_rows_ex: null geometry"); return ALADIN_ERR_ARG; }
+  if (flags & ~ALADIN_BWD_PARTNERS_FP16) { aladin_set_error("align_bwd_rows_ex: unknown flags %d", flags); return ALADIN_ERR_ARG; }
+  if (d_im_stride_b < 1 || d_im_stride_r < 1 || d_s_stride_b < 1 || d_s_stride_t < 1) { aladin_set_error("align_bwd_rows_ex: bad output strides"); return ALADIN_ERR_ARG; }
+  return align_bwd_impl(im, im_sb, im_sr, im_len, s, s_sb, s_st, s_len, geom->Bi, geom->Bc, geom->R, geom->T, geom->D, dS, ld_dS,
+                        gscale, xm, xe, y, geom, nullptr, nullptr, d_im, d_s, bwd_workspace, stream,
+                        geom->x_tail, geom->y_tail, d_im_stride_b, d_im_stride_r, d_s_stride_b, d_s_stride_t, BWD_ROWS, nullptr, flags);
 }
 
 extern "C" int aladin_heads_small_fwd_argmax(const float* img, int64_t ld_img, const float* cap, int64_t ld_cap, const float* S,

@@ -101,6 +101,29 @@ def set_eval_precision(precision):
     return old
 
 
+# How the backward's row kernel fetches its partner rows:
+#   'exact'  the raw fp32 sets, normalised again in fp32 (default: gradients within ~3e-5 of the reference's autograd);
+#   'fp16'   ALADIN_BWD_PARTNERS_FP16 -- the forward's packed fp16 unit vectors: fewer bytes, ~1.5e-4 of the largest
+#            gradient entry (inside north_star's 1e-3).  Needs the packed operands, i.e. the fp16 pair kernel's shapes.
+_BWD_PARTNERS = ['exact']
+
+
+def set_backward_precision(mode):
+    """'exact' (default) or 'fp16' partner rows in the alignment backward; returns the previous setting."""
+    if mode not in ('exact', 'fp16'):
+        raise ValueError("aladin_amd: backward precision must be 'exact' or 'fp16'")
+    old = _BWD_PARTNERS[0]
+    _BWD_PARTNERS[0] = mode
+    return old
+
+
+def _bwd_flags(packed):
+    """flags word of the *_ex backward entry points for this problem (0 unless the opt-in applies)."""
+    if _BWD_PARTNERS[0] == 'fp16' and packed is not None and packed[1] is not None and packed[3] is not None and not packed[0].split:
+        return _lib.BWD_PARTNERS_FP16
+    return 0
+
+
 def _precision_code(precision):
     if precision in (None, 'fp16', _lib.PRECISION_FP16):
         return _lib.PRECISION_FP16
@@ -208,13 +231,14 @@ def _align_backward(im, s, im_len_t, s_len_t, dS, gscale=None, packed=None, pair
         geom, xm, xe, y = align_geometry(Bi, Bc, R, T, D), None, None, None
     else:
         geom, xm, xe, y = packed
-    _lib.check(lib.aladin_align_bwd_packed_strided(_ptr(im), im.stride(0), im.stride(1), _ptr(im_len_t),
-                                                   _ptr(s), s.stride(0), s.stride(1), _ptr(s_len_t),
-                                                   _ptr(dS), ld_dS, _ptr(gscale), _ptr(xm), _ptr(xe), _ptr(y),
-                                                   C.byref(geom), _ptr(pairs[0] if pairs else None),
-                                                   _ptr(pairs[1] if pairs else None), _ptr(d_im), d_im.stride(0), d_im.stride(1),
-                                                   _ptr(d_s), d_s.stride(0), d_s.stride(1), _ptr(ws), _stream()),
-               'align_bwd_packed_strided')
+    _lib.check(lib.aladin_align_bwd_packed_strided_ex(_ptr(im), im.stride(0), im.stride(1), _ptr(im_len_t),
+                                                      _ptr(s), s.stride(0), s.stride(1), _ptr(s_len_t),
+                                                      _ptr(dS), ld_dS, _ptr(gscale), _ptr(xm), _ptr(xe), _ptr(y),
+                                                      C.byref(geom), _ptr(pairs[0] if pairs else None),
+                                                      _ptr(pairs[1] if pairs else None), _ptr(d_im), d_im.stride(0), d_im.stride(1),
+                                                      _ptr(d_s), d_s.stride(0), d_s.stride(1), _ptr(ws),
+                                                      _bwd_flags((geom, xm, xe, y)), _stream()),
+               'align_bwd_packed_strided_ex')
     return d_im, d_s
 
 
@@ -244,14 +268,17 @@ def _hinge_argmax_fused(S, margin, im, s, im_len_t, s_len_t, packed, loss_out=No
     return loss, dS, im_c, s_c, table_ws
 
 
-def _align_backward_rows(im, s, im_len_t, s_len_t, dS, gscale, geom, table_ws):
-    """The row kernel alone: the argmax table is already in table_ws (_hinge_argmax_fused)."""
+def _align_backward_rows(im, s, im_len_t, s_len_t, dS, gscale, geom, table_ws, packed=None):
+    """The row kernel alone: the argmax table is already in table_ws (_hinge_argmax_fused).  packed = (geom, xm, xe, y):
+    the forward's operands, read only under set_backward_precision('fp16')."""
     lib = _lib.load()
     d_im, d_s = _grad_like(im), _grad_like(s)
-    _lib.check(lib.aladin_align_bwd_rows(_ptr(im), im.stride(0), im.stride(1), _ptr(im_len_t), _ptr(s), s.stride(0),
-                                         s.stride(1), _ptr(s_len_t), _ptr(dS), dS.shape[1], _ptr(gscale), C.byref(geom),
-                                         _ptr(d_im), d_im.stride(0), d_im.stride(1), _ptr(d_s), d_s.stride(0),
-                                         d_s.stride(1), _ptr(table_ws), _stream()), 'align_bwd_rows')
+    xm, xe, y = (packed[1], packed[2], packed[3]) if packed is not None else (None, None, None)
+    _lib.check(lib.aladin_align_bwd_rows_ex(_ptr(im), im.stride(0), im.stride(1), _ptr(im_len_t), _ptr(s), s.stride(0),
+                                            s.stride(1), _ptr(s_len_t), _ptr(dS), dS.shape[1], _ptr(gscale), _ptr(xm), _ptr(xe),
+                                            _ptr(y), C.byref(geom), _ptr(d_im), d_im.stride(0), d_im.stride(1), _ptr(d_s),
+                                            d_s.stride(0), d_s.stride(1), _ptr(table_ws), _bwd_flags(packed), _stream()),
+               'align_bwd_rows_ex')
     return d_im, d_s
 
 
@@ -337,7 +364,7 @@ class _AlignTriplet(torch.autograd.Function):
         if g_scores is None and table_ws is not None:
             # the argmax table is already there (forward): only the row kernel is left
             g = g_loss.to(torch.float32).contiguous()
-            d_im, d_s = _align_backward_rows(im, s, im_len_t, s_len_t, dS, g, ctx.geom, table_ws)
+            d_im, d_s = _align_backward_rows(im, s, im_len_t, s_len_t, dS, g, ctx.geom, table_ws, packed)
         elif g_scores is None:
             # the training path: only the loss is differentiated; dloss/dS (<= 3B non-zeros with the hardest-negative
             # hinge) never leaves the device and the upstream scalar goes to the kernels as a pointer
@@ -851,7 +878,7 @@ class _SmallHeads(torch.autograd.Function):
             scale = g * float(w[1])
         if dS is not None and any(ctx.needs_input_grad[2:4]):
             if table_ws is not None:
-                d_im, d_s = _align_backward_rows(im, s, im_len_t, s_len_t, dS, scale, ctx.geom, table_ws)
+                d_im, d_s = _align_backward_rows(im, s, im_len_t, s_len_t, dS, scale, ctx.geom, table_ws, (ctx.geom, xm, xe, y))
             else:
                 d_im, d_s = _align_backward(im, s, im_len_t, s_len_t, dS, gscale=scale, packed=(ctx.geom, xm, xe, y), pairs=ctx.pairs)
         return d_a, d_b, d_im, d_s, None, None, None, None, None, None, None, None
@@ -939,7 +966,7 @@ class _BigHeads(torch.autograd.Function):
                 d_b = torch.empty((B, D), dtype=torch.float32, device=dev)
                 _sgemm(B, D, B, C_tot, 1, C_tot.stride(0), a, a.stride(0), a.stride(1), d_b)          # C.T @ img
         if want_a and table_ws is not None:
-            d_im, d_s = _align_backward_rows(im, s, im_len_t, s_len_t, dS, scale, ctx.geom, table_ws)
+            d_im, d_s = _align_backward_rows(im, s, im_len_t, s_len_t, dS, scale, ctx.geom, table_ws, (ctx.geom, xm, xe, y))
         elif want_a:
             d_im, d_s = _align_backward(im, s, im_len_t, s_len_t, dS, gscale=scale, packed=(ctx.geom, xm, xe, y), pairs=ctx.pairs)
         return d_a, d_b, d_im, d_s, None, None, None, None, None, None, None, None

@@ -50,6 +50,9 @@ def parse():
     ap.add_argument('--exchange', default='tune', choices=['tune', 'dense', 'sparse'],
                     help='multi-GPU backward exchange of d(image sets): dense reduce-scatter, pair-driven sparse '
                          'all-to-all, or time both during warm-up and keep the faster (default)')
+    ap.add_argument('--bwd-partners', default='exact', choices=['exact', 'fp16'],
+                    help="backward row kernel's partner rows: 'exact' (default, fp32: gradients ~3e-5 of the reference) or the "
+                         "opt-in 'fp16' (packed unit vectors: ~1.5e-4, inside the 1e-3 tolerance; ops.set_backward_precision)")
     return ap.parse_args()
 
 
@@ -211,9 +214,10 @@ def main():
         else:
             dist.init_process_group('nccl', device_id=dev)
 
-    from aladin_amd import synth
+    from aladin_amd import synth, ops
     from aladin_amd.loss import AlignmentContrastiveLoss
     from aladin_amd import distributed as AD
+    ops.set_backward_precision(args.bwd_partners)
 
     im_np, s_np, il, sl = synth.alignment_batch(B, R, T, D, seed=1234 + 17 * rank, ragged=False)
     im = torch.from_numpy(im_np).to(dev).requires_grad_(True)
@@ -370,7 +374,7 @@ def main():
                            'features per GPU (R=34,T=50,D=768, full lengths)' +
                            ('' if world == 1 else '; configs[3]: global %dx%d matrix, images all-gathered '
                             'over RCCL, caption-block sharding' % (B * world, B * world)),
-               'global_pairs_per_step': pairs, 'loss': float(loss.detach()), 'launch': launch, 'backward_seed': 'preallocated ones',
+               'global_pairs_per_step': pairs, 'loss': float(loss.detach()), 'launch': launch, 'bwd_partners': args.bwd_partners, 'backward_seed': 'preallocated ones',
                'launch_trial_ms': launch_trial, 'hip_env': {'DEBUG_CLR_GRAPH_PACKET_CAPTURE': os.environ.get('DEBUG_CLR_GRAPH_PACKET_CAPTURE')},
                'timing': {'preroll_s': args.preroll_s, 'preroll_steps': n_pre, 'repeats': len(region_ms), 'statistic': 'median',
                           'ms_per_step_min': round(min(region_ms), 4), 'ms_per_step_max': round(max(region_ms), 4)},

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define ALADIN_ABI_VERSION 6
+#define ALADIN_ABI_VERSION 7
 
 /* The library is built with -fvisibility=hidden: the entry points declared here are its ONLY exports. */
 #if defined(__GNUC__)
@@ -185,6 +185,29 @@ ALADIN_API int aladin_align_bwd_rows(const float* im, int64_t im_stride_b, int64
                                      const float* dS, int64_t ld_dS, const float* gscale, const aladin_align_geom* geom,
                                      float* d_im, int64_t d_im_stride_b, int64_t d_im_stride_r, float* d_s,
                                      int64_t d_s_stride_b, int64_t d_s_stride_t, void* bwd_workspace, void* stream);
+
+/* Opt-in forms of the two entry points above with a `flags` word.
+ *   ALADIN_BWD_PARTNERS_FP16  the row kernel gathers the partner rows (the unit vectors an output row's gradient is a
+ *       weighted sum of) from the forward's PACKED fp16 operands xm / xe / y instead of normalising the raw fp32 rows
+ *       again: half the bytes per partner, no norm reduction (bwd_rows 43.6 -> ~39 us at B = 256, traffic past L2
+ *       302 -> 217 MB).  The one fp16 rounding of the partners leaves the gradients ~1.5e-4 of their largest entry
+ *       away from the reference's autograd -- inside north_star's 1e-3, but 5x the 3e-5 the default exact path holds --
+ *       so it is not the default.  The arg-maxima are the exact fp32 ones either way.
+ * aladin_align_bwd_rows_ex additionally takes the packed operands (ignored when flags == 0). */
+#define ALADIN_BWD_PARTNERS_FP16 1
+ALADIN_API int aladin_align_bwd_packed_strided_ex(const float* im, int64_t im_stride_b, int64_t im_stride_r, const int32_t* im_len,
+                                                  const float* s, int64_t s_stride_b, int64_t s_stride_t, const int32_t* s_len,
+                                                  const float* dS, int64_t ld_dS, const float* gscale, const void* xm, const void* xe,
+                                                  const void* y, const aladin_align_geom* geom, const int32_t* pairs,
+                                                  const int32_t* pair_count, float* d_im, int64_t d_im_stride_b,
+                                                  int64_t d_im_stride_r, float* d_s, int64_t d_s_stride_b, int64_t d_s_stride_t,
+                                                  void* workspace, int flags, void* stream);
+ALADIN_API int aladin_align_bwd_rows_ex(const float* im, int64_t im_stride_b, int64_t im_stride_r, const int32_t* im_len,
+                                        const float* s, int64_t s_stride_b, int64_t s_stride_t, const int32_t* s_len,
+                                        const float* dS, int64_t ld_dS, const float* gscale, const void* xm, const void* xe,
+                                        const void* y, const aladin_align_geom* geom, float* d_im, int64_t d_im_stride_b,
+                                        int64_t d_im_stride_r, float* d_s, int64_t d_s_stride_b, int64_t d_s_stride_t,
+                                        void* bwd_workspace, int flags, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * 'sum' / 'mean' pooling (alad/loss.py:120-123): sum_r sum_w <im^,s^> = <sum_r im^, sum_w s^>.

