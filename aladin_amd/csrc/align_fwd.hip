@@ -29,6 +29,9 @@
 
 #include "../../include/aladin_hip.h"
 #include "gemm_core.hpp"
+#ifdef ALADIN_DIAG
+#include "gemm_bdirect.hpp"
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // geometry
@@ -686,6 +689,86 @@ static int launch_scores16_tall(const aladin_align_geom* g, const half_t* xm, co
   return aladin_check_launch("align_scores16_tall_kernel");
 }
 
+#ifdef ALADIN_DIAG
+// ---- EXPERIMENT (ALADIN_SCORE_VARIANT=8): B fragments straight from L2, only the A panel through the LDS (gemm_bdirect.hpp)
+static int g_scores_flags = 0;                   // flags of the aladin_align_scores_ex call being dispatched (diag build only)
+
+// y (rows x ldk halfs, row-major) -> fragment-major copy: block ((strip * KB + kb) * 6 + j) of 1 KiB holds, lane by lane,
+// the 16 B that lane l = (row & 15) + 16 * kgroup of a v_mfma_f32_16x16x32_f16 B fragment reads: y[(strip*6 + j)*16 + (l&15)][kb*32 + 8*(l>>4) ..]
+__global__ __launch_bounds__(256) void y_fragment_major_kernel(const half_t* __restrict__ y, char* __restrict__ yf, int64_t ldk,
+                                                               int KB, int64_t n_chunks) {
+  for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < n_chunks; c += (int64_t)gridDim.x * blockDim.x) {
+    const int l = (int)(c & 63);
+    const int64_t blk = c >> 6;
+    const int j = (int)(blk % 6);
+    const int64_t sk = blk / 6;
+    const int kb = (int)(sk % KB);
+    const int64_t strip = sk / KB;
+    const int64_t row = (strip * 6 + j) * 16 + (l & 15);
+    const uint4 v = *reinterpret_cast<const uint4*>(y + row * ldk + kb * 32 + 8 * (l >> 4));
+    *reinterpret_cast<uint4*>(yf + c * 16) = v;
+  }
+}
+
+template <bool HAS_E, int TP16, int REMC, int Q = 1>
+__global__ __launch_bounds__(512) void align_scores16_tall_bdirect_kernel(const half_t* __restrict__ xm, const char* __restrict__ yf,
+                                                                          const float* __restrict__ E, int64_t ldE,
+                                                                          float* __restrict__ S, int64_t ldS, int Bi, int Bc,
+                                                                          int64_t ldk, int ktiles, int n_nblk, int n_blocks, int rem) {
+  using Cfg = GemmCfg<2, 4, 4, 3>;                // the workgroup tile (epilogue, tile order)
+  using ACfg = GemmCfg<2, 4, 4, 0>;               // what is staged: the 256 A rows only
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int mb, nb;
+  tile_coords(blockIdx.x, n_blocks / n_nblk, n_nblk, 8, mb, nb);
+  f32x4 acc[8][6];
+#pragma unroll
+  for (int rt = 0; rt < 8; ++rt)
+#pragma unroll
+    for (int ct = 0; ct < 6; ++ct) acc[rt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int wave_u = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if constexpr (HAS_E && REMC == 1 && Q == 1) {
+    // side-row values into this XCD's L2 (as in align_scores16_tall_kernel), parked in stage 2, which this wave's own
+    // refill overwrites later (same wave, same piece: in order)
+    const int lane_p = threadIdx.x & 63;
+    const int img_p = (mb * 2 + wave_u / 4) * 4 + ((lane_p % 12) / 3);
+    const float* src = E + (int64_t)img_p * ldE + (int64_t)nb * Cfg::BN + (wave_u % 4) * 96 + (lane_p % 3) * 32;
+    __builtin_amdgcn_global_load_lds(GLOBAL_PTR(src), LDS_PTR(smem + 2 * ACfg::STAGE_BYTES + wave_u * 1024), 4, 0, 0);
+  }
+  const int64_t strip = (int64_t)nb * 4 + (wave_u % 4);            // 96-row strips of y
+  const char* yf_strip = yf + strip * (2 * ktiles) * 6 * 1024;
+  gemm_mainloop16_tall_bdirect<ACfg>(xm + (int64_t)mb * Cfg::BM * ldk, yf_strip, ldk, ktiles, smem, acc);
+  scores16_epilogue_tall<HAS_E, TP16, REMC, Q>(acc, mb, nb, E, ldE, rem, S, ldS, Bi, Bc);
+}
+
+template <bool HAS_E, int TP16, int REMC, int Q = 1>
+static int launch_scores16_tall_bdirect(const aladin_align_geom* g, const half_t* xm, const half_t* y, const float* E, float* S,
+                                        int64_t ldS, hipStream_t stream) {
+  using Cfg = GemmCfg<2, 4, 4, 3>;
+  using ACfg = GemmCfg<2, 4, 4, 0>;
+  const int n_mblk = (int)(g->xm_rows / Cfg::BM), n_nblk = (int)(g->y_rows / Cfg::BN);
+  if ((int64_t)n_mblk * Cfg::BM != g->xm_rows || (int64_t)n_nblk * Cfg::BN != g->y_rows) { aladin_set_error("align_scores16 bdirect: packed rows do not tile"); return ALADIN_ERR_ARG; }
+  static char* yf = nullptr;
+  static size_t yf_bytes = 0;
+  if ((size_t)g->y_bytes > yf_bytes) {            // experiment only: the library proper never allocates
+    if (yf) (void)hipFree(yf);
+    if (hipMalloc((void**)&yf, (size_t)g->y_bytes) != hipSuccess) { yf = nullptr; yf_bytes = 0; aladin_set_error("bdirect: hipMalloc failed"); return ALADIN_ERR_HIP; }
+    yf_bytes = (size_t)g->y_bytes;
+  }
+  if (!(g_scores_flags & ALADIN_SCORES_REUSE_SIDE)) {
+    const int64_t n_chunks = g->y_bytes / 16;
+    hipLaunchKernelGGL(y_fragment_major_kernel, dim3(2048), dim3(256), 0, stream, y, yf, (int64_t)g->Dp, g->Dp / 32, n_chunks);
+    if (int rc = aladin_check_launch("y_fragment_major_kernel")) return rc;
+  }
+  auto kern = align_scores16_tall_bdirect_kernel<HAS_E, TP16, REMC, Q>;
+  static unsigned long long lds_reserved = 0;
+  if (int rc = aladin_reserve_lds((const void*)kern, 3 * ACfg::STAGE_BYTES, &lds_reserved, "align_scores16_tall_bdirect")) return rc;
+  const int n_blocks = n_mblk * n_nblk;
+  hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(Cfg::THREADS), 3 * ACfg::STAGE_BYTES, stream, xm, (const char*)yf, E, g->y_rows, S, ldS,
+                     g->Bi, g->Bc, (int64_t)g->Dp, g->Dp / 64, n_nblk, n_blocks, g->rem);
+  return aladin_check_launch("align_scores16_tall_bdirect_kernel");
+}
+#endif
+
 // WGM x WGN waves of 64 x 192 each: 4 x 2 with a double buffer is the kernel above; 2 x 1 (128 x 192, two waves) with a
 // three-stage ring is the SMALL-GRID variant: when the 256 x 384 tiling leaves most CUs idle (B <= 64: at most 64
 // workgroups) a workgroup's 12 K steps are a chain of exposed memory latencies (24 us at B = 32, the same as B = 256's
@@ -770,6 +853,8 @@ static int launch_scores16(const aladin_align_geom* g, const half_t* xm, const h
     if (variant == 1) return launch_scores16_cfg<HAS_E, TP16, false, Q, REMC, 2, 1, 2>(g, xm, y, E, S, ldS, stream);
     if (variant == 2) return launch_scores16_cfg<HAS_E, TP16, false, Q, REMC, 2, 1, 3>(g, xm, y, E, S, ldS, stream);
     if (variant == 4) return launch_scores16_cfg<HAS_E, TP16, false, Q, REMC, 4, 2, 2>(g, xm, y, E, S, ldS, stream);   // 64 x 192 wave tiles
+    if constexpr (6 % TP16 == 0)
+      if (variant == 8 && !g->split) return launch_scores16_tall_bdirect<HAS_E, TP16, REMC, Q>(g, xm, y, E, S, ldS, stream);   // B straight from L2
 #endif
     if ((g->xm_rows / 256) * (g->y_rows / 384) <= 64)
       return launch_scores16_cfg<HAS_E, TP16, false, Q, REMC, 2, 1, 3>(g, xm, y, E, S, ldS, stream);
@@ -892,6 +977,9 @@ extern "C" int aladin_align_scores_ex(const void* xm, const void* xe, const void
   const half_t* a = (const half_t*)xm; const half_t* b = (const half_t*)xe; const half_t* c = (const half_t*)y;
   float* E = (float*)e_scratch;
   int rc;
+#ifdef ALADIN_DIAG
+  g_scores_flags = flags;
+#endif
   switch (g->tp16) {
     case 1: rc = dispatch_tp<1>(g, a, b, c, E, S, ldS, flags, st); break;
     case 2: rc = dispatch_tp<2>(g, a, b, c, E, S, ldS, flags, st); break;

@@ -15,23 +15,49 @@ gradients the replay produced (scaled by the incoming gradient).  Shapes are par
 slices its sets to the batch maxima (alad_model.py:174-175) and a set padded beyond the batch maximum would
 change the max over regions (the zero fill competes, alad/loss.py:116,124), so graphs are cached per
 (B, R, T, D, distillation active) -- a few dozen small graphs over a COCO epoch (LRU, `cache_size`).
-The lengths travel as device int32 tensors refreshed before each replay; `model.logger` is fed after the replay
-from one device->host copy (or not at all when it is None).
+Host cost per step is what is left around the replay, so it is kept minimal: the four inputs are staged by ONE
+multi-tensor copy, the lengths by ONE host->device copy from a rotating pinned buffer (skipped when they equal the
+previous step's), the logged terms leave by ONE asynchronous device->host copy that `model.logger` receives when the
+next step is issued (log='deferred'; log='sync' keeps the reference's immediate `.item()` protocol) -- the host never
+waits for the device, so issuing step n + 1 overlaps the replay of step n.
 """
-from collections import OrderedDict
+from collections import OrderedDict, deque
 
+import numpy as np
 import torch
 
 
 class _Entry:
-    __slots__ = ('graph', 'inputs', 'lens', 'lens_host', 'lens_event', 'loss', 'terms', 'grads', 'logged', 'generation')
+    __slots__ = ('graph', 'inputs', 'lens', 'lens_both', 'lens_key', 'lens_slots', 'lens_k', 'loss', 'terms', 'grads', 'logged',
+                 'log_buf', 'generation')
+
+
+class _PinnedSlot:
+    """One pinned staging buffer + the event of the last asynchronous copy that used it."""
+    __slots__ = ('host', 'view', 'event', 'used')
+
+    def __init__(self, numel, dtype):
+        self.host = torch.empty(numel, dtype=dtype).pin_memory()
+        self.view = self.host.numpy()                       # same memory: filled without a tensor construction
+        self.event = torch.cuda.Event()
+        self.used = False
+
+    def acquire(self):
+        if self.used:
+            self.event.synchronize()                        # the copy last issued from / into this buffer has EXECUTED
+        self.used = True
+        return self
 
 
 class _Replay(torch.autograd.Function):
     @staticmethod
     def forward(ctx, entry, *embs):
-        for dst, src in zip(entry.inputs, embs):
-            dst.copy_(src)                                   # also lays permuted (S,B,D)<->(B,S,D) views out as captured
+        # also lays permuted (S,B,D)<->(B,S,D) views out as captured; one multi-tensor launch when the layouts agree
+        if all(d.stride() == s.stride() and d.dtype == s.dtype for d, s in zip(entry.inputs, embs)):
+            torch._foreach_copy_(entry.inputs, [s.detach() for s in embs])
+        else:
+            for dst, src in zip(entry.inputs, embs):
+                dst.copy_(src)
         entry.graph.replay()
         entry.generation += 1                                # the static gradient buffers now belong to THIS replay
         ctx.entry, ctx.generation = entry, entry.generation
@@ -51,10 +77,21 @@ class _Replay(torch.autograd.Function):
 
 
 class GraphedLossStep:
-    def __init__(self, model, cache_size=32):
+    """log: 'deferred' (default) -- the logged loss terms leave the device by ONE asynchronous copy per step and reach
+    `model.logger` when the next step is issued (or at flush()): the host never waits for the GPU, so issuing step n + 1
+    overlaps the replay of step n; 'sync' -- the reference's protocol (`.item()` right after the forward,
+    alad_model.py:383,390,408): the logger is current when the call returns, at the price of one host wait per step."""
+
+    def __init__(self, model, cache_size=32, log='deferred'):
+        if log not in ('deferred', 'sync'):
+            raise ValueError("aladin_amd.graphs: log must be 'deferred' or 'sync'")
         self.model = model
         self.cache_size = int(cache_size)
+        self.log = log
         self._cache = OrderedDict()
+        self._pending = deque()                              # (slot, [(key, index, n)], logger)
+        self._log_slots = [None] * 4
+        self._log_k = 0
 
     def _run(self, e, epoch_before_distill):
         m = self.model
@@ -70,16 +107,18 @@ class GraphedLossStep:
         B, R, T, D, before, dev = key
         e = _Entry()
         e.generation = 0
-        e.lens_event = None
-        e.lens_host = (torch.empty(B, dtype=torch.int32).pin_memory(), torch.empty(B, dtype=torch.int32).pin_memory())
+        e.lens_key = None
+        e.lens_slots = [_PinnedSlot(2 * B, torch.int32) for _ in range(3)]
+        e.lens_k = 0
         cur = torch.cuda.current_stream()
         side = torch.cuda.Stream()
         side.wait_stream(cur)
         with torch.cuda.stream(side):
-            e.inputs = [torch.zeros_like(x, memory_format=torch.contiguous_format).requires_grad_(True) for x in embs]
+            e.inputs = [torch.zeros_like(x, memory_format=torch.preserve_format).requires_grad_(True) for x in embs]
             for dst, src in zip(e.inputs, embs):
                 dst.data.copy_(src)
-            e.lens = (torch.full((B,), R, dtype=torch.int32, device=dev), torch.full((B,), T, dtype=torch.int32, device=dev))
+            e.lens_both = torch.cat([torch.full((B,), R, dtype=torch.int32, device=dev), torch.full((B,), T, dtype=torch.int32, device=dev)])
+            e.lens = (e.lens_both[:B], e.lens_both[B:])      # static addresses: refreshed by ONE host->device copy per new batch
             for _ in range(2):                               # warm-up outside capture: lazy initialisation, LDS reservations
                 self._run(e, before)
         cur.wait_stream(side)
@@ -91,13 +130,50 @@ class GraphedLossStep:
             loss, losses = self._run(e, before)
             e.loss = loss.detach()
             e.terms = OrderedDict((k, v.detach()) for k, v in losses.items())
+            # the logged values as ONE device buffer, filled inside the graph: a single copy brings them to the host
+            e.log_buf = torch.stack([torch.as_tensor(t).detach().reshape(()).to(torch.float32) for _, t, _ in e.logged]) \
+                if e.logged else None
         e.grads = [t.grad for t in e.inputs]
         return e
+
+    # ------------------------------------------------------------------------------------------ logging
+    def _drain(self, wait):
+        while self._pending:
+            slot, names, logger = self._pending[0]
+            if not wait and not slot.event.query():
+                break
+            slot.event.synchronize()
+            vals = slot.view.tolist()
+            for (key, n), v in zip(names, vals):
+                logger.update(key, v, n)
+            self._pending.popleft()
+
+    def flush(self):
+        """Hand every outstanding logged value to its logger (waits for the device)."""
+        self._drain(True)
+
+    def _log(self, e):
+        logger = self.model.logger
+        if logger is None or e.log_buf is None:
+            return
+        k = self._log_k % len(self._log_slots)
+        self._log_k += 1
+        if self._log_slots[k] is None or self._log_slots[k].host.numel() != e.log_buf.numel():
+            self._log_slots[k] = _PinnedSlot(e.log_buf.numel(), torch.float32)
+        if len(self._pending) >= len(self._log_slots) - 1:
+            self._drain(True)                                # never more copies in flight than staging buffers
+        slot = self._log_slots[k].acquire()
+        slot.host.copy_(e.log_buf, non_blocking=True)
+        slot.event.record()
+        self._pending.append((slot, [(key, n) for key, _, n in e.logged], logger))
+        if self.log == 'sync':
+            self._drain(True)
 
     def __call__(self, img_emb, cap_emb, img_emb_set, cap_emb_seq, img_lengths, cap_lengths, reg_loss=0, epoch=0,
                  distill_epoch=2):
         if 'regularizehidden' in self.model.losses_types:
             raise NotImplementedError('aladin_amd.graphs: the regularisation term comes from the encoder; add it outside')
+        self._drain(False)                                   # values of earlier steps that have arrived meanwhile
         embs = (img_emb, cap_emb, img_emb_set, cap_emb_seq)
         B, D = img_emb.shape
         key = (B, img_emb_set.shape[0], cap_emb_seq.shape[0], D, bool(epoch < distill_epoch), img_emb.device)
@@ -109,18 +185,17 @@ class GraphedLossStep:
                 self._cache.popitem(last=False)
         else:
             self._cache.move_to_end(key)
-        if e.lens_event is not None:
-            # the pinned staging buffers are reused: the previous step's asynchronous host->device copies must have been
-            # EXECUTED before they are rewritten (with logger None nothing else makes the host wait for the device)
-            e.lens_event.synchronize()
-        for host, dst, src in zip(e.lens_host, e.lens, (img_lengths, cap_lengths)):
-            host.copy_(torch.as_tensor([int(v) for v in src], dtype=torch.int32))
-            dst.copy_(host, non_blocking=True)
-        if e.lens_event is None:
-            e.lens_event = torch.cuda.Event()
-        e.lens_event.record()
+        lk = (tuple(img_lengths), tuple(cap_lengths))
+        if lk != e.lens_key:
+            # one pinned buffer per in-flight copy (rotation + event): the host may run ahead of the device by several
+            # steps, and a staging buffer must not be rewritten before its host->device copy has executed
+            slot = e.lens_slots[e.lens_k % len(e.lens_slots)].acquire()
+            e.lens_k += 1
+            slot.view[:B] = lk[0]
+            slot.view[B:] = lk[1]
+            e.lens_both.copy_(slot.host, non_blocking=True)
+            slot.event.record()
+            e.lens_key = lk
         loss = _Replay.apply(e, *embs)
-        m = self.model
-        m.pending_log = e.logged
-        m.flush_log()
+        self._log(e)
         return loss, OrderedDict(e.terms)

@@ -1657,8 +1657,9 @@ def test_config4_shape_level_step_with_the_real_head(eval_precision):
     assert img_embs.shape == (bs, 71, 768) and il == feat_len and cl == cap_len
 
 
+@pytest.mark.parametrize('log', ['deferred', 'sync'])
 @pytest.mark.parametrize('loss_type,weights', [('alignment-distillation', [1, 1]), ('alignment-distillation-matching', [1, 1, 0.1])])
-def test_graphed_loss_step_equals_eager(eval_precision, loss_type, weights):
+def test_graphed_loss_step_equals_eager(eval_precision, loss_type, weights, log):
     """aladin_amd.graphs.GraphedLossStep (HIP-graph replay of forward_loss + weighted sum + backward at the shipped
     batch size 32) gives the eager path's loss, terms, logger entries and input gradients bit for bit, on fresh data and
     fresh lengths of the captured shape, before and after the distillation epoch."""
@@ -1672,7 +1673,7 @@ def test_graphed_loss_step_equals_eager(eval_precision, loss_type, weights):
                            'max-violation': True, 'alignment-mode': 'MrSw', 'distillation-mode': 'listnet'}}
     B, R, Tn, D = 32, 34, 50, 768
     model = ALADModel(config)
-    step = GraphedLossStep(model)
+    step = GraphedLossStep(model, log=log)
     for seed, epoch in ((1, 5), (2, 5), (3, 0), (4, 0), (5, 5)):
         im, s, il, sl = synth.structured_alignment_batch(B, R, Tn, D, seed=seed, noise=3.0, ragged=True)
         ge, gc = synth.global_embeddings(B, D, seed=seed + 50, noise=1.0)
@@ -1687,6 +1688,9 @@ def test_graphed_loss_step_equals_eager(eval_precision, loss_type, weights):
                 d = model.forward_loss(t[0], t[1], t[2], t[3], il, sl, 0)
                 loss = model.weighted_total(d, epoch, 2)
             (2.0 * loss).backward()                           # a power of two: scaling before or after the kernels gives the same bits
+            if graphed and log == 'deferred':
+                assert not model.logger.meters                # nothing has made the host wait for the device yet
+                step.flush()
             outs.append((loss.detach().clone(), {k: v.detach().clone() for k, v in d.items()}, [None if x.grad is None else x.grad.clone() for x in t],
                          {k: m.val for k, m in model.logger.meters.items()}))
         (l0, d0, g0, log0), (l1, d1, g1, log1) = outs
@@ -1698,6 +1702,44 @@ def test_graphed_loss_step_equals_eager(eval_precision, loss_type, weights):
             else:
                 assert torch.equal(a, b)
     assert len(step._cache) == 2                                     # one graph per (shape, distillation active)
+
+
+def test_graphed_loss_step_runs_ahead_safely(eval_precision):
+    """With no logger nothing makes the host wait: many steps of the same shape with DIFFERENT lengths are issued back to
+    back (the pinned length buffers rotate behind events), every loss must be its own batch's eager loss; and a
+    backward() that comes after a later step of the same shape is refused (the graph holds one set of gradient buffers)."""
+    if eval_precision != 'fp16':
+        pytest.skip('training step; run once')
+    from aladin_amd import synth
+    from aladin_amd.alad_model import ALADModel
+    from aladin_amd.graphs import GraphedLossStep
+    config = {'training': {'loss-type': 'alignment-distillation', 'loss-weights': [1, 1], 'margin': 0.2, 'measure': 'dot',
+                           'max-violation': True, 'alignment-mode': 'MrSw', 'distillation-mode': 'listnet'}}
+    B, R, Tn, D = 32, 34, 50, 768
+    model = ALADModel(config)
+    step = GraphedLossStep(model)
+    batches = []
+    for seed in range(12):
+        im, s, il, sl = synth.structured_alignment_batch(B, R, Tn, D, seed=300 + seed, noise=3.0, ragged=True)
+        il[0], sl[0] = R, Tn                                           # same captured shape, different lengths elsewhere
+        ge, gc = synth.global_embeddings(B, D, seed=400 + seed, noise=1.0)
+        batches.append(([T(ge), T(gc), T(im.transpose(1, 0, 2).copy()), T(s.transpose(1, 0, 2).copy())], il, sl))
+    losses = []
+    for t, il, sl in batches:                                         # no sync anywhere in this loop
+        t = [x.requires_grad_(True) for x in t]
+        loss, _ = step(t[0], t[1], t[2], t[3], il, sl, epoch=5)
+        loss.backward()
+        losses.append(loss.detach())
+    torch.cuda.synchronize()
+    for (t, il, sl), got in zip(batches, losses):
+        d = model.forward_loss(t[0].detach(), t[1].detach(), t[2].detach(), t[3].detach(), il, sl, 0)
+        assert torch.equal(model.weighted_total(d, 5, 2), got)
+    t, il, sl = batches[0]
+    l_a, _ = step(t[0], t[1], t[2], t[3], il, sl, epoch=5)
+    l_b, _ = step(t[0], t[1], t[2], t[3], il, sl, epoch=5)
+    with pytest.raises(RuntimeError, match='later step'):
+        l_a.backward()
+    l_b.backward()
 
 
 @pytest.mark.parametrize('B,D', [(5, 64), (32, 768), (64, 768), (33, 100)])

@@ -66,7 +66,8 @@ def main():
     from aladin_amd import synth
     from aladin_amd.loss import AlignmentContrastiveLoss, ContrastiveLoss, DistillationLoss
     dev = torch.device('cuda:0')
-    batches = [int(v) for v in sys.argv[1:]] or [32, 256]
+    profile = '--profile' in sys.argv
+    batches = [int(v) for v in sys.argv[1:] if not v.startswith('--')] or [32, 256]
     for B in batches:
         im, s, il, sl = synth.alignment_batch(B, 34, 50, 768, seed=7, ragged=True)
         gi, gc = synth.global_embeddings(B, 768, seed=8)
@@ -111,11 +112,38 @@ def main():
             next(iter(gstep._cache.values())).graph.replay()
 
         graphed()
+        # the same with a logger attached: deferred logging (one asynchronous D2H per step, the host never waits) and the
+        # reference's protocol (a host wait per step)
+        from aladin_amd.evaluation import LogCollector
+        model.logger = LogCollector()
+        t_logged = timed(graphed, 200)
+        gstep.flush()
+        gsync = GraphedLossStep(model, log='sync')
+
+        def graphed_sync():
+            for t in (a_s, b_s, x, y):
+                t.grad = None
+            loss, _ = gsync(x, y, a_s, b_s, il, sl, epoch=5)
+            loss.backward()
+        t_sync = timed(graphed_sync, 200)
+        model.logger = None
+        if profile:
+            import cProfile
+            import pstats
+            pr = cProfile.Profile()
+            timed(graphed, 50)
+            pr.enable()
+            for _ in range(500):
+                graphed()
+            pr.disable()
+            torch.cuda.synchronize()
+            pstats.Stats(pr).sort_stats('cumulative').print_stats(18)
         with torch.no_grad():
             l1 = float(ac(a, b, il, sl)) + float(dc(ac(a, b, il, sl, return_loss=False, return_similarity_mat=True), x.mm(y.t())))
             Sr = ref_alignment(a, b, il, sl)
             l2 = float(ref_hinge(Sr)) + float(ref_listnet(Sr, x.mm(y.t())))
         print(json.dumps({'batch': B, 'hip_ms': round(timed(ours, 50), 4), 'hip_graphed_step_ms': round(timed(graphed, 200), 4),
+                          'hip_graphed_step_deferred_log_ms': round(t_logged, 4), 'hip_graphed_step_sync_log_ms': round(t_sync, 4),
                           'hip_graph_replay_only_ms': round(timed(graph_only, 500), 4), 'torch_rocm_eager_ms': round(timed(ref, 10), 3),
                           'loss_hip': round(l1, 5), 'loss_eager': round(l2, 5)}), flush=True)
 
