@@ -29,7 +29,7 @@ import torch
 
 class _Entry:
     __slots__ = ('graph', 'inputs', 'lens', 'lens_both', 'lens_key', 'lens_slots', 'lens_k', 'loss', 'terms', 'grads', 'logged',
-                 'log_buf', 'generation')
+                 'log_buf', 'log_names', 'generation')
 
 
 class _PinnedSlot:
@@ -134,6 +134,7 @@ class GraphedLossStep:
             e.log_buf = torch.stack([torch.as_tensor(t).detach().reshape(()).to(torch.float32) for _, t, _ in e.logged]) \
                 if e.logged else None
         e.grads = [t.grad for t in e.inputs]
+        e.log_names = [(key, n) for key, _, n in e.logged] if e.logged else []
         return e
 
     # ------------------------------------------------------------------------------------------ logging
@@ -165,7 +166,7 @@ class GraphedLossStep:
         slot = self._log_slots[k].acquire()
         slot.host.copy_(e.log_buf, non_blocking=True)
         slot.event.record()
-        self._pending.append((slot, [(key, n) for key, _, n in e.logged], logger))
+        self._pending.append((slot, e.log_names, logger))
         if self.log == 'sync':
             self._drain(True)
 

@@ -20,15 +20,20 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument('--lib', action='append', required=True, help='name=path/to/lib.so (repeatable)')
+    ap.add_argument('--lib', action='append', required=True,
+                    help='name=path/to/lib.so[;ENV=VALUE;...] (repeatable; the ENV settings select a variant inside the diag build)')
     ap.add_argument('--reps', type=int, default=3)
     ap.add_argument('--steps', type=int, default=1000)
     args = ap.parse_args()
-    libs = [a.split('=', 1) for a in args.lib]
-    rows = {n: [] for n, _ in libs}
+    libs = []
+    for a in args.lib:
+        name, rest = a.split('=', 1)
+        parts = rest.split(';')
+        libs.append((name, parts[0], dict(p.split('=', 1) for p in parts[1:] if p)))
+    rows = {n: [] for n, _, _ in libs}
     for _ in range(args.reps):
-        for name, path in libs:
-            env = dict(os.environ, ALADIN_LIB=os.path.abspath(path))
+        for name, path, extra in libs:
+            env = dict(os.environ, ALADIN_LIB=os.path.abspath(path), **extra)
             out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', str(args.steps), '--warmup',
                                   str(max(10, args.steps // 10)), '--no-cpu-baseline', '--no-eval', '--repeats', '3'], env=env, capture_output=True, text=True)
             line = [l for l in out.stdout.splitlines() if l.startswith('{')]
