@@ -24,6 +24,7 @@
 //                operand (one row per image) whose plain GEMM against the captions (E) is folded
 //                into the max by the score kernel -- 33/32 of the MFMA work instead of 64/32.
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -732,7 +733,7 @@ __global__ __launch_bounds__(512) void align_scores16_tall_bdirect_kernel(const 
     const int lane_p = threadIdx.x & 63;
     const int img_p = (mb * 2 + wave_u / 4) * 4 + ((lane_p % 12) / 3);
     const float* src = E + (int64_t)img_p * ldE + (int64_t)nb * Cfg::BN + (wave_u % 4) * 96 + (lane_p % 3) * 32;
-    __builtin_amdgcn_global_load_lds(GLOBAL_PTR(src), LDS_PTR(smem + 2 * ACfg::STAGE_BYTES + wave_u * 1024), 4, 0, 0);
+    __builtin_amdgcn_global_load_lds(GLOBAL_PTR(src), LDS_PTR(smem + (BD_NS - 1) * ACfg::STAGE_BYTES + wave_u * 1024), 4, 0, 0);
   }
   const int64_t strip = (int64_t)nb * 4 + (wave_u % 4);            // 96-row strips of y
   const char* yf_strip = yf + strip * (2 * ktiles) * 6 * 1024;
@@ -751,20 +752,22 @@ static int launch_scores16_tall_bdirect(const aladin_align_geom* g, const half_t
   static size_t yf_bytes = 0;
   if ((size_t)g->y_bytes > yf_bytes) {            // experiment only: the library proper never allocates
     if (yf) (void)hipFree(yf);
-    if (hipMalloc((void**)&yf, (size_t)g->y_bytes) != hipSuccess) { yf = nullptr; yf_bytes = 0; aladin_set_error("bdirect: hipMalloc failed"); return ALADIN_ERR_HIP; }
+    if (hipMalloc((void**)&yf, (size_t)g->y_bytes + 8192) != hipSuccess)   /* + one block: the loop's last prefetch */ { yf = nullptr; yf_bytes = 0; aladin_set_error("bdirect: hipMalloc failed"); return ALADIN_ERR_HIP; }
     yf_bytes = (size_t)g->y_bytes;
   }
   if (!(g_scores_flags & ALADIN_SCORES_REUSE_SIDE)) {
     const int64_t n_chunks = g->y_bytes / 16;
     hipLaunchKernelGGL(y_fragment_major_kernel, dim3(2048), dim3(256), 0, stream, y, yf, (int64_t)g->Dp, g->Dp / 32, n_chunks);
     if (int rc = aladin_check_launch("y_fragment_major_kernel")) return rc;
+    if (diag_env("ALADIN_BD_SYNC", 0)) { hipError_t e = hipStreamSynchronize(stream); fprintf(stderr, "bdirect: repack done (%s) yf=%p bytes=%zu KB=%d chunks=%lld\n", hipGetErrorString(e), (void*)yf, yf_bytes, g->Dp / 32, (long long)n_chunks); }
   }
   auto kern = align_scores16_tall_bdirect_kernel<HAS_E, TP16, REMC, Q>;
   static unsigned long long lds_reserved = 0;
-  if (int rc = aladin_reserve_lds((const void*)kern, 3 * ACfg::STAGE_BYTES, &lds_reserved, "align_scores16_tall_bdirect")) return rc;
+  if (int rc = aladin_reserve_lds((const void*)kern, BD_NS * ACfg::STAGE_BYTES, &lds_reserved, "align_scores16_tall_bdirect")) return rc;
   const int n_blocks = n_mblk * n_nblk;
-  hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(Cfg::THREADS), 3 * ACfg::STAGE_BYTES, stream, xm, (const char*)yf, E, g->y_rows, S, ldS,
+  hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(Cfg::THREADS), BD_NS * ACfg::STAGE_BYTES, stream, xm, (const char*)yf, E, g->y_rows, S, ldS,
                      g->Bi, g->Bc, (int64_t)g->Dp, g->Dp / 64, n_nblk, n_blocks, g->rem);
+  if (diag_env("ALADIN_BD_SYNC", 0)) { hipError_t e = hipStreamSynchronize(stream); fprintf(stderr, "bdirect: score kernel done (%s) blocks=%d ktiles=%d\n", hipGetErrorString(e), n_blocks, g->Dp / 64); }
   return aladin_check_launch("align_scores16_tall_bdirect_kernel");
 }
 #endif

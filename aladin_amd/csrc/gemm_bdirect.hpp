@@ -23,29 +23,65 @@
 // re-reads the last K step into a stage nobody reads again).
 #pragma once
 #include "gemm_core.hpp"
+#ifndef BD_NS
+#define BD_NS 3
+#endif
+
+// LDS-DMA issued as inline asm (ALADIN_BD_ASM_DMA): the compiler models global_load_lds as a write to the LDS and guards every
+// later ds_read with vmcnt(0) while one is outstanding -- which also waits for the B fragments just issued.  Hidden from
+// its bookkeeping, the compiler's own counts for the B loads stay valid upper bounds (loads complete in order).
+template <class Cfg, int C0, int C1>
+__device__ __forceinline__ void bd_stage_asm(const half_t* __restrict__ a_rows, int64_t ldk, int kt, char* stage, int wave, uint32_t lane_off) {
+#pragma unroll
+  for (int c = C0; c < C1; ++c) {
+    const int chunk = wave + c * Cfg::NWAVES;
+    const char* src = reinterpret_cast<const char*>(a_rows + (int64_t)chunk * 8 * ldk + (int64_t)kt * 64) + lane_off;
+    const uint32_t dst = (uint32_t)(uintptr_t)LDS_PTR(stage + chunk * 1024);
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(src), "s"(dst) : "memory", "m0");
+  }
+}
 
 // yf_strip: this wave's strip of the fragment-major operand at k32 block 0 (wave-uniform); tile t of block kb sits at
 // (kb * 6 + t) KiB.
 template <class ACfg>
 __device__ __forceinline__ void gemm_mainloop16_tall_bdirect(const half_t* __restrict__ a_rows, const char* __restrict__ yf_strip,
                                                              int64_t ldk, int ktiles, char* smem, f32x4 (&acc)[8][6]) {
-  constexpr int NS = 3, LEAD = 2, CPW = ACfg::CHUNKS_PER_WAVE;
+  constexpr int NS = BD_NS, LEAD = BD_NS - 1, CPW = ACfg::CHUNKS_PER_WAVE;
   static_assert(CPW == 4 && ACfg::BN == 0, "A-only stage: 256 rows = 32 pieces over 8 waves");
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   const int wm = wave / 4;
   const uint32_t lane_off = stage_lane_offset<ACfg>(ldk, wave, lane);
   const int a_row0 = wm * 128 + (lane & 15);
-  const int nkb = 2 * ktiles;
-  const uint32_t b_lane = (uint32_t)lane * 16u;
-  // the base points 3 KiB into the 6-KiB block of a 32-deep step: the six tiles sit at immediates -3072 .. +2048
-#define BD_LOAD(dst, kb_, T_)                                                                                        \
-  do {                                                                                                                \
-    const int kc_ = (kb_) < nkb ? (kb_) : nkb - 1; /* past the end: a harmless re-read, never consumed */             \
-    const char* sb_ = yf_strip + (int64_t)kc_ * 6144 + 3072;                                                          \
-    asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=&v"(dst) : "v"(b_lane), "s"(sb_), "n"((T_) * 1024 - 3072) : "memory"); \
-  } while (0)
+  // Addressing: a wave-uniform running block pointer (SGPR pair, advanced by one 6-KiB block twice per K step) + ONE 32-bit
+  // lane offset + an immediate per tile (-3072 .. +2048 around the block's middle; the 3 KiB sit in the lane offset so
+  // that lane offset + immediate is never negative).  The last K step reads one block past the end of the strip (never
+  // consumed): the fragment-major buffer is over-allocated by one block.
+  //   ALADIN_BD_ASM_VADDR: the loads as inline asm with a 64-bit per-lane pointer and hand-counted waits -- two registers
+  //     too many: the loop spills two dwords and reloads them behind vmcnt(0) at the top of every K step.
+  //   (inline asm in the scalar-base form -- "s" base, "v" lane offset -- faults on the GPU at garbage addresses, with
+  //     or without s_nop wait states in front; the per-lane form of the same addresses is fine.  Not understood.)
+  //   default: C++ loads -- the compiler picks the scalar-base form itself and counts its own waits, which are exact now
+  //     that the LDS-DMA refill is unconditional (straight-line loop body); the hand-counted waits stay as upper bounds.
+  const char* bs = yf_strip;
+  const uint32_t b_lane = (uint32_t)lane * 16u + 3072u;
+#if defined(ALADIN_BD_ASM_SADDR)
+#define BD_LOAD(dst, T_) asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2 offset:%3" : "=&v"(dst) : "v"(b_lane), "s"(bs), "n"((T_) * 1024 - 3072) : "memory");
+#define BD_ADVANCE() bs += 6144
+#elif defined(ALADIN_BD_ASM_VADDR)
+  const char* bp = yf_strip + b_lane;
+#define BD_LOAD(dst, T_) asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=&v"(dst) : "v"(bp), "n"((T_) * 1024 - 3072) : "memory");
+#define BD_ADVANCE() bp += 6144
+#else
+#define BD_LOAD(dst, T_) dst = *reinterpret_cast<const half8*>(bs + b_lane + ((T_) * 1024 - 3072));
+#define BD_ADVANCE() bs += 6144
+#endif
 #define BD_WAIT(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
+#ifndef ALADIN_BD_BUILTIN_DMA      /* default: asm LDS-DMA (see bd_stage_asm) */
+#define BD_STAGE(C0_, C1_) bd_stage_asm<ACfg, C0_, C1_>(a_rows, ldk, kref, nxt, wave, lane_off)
+#else
+#define BD_STAGE(C0_, C1_) gemm_stage<ACfg, C0_, C1_>(a_rows, nullptr, ACfg::BM, nullptr, ldk, kref, nxt, wave, lane_off)
+#endif
   // one cluster = 16 MFMAs: 8 row tiles x the pair's two column tiles 2C, 2C + 1
 #define BD_CLUSTER(PAIR, C, K32, ROWMAJOR)                                                                      \
     __builtin_amdgcn_sched_barrier(0);                                                                          \
@@ -70,13 +106,12 @@ __device__ __forceinline__ void gemm_mainloop16_tall_bdirect(const half_t* __res
     const int ks = st < ktiles ? st : ktiles - 1;
     gemm_stage<ACfg>(a_rows, nullptr, ACfg::BM, nullptr, ldk, ks, smem + st * ACfg::STAGE_BYTES, wave, lane_off);
   }
-  BD_LOAD(p0[0], 0, 0); BD_LOAD(p0[1], 0, 1);
-  BD_LOAD(p1[0], 0, 2); BD_LOAD(p1[1], 0, 3);
+  BD_LOAD(p0[0], 0); BD_LOAD(p0[1], 1);
+  BD_LOAD(p1[0], 2); BD_LOAD(p1[1], 3);
   for (int kt = 0; kt < ktiles; ++kt) {
     const int kref = kt + LEAD < ktiles ? kt + LEAD : ktiles - 1;   // always issued (uniform wait counts); see above
     const char* cur = smem + (kt % NS) * ACfg::STAGE_BYTES;
     char* nxt = smem + ((kt + LEAD) % NS) * ACfg::STAGE_BYTES;
-    const int kb = 2 * kt;
     // The wait before a cluster = the number of loads issued AFTER the pair it consumes.
     // cluster (0,0) needs p0: p1's reload (2) is younger; this wave's LDS-DMA pieces of stage kt are older still
     BD_WAIT(2);
@@ -86,28 +121,32 @@ __device__ __forceinline__ void gemm_mainloop16_tall_bdirect(const half_t* __res
     for (int rt = 1; rt < 8; ++rt) a[rt] = lds_frag16(cur, a_row0 + rt * 16, 0, lane);
     // ---- k32 = 0
     BD_CLUSTER(p0, 0, 0, true)                                       // tiles 0, 1
-    BD_LOAD(p0[0], kb, 4); BD_LOAD(p0[1], kb, 5);                   // -> cluster (0, 2)
-    gemm_stage<ACfg, 0, 2>(a_rows, nullptr, ACfg::BM, nullptr, ldk, kref, nxt, wave, lane_off);
+    BD_LOAD(p0[0], 4); BD_LOAD(p0[1], 5);                           // -> cluster (0, 2)
+    BD_ADVANCE();                                                    // block 2 kt + 1
+    BD_STAGE(0, 2);
     BD_WAIT(4);                                                      // behind p1: p0's reload + two LDS-DMA pieces
     BD_CLUSTER(p1, 1, 0, false)                                      // tiles 2, 3
-    BD_LOAD(p1[0], kb + 1, 0); BD_LOAD(p1[1], kb + 1, 1);           // -> cluster (1, 0)
+    BD_LOAD(p1[0], 0); BD_LOAD(p1[1], 1);                           // -> cluster (1, 0)
     BD_WAIT(4);                                                      // behind p0: two LDS-DMA pieces + p1's reload
     BD_CLUSTER(p0, 2, 0, true)                                       // tiles 4, 5 (+ the next 32-deep step's A fragments)
-    BD_LOAD(p0[0], kb + 1, 2); BD_LOAD(p0[1], kb + 1, 3);           // -> cluster (1, 1)
-    gemm_stage<ACfg, 2, 4>(a_rows, nullptr, ACfg::BM, nullptr, ldk, kref, nxt, wave, lane_off);
+    BD_LOAD(p0[0], 2); BD_LOAD(p0[1], 3);                           // -> cluster (1, 1)
+    BD_STAGE(2, 4);
     // ---- k32 = 1
     BD_WAIT(4);                                                      // behind p1: p0's reload + two LDS-DMA pieces
     BD_CLUSTER(p1, 0, 1, true)
-    BD_LOAD(p1[0], kb + 1, 4); BD_LOAD(p1[1], kb + 1, 5);           // -> cluster (1, 2)
+    BD_LOAD(p1[0], 4); BD_LOAD(p1[1], 5);                           // -> cluster (1, 2)
+    BD_ADVANCE();                                                    // block 2 kt + 2 (one past the end in the last K step)
     BD_WAIT(4);                                                      // behind p0: two LDS-DMA pieces + p1's reload
     BD_CLUSTER(p0, 1, 1, false)
-    BD_LOAD(p0[0], kb + 2, 0); BD_LOAD(p0[1], kb + 2, 1);           // -> next K step, cluster (0, 0)
+    BD_LOAD(p0[0], 0); BD_LOAD(p0[1], 1);                           // -> next K step, cluster (0, 0)
     BD_WAIT(2);                                                      // behind p1: p0's reload
     BD_CLUSTER(p1, 2, 1, true)
-    BD_LOAD(p1[0], kb + 2, 2); BD_LOAD(p1[1], kb + 2, 3);           // -> next K step, cluster (0, 1)
+    BD_LOAD(p1[0], 2); BD_LOAD(p1[1], 3);                           // -> next K step, cluster (0, 1)
   }
   BD_WAIT(0);                                                        // the clamped tail loads and refills
 #undef BD_CLUSTER
 #undef BD_LOAD
+#undef BD_STAGE
+#undef BD_ADVANCE
 #undef BD_WAIT
 }

@@ -71,7 +71,7 @@ class AlignmentContrastiveLoss(Contrastive):
             raise ValueError("aladin_amd: unknown alignment aggregation %r (supported: 'MrSw', 'MrAVGw', 'MwSr', "
                              "'symm', 'sum', 'mean', 'scan-sentences')" % (self.aggregation,))
         if return_loss and self.aggregation == 'MrSw':
-            # fused scores + hinge node; the returned matrix is detached (see ops.alignment_triplet_loss)
+            # fused scores + hinge node; both outputs are differentiable, as the reference's (ops.alignment_triplet_loss)
             loss, aggr_similarity = ops.alignment_triplet_loss(im_set, s_seq, im_len, s_len, self.margin,
                                                                self.max_violation)
             return (loss, aggr_similarity) if return_similarity_mat else loss
