@@ -405,9 +405,83 @@ def _host_lengths(lens):
     return [int(v) for v in (lens.tolist() if isinstance(lens, torch.Tensor) else lens)]
 
 
+# ------------------------------------------------------------------------------------------------
+# Length-bucketed evaluation grids.  The packed geometry pads the max side to whole 32-row region tiles (32, 32 + up to 8
+# side rows, 64, 96) and the sum side to whole 16-word tiles (16, 32, 48, 64, 96): one launch over the whole grid pays
+# for the LONGEST image and caption at every pair.  Real sets are ragged (COCO: 10-50 boxes, captions of ~12 tokens),
+# so the samples of each side are grouped by the tile class their own length needs, every (image class x caption
+# class) block is scored with its own geometry, and the blocks are laid back in the callers' order.  A score only
+# depends on its own image and caption rows (masked positions are zero rows whatever the class), so the scores are
+# those of the single launch up to the summation order of a different kernel variant (~1e-7 in split precision).
+# ------------------------------------------------------------------------------------------------
+X_CLASS_BOUNDS = (32, 40, 64, 96)          # scored max-side positions (incl. the one masked position kept for the zero fill)
+Y_CLASS_BOUNDS = (16, 32, 48, 64, 96)      # scored sum-side positions
+BUCKET_MIN_PAIRS = 1 << 18                 # below this a grid is one launch
+BUCKET_MIN_SAMPLES = 64                    # smaller classes join the next longer one
+BUCKET_MIN_GAIN = 0.10                     # padded work saved before bucketing is worth its extra launches
+
+
+def _needed_positions(lens, tail, total, keep_masked):
+    """Positions of the packed operand sample k needs: its scored positions (len - 1 - tail, clamped to the set), plus one
+    masked position on the max side when the sample is shorter than the set (alad/loss.py:116,124: the zero fill takes
+    part in the max)."""
+    cap = max(total - 1 - tail, 1)
+    out = []
+    for v in lens:
+        n = min(max(int(v) - 1 - tail, 1), cap)
+        out.append(min(n + 1, cap) if keep_masked and n < cap else n)
+    return out
+
+
+def bucket_plan(x_need, y_need):
+    """-> (x_groups, y_groups) lists of index lists (callers' order inside a group), or None when one launch is the better
+    choice.  x_need / y_need: positions per sample (_needed_positions)."""
+    def groups(need, bounds):
+        cls = [[] for _ in bounds]
+        for k, n in enumerate(need):
+            for c, b in enumerate(bounds):
+                if n <= b or c == len(bounds) - 1:
+                    cls[c].append(k)
+                    break
+        for c in range(len(cls) - 1):                               # small classes join the next longer one
+            if 0 < len(cls[c]) < BUCKET_MIN_SAMPLES:
+                cls[c + 1] = sorted(cls[c] + cls[c + 1])
+                cls[c] = []
+        last = [c for c in range(len(cls)) if cls[c]]
+        if len(last) > 1 and len(cls[last[-1]]) < BUCKET_MIN_SAMPLES:   # a small LAST class takes its neighbour in
+            cls[last[-1]] = sorted(cls[last[-2]] + cls[last[-1]])
+            cls[last[-2]] = []
+        return [(g, bounds[c]) for c, g in enumerate(cls) if g]
+    if len(x_need) * len(y_need) < BUCKET_MIN_PAIRS:
+        return None
+    gx, gy = groups(x_need, X_CLASS_BOUNDS), groups(y_need, Y_CLASS_BOUNDS)
+    if len(gx) == 1 and len(gy) == 1:
+        return None
+
+    def padded(n, bounds):
+        return next((b for b in bounds if n <= b), bounds[-1])
+    one = len(x_need) * len(y_need) * padded(max(x_need), X_CLASS_BOUNDS) * padded(max(y_need), Y_CLASS_BOUNDS)
+    work = sum(len(a) * len(b) * padded(max(x_need[k] for k in a), X_CLASS_BOUNDS) * padded(max(y_need[k] for k in b), Y_CLASS_BOUNDS)
+               for a, _ in gx for b, _ in gy)
+    if work > (1.0 - BUCKET_MIN_GAIN) * one:
+        return None
+    return [a for a, _ in gx], [b for b, _ in gy]
+
+
+def _assemble_blocks(blocks, gx, gy, Bx, By, device):
+    """Blocks scored in group order -> the (Bx, By) matrix in the callers' order."""
+    rows = [torch.cat([blocks[(a, b)] for b in range(len(gy))], dim=1) for a in range(len(gx))]
+    S_sorted = torch.cat(rows, dim=0)
+    inv_x = torch.empty(Bx, dtype=torch.int64)
+    inv_x[torch.tensor([k for g in gx for k in g], dtype=torch.int64)] = torch.arange(Bx, dtype=torch.int64)
+    inv_y = torch.empty(By, dtype=torch.int64)
+    inv_y[torch.tensor([k for g in gy for k in g], dtype=torch.int64)] = torch.arange(By, dtype=torch.int64)
+    return S_sorted.index_select(0, inv_x.to(device)).index_select(1, inv_y.to(device))
+
+
 def _scores_nograd(xs, ys, x_len, y_len, x_tail, y_tail, precision):
     """(Bx, By) scores of a max-side set xs (Bx, N, D) against a sum-side set ys (By, M, D) outside autograd:
-    the evaluation path.  Three things the differentiable path does not do:
+    the evaluation path.  Four things the differentiable path does not do:
       * operands in the evaluation precision (split fp16 by default: rank-exact Recall);
       * both sets are trimmed to the positions that can matter.  encode_data pads every set to 71 positions
         (alad/evaluation.py:98-99); positions past a set's length are masked to 0 by alad/loss.py:103-116
@@ -416,10 +490,38 @@ def _scores_nograd(xs, ys, x_len, y_len, x_tail, y_tail, precision):
         (`max(real dots, 0)`, alad/loss.py:116,124) for every sample shorter than the padded set, so ONE
         masked position is kept: the set is cut at the longest length + 1 (or not at all when some sample
         fills it).  The 70 x 68 padded block per pair shrinks to the real one and no score changes;
+      * large ragged grids are scored in length classes (bucket_plan above): a pair pays for the tile class of ITS image
+        and caption, not for the longest of the evaluation set;
       * the sum side is chunked so the side-row scratch of the score kernel stays under E_SCRATCH_LIMIT
         (16 GB at 5000 x 25000 otherwise); a score does not depend on the chunking."""
     x_len, y_len = _host_lengths(x_len), _host_lengths(y_len)
-    n_eff = min(xs.shape[1], max(2 + x_tail, max(x_len) + 1))
+    plan = bucket_plan(_needed_positions(x_len, x_tail, xs.shape[1], True), _needed_positions(y_len, y_tail, ys.shape[1], False))
+    if plan is None:
+        return _scores_nograd_block(xs, ys, x_len, y_len, x_tail, y_tail, precision)
+    gx, gy = plan
+    dev = xs.device
+    blocks = {}
+    ysub = []
+    for b in gy:
+        m_eff = min(ys.shape[1], max(2 + y_tail, max(y_len[k] for k in b)))
+        ysub.append((ys[:, :m_eff].index_select(0, torch.tensor(b, dtype=torch.int64, device=dev)), [y_len[k] for k in b]))
+    for ia, a in enumerate(gx):
+        n_eff = min(xs.shape[1], max(2 + x_tail, max(x_len[k] for k in a) + 1))
+        xa = xs[:, :n_eff].index_select(0, torch.tensor(a, dtype=torch.int64, device=dev))
+        la = [x_len[k] for k in a]
+        for ib, (yb, lb) in enumerate(ysub):
+            # the block keeps the FULL set's zero-fill rule: a sample is "shorter than the padded set" relative to xs, not to
+            # its class, which _scores_nograd_block reproduces because every class member is cut at its class's longest + 1
+            blocks[(ia, ib)] = _scores_nograd_block(xa, yb, la, lb, x_tail, y_tail, precision, x_total=xs.shape[1])
+    return _assemble_blocks(blocks, gx, gy, xs.shape[0], ys.shape[0], dev)
+
+
+def _scores_nograd_block(xs, ys, x_len, y_len, x_tail, y_tail, precision, x_total=None):
+    """One geometry for the whole block (see _scores_nograd).  x_total: positions of the set the block's max side was cut
+    from (a sample that fills IT has no masked position; default: xs itself)."""
+    x_total = xs.shape[1] if x_total is None else x_total
+    longest = max(x_len)
+    n_eff = min(xs.shape[1], max(2 + x_tail, longest + (1 if longest < x_total else 0)))
     m_eff = min(ys.shape[1], max(2 + y_tail, max(y_len)))
     xs, ys = xs[:, :n_eff], ys[:, :m_eff]
     dev = xs.device

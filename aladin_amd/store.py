@@ -143,10 +143,35 @@ def _unwrap(x):
 
 
 def alignment_scores_from_stores(img, cap):
-    """(N_img, N_cap) 'MrSw' scores (reference alad/loss.py:80-125) between two stores / views:
-    operands are row copies of the stores (no fp32 read, no normalisation).  One score launch, or one
-    per caption chunk when the side-row scratch (N_img x 16*tp16*N_cap floats when R' = 33) would pass
-    E_SCRATCH_LIMIT -- 16 GB for a 5000 x 25000 grid otherwise; a score does not depend on the chunking."""
+    """(N_img, N_cap) 'MrSw' scores (reference alad/loss.py:80-125) between two stores / views: operands are row
+    copies of the stores (no fp32 read, no normalisation).  Large ragged grids are scored in length classes
+    (ops.bucket_plan: a pair pays for the tile class of its own image and caption); each class block is
+    _store_scores_block."""
+    si, ids_i, _ = _unwrap(img)
+    sc, ids_c, _ = _unwrap(cap)
+    if len(img) < 1 or len(cap) < 1:
+        raise ValueError('aladin_amd: empty store')
+    ids_i = list(range(len(si))) if ids_i is None else list(ids_i)
+    ids_c = list(range(len(sc))) if ids_c is None else list(ids_c)
+    cap_x = max(si.padded_len - 1 - si.tail, 1)
+    need_x = [min(max(si._counts[k], 1) + 1, cap_x) if si._counts[k] < cap_x else cap_x for k in ids_i]
+    need_y = [max(sc._counts[k], 1) for k in ids_c]
+    plan = ops.bucket_plan(need_x, need_y)
+    if plan is None:
+        return _store_scores_block(img, cap)
+    gx, gy = plan
+    blocks = {}
+    for a, ga in enumerate(gx):
+        va = StoreView(si, [ids_i[k] for k in ga])
+        for b, gb in enumerate(gy):
+            blocks[(a, b)] = _store_scores_block(va, StoreView(sc, [ids_c[k] for k in gb]))
+    return ops._assemble_blocks(blocks, gx, gy, len(ids_i), len(ids_c), si.device)
+
+
+def _store_scores_block(img, cap):
+    """One geometry for the whole block.  One score launch, or one per caption chunk when the side-row scratch
+    (N_img x 16*tp16*N_cap floats when R' = 33) would pass E_SCRATCH_LIMIT -- 16 GB for a 5000 x 25000 grid otherwise;
+    a score does not depend on the chunking."""
     si, ids_i, idt_i = _unwrap(img)
     sc, ids_c, idt_c = _unwrap(cap)
     if si.D != sc.D:

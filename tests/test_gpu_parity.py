@@ -691,6 +691,35 @@ def test_alignment_head_retrieval_coco1k(eval_precision, fixture):
     assert torch.equal(E.compute_sim_matrix(si.view(slice(0, None, 5)), sc, mode='alignment').cpu(), torch.from_numpy(S))
 
 
+def test_length_bucketed_grid_equals_the_single_launch(eval_precision, monkeypatch):
+    """ops.bucket_plan: a large ragged evaluation grid is scored in length classes (each image / caption pays for the tile
+    class of its own length).  Against the single launch over the whole grid (the planner switched off) and the oracle, for
+    (N, 71, D) tensors and for packed stores; images that fill the padded set (no zero fill in their max) included."""
+    from aladin_amd import evaluation as E, ops, synth
+    n_img, D = 90, 128
+    images, captions, il, cl = synth.eval_sets(n_img, D, seed=77, img_len_range=(6, 70), cap_len_range=(5, 66), n_full=4)
+    assert max(il) == 71 and min(il) < 30
+    ims, ils = images[0::5], il[0::5]
+    monkeypatch.setattr(ops, 'BUCKET_MIN_PAIRS', 1)
+    monkeypatch.setattr(ops, 'BUCKET_MIN_SAMPLES', 8)
+    plan = ops.bucket_plan(ops._needed_positions(ils, 0, 71, True), ops._needed_positions(cl, 2, 71, False))
+    assert plan is not None and len(plan[0]) >= 3 and len(plan[1]) >= 3
+    assert sorted(k for g in plan[0] for k in g) == list(range(n_img)) and sorted(k for g in plan[1] for k in g) == list(range(5 * n_img))
+    S_b = E.compute_sim_matrix(T(ims), T(captions), ils, cl, mode='alignment')
+    si, sc = _fill_stores(images, captions, il, cl, batch=53)
+    S_bs = E.compute_sim_matrix(si.view(slice(0, None, 5)), sc, mode='alignment')
+    assert torch.equal(S_b, S_bs)                                   # same plan, same operand bits
+    monkeypatch.setattr(ops, 'bucket_plan', lambda *a: None)
+    S_1 = E.compute_sim_matrix(T(ims), T(captions), ils, cl, mode='alignment')
+    ref = O.alignment_scores(ims, captions, ils, cl, dtype=np.float64)
+    if eval_precision == 'split':
+        np.testing.assert_allclose(S_b.cpu().numpy(), S_1.cpu().numpy(), rtol=0, atol=2e-6)
+        np.testing.assert_allclose(S_b.cpu().numpy(), ref, rtol=2e-6, atol=3e-6)
+    else:
+        assert_scores_close(S_b.cpu().numpy(), S_1.cpu().numpy(), rtol=1e-6, atol_rel=1e-6)      # same operands: summation order only
+        assert_scores_close(S_b.cpu().numpy(), ref)
+
+
 def _fill_store(sets, lens, tail, precision, batch=4):
     from aladin_amd.store import PackedSetStore
     st = PackedSetStore(sets.shape[2], tail, dev(), capacity_rows=64, precision=precision)
