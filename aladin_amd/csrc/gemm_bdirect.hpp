@@ -144,6 +144,13 @@ __device__ __forceinline__ void gemm_mainloop16_tall_bdirect(const half_t* __res
     BD_LOAD(p1[0], 2); BD_LOAD(p1[1], 3);                           // -> next K step, cluster (0, 1)
   }
   BD_WAIT(0);                                                        // the clamped tail loads and refills
+#if defined(ALADIN_BD_ASM_SADDR) || defined(ALADIN_BD_ASM_VADDR)
+  // The compiler believes an asm output is written when the asm statement ends.  The last iteration's prefetches are never
+  // consumed, so their registers are free the moment the loop is left -- and the epilogue's address arithmetic, hoisted
+  // above the wait, landed in them while the loads were still in flight (faults at addresses made of fp16 data).  Naming the
+  // four registers AFTER the wait keeps them allocated until the loads have landed.
+  asm volatile("" :: "v"(p0[0]), "v"(p0[1]), "v"(p1[0]), "v"(p1[1]));
+#endif
 #undef BD_CLUSTER
 #undef BD_LOAD
 #undef BD_STAGE
