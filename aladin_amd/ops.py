@@ -468,15 +468,49 @@ def bucket_plan(x_need, y_need):
     return [a for a, _ in gx], [b for b, _ in gy]
 
 
-def _assemble_blocks(blocks, gx, gy, Bx, By, device):
-    """Blocks scored in group order -> the (Bx, By) matrix in the callers' order."""
-    rows = [torch.cat([blocks[(a, b)] for b in range(len(gy))], dim=1) for a in range(len(gx))]
-    S_sorted = torch.cat(rows, dim=0)
-    inv_x = torch.empty(Bx, dtype=torch.int64)
-    inv_x[torch.tensor([k for g in gx for k in g], dtype=torch.int64)] = torch.arange(Bx, dtype=torch.int64)
-    inv_y = torch.empty(By, dtype=torch.int64)
-    inv_y[torch.tensor([k for g in gy for k in g], dtype=torch.int64)] = torch.arange(By, dtype=torch.int64)
-    return S_sorted.index_select(0, inv_x.to(device)).index_select(1, inv_y.to(device))
+def _index_tensor(ids, device, dtype=torch.int64):
+    """Index list -> device tensor WITHOUT making the host wait for the device (torch.tensor(..., device=...) is a blocking
+    copy: it drains the stream, and a grid scored in blocks would serialise host and GPU work block by block)."""
+    return torch.tensor(ids, dtype=dtype).to(device, non_blocking=True)
+
+
+class GridPlan:
+    """The length classes of one evaluation grid, with everything the blocks need already on the device: per-class index
+    tensors and the permutation that lays the class-ordered blocks back in the callers' order.  Built once per
+    (lengths, device) and cached: validation scores the same sets twice per epoch (i2t, t2i) and every epoch again."""
+
+    def __init__(self, gx, gy, device):
+        self.gx, self.gy = gx, gy
+        self.ix = [_index_tensor(g, device) for g in gx]
+        self.iy = [_index_tensor(g, device) for g in gy]
+        Bx, By = sum(len(g) for g in gx), sum(len(g) for g in gy)
+        inv_x = torch.empty(Bx, dtype=torch.int64)
+        inv_x[torch.tensor([k for g in gx for k in g], dtype=torch.int64)] = torch.arange(Bx, dtype=torch.int64)
+        inv_y = torch.empty(By, dtype=torch.int64)
+        inv_y[torch.tensor([k for g in gy for k in g], dtype=torch.int64)] = torch.arange(By, dtype=torch.int64)
+        self.inv_x, self.inv_y = inv_x.to(device, non_blocking=True), inv_y.to(device, non_blocking=True)
+        self.extra = {}                                   # per-caller attachments (store views)
+
+    def assemble(self, blocks):
+        """Blocks scored in class order -> the (Bx, By) matrix in the callers' order."""
+        rows = [torch.cat([blocks[(a, b)] for b in range(len(self.gy))], dim=1) for a in range(len(self.gx))]
+        return torch.cat(rows, dim=0).index_select(0, self.inv_x).index_select(1, self.inv_y)
+
+
+_PLAN_CACHE = {}
+
+
+def grid_plan(key, x_need_fn, y_need_fn, device):
+    """Cached GridPlan (or None: one launch) for `key`; the *_need_fn callables are only evaluated on a miss."""
+    key = key + (str(device),)
+    if key in _PLAN_CACHE:
+        return _PLAN_CACHE[key]
+    plan = bucket_plan(x_need_fn(), y_need_fn())
+    entry = GridPlan(plan[0], plan[1], device) if plan is not None else None
+    if len(_PLAN_CACHE) >= 8:
+        _PLAN_CACHE.clear()
+    _PLAN_CACHE[key] = entry
+    return entry
 
 
 def _scores_nograd(xs, ys, x_len, y_len, x_tail, y_tail, precision):
@@ -495,25 +529,28 @@ def _scores_nograd(xs, ys, x_len, y_len, x_tail, y_tail, precision):
       * the sum side is chunked so the side-row scratch of the score kernel stays under E_SCRATCH_LIMIT
         (16 GB at 5000 x 25000 otherwise); a score does not depend on the chunking."""
     x_len, y_len = _host_lengths(x_len), _host_lengths(y_len)
-    plan = bucket_plan(_needed_positions(x_len, x_tail, xs.shape[1], True), _needed_positions(y_len, y_tail, ys.shape[1], False))
+    dev = xs.device
+    plan = None
+    if len(x_len) * len(y_len) >= BUCKET_MIN_PAIRS:
+        plan = grid_plan(('dense', tuple(x_len), tuple(y_len), x_tail, y_tail, xs.shape[1], ys.shape[1]),
+                         lambda: _needed_positions(x_len, x_tail, xs.shape[1], True),
+                         lambda: _needed_positions(y_len, y_tail, ys.shape[1], False), dev)
     if plan is None:
         return _scores_nograd_block(xs, ys, x_len, y_len, x_tail, y_tail, precision)
-    gx, gy = plan
-    dev = xs.device
     blocks = {}
     ysub = []
-    for b in gy:
+    for b, ib in zip(plan.gy, plan.iy):
         m_eff = min(ys.shape[1], max(2 + y_tail, max(y_len[k] for k in b)))
-        ysub.append((ys[:, :m_eff].index_select(0, torch.tensor(b, dtype=torch.int64, device=dev)), [y_len[k] for k in b]))
-    for ia, a in enumerate(gx):
+        ysub.append((ys[:, :m_eff].index_select(0, ib), [y_len[k] for k in b]))
+    for ia, (a, ixa) in enumerate(zip(plan.gx, plan.ix)):
         n_eff = min(xs.shape[1], max(2 + x_tail, max(x_len[k] for k in a) + 1))
-        xa = xs[:, :n_eff].index_select(0, torch.tensor(a, dtype=torch.int64, device=dev))
+        xa = xs[:, :n_eff].index_select(0, ixa)
         la = [x_len[k] for k in a]
         for ib, (yb, lb) in enumerate(ysub):
             # the block keeps the FULL set's zero-fill rule: a sample is "shorter than the padded set" relative to xs, not to
             # its class, which _scores_nograd_block reproduces because every class member is cut at its class's longest + 1
             blocks[(ia, ib)] = _scores_nograd_block(xa, yb, la, lb, x_tail, y_tail, precision, x_total=xs.shape[1])
-    return _assemble_blocks(blocks, gx, gy, xs.shape[0], ys.shape[0], dev)
+    return plan.assemble(blocks)
 
 
 def _scores_nograd_block(xs, ys, x_len, y_len, x_tail, y_tail, precision, x_total=None):

@@ -151,21 +151,32 @@ def alignment_scores_from_stores(img, cap):
     sc, ids_c, _ = _unwrap(cap)
     if len(img) < 1 or len(cap) < 1:
         raise ValueError('aladin_amd: empty store')
+    if len(img) * len(cap) < ops.BUCKET_MIN_PAIRS:
+        return _store_scores_block(img, cap)
     ids_i = list(range(len(si))) if ids_i is None else list(ids_i)
     ids_c = list(range(len(sc))) if ids_c is None else list(ids_c)
     cap_x = max(si.padded_len - 1 - si.tail, 1)
-    need_x = [min(max(si._counts[k], 1) + 1, cap_x) if si._counts[k] < cap_x else cap_x for k in ids_i]
-    need_y = [max(sc._counts[k], 1) for k in ids_c]
-    plan = ops.bucket_plan(need_x, need_y)
+
+    def need_x():
+        return [min(max(si._counts[k], 1) + 1, cap_x) if si._counts[k] < cap_x else cap_x for k in ids_i]
+
+    def need_y():
+        return [max(sc._counts[k], 1) for k in ids_c]
+    # keyed on the stores' identity and fill state: an append invalidates the plan
+    plan = ops.grid_plan(('store', id(si), si.n_rows, len(si), id(sc), sc.n_rows, len(sc), tuple(ids_i), tuple(ids_c)),
+                         need_x, need_y, si.device)
     if plan is None:
         return _store_scores_block(img, cap)
-    gx, gy = plan
-    blocks = {}
-    for a, ga in enumerate(gx):
-        va = StoreView(si, [ids_i[k] for k in ga])
-        for b, gb in enumerate(gy):
-            blocks[(a, b)] = _store_scores_block(va, StoreView(sc, [ids_c[k] for k in gb]))
-    return ops._assemble_blocks(blocks, gx, gy, len(ids_i), len(ids_c), si.device)
+    views = plan.extra.get('views')
+    if views is None:                                   # the class views (with their device index tensors), built once per plan
+        vx = [StoreView(si, [ids_i[k] for k in g]) for g in plan.gx]
+        vy = [StoreView(sc, [ids_c[k] for k in g]) for g in plan.gy]
+        for v in vx + vy:
+            v._ids_t = ops._index_tensor(v.ids, si.device, torch.int32)
+        views = plan.extra['views'] = (vx, vy)
+    vx, vy = views
+    blocks = {(a, b): _store_scores_block(va, vb) for a, va in enumerate(vx) for b, vb in enumerate(vy)}
+    return plan.assemble(blocks)
 
 
 def _store_scores_block(img, cap):

@@ -702,6 +702,7 @@ def test_length_bucketed_grid_equals_the_single_launch(eval_precision, monkeypat
     ims, ils = images[0::5], il[0::5]
     monkeypatch.setattr(ops, 'BUCKET_MIN_PAIRS', 1)
     monkeypatch.setattr(ops, 'BUCKET_MIN_SAMPLES', 8)
+    ops._PLAN_CACHE.clear()
     plan = ops.bucket_plan(ops._needed_positions(ils, 0, 71, True), ops._needed_positions(cl, 2, 71, False))
     assert plan is not None and len(plan[0]) >= 3 and len(plan[1]) >= 3
     assert sorted(k for g in plan[0] for k in g) == list(range(n_img)) and sorted(k for g in plan[1] for k in g) == list(range(5 * n_img))
@@ -710,7 +711,9 @@ def test_length_bucketed_grid_equals_the_single_launch(eval_precision, monkeypat
     S_bs = E.compute_sim_matrix(si.view(slice(0, None, 5)), sc, mode='alignment')
     assert torch.equal(S_b, S_bs)                                   # same plan, same operand bits
     monkeypatch.setattr(ops, 'bucket_plan', lambda *a: None)
+    ops._PLAN_CACHE.clear()
     S_1 = E.compute_sim_matrix(T(ims), T(captions), ils, cl, mode='alignment')
+    ops._PLAN_CACHE.clear()
     ref = O.alignment_scores(ims, captions, ils, cl, dtype=np.float64)
     if eval_precision == 'split':
         np.testing.assert_allclose(S_b.cpu().numpy(), S_1.cpu().numpy(), rtol=0, atol=2e-6)

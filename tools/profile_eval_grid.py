@@ -25,6 +25,7 @@ def main():
             saved = ops.bucket_plan
             if not bucket:
                 ops.bucket_plan = lambda *a: None
+            ops._PLAN_CACHE.clear()
             fn = lambda: E.compute_sim_matrix(ia, ca, ilen, cl, mode='alignment')
             for _ in range(3):
                 fn()
@@ -49,6 +50,7 @@ def main():
                 pr.disable()
                 pstats.Stats(pr).sort_stats('tottime').print_stats(14)
             ops.bucket_plan = saved
+            ops._PLAN_CACHE.clear()
 
 
 if __name__ == '__main__':
