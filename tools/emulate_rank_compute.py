@@ -11,22 +11,27 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
 
-def timed(fn, n=10):
-    for _ in range(2):
-        fn()
-    torch.cuda.synchronize()
+def timed(fn, n=30, preroll_s=0.5):
+    """HIP-event time per call after a clock-settling pre-roll (round 2 timed 10 eager calls on a cold clock)."""
     t0 = time.perf_counter()
+    while time.perf_counter() - t0 < preroll_s:
+        for _ in range(5):
+            fn()
+        torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
     for _ in range(n):
         fn()
+    e1.record()
     torch.cuda.synchronize()
-    return (time.perf_counter() - t0) / n * 1e3
+    return e0.elapsed_time(e1) / n
 
 
 def main():
     from aladin_amd import distributed as DD, ops, synth
     dev = torch.device('cuda:0')
     B, R, T, D = 256, 34, 50, 768
-    for W in [int(a) for a in sys.argv[1:]] or [2, 4, 8]:
+    for W in [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]:
         ims, caps = [], []
         for r in range(W):
             im, s, il, sl = synth.alignment_batch(B, R, T, D, seed=1234 + 17 * r)
@@ -42,6 +47,13 @@ def main():
         im_all = torch.cat(ims)
         t_pack = timed(lambda: ops.pack_images(ims[0], ilt, g_loc))
         t_scores = timed(lambda: DD.rank_scores_block(xm_all, xe_all, caps[0], slt, g_glob))
+        # its parts: caption pack, side GEMM + score kernel, score kernel alone (side result reused)
+        y0 = ops.pack_captions(caps[0], slt, g_glob)
+        S0 = torch.empty((W * B, B), dtype=torch.float32, device=dev)
+        e0 = torch.empty(g_glob.e_bytes, dtype=torch.uint8, device=dev)
+        t_packc = timed(lambda: ops.pack_captions(caps[0], slt, g_glob))
+        t_side_score = timed(lambda: ops.scores_from_packed(xm_all, xe_all, y0, g_glob, S0, e0))
+        t_score_only = timed(lambda: ops.scores_from_packed(xm_all, xe_all, y0, g_glob, S0, e0, reuse_side=True))
         blocks = [DD.rank_scores_block(xm_all, xe_all, caps[r], slt, g_glob) for r in range(W)]
         S_full = torch.cat([b[0] for b in blocks], dim=1).contiguous()
         t_hinge = timed(lambda: ops._hinge_raw(S_full, 0.2, True, True))
@@ -51,7 +63,9 @@ def main():
         im_need, il_need = im_all.index_select(0, need), il_all.index_select(0, need)
         dS_need = dS_full.index_select(0, need)[:, :B].contiguous()
         t_sparse = timed(lambda: ops._align_backward(im_need, caps[0], il_need, slt, dS_need))
-        print(json.dumps({'W': W, 'pack_ms': round(t_pack, 3), 'scores_block_ms': round(t_scores, 3), 'hinge_ms': round(t_hinge, 3),
+        print(json.dumps({'W': W, 'pack_ms': round(t_pack, 3), 'scores_block_ms': round(t_scores, 3), 'pack_captions_ms': round(t_packc, 4),
+                          'side_plus_score_ms': round(t_side_score, 4), 'score_kernel_ms': round(t_score_only, 4),
+                          'score_kernel_us_per_256x256_block': round(t_score_only * 1e3 / W, 2), 'hinge_ms': round(t_hinge, 3),
                           'bwd_dense_ms': round(t_dense, 3), 'bwd_compact_ms': round(t_sparse, 3), 'images_needed': int(need.numel()),
                           'of': W * B, 'dense_exchange_MB': round(2 * W * B * R * D * 4 / 2 ** 20, 1),
                           'sparse_exchange_MB': round(2 * int(need.numel()) * R * D * 4 / 2 ** 20 * (W - 1) / W, 1)}), flush=True)
