@@ -62,7 +62,8 @@ while time.time() - t0 < budget:
             scale = max(1e-6, float(np.abs(ref).max()))
             if prec == 'split':
                 worst['bucket_split'] = max(worst['bucket_split'], d2)
-                assert d1 <= 4e-6 and d2 <= 4e-6 + 3e-6 * scale, ('bucket split', case_seed, d1, d2)
+                # a different kernel class sums in a different order: a few fp32 ulps of the score
+                assert d1 <= 2e-6 + 1e-6 * scale and d2 <= 4e-6 + 3e-6 * scale, ('bucket split', case_seed, d1, d2, scale)
             else:
                 assert d1 <= 1e-5 * scale + 1e-6 and d2 <= 1e-3 * scale, ('bucket fp16', case_seed, d1, d2)
         ops.bucket_plan = real_plan
