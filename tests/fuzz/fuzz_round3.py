@@ -87,11 +87,16 @@ while time.time() - t0 < budget:
         ops.set_backward_precision('exact')
         _, dS = O.hinge_loss(grads['fp16'][2], 0.2, mv, return_grad=True)
         dim, ds = O.alignment_scores_backward(im, s, il, sl, dS)
+        # The opt-in changes the partner VALUES only, the arg-maxima are the exact path's: judged against the exact kernel path
+        # (an fp32 near-tie that the float64 oracle resolves the other way swaps a whole partner row in BOTH modes; the exact
+        # path's own agreement with the oracle is fuzz_parity.py's subject, which sets such ties aside).
         for got, ex, ref in ((grads['fp16'][0], grads['exact'][0], dim), (grads['fp16'][1], grads['exact'][1], ds)):
-            scale = max(1e-9, float(np.abs(ref).max()))
-            err = float(np.abs(got - ref).max()) / scale
+            scale = max(1e-9, float(np.abs(ex).max()))
+            err = float(np.abs(got - ex).max()) / scale
             worst['partners'] = max(worst['partners'], err)
-            assert np.all(np.abs(got - ref) <= 1e-3 * np.abs(ref) + 5e-4 * scale), ('partners', case_seed, err)
+            assert np.all(np.abs(got - ex) <= 1e-3 * np.abs(ex) + 5e-4 * scale), ('partners', case_seed, B, R, Tn, D, mv, err)
             assert np.array_equal(got == 0, ex == 0) or np.abs(got[(got == 0) != (ex == 0)]).max() <= 1e-6 * scale, ('zero pattern', case_seed)
+            if float(np.abs(ex - ref).max()) <= 1e-4 * scale:          # no near-tie swap in this case: the oracle applies too
+                assert np.all(np.abs(got - ref) <= 1e-3 * np.abs(ref) + 5e-4 * scale), ('partners vs oracle', case_seed, B, R, Tn, D, mv)
     counts[kind] += 1
 print('fuzz_round3 ok:', counts, 'worst', {k: float('%.3g' % v) for k, v in worst.items()}, 'seed', seed)
