@@ -17,7 +17,7 @@ from .loss import AlignmentContrastiveLoss, ContrastiveLoss, DistillationLoss, d
 
 
 class ALADModel(nn.Module):
-    def __init__(self, config, oscar_checkpoint=None, encoder=None, backbone=None, shard_group=False):
+    def __init__(self, config, oscar_checkpoint=None, encoder=None, backbone=None, shard_group=False, backbone_autocast=None):
         """shard_group: False = single device (the reference, alad/train.py:251-255); None or a torch.distributed group =
         one process per GPU, the loss heads run on the GLOBAL batch (all ranks' samples) with the score matrices sharded
         by caption block (aladin_amd.distributed.sharded_loss_heads; BASELINE configs[3] for the shipped YAMLs).
@@ -28,7 +28,7 @@ class ALADModel(nn.Module):
         super().__init__()
         if encoder is None and (backbone is not None or oscar_checkpoint is not None):
             from .encoder import JointTextImageTransformerEncoder
-            encoder = JointTextImageTransformerEncoder(config, backbone, oscar_checkpoint)     # :259
+            encoder = JointTextImageTransformerEncoder(config, backbone, oscar_checkpoint, backbone_autocast)     # :259
         self.img_txt_enc = encoder                                   # alad_model.py:259 (injected here)
         training = config['training']
         self.losses_types = training['loss-type'].split('-')          # :265

@@ -86,8 +86,13 @@ class JointTextImageTransformerEncoder(nn.Module):
         examples_imgs = (input_ids, attention_mask, token_type_ids, img_feats, <unused>, feat_len)
     and returns (img_glob (B,D), cap_glob (B,D), img_set (R,B,D), cap_seq (T,B,D), feat_len, cap_len, reg_loss)."""
 
-    def __init__(self, config, backbone=None, oscar_checkpoint=None):
+    def __init__(self, config, backbone=None, oscar_checkpoint=None, backbone_autocast=None):
+        """backbone_autocast: None (default: the backbone runs in fp32, as the reference trains) or a torch dtype
+        (torch.bfloat16 / torch.float16): the two BERT passes run under torch.autocast -- 16-bit MFMA GEMMs instead of fp32
+        ones; the hand-off, the matching head and the loss heads stay fp32.  An MI355X-side option, not reference behaviour:
+        the end-to-end step of the shipped YAML is 99 % backbone (tools/bench_e2e_config4.py)."""
         super().__init__()
+        self.backbone_autocast = backbone_autocast
         m = config['model']
         if backbone is None:
             if oscar_checkpoint is None:
@@ -117,11 +122,14 @@ class JointTextImageTransformerEncoder(nn.Module):
 
     def forward(self, examples_imgs, examples_txts):
         from .loss import l2norm
-        with torch.set_grad_enabled(torch.is_grad_enabled() and not self.freeze_teran):        # :121-123
+        with torch.set_grad_enabled(torch.is_grad_enabled() and not self.freeze_teran), \
+                torch.autocast('cuda', dtype=self.backbone_autocast or torch.bfloat16, enabled=self.backbone_autocast is not None):   # :121-123
             txt_out = self.oscar_model.bert(input_ids=examples_txts[0], attention_mask=examples_txts[1],
                                             token_type_ids=examples_txts[2], img_feats=None)
             img_out = self.oscar_model.bert(input_ids=examples_imgs[0], attention_mask=examples_imgs[1],
                                             token_type_ids=examples_imgs[2], img_feats=examples_imgs[3])
+        if self.backbone_autocast is not None:                         # everything downstream is fp32
+            txt_out, img_out = (txt_out[0].float(),), (img_out[0].float(),)
         cap_len, feat_len = examples_txts[4], examples_imgs[5]
         n_tok = examples_txts[0].shape[1]                              # max_language_token_len (:147)
         max_cap, max_img = max(cap_len), max(feat_len)

@@ -39,7 +39,8 @@ def main():
               'training': {'max-violation': True, 'loss-type': 'alignment-distillation', 'loss-weights': [1, 1], 'alignment-mode': 'MrSw',
                            'distillation-mode': 'listnet', 'measure': 'dot', 'margin': 0.2, 'bs': 32}}
     torch.manual_seed(0)
-    model = ALADModel(config, backbone=ImageBertForSequenceClassification(BertConfig())).to(dev).train()
+    ac = {'bf16': torch.bfloat16, 'fp16': torch.float16}.get(sys.argv[2]) if len(sys.argv) > 2 else None
+    model = ALADModel(config, backbone=ImageBertForSequenceClassification(BertConfig()), backbone_autocast=ac).to(dev).train()
     bs = int(sys.argv[1]) if len(sys.argv) > 1 else 32
     n_tok, n_reg = 35, 50
     rng = np.random.default_rng(1)
@@ -80,7 +81,7 @@ def main():
         loss.backward()
 
     res = {'workload': 'configs[4] shape-level: alad-alignment-and-matching-distill.yaml step, bs %d, %d tokens, %d regions, VinVL-base '
-                       'BertImgModel with random weights, fp32' % (bs, n_tok, n_reg),
+                       'BertImgModel with random weights, backbone %s' % (bs, n_tok, n_reg, 'fp32' if ac is None else 'autocast ' + sys.argv[2]),
            'parameters_M': round(sum(p.numel() for p in params) / 1e6, 1)}
     for name, fn in (('full_step', full_step), ('encoder_only', encoder_only), ('loss_heads_only', heads_only)):
         wall, gpu = timed(fn)
