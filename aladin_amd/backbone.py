@@ -292,6 +292,36 @@ class BertImgModel(nn.Module):
         return (enc[0], self.pooler(enc[0])) + enc[1:]                 # :274-279
 
 
+    def forward_pair(self, txt_input_ids, txt_token_type_ids, txt_attention_mask, img_input_ids, img_token_type_ids,
+                     img_attention_mask, img_feats):
+        """The two passes ALADIN makes per step (alad_model.py:124-140: captions alone, then tags + regions) as ONE pass over
+        a batch of 2B sequences: the caption embeddings are zero-padded to the image pass's length and masked.  A training
+        step of this model on an MI355X is bound by the NUMBER of kernels (thousands of launches of a few microseconds each,
+        tools/bench_e2e_config4.py), not by their work, so one pass of twice the batch costs about what one of the two did.
+        Masked positions get exp(-10000) = 0 attention weight exactly, every other operation is per position: the real
+        positions' states equal those of the two separate passes up to GEMM summation order.
+        -> (txt_sequence_output (B, T_txt, H), img_sequence_output (B, T_img + R, H))"""
+        if self.encoder.output_attentions or self.encoder.output_hidden_states:
+            raise NotImplementedError('forward_pair returns the last hidden states only')
+        B, Tt = txt_input_ids.shape
+        e_txt = self.embeddings(txt_input_ids, token_type_ids=txt_token_type_ids)
+        e_img = self.embeddings(img_input_ids, token_type_ids=img_token_type_ids)
+        f = self.img_embedding(img_feats)
+        if self.use_img_layernorm:
+            f = self.LayerNorm(f)
+        e_img = torch.cat((e_img, self.dropout(f)), 1)
+        L = e_img.size(1)
+        if L < Tt:
+            raise ValueError('forward_pair expects the image pass to be at least as long as the caption pass')
+        x = torch.cat((F.pad(e_txt, (0, 0, 0, L - Tt)), e_img), 0)                                   # (2B, L, H)
+        if txt_attention_mask is None:
+            txt_attention_mask = torch.ones_like(txt_input_ids)
+        m = torch.cat((F.pad(txt_attention_mask, (0, L - Tt)), img_attention_mask), 0)                 # (2B, L)
+        ext = (1.0 - m[:, None, None, :].to(x.dtype)) * -10000.0
+        h = self.encoder(x, ext)[0]
+        return h[:B, :Tt], h[B:]
+
+
 class ImageBertForSequenceClassification(nn.Module):
     """The shell the reference loads the VinVL checkpoint into (oscar/modeling/modeling_bert.py:290-320): ALADIN only calls
     `.bert(...)` (alad_model.py:131,140); `classifier` is kept so that the checkpoint's keys load with strict=True."""

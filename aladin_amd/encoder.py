@@ -93,6 +93,7 @@ class JointTextImageTransformerEncoder(nn.Module):
         the end-to-end step of the shipped YAML is 99 % backbone (tools/bench_e2e_config4.py)."""
         super().__init__()
         self.backbone_autocast = backbone_autocast
+        self.batch_passes = True              # use the backbone's forward_pair when it has one (aladin_amd.backbone does)
         m = config['model']
         if backbone is None:
             if oscar_checkpoint is None:
@@ -124,10 +125,17 @@ class JointTextImageTransformerEncoder(nn.Module):
         from .loss import l2norm
         with torch.set_grad_enabled(torch.is_grad_enabled() and not self.freeze_teran), \
                 torch.autocast('cuda', dtype=self.backbone_autocast or torch.bfloat16, enabled=self.backbone_autocast is not None):   # :121-123
-            txt_out = self.oscar_model.bert(input_ids=examples_txts[0], attention_mask=examples_txts[1],
-                                            token_type_ids=examples_txts[2], img_feats=None)
-            img_out = self.oscar_model.bert(input_ids=examples_imgs[0], attention_mask=examples_imgs[1],
-                                            token_type_ids=examples_imgs[2], img_feats=examples_imgs[3])
+            pair = getattr(self.oscar_model.bert, 'forward_pair', None) if self.batch_passes else None
+            if pair is not None and examples_imgs[1] is not None:
+                # both passes (:124-140) as one pass of 2B sequences: half the launches of a launch-bound step (backbone.py)
+                t_seq, i_seq = pair(examples_txts[0], examples_txts[2], examples_txts[1], examples_imgs[0], examples_imgs[2],
+                                    examples_imgs[1], examples_imgs[3])
+                txt_out, img_out = (t_seq,), (i_seq,)
+            else:
+                txt_out = self.oscar_model.bert(input_ids=examples_txts[0], attention_mask=examples_txts[1],
+                                                token_type_ids=examples_txts[2], img_feats=None)
+                img_out = self.oscar_model.bert(input_ids=examples_imgs[0], attention_mask=examples_imgs[1],
+                                                token_type_ids=examples_imgs[2], img_feats=examples_imgs[3])
         if self.backbone_autocast is not None:                         # everything downstream is fp32
             txt_out, img_out = (txt_out[0].float(),), (img_out[0].float(),)
         cap_len, feat_len = examples_txts[4], examples_imgs[5]

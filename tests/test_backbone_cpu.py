@@ -84,6 +84,38 @@ def test_padded_positions_do_not_reach_attended_ones():
     np.testing.assert_allclose(b[keep].numpy(), a[keep].numpy(), rtol=1e-5, atol=1e-6)
 
 
+def test_forward_pair_equals_the_two_passes():
+    """BertImgModel.forward_pair (the caption pass and the tags + regions pass of alad_model.py:124-140 as one pass of 2B
+    sequences) against the two separate passes -- themselves pinned to the reference above: states of the real positions and
+    gradients."""
+    from aladin_amd import synth
+    g, model, (ids, tmask, fmask, types_, feats) = backbone_case()
+    f1 = feats.clone().requires_grad_(True)
+    a_txt = model(ids, token_type_ids=types_, attention_mask=tmask, img_feats=None)[0]
+    a_img = model(ids, token_type_ids=types_, attention_mask=fmask, img_feats=f1)[0]
+    w_t = torch.from_numpy(synth.normal(tuple(a_txt.shape), 5)) * tmask[:, :, None]
+    w_i = torch.from_numpy(synth.normal(tuple(a_img.shape), 6)) * fmask[:, :, None]
+    model.zero_grad()
+    ((a_txt * w_t).sum() + (a_img * w_i).sum()).backward()
+    g_ref = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+    f2 = feats.clone().requires_grad_(True)
+    b_txt, b_img = model.forward_pair(ids, types_, tmask, ids, types_, fmask, f2)
+    model.zero_grad()
+    ((b_txt * w_t).sum() + (b_img * w_i).sum()).backward()
+    keep_t, keep_i = tmask.bool(), fmask.bool()
+    np.testing.assert_allclose(b_txt[keep_t].detach().numpy(), a_txt[keep_t].detach().numpy(), rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(b_img[keep_i].detach().numpy(), a_img[keep_i].detach().numpy(), rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(f2.grad.numpy(), f1.grad.numpy(), rtol=1e-4, atol=1e-6 * float(f1.grad.abs().max()))
+    top = max(float(v.abs().max()) for v in g_ref.values())
+    for n, p in model.named_parameters():
+        if n in g_ref:
+            if n.endswith('key.bias'):          # zero in exact arithmetic (softmax is shift-invariant): rounding noise in both
+                assert float(p.grad.abs().max()) <= 1e-4 * top and float(g_ref[n].abs().max()) <= 1e-4 * top
+                continue
+            scale = max(float(g_ref[n].abs().max()), 1e-3 * top)
+            np.testing.assert_allclose(p.grad.numpy(), g_ref[n].numpy(), rtol=1e-4, atol=2e-6 * scale, err_msg=n)
+
+
 def test_checkpoint_directory_loads_strictly_and_feeds_the_encoder(tmp_path):
     """A VinVL-style checkpoint directory (config.json + pytorch_model.bin with the reference's key names) -> encoder built
     from it as alad_model.py:39-43 does -> reference ALADIN checkpoint keys load with strict=True."""
