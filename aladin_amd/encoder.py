@@ -93,7 +93,10 @@ class JointTextImageTransformerEncoder(nn.Module):
         the end-to-end step of the shipped YAML is 99 % backbone (tools/bench_e2e_config4.py)."""
         super().__init__()
         self.backbone_autocast = backbone_autocast
-        self.batch_passes = True              # use the backbone's forward_pair when it has one (aladin_amd.backbone does)
+        # The backbone's forward_pair (both BERT passes as one pass of 2B sequences) halves the launches but pads the caption pass
+        # to the image pass's length: measured at bs 32 (tools/bench_e2e_config4.py) it pays when the step is launch-bound
+        # (16-bit autocast: 32.1 -> 19.4 ms) and costs 5 % when the fp32 GEMMs dominate (33.5 -> 35.3 ms)
+        self.batch_passes = backbone_autocast is not None
         m = config['model']
         if backbone is None:
             if oscar_checkpoint is None:
