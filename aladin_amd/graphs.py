@@ -227,9 +227,9 @@ def graph_backbone(encoder, example_imgs, example_txts, autocast_dtype=None):
     mod = _PairPass(bert)
     if autocast_dtype is not None:
         with torch.autocast('cuda', dtype=autocast_dtype, cache_enabled=False):
-            graphed = torch.cuda.make_graphed_callables(mod, sample)
+            graphed = torch.cuda.make_graphed_callables(mod, sample, allow_unused_input=True)     # the pooler is never read
     else:
-        graphed = torch.cuda.make_graphed_callables(mod, sample)
+        graphed = torch.cuda.make_graphed_callables(mod, sample, allow_unused_input=True)
     encoder.graphed_pair = graphed
     encoder.graphed_shapes = tuple(tuple(t.shape) for t in sample)
     return encoder
