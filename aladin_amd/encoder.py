@@ -129,12 +129,6 @@ class JointTextImageTransformerEncoder(nn.Module):
         with torch.set_grad_enabled(torch.is_grad_enabled() and not self.freeze_teran), \
                 torch.autocast('cuda', dtype=self.backbone_autocast or torch.bfloat16, enabled=self.backbone_autocast is not None):   # :121-123
             pair = getattr(self.oscar_model.bert, 'forward_pair', None) if self.batch_passes else None
-            graphed = getattr(self, 'graphed_pair', None)           # aladin_amd.graphs.graph_backbone: HIP-graph replay of both passes
-            if graphed is not None and torch.is_grad_enabled() and self.training:
-                args = (examples_txts[0], examples_txts[2], examples_txts[1], examples_imgs[0], examples_imgs[2], examples_imgs[1],
-                        examples_imgs[3])
-                if tuple(tuple(t.shape) for t in args) == self.graphed_shapes:
-                    pair = graphed
             if pair is not None and examples_imgs[1] is not None:
                 # both passes (:124-140) as one pass of 2B sequences: half the launches of a launch-bound step (backbone.py)
                 t_seq, i_seq = pair(examples_txts[0], examples_txts[2], examples_txts[1], examples_imgs[0], examples_imgs[2],

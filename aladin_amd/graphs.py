@@ -201,35 +201,3 @@ class GraphedLossStep:
         self._log(e)
         return loss, OrderedDict(e.terms)
 
-
-class _PairPass(torch.nn.Module):
-    """Tensor-only call surface for torch.cuda.make_graphed_callables over BertImgModel.forward_pair."""
-
-    def __init__(self, bert):
-        super().__init__()
-        self.bert = bert
-
-    def forward(self, txt_ids, txt_types, txt_mask, img_ids, img_types, img_mask, img_feats):
-        return self.bert.forward_pair(txt_ids, txt_types, txt_mask, img_ids, img_types, img_mask, img_feats)
-
-
-def graph_backbone(encoder, example_imgs, example_txts, autocast_dtype=None):
-    """Capture the backbone's two BERT passes -- forward AND backward -- of `encoder` (aladin_amd.encoder.
-    JointTextImageTransformerEncoder over aladin_amd.backbone) into HIP graphs (torch.cuda.make_graphed_callables) and route the
-    encoder through them.  The reference pads captions and region sets to fixed lengths (max_seq_length / max_img_seq_length,
-    alad/dataset.py:212-238), so the backbone sees ONE shape per batch size: a training step that is thousands of short launches
-    (tools/bench_e2e_config4.py) becomes two replays.  `example_*`: one collated batch of the shapes to capture (the reference's
-    tuples).  Dropout stays live (graph-safe Philox state).  Returns the encoder."""
-    bert = encoder.oscar_model.bert
-    if not hasattr(bert, 'forward_pair'):
-        raise TypeError('graph_backbone needs aladin_amd.backbone.BertImgModel')
-    sample = (example_txts[0], example_txts[2], example_txts[1], example_imgs[0], example_imgs[2], example_imgs[1], example_imgs[3])
-    mod = _PairPass(bert)
-    if autocast_dtype is not None:
-        with torch.autocast('cuda', dtype=autocast_dtype, cache_enabled=False):
-            graphed = torch.cuda.make_graphed_callables(mod, sample, allow_unused_input=True)     # the pooler is never read
-    else:
-        graphed = torch.cuda.make_graphed_callables(mod, sample, allow_unused_input=True)
-    encoder.graphed_pair = graphed
-    encoder.graphed_shapes = tuple(tuple(t.shape) for t in sample)
-    return encoder

@@ -55,9 +55,6 @@ def main():
     ex_txt = (ids * tmask, tmask, types, None, cap_len)
     ex_img = (ids * tmask, torch.cat([tmask, rmask], 1), types, feats * rmask[:, :, None], None, feat_len)
     params = [p for p in model.parameters() if p.requires_grad]
-    if '--graph' in sys.argv:
-        from aladin_amd.graphs import graph_backbone
-        graph_backbone(model.img_txt_enc, ex_img, ex_txt, autocast_dtype=ac)
 
     def zero():
         for p in params:
@@ -84,8 +81,7 @@ def main():
         loss.backward()
 
     res = {'workload': 'configs[4] shape-level: alad-alignment-and-matching-distill.yaml step, bs %d, %d tokens, %d regions, VinVL-base '
-                       'BertImgModel with random weights, backbone %s%s' % (bs, n_tok, n_reg, 'fp32' if ac is None else 'autocast ' + sys.argv[2],
-                                                                           ', both passes replayed as HIP graphs' if '--graph' in sys.argv else ''),
+                       'BertImgModel with random weights, backbone %s' % (bs, n_tok, n_reg, 'fp32' if ac is None else 'autocast ' + sys.argv[2]),
            'parameters_M': round(sum(p.numel() for p in params) / 1e6, 1)}
     for name, fn in (('full_step', full_step), ('encoder_only', encoder_only), ('loss_heads_only', heads_only)):
         wall, gpu = timed(fn)
