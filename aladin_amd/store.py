@@ -167,14 +167,19 @@ def alignment_scores_from_stores(img, cap):
                          need_x, need_y, si.device)
     if plan is None:
         return _store_scores_block(img, cap)
-    views = plan.extra.get('views')
-    if views is None:                                   # the class views (with their device index tensors), built once per plan
-        vx = [StoreView(si, [ids_i[k] for k in g]) for g in plan.gx]
-        vy = [StoreView(sc, [ids_c[k] for k in g]) for g in plan.gy]
-        for v in vx + vy:
-            v._ids_t = ops._index_tensor(v.ids, si.device, torch.int32)
-        views = plan.extra['views'] = (vx, vy)
-    vx, vy = views
+    # class views: python id lists for the host-side geometry, device id tensors by an index_select of the callers' ids
+    # (no blocking copy between the blocks); nothing that references the stores is kept in the cached plan
+    base_i = img.ids_t if isinstance(img, StoreView) else torch.arange(len(si), dtype=torch.int32, device=si.device)
+    base_c = cap.ids_t if isinstance(cap, StoreView) else torch.arange(len(sc), dtype=torch.int32, device=sc.device)
+    vx, vy = [], []
+    for g, ig in zip(plan.gx, plan.ix):
+        v = StoreView(si, [ids_i[k] for k in g])
+        v._ids_t = base_i.index_select(0, ig)
+        vx.append(v)
+    for g, ig in zip(plan.gy, plan.iy):
+        v = StoreView(sc, [ids_c[k] for k in g])
+        v._ids_t = base_c.index_select(0, ig)
+        vy.append(v)
     blocks = {(a, b): _store_scores_block(va, vb) for a, va in enumerate(vx) for b, vb in enumerate(vy)}
     return plan.assemble(blocks)
 
