@@ -10,9 +10,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # ALADIN_LIB points at an alternative build of the same ABI (kernel A/B runs, tools/ab_bench.py)
 LIB_PATH = os.environ.get('ALADIN_LIB') or os.path.join(_HERE, 'lib', 'libaladin_hip.so')
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 PRECISION_FP16, PRECISION_SPLIT = 0, 1      # ALADIN_PRECISION_* of include/aladin_hip.h
-BWD_PARTNERS_FP16 = 1                       # ALADIN_BWD_PARTNERS_FP16
+BWD_PARTNERS_FP16, BWD_DENSE = 1, 2          # ALADIN_BWD_PARTNERS_FP16, ALADIN_BWD_DENSE
 
 # every symbol include/aladin_hip.h declares (tests check that the library exports all of them)
 SYMBOLS = [
@@ -32,7 +32,7 @@ SYMBOLS = [
     'aladin_scan_workspace_bytes', 'aladin_scan_fwd', 'aladin_scan_bwd',
     'aladin_store_row_width', 'aladin_store_append', 'aladin_align_pack_store_x', 'aladin_align_pack_store_y',
     'aladin_store_row_width_mode', 'aladin_store_append_mode', 'aladin_topk',
-    'aladin_align_bwd_packed_strided_ex', 'aladin_align_bwd_rows_ex',
+    'aladin_align_bwd_packed_strided_ex', 'aladin_align_bwd_rows_ex', 'aladin_align_bwd_workspace_bytes_ex',
     'aladin_loss_total', 'aladin_grad_combine', 'aladin_heads_small_workspace_bytes', 'aladin_heads_small_fwd', 'aladin_heads_small_bwd',
 ]
 
@@ -63,6 +63,7 @@ def _declare(lib):
         'aladin_align_scores': (C.c_int, [p, p, p, G, p, p, i64, p]),
         'aladin_align_scores_ex': (C.c_int, [p, p, p, G, p, p, i64, i32, p]),
         'aladin_align_bwd_workspace_bytes': (sz, [i32, i32, i32, i32, i32]),
+        'aladin_align_bwd_workspace_bytes_ex': (sz, [i32, i32, i32, i32, i32, i32]),
         'aladin_align_bwd': (C.c_int, [p, i64, i64, p, p, i64, i64, p, i32, i32, i32, i32, i32, p, i64, p, p, p, p, p]),
         'aladin_align_bwd_packed': (C.c_int, [p, i64, i64, p, p, i64, i64, p, p, i64, p, p, p, p, G, p, p, p, p, p, p]),
         'aladin_align_bwd_packed_strided': (C.c_int, [p, i64, i64, p, p, i64, i64, p, p, i64, p, p, p, p, G, p, p, p, i64, i64, p, i64, i64,

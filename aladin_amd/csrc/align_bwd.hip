@@ -51,6 +51,41 @@ extern "C" size_t aladin_align_bwd_workspace_bytes(int Bi, int Bc, int R, int T,
   return bwd_ws_layout(Bi, Bc, T - 1, nullptr, nullptr);      // sized for the longest possible word axis (tail 0)
 }
 
+// ALADIN_BWD_DENSE scratch behind the base workspace: the split-precision operands of the arg-max tile kernel
+// (align_fwd.hip: aladin_internal_align_argmax), its side scratch and one flag byte per pair
+struct DenseWs { void* xm; void* xe; void* y; float* E; uint8_t* flags; };
+static size_t dense_ws_layout(const aladin_align_geom* gs, char* base, DenseWs* ws) {
+  auto up = [](size_t v) { return (v + 255) / 256 * 256; };
+  size_t off = 0;
+  if (ws) ws->xm = base + off;
+  off += up((size_t)gs->xm_bytes);
+  if (ws) ws->xe = base + off;
+  off += up((size_t)gs->xe_bytes + 16);
+  if (ws) ws->y = base + off;
+  off += up((size_t)gs->y_bytes);
+  if (ws) ws->E = (float*)(base + off);
+  off += up((size_t)gs->e_bytes + 16);
+  if (ws) ws->flags = (uint8_t*)(base + off);
+  off += up((size_t)gs->Bi * gs->Bc);
+  return off;
+}
+// the tile classes the arg-max kernel covers; fills the split geometry of the problem
+static bool dense_supported(int Bi, int Bc, int R, int T, int D, int x_tail, int y_tail, aladin_align_geom* gs) {
+  if (aladin_align_geometry_mode(Bi, Bc, R, T, D, x_tail, y_tail, ALADIN_PRECISION_SPLIT, gs) != ALADIN_OK) return false;
+  return gs->mtiles == 1 && gs->rem <= 1 && 6 % gs->tp16 == 0 && (gs->xm_rows / 256) * (gs->y_rows / 384) > 64 &&
+         gs->xm_rows % 256 == 0 && gs->y_rows % 384 == 0;
+}
+
+extern "C" size_t aladin_align_bwd_workspace_bytes_ex(int Bi, int Bc, int R, int T, int D, int flags) {
+  size_t n = aladin_align_bwd_workspace_bytes(Bi, Bc, R, T, D);
+  if (n == 0 || !(flags & ALADIN_BWD_DENSE)) return n;
+  aladin_align_geom gs;
+  // sized for the image / caption convention; the role-swapped poolings have shorter scored axes
+  if (dense_supported(Bi, Bc, R, T, D, 0, 2, &gs) || dense_supported(Bi, Bc, R, T, D, 2, 0, &gs) || dense_supported(Bi, Bc, R, T, D, 0, 0, &gs))
+    n += dense_ws_layout(&gs, nullptr, nullptr) + (size_t)Bi * Bc * 16;      // + slack for the other tails' row padding
+  return n;
+}
+
 // ------------------------------------------------------------------------------------------------
 // 1. compaction
 // ------------------------------------------------------------------------------------------------
@@ -61,6 +96,24 @@ __global__ __launch_bounds__(256) void bwd_compact_kernel(const float* __restric
     const int64_t e = e0 + threadIdx.x;
     bool nz = false;
     if (e < n) nz = dS[(e / Bc) * ld + (e % Bc)] != 0.f;
+    const unsigned long long mask = __ballot(nz);
+    const int lane = threadIdx.x & 63;
+    int base = 0;
+    if (lane == 0 && mask) base = atomicAdd(counter, __popcll(mask));
+    base = __shfl(base, 0, 64);
+    if (nz) pairs[base + __popcll(mask & ((1ull << lane) - 1))] = (int)e;
+  }
+}
+
+// the pairs the arg-max tile kernel could not decide (flag byte set) among those that carry a gradient
+__global__ __launch_bounds__(256) void bwd_compact_flagged_kernel(const float* __restrict__ dS, int64_t ld, int Bi, int Bc,
+                                                                  const uint8_t* __restrict__ flags, int* __restrict__ counter,
+                                                                  int* __restrict__ pairs) {
+  const int64_t n = (int64_t)Bi * Bc;
+  for (int64_t e0 = (int64_t)blockIdx.x * blockDim.x; e0 < n; e0 += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t e = e0 + threadIdx.x;
+    bool nz = false;
+    if (e < n) nz = flags[e] != 0 && dS[(e / Bc) * ld + (e % Bc)] != 0.f;
     const unsigned long long mask = __ballot(nz);
     const int lane = threadIdx.x & 63;
     int base = 0;
@@ -750,7 +803,30 @@ static int align_bwd_impl(const float* im, int64_t im_sb, int64_t im_sr, const i
                        ws.table, tstride, x_tail, y_tail, hf, SmallFin{});
     return aladin_check_launch("bwd_pair_argmax16_kernel<hinge>");
   }
-  if (phase == BWD_ROWS) {
+  // ALADIN_BWD_DENSE: (almost) every pair carries a gradient.  The table of ALL pairs comes from the forward's own tile
+  // kernel in split precision (64 pairs per workgroup sharing their panels); only the pairs with a word it could not
+  // decide go through the one-workgroup-per-pair exact kernel below.
+  bool dense = false;
+  if ((flags & ALADIN_BWD_DENSE) && phase == BWD_ALL && packed) {
+    aladin_align_geom gs;
+    if (dense_supported(Bi, Bc, R, T, D, x_tail, y_tail, &gs)) {
+      DenseWs dw;
+      dense_ws_layout(&gs, (char*)workspace + bwd_ws_layout(Bi, Bc, T - 1, nullptr, nullptr), &dw);
+      rc = aladin_align_pack_both(im, im_sb, im_sr, im_len, s, s_sb, s_st, s_len, &gs, dw.xm, dw.xe, dw.y, stream);
+      if (rc) return rc;
+      rc = aladin_internal_align_argmax(&gs, dw.xm, dw.xe, dw.y, dw.E, im_len, s_len, ws.table, tstride, dw.flags, st);
+      if (rc) return rc;
+      if (hipMemsetAsync(ws.counter, 0, 256, st) != hipSuccess) { aladin_set_error("align_bwd: memset failed"); return ALADIN_ERR_HIP; }
+      int grid = (int)((n + 255) / 256); if (grid > 1024) grid = 1024;
+      hipLaunchKernelGGL(bwd_compact_flagged_kernel, dim3(grid), dim3(256), 0, st, dS, ld_dS, Bi, Bc, dw.flags, ws.counter, ws.pairs);
+      rc = aladin_check_launch("bwd_compact_flagged_kernel");
+      if (rc) return rc;
+      dense = true;
+    }
+  }
+  if (dense) {
+    // list = the undecided pairs
+  } else if (phase == BWD_ROWS) {
     // the argmax table of this problem is already in the workspace (aladin_hinge_argmax_fused)
   } else if (pairs_in && count_in) {                    // list already built by aladin_hinge_fused
     ws.pairs = const_cast<int*>(pairs_in);
@@ -849,7 +925,7 @@ extern "C" int aladin_align_bwd_packed_strided_ex(const float* im, int64_t im_sb
                                                   int64_t d_s_stride_b, int64_t d_s_stride_t, void* workspace, int flags, void* stream) {
   if (!geom) { aladin_set_error("align_bwd_packed_strided_ex: null geometry"); return ALADIN_ERR_ARG; }
   if (geom->split) { aladin_set_error("align_bwd_packed_strided_ex: split-precision operands are forward-only (evaluation); pack with ALADIN_PRECISION_FP16"); return ALADIN_ERR_UNSUPPORTED; }
-  if (flags & ~ALADIN_BWD_PARTNERS_FP16) { aladin_set_error("align_bwd_packed_strided_ex: unknown flags %d", flags); return ALADIN_ERR_ARG; }
+  if (flags & ~(ALADIN_BWD_PARTNERS_FP16 | ALADIN_BWD_DENSE)) { aladin_set_error("align_bwd_packed_strided_ex: unknown flags %d", flags); return ALADIN_ERR_ARG; }
   if (d_im_stride_b < 1 || d_im_stride_r < 1 || d_s_stride_b < 1 || d_s_stride_t < 1) { aladin_set_error("align_bwd_packed_strided_ex: bad output strides"); return ALADIN_ERR_ARG; }
   return align_bwd_impl(im, im_sb, im_sr, im_len, s, s_sb, s_st, s_len, geom->Bi, geom->Bc, geom->R, geom->T, geom->D, dS,
                         ld_dS, gscale, (xm && y) ? xm : nullptr, xe, (xm && y) ? y : nullptr, (xm && y) ? geom : nullptr, pairs,

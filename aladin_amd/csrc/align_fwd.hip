@@ -690,6 +690,177 @@ static int launch_scores16_tall(const aladin_align_geom* g, const half_t* xm, co
   return aladin_check_launch("align_scores16_tall_kernel");
 }
 
+// ------------------------------------------------------------------------------------------------
+// Arg-max table for EVERY pair of a batch from the forward's own tile kernel (dense dS: max_violation = False, or a
+// gradient arriving on the score matrix).  The one-workgroup-per-pair kernel of align_bwd.hip pays a ~22 us latency chain and
+// 132 KB of operand traffic per pair: 1.88 ms for the 65 536 pairs of B = 256.  Here the split-precision operands
+// ([hi | lo | hi] x [hi | hi | lo], K = 3 D: cosines good to ~1e-6) run through gemm_mainloop16_tall once, 64 pairs per
+// workgroup sharing their panels, and the epilogue -- instead of max over regions / sum over words -- records for every
+// (image, caption, word) WHICH region won:
+//   * a lane packs the region index of each of its 8 accumulator values into the 6 low mantissa bits (values are
+//     cos * 2^28: at most 3.8e-6 of a cosine), keeps the largest and the second largest DISTINCT value, and the same
+//     permlane32-swap / 16-lane exchange network as the score epilogue merges (top1, top2) across the 32 rows of the image;
+//     the side row (region 33) joins from E;
+//   * masked regions (zero rows) all pack to the same value, so they count as ONE candidate (the zero fill of
+//     alad/loss.py:116); a winner with index >= Li is NO_GRAD; tile-filling copies of region 0 are left out;
+//   * a word whose top two candidates are closer than ARGMAX_TAU (1.6e-5 of a cosine: four times the packing + split error)
+//     marks its PAIR in `flags`: those pairs (a few per cent) are re-decided exactly by the list-driven pair kernel.
+// The table is the one bwd_rows_kernel reads (uint8, row stride tstride per pair).
+// ------------------------------------------------------------------------------------------------
+#define ARGMAX_TAU_ACC 4295.0f          // 1.6e-5 * 2^28
+__device__ __forceinline__ void top2_merge(float& a1, float& a2, float b1, float b2) {
+  const float hi = vmax(a1, b1), lo = fminf(a1, b1);
+  // equal tops are the SAME candidate (the shared zero fill, or a value met twice through the exchange network)
+  a2 = (a1 == b1) ? vmax(a2, b2) : vmax(lo, vmax(a2, b2));
+  a1 = hi;
+}
+__device__ __forceinline__ float xchg16(float v) {          // the value of lane ^ 16
+  auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  const float a = __uint_as_float(sw[0]), b = __uint_as_float(sw[1]);
+  return (threadIdx.x & 16) ? a : b;
+}
+
+template <bool HAS_E, int TP16>
+__device__ __forceinline__ void argmax16_epilogue_tall(f32x4 (&acc)[8][6], int mb, int nb, const float* __restrict__ E, int64_t ldE,
+                                                       const int32_t* __restrict__ im_len, int x_tail, int Rq,
+                                                       const int32_t* __restrict__ s_len, int y_tail, int Tq,
+                                                       uint8_t* __restrict__ table, int tstride, uint8_t* __restrict__ flags,
+                                                       int Bi, int Bc) {
+  using Cfg = GemmCfg<2, 4, 4, 3>;
+  constexpr int CT = 6, NC = CT / TP16;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wm = wave / 4, wn = wave % 4;
+  const int half = lane >> 5, l4 = lane & 15, q4 = lane >> 4;
+  const int cap0 = (nb * 4 + wn) * NC;
+  const float NEG = -3.0e38f;
+  // words past the caption's length are zero columns: all their candidates tie at 0 -- they neither count nor flag
+  int Lc[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    Lc[c] = 0;
+    if (cap0 + c < Bc) { int l = s_len[cap0 + c] - 1 - y_tail; Lc[c] = l < 0 ? 0 : (l > Tq ? Tq : l); }
+  }
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    // as in scores16_epilogue_tall: the pair's 64 rows are two images; lanes 0-31 finish the first, 32-63 the second
+    const int img = (mb * 2 + wm) * 4 + 2 * p + half;
+    int Li = 0;
+    if (img < Bi) { Li = im_len[img] - 1 - x_tail; Li = Li < 0 ? 0 : (Li > Rq ? Rq : Li); }
+    const int Li_a = __shfl(Li, lane & 31, 64), Li_b = __shfl(Li, (lane & 31) + 32, 64);     // lengths of the pair's two images
+    const float* e = HAS_E ? E + (int64_t)img * ldE + (int64_t)nb * Cfg::BN + wn * 96 + l4 : nullptr;
+    bool pair_flag[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) pair_flag[c] = false;
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+      // this lane's 8 values of image A (row tiles 4p, 4p+1) and of image B (4p+2, 4p+3): regions 16 t + 4 q4 + reg
+      float a1 = NEG, a2 = NEG, b1 = NEG, b2 = NEG;
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          const int r = 16 * t + 4 * q4 + reg;
+          {
+            float v = acc[4 * p + t][ct][reg];
+            unsigned bits = (__float_as_uint(v) & ~63u) | (unsigned)r;
+            if (r >= Li_a) bits = 63u;                               // every masked region is the one zero-fill candidate
+            v = (r >= Rq) ? NEG : __uint_as_float(bits);               // rows past R' only fill the tile
+            top2_merge(a1, a2, v, NEG);
+          }
+          {
+            float v = acc[4 * p + 2 + t][ct][reg];
+            unsigned bits = (__float_as_uint(v) & ~63u) | (unsigned)r;
+            if (r >= Li_b) bits = 63u;
+            v = (r >= Rq) ? NEG : __uint_as_float(bits);
+            top2_merge(b1, b2, v, NEG);
+          }
+        }
+      // lanes 0-31 take image A's partials of lane + 32, lanes 32-63 image B's of lane - 32
+      auto s1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(a1), __float_as_uint(b1), false, false);
+      auto s2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(a2), __float_as_uint(b2), false, false);
+      float t1 = __uint_as_float(s1[0]), t2 = __uint_as_float(s2[0]);
+      top2_merge(t1, t2, __uint_as_float(s1[1]), __uint_as_float(s2[1]));
+      { const float o1 = xchg16(t1), o2 = xchg16(t2); top2_merge(t1, t2, o1, o2); }
+      if constexpr (HAS_E) {
+        const float ev = e[ct * 16];
+        const float ep = (Rq > 32) ? __uint_as_float((32 >= Li ? 63u : ((__float_as_uint(ev) & ~63u) | 32u))) : NEG;
+        top2_merge(t1, t2, ep, NEG);
+      }
+      const unsigned idx = __float_as_uint(t1) & 63u;
+      const int c = ct / TP16, w = (ct % TP16) * 16 + l4;
+      // NO_GRAD: the zero fill won, or the word is padding (its raw row is not zero: bwd_rows_kernel must skip it)
+      const uint8_t res = (idx >= (unsigned)Li || w >= Lc[c]) ? (uint8_t)255 : (uint8_t)idx;
+      const bool close = (t1 - t2) < ARGMAX_TAU_ACC;                   // t2 == NEG when there is one candidate only
+      if ((lane & 16) == 0 && img < Bi && cap0 + c < Bc && w < tstride) table[((int64_t)img * Bc + cap0 + c) * tstride + w] = res;
+      pair_flag[c] = pair_flag[c] || (close && w < Lc[c]);
+    }
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const bool any = __ballot(pair_flag[c] && img < Bi && cap0 + c < Bc) & (half ? 0xffffffff00000000ull : 0x00000000ffffffffull);
+      if ((lane & 31) == 0 && any) flags[(int64_t)img * Bc + cap0 + c] = 1;
+    }
+  }
+}
+
+template <bool HAS_E, int TP16>
+__global__ __launch_bounds__(512) void align_argmax16_tall_kernel(const half_t* __restrict__ xm, const half_t* __restrict__ y,
+                                                                  const float* __restrict__ E, int64_t ldE,
+                                                                  const int32_t* __restrict__ im_len, int x_tail, int Rq,
+                                                                  const int32_t* __restrict__ s_len, int y_tail, int Tq,
+                                                                  uint8_t* __restrict__ table, int tstride, uint8_t* __restrict__ flags,
+                                                                  int Bi, int Bc, int64_t ldk, int ktiles, int n_nblk, int n_blocks) {
+  using Cfg = GemmCfg<2, 4, 4, 3>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int mb, nb;
+  tile_coords(blockIdx.x, n_blocks / n_nblk, n_nblk, 8, mb, nb);
+  f32x4 acc[8][6];
+#pragma unroll
+  for (int rt = 0; rt < 8; ++rt)
+#pragma unroll
+    for (int ct = 0; ct < 6; ++ct) acc[rt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+  gemm_mainloop16_tall<Cfg, true>(xm + (int64_t)mb * Cfg::BM * ldk, y + (int64_t)nb * Cfg::BN * ldk, ldk, ktiles, smem, acc);
+  argmax16_epilogue_tall<HAS_E, TP16>(acc, mb, nb, E, ldE, im_len, x_tail, Rq, s_len, y_tail, Tq, table, tstride, flags, Bi, Bc);
+}
+
+template <int NT> static int launch_side(const aladin_align_geom* g, const half_t* xe, const half_t* y, float* E, hipStream_t stream);
+
+// g: a SPLIT-precision geometry of the one-region-tile classes (mtiles == 1, rem <= 1, captions tiling a 96-column strip);
+// xm / xe / y: its packed operands; E: its side scratch (g->e_bytes); flags: Bi * Bc bytes, zeroed here.
+int aladin_internal_align_argmax(const aladin_align_geom* g, const void* xm, const void* xe, const void* y, float* E,
+                                 const int32_t* im_len, const int32_t* s_len, uint8_t* table, int tstride, uint8_t* flags,
+                                 hipStream_t stream) {
+  using Cfg = GemmCfg<2, 4, 4, 3>;
+  if (!g || !g->split || g->mtiles != 1 || g->rem > 1 || 6 % g->tp16 != 0) { aladin_set_error("align_argmax: unsupported tile class (mtiles=%d rem=%d tp16=%d split=%d)", g ? g->mtiles : -1, g ? g->rem : -1, g ? g->tp16 : -1, g ? g->split : -1); return ALADIN_ERR_UNSUPPORTED; }
+  const int n_mblk = (int)(g->xm_rows / Cfg::BM), n_nblk = (int)(g->y_rows / Cfg::BN);
+  if ((int64_t)n_mblk * Cfg::BM != g->xm_rows || (int64_t)n_nblk * Cfg::BN != g->y_rows) { aladin_set_error("align_argmax: packed rows do not tile"); return ALADIN_ERR_UNSUPPORTED; }
+  if (hipMemsetAsync(flags, 0, (size_t)g->Bi * g->Bc, stream) != hipSuccess) { aladin_set_error("align_argmax: memset failed"); return ALADIN_ERR_HIP; }
+  const int n_blocks = n_mblk * n_nblk;
+#define ARGMAX_LAUNCH(HE, TP)                                                                                          \
+  do {                                                                                                                  \
+    auto kern = align_argmax16_tall_kernel<HE, TP>;                                                                     \
+    static unsigned long long lds_reserved = 0;                                                                         \
+    if (int rc = aladin_reserve_lds((const void*)kern, Cfg::LDS_BYTES, &lds_reserved, "align_argmax16_tall")) return rc; \
+    hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(Cfg::THREADS), Cfg::LDS_BYTES, stream, (const half_t*)xm, (const half_t*)y, \
+                       (const float*)E, g->y_rows, im_len, g->x_tail, g->Rq, s_len, g->y_tail, g->Tq, table, tstride, flags, g->Bi, g->Bc,       \
+                       (int64_t)g->Dp, g->Dp / 64, n_nblk, n_blocks);                                                   \
+  } while (0)
+  if (g->rem) {
+    int rc = ALADIN_OK;
+    switch (g->tp16) {
+      case 1: rc = launch_side<1>(g, (const half_t*)xe, (const half_t*)y, E, stream); break;
+      case 2: rc = launch_side<1>(g, (const half_t*)xe, (const half_t*)y, E, stream); break;
+      case 3: rc = launch_side<3>(g, (const half_t*)xe, (const half_t*)y, E, stream); break;
+      default: rc = launch_side<3>(g, (const half_t*)xe, (const half_t*)y, E, stream); break;
+    }
+    if (rc) return rc;
+    switch (g->tp16) { case 1: ARGMAX_LAUNCH(true, 1); break; case 2: ARGMAX_LAUNCH(true, 2); break; case 3: ARGMAX_LAUNCH(true, 3); break; default: ARGMAX_LAUNCH(true, 6); break; }
+  } else {
+    switch (g->tp16) { case 1: ARGMAX_LAUNCH(false, 1); break; case 2: ARGMAX_LAUNCH(false, 2); break; case 3: ARGMAX_LAUNCH(false, 3); break; default: ARGMAX_LAUNCH(false, 6); break; }
+  }
+#undef ARGMAX_LAUNCH
+  return aladin_check_launch("align_argmax16_tall_kernel");
+}
+
 #ifdef ALADIN_DIAG
 // ---- EXPERIMENT (ALADIN_SCORE_VARIANT=8): B fragments straight from L2, only the A panel through the LDS (gemm_bdirect.hpp)
 static int g_scores_flags = 0;                   // flags of the aladin_align_scores_ex call being dispatched (diag build only)

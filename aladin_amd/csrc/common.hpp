@@ -23,6 +23,10 @@ int aladin_check_launch(const char* what);
 // Raise a kernel's dynamic-LDS limit once per DEVICE (the attribute is per device; `done` is a per-call-site
 // bit mask indexed by the current device, thread-safe).  Returns ALADIN_OK or ALADIN_ERR_HIP.
 int aladin_reserve_lds(const void* kernel, int bytes, unsigned long long* done, const char* what);
+struct aladin_align_geom;
+// align_fwd.hip: arg-max table of every pair from the split-precision tile kernel (see there)
+int aladin_internal_align_argmax(const aladin_align_geom* g, const void* xm, const void* xe, const void* y, float* E,
+                                 const int32_t* im_len, const int32_t* s_len, uint8_t* table, int tstride, uint8_t* flags, hipStream_t stream);
 
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 #define GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void*)(p))

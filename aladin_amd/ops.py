@@ -215,7 +215,13 @@ def _grad_like(x):
     return torch.empty(tuple(x.shape), dtype=torch.float32, device=x.device)
 
 
-def _align_backward(im, s, im_len_t, s_len_t, dS, gscale=None, packed=None, pairs=None, x_tails=(0, 2)):
+DENSE_MIN_PAIRS = 1 << 14    # below: the per-pair kernel is launch-bound and already faster (B = 64: 0.20 vs 0.26 ms)
+DENSE_BACKWARD = True        # False: always one workgroup per gradient-carrying pair (the A/B switch of tests/ and tools/bench_dense_ds.py)
+
+
+def _align_backward(im, s, im_len_t, s_len_t, dS, gscale=None, packed=None, pairs=None, x_tails=(0, 2), dense=False):
+    """dense: the caller knows that (almost) every pair carries a gradient (sum-of-violations hinge, a gradient on S):
+    ALADIN_BWD_DENSE -- the arg-max table of all pairs from the split-precision tile kernel instead of one workgroup per pair."""
     lib = _lib.load()
     im = _rows_inner_contig(im)
     s = _rows_inner_contig(s)
@@ -224,7 +230,8 @@ def _align_backward(im, s, im_len_t, s_len_t, dS, gscale=None, packed=None, pair
     Bi, R, D = im.shape
     Bc, T, _ = s.shape
     d_im, d_s = _grad_like(im), _grad_like(s)
-    ws = _workspace(lib.aladin_align_bwd_workspace_bytes(Bi, Bc, R, T, D), im.device)
+    dense_flag = _lib.BWD_DENSE if (dense and DENSE_BACKWARD and packed is not None and packed[1] is not None and Bi * Bc >= DENSE_MIN_PAIRS) else 0
+    ws = _workspace(lib.aladin_align_bwd_workspace_bytes_ex(Bi, Bc, R, T, D, dense_flag), im.device)
     if packed is None:
         if x_tails != (0, 2):
             raise NotImplementedError('aladin_amd: the stand-alone backward entry point is the image/caption form')
@@ -237,7 +244,7 @@ def _align_backward(im, s, im_len_t, s_len_t, dS, gscale=None, packed=None, pair
                                                       C.byref(geom), _ptr(pairs[0] if pairs else None),
                                                       _ptr(pairs[1] if pairs else None), _ptr(d_im), d_im.stride(0), d_im.stride(1),
                                                       _ptr(d_s), d_s.stride(0), d_s.stride(1), _ptr(ws),
-                                                      _bwd_flags((geom, xm, xe, y)), _stream()),
+                                                      _bwd_flags((geom, xm, xe, y)) | dense_flag, _stream()),
                'align_bwd_packed_strided_ex')
     return d_im, d_s
 
@@ -341,6 +348,7 @@ class _AlignTriplet(torch.autograd.Function):
             ctx.geom = geom
             ctx.pairs = None
             ctx.table_ws = True
+            ctx.dense = False
             ctx.set_materialize_grads(False)
             return loss, S
         loss, dS, pairs = _hinge_raw(S, margin, max_violation, need, want_pairs=True)
@@ -348,6 +356,7 @@ class _AlignTriplet(torch.autograd.Function):
             ctx.save_for_backward(im, s, im_len_t, s_len_t, packed[1], packed[2], packed[3], dS)
             ctx.geom = geom
             ctx.pairs = pairs
+        ctx.dense = not max_violation                   # sum of violations: dloss/dS is dense
         ctx.set_materialize_grads(False)
         return loss, S
 
@@ -369,14 +378,14 @@ class _AlignTriplet(torch.autograd.Function):
             # the training path: only the loss is differentiated; dloss/dS (<= 3B non-zeros with the hardest-negative
             # hinge) never leaves the device and the upstream scalar goes to the kernels as a pointer
             g = g_loss.to(torch.float32).contiguous()
-            d_im, d_s = _align_backward(im, s, im_len_t, s_len_t, dS, gscale=g, packed=packed, pairs=ctx.pairs)
+            d_im, d_s = _align_backward(im, s, im_len_t, s_len_t, dS, gscale=g, packed=packed, pairs=ctx.pairs, dense=ctx.dense)
         else:
             # the returned score matrix was used too (the reference's S carries grad, alad/loss.py:151-159):
             # total dS = g_loss * dloss/dS + g_scores, generally dense
             total = g_scores.to(torch.float32)
             if g_loss is not None:
                 total = total + dS * g_loss.to(torch.float32)
-            d_im, d_s = _align_backward(im, s, im_len_t, s_len_t, total.contiguous(), packed=packed)
+            d_im, d_s = _align_backward(im, s, im_len_t, s_len_t, total.contiguous(), packed=packed, dense=True)
         return d_im, d_s, None, None, None, None
 
 

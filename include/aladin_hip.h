@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define ALADIN_ABI_VERSION 7
+#define ALADIN_ABI_VERSION 8
 
 /* The library is built with -fvisibility=hidden: the entry points declared here are its ONLY exports. */
 #if defined(__GNUC__)
@@ -195,6 +195,16 @@ ALADIN_API int aladin_align_bwd_rows(const float* im, int64_t im_stride_b, int64
  *       so it is not the default.  The arg-maxima are the exact fp32 ones either way.
  * aladin_align_bwd_rows_ex additionally takes the packed operands (ignored when flags == 0). */
 #define ALADIN_BWD_PARTNERS_FP16 1
+/*   ALADIN_BWD_DENSE  (aladin_align_bwd_packed_strided_ex only) the caller states that (almost) every pair carries a
+ *       gradient -- the sum-of-violations hinge (max_violation = False, alad/loss.py:60-67), or a gradient arriving on the
+ *       score matrix itself.  The arg-max table of ALL pairs then comes from the forward's own tile kernel run in split
+ *       precision (64 pairs per workgroup sharing their operand panels) instead of one workgroup per pair; only the pairs with
+ *       a word whose two best regions it cannot separate (a few per cent) go through the exact per-pair kernel.  Same table,
+ *       same gradients.  Needs the workspace of aladin_align_bwd_workspace_bytes_ex(..., flags) and the packed fp16 operands;
+ *       classes the tile kernel does not cover (more than one region tile per image, small batches) silently take the list
+ *       path.  `pairs` / `pair_count` are ignored. */
+#define ALADIN_BWD_DENSE 2
+ALADIN_API size_t aladin_align_bwd_workspace_bytes_ex(int Bi, int Bc, int R, int T, int D, int flags);
 ALADIN_API int aladin_align_bwd_packed_strided_ex(const float* im, int64_t im_stride_b, int64_t im_stride_r, const int32_t* im_len,
                                                   const float* s, int64_t s_stride_b, int64_t s_stride_t, const int32_t* s_len,
                                                   const float* dS, int64_t ld_dS, const float* gscale, const void* xm, const void* xe,

@@ -1014,6 +1014,59 @@ def test_b256_triplet_step_gradients_vs_oracle(ragged):
         np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=1e-3, atol=2e-5 * scale)
 
 
+@pytest.mark.parametrize('B,kind', [(128, 'random'), (256, 'random'), (256, 'structured'), (192, 'ties')])
+def test_dense_backward_table_equals_the_per_pair_path(B, kind):
+    """ALADIN_BWD_DENSE (sum-of-violations hinge: every pair carries a gradient): the arg-max table written by the
+    split-precision tile kernel + the per-pair kernel on the flagged near-ties must give EXACTLY the gradients of the
+    per-pair kernel on every pair (same winners => same rows kernel input => bit-identical sums)."""
+    from aladin_amd import ops, synth
+    from aladin_amd.loss import AlignmentContrastiveLoss
+    if kind == 'random':
+        im, s, il, sl = synth.alignment_batch(B, 34, 50, 768, seed=B + 5, ragged=True)
+    else:
+        im, s, il, sl = synth.structured_alignment_batch(B, 34, 50, 768, seed=B + 9, noise=3.0, ragged=True)
+    if kind == 'ties':
+        im[:, 5] = im[:, 3]                               # exact duplicate regions: every word ties between r = 2 and r = 4
+        im[1::2, 9] = im[1::2, 8] * (1 + 1e-7)           # and a near-tie below the fp16 operand resolution
+    crit = AlignmentContrastiveLoss(margin=0.2, measure='dot', max_violation=False, aggregation='MrSw')
+    grads = {}
+    for dense in (False, True):
+        a, b = T(im).requires_grad_(True), T(s).requires_grad_(True)
+        old, ops.DENSE_BACKWARD = ops.DENSE_BACKWARD, dense
+        try:
+            loss = crit(a, b, il, sl)
+            loss.backward()
+        finally:
+            ops.DENSE_BACKWARD = old
+        grads[dense] = (loss.item(), a.grad.clone(), b.grad.clone())
+    assert grads[True][0] == grads[False][0]
+    assert torch.equal(grads[True][1], grads[False][1])
+    assert torch.equal(grads[True][2], grads[False][2])
+    assert grads[True][1].abs().sum() > 0
+
+
+def test_dense_backward_through_the_score_matrix():
+    """The other dense caller: a gradient arriving on the returned S (listnet on top of the alignment scores)."""
+    from aladin_amd import ops, synth
+    from aladin_amd.loss import AlignmentContrastiveLoss
+    B = 128
+    im, s, il, sl = synth.alignment_batch(B, 34, 50, 768, seed=31, ragged=True)
+    crit = AlignmentContrastiveLoss(margin=0.2, measure='dot', max_violation=True, aggregation='MrSw')
+    w = torch.randn(B, B, device='cuda', generator=torch.Generator('cuda').manual_seed(3))
+    grads = {}
+    for dense in (False, True):
+        a, b = T(im).requires_grad_(True), T(s).requires_grad_(True)
+        old, ops.DENSE_BACKWARD = ops.DENSE_BACKWARD, dense
+        try:
+            loss, S = crit(a, b, il, sl, return_similarity_mat=True)
+            (loss + (S * w).sum()).backward()
+        finally:
+            ops.DENSE_BACKWARD = old
+        grads[dense] = (a.grad.clone(), b.grad.clone())
+    assert torch.equal(grads[True][0], grads[False][0])
+    assert torch.equal(grads[True][1], grads[False][1])
+
+
 def test_b256_triplet_step_gradient_sparsity():
     from aladin_amd import synth
     from aladin_amd.loss import AlignmentContrastiveLoss

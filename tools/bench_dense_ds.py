@@ -26,12 +26,16 @@ def timed(fn, steps):
 
 def main():
     dev = torch.device('cuda:0')
-    for B in (64, 256):
+    only = os.environ.get('DENSE_ONLY')                     # profiling: one mode, B = 256 only
+    for B in ((256,) if only else (64, 128, 256)):
         im, s, il, sl = synth.alignment_batch(B, 34, 50, 768, seed=1234)
         a = torch.from_numpy(im).to(dev).requires_grad_(True)
         b = torch.from_numpy(s).to(dev).requires_grad_(True)
         out = {'batch': B}
-        for mv in (True, False):
+        if only:
+            from aladin_amd import ops
+            ops.DENSE_BACKWARD = only == '1'
+        for mv in ((False,) if only else (True, False)):
             crit = AlignmentContrastiveLoss(0.2, 'dot', mv, 'MrSw')
 
             def step():
@@ -39,6 +43,11 @@ def main():
                 b.grad = None
                 crit(a, b, il, sl).backward()
             out['max_violation_%s_ms' % mv] = round(timed(step, 30), 4)
+            if not mv and not only:
+                from aladin_amd import ops
+                ops.DENSE_BACKWARD = False
+                out['max_violation_False_per_pair_ms'] = round(timed(step, 30), 4)
+                ops.DENSE_BACKWARD = True
         print(json.dumps(out), flush=True)
 
 
