@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get('ALADIN_LIB') or os.path.join(_HERE, 'lib', 'libaladin
 
 ABI_VERSION = 8
 PRECISION_FP16, PRECISION_SPLIT = 0, 1      # ALADIN_PRECISION_* of include/aladin_hip.h
-BWD_PARTNERS_FP16, BWD_DENSE = 1, 2          # ALADIN_BWD_PARTNERS_FP16, ALADIN_BWD_DENSE
+BWD_PARTNERS_FP16, BWD_DENSE, BWD_DENSE_GATHER = 1, 2, 4          # ALADIN_BWD_PARTNERS_FP16, ALADIN_BWD_DENSE
 
 # every symbol include/aladin_hip.h declares (tests check that the library exports all of them)
 SYMBOLS = [

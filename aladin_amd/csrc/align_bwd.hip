@@ -81,8 +81,14 @@ extern "C" size_t aladin_align_bwd_workspace_bytes_ex(int Bi, int Bc, int R, int
   if (n == 0 || !(flags & ALADIN_BWD_DENSE)) return n;
   aladin_align_geom gs;
   // sized for the image / caption convention; the role-swapped poolings have shorter scored axes
-  if (dense_supported(Bi, Bc, R, T, D, 0, 2, &gs) || dense_supported(Bi, Bc, R, T, D, 2, 0, &gs) || dense_supported(Bi, Bc, R, T, D, 0, 0, &gs))
+  if (dense_supported(Bi, Bc, R, T, D, 0, 2, &gs) || dense_supported(Bi, Bc, R, T, D, 2, 0, &gs) || dense_supported(Bi, Bc, R, T, D, 0, 0, &gs)) {
     n += dense_ws_layout(&gs, nullptr, nullptr) + (size_t)Bi * Bc * 16;      // + slack for the other tails' row padding
+    // + the GEMM form of the row step (align_bwd_dense.hip): transposed operands and split-K partial sums
+    size_t rows = 0;
+    const int tails[3][2] = {{0, 2}, {2, 0}, {0, 0}};
+    for (auto& t : tails) { const size_t b = aladin_internal_dense_rows_bytes(Bi, Bc, R, T, D, t[0], t[1]); rows = b > rows ? b : rows; }
+    n += rows + 512;
+  }
   return n;
 }
 
@@ -113,9 +119,21 @@ __global__ __launch_bounds__(256) void bwd_compact_flagged_kernel(const float* _
   for (int64_t e0 = (int64_t)blockIdx.x * blockDim.x; e0 < n; e0 += (int64_t)gridDim.x * blockDim.x) {
     const int64_t e = e0 + threadIdx.x;
     bool nz = false;
-    if (e < n) nz = flags[e] != 0 && dS[(e / Bc) * ld + (e % Bc)] != 0.f;
+    float av = 0.f;
+    if (e < n) { const float g = dS[(e / Bc) * ld + (e % Bc)]; av = fabsf(g); nz = flags[e] != 0 && g != 0.f; }
     const unsigned long long mask = __ballot(nz);
     const int lane = threadIdx.x & 63;
+    // counter[1]: bits of max |dS| (the fp16 scale of the GEMM row step, align_bwd_dense.hip)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) av = fmaxf(av, __shfl_xor(av, o, 64));
+    if (lane == 0 && av > 0.f) atomicMax(reinterpret_cast<unsigned*>(counter) + 1, __float_as_uint(av));
+    // counter[2]: OR of the low 13 mantissa bits, counter[3]: 0x7F800000 - bits of the smallest non-zero |dS| (dr_has_lo)
+    unsigned low = 0, mnv = 0;
+    if (e < n) { const float g = dS[(e / Bc) * ld + (e % Bc)]; if (g != 0.f) { low = __float_as_uint(g) & 0x1FFFu; mnv = 0x7F800000u - (__float_as_uint(g) & 0x7FFFFFFFu); } }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { low |= __shfl_xor(low, o, 64); const unsigned other = __shfl_xor(mnv, o, 64); mnv = other > mnv ? other : mnv; }
+    if (lane == 0 && low) atomicOr(reinterpret_cast<unsigned*>(counter) + 2, low);
+    if (lane == 0 && mnv) atomicMax(reinterpret_cast<unsigned*>(counter) + 3, mnv);
     int base = 0;
     if (lane == 0 && mask) base = atomicAdd(counter, __popcll(mask));
     base = __shfl(base, 0, 64);
@@ -807,11 +825,14 @@ static int align_bwd_impl(const float* im, int64_t im_sb, int64_t im_sr, const i
   // kernel in split precision (64 pairs per workgroup sharing their panels); only the pairs with a word it could not
   // decide go through the one-workgroup-per-pair exact kernel below.
   bool dense = false;
+  char* dense_rows_scratch = nullptr;
   if ((flags & ALADIN_BWD_DENSE) && phase == BWD_ALL && packed) {
     aladin_align_geom gs;
     if (dense_supported(Bi, Bc, R, T, D, x_tail, y_tail, &gs)) {
       DenseWs dw;
-      dense_ws_layout(&gs, (char*)workspace + bwd_ws_layout(Bi, Bc, T - 1, nullptr, nullptr), &dw);
+      const size_t dense_bytes = dense_ws_layout(&gs, (char*)workspace + bwd_ws_layout(Bi, Bc, T - 1, nullptr, nullptr), &dw);
+      dense_rows_scratch = (char*)workspace + bwd_ws_layout(Bi, Bc, T - 1, nullptr, nullptr) + dense_bytes + (size_t)Bi * Bc * 16;
+      dense_rows_scratch = (char*)(((uintptr_t)dense_rows_scratch + 255) / 256 * 256);
       rc = aladin_align_pack_both(im, im_sb, im_sr, im_len, s, s_sb, s_st, s_len, &gs, dw.xm, dw.xe, dw.y, stream);
       if (rc) return rc;
       rc = aladin_internal_align_argmax(&gs, dw.xm, dw.xe, dw.y, dw.E, im_len, s_len, ws.table, tstride, dw.flags, st);
@@ -855,6 +876,13 @@ static int align_bwd_impl(const float* im, int64_t im_sb, int64_t im_sr, const i
   const int64_t rows = (int64_t)Bi * R + (int64_t)Bc * T;
   const unsigned rgrid = (unsigned)((rows + 3) / 4);
   const int nch = (D + 255) / 256;
+  if (dense && dense_rows_scratch && !(flags & ALADIN_BWD_DENSE_GATHER)) {
+    // every pair carries a gradient: the row step as two MFMA GEMMs over the table (align_bwd_dense.hip)
+    rc = aladin_internal_dense_rows(im, im_sb, im_sr, im_len, s, s_sb, s_st, s_len, Bi, Bc, R, T, D, x_tail, y_tail, dS, ld_dS, gscale,
+                                    ws.table, reinterpret_cast<const unsigned*>(ws.counter) + 1, d_im, d_s, dim_sb, dim_sr, ds_sb, ds_st,
+                                    (flags & ALADIN_BWD_PARTNERS_FP16) != 0, dense_rows_scratch, st);
+    if (rc != ALADIN_ERR_UNSUPPORTED) return rc;
+  }
   // ALADIN_BWD_PARTNERS_FP16: gather the partner rows from the packed fp16 operands (must be this problem's, non-split)
   const bool p16 = (flags & ALADIN_BWD_PARTNERS_FP16) != 0;
   PackedRows pk = {nullptr, nullptr, nullptr, 0, 0, 0, 0};
@@ -925,7 +953,7 @@ extern "C" int aladin_align_bwd_packed_strided_ex(const float* im, int64_t im_sb
                                                   int64_t d_s_stride_b, int64_t d_s_stride_t, void* workspace, int flags, void* stream) {
   if (!geom) { aladin_set_error("align_bwd_packed_strided_ex: null geometry"); return ALADIN_ERR_ARG; }
   if (geom->split) { aladin_set_error("align_bwd_packed_strided_ex: split-precision operands are forward-only (evaluation); pack with ALADIN_PRECISION_FP16"); return ALADIN_ERR_UNSUPPORTED; }
-  if (flags & ~(ALADIN_BWD_PARTNERS_FP16 | ALADIN_BWD_DENSE)) { aladin_set_error("align_bwd_packed_strided_ex: unknown flags %d", flags); return ALADIN_ERR_ARG; }
+  if (flags & ~(ALADIN_BWD_PARTNERS_FP16 | ALADIN_BWD_DENSE | ALADIN_BWD_DENSE_GATHER)) { aladin_set_error("align_bwd_packed_strided_ex: unknown flags %d", flags); return ALADIN_ERR_ARG; }
   if (d_im_stride_b < 1 || d_im_stride_r < 1 || d_s_stride_b < 1 || d_s_stride_t < 1) { aladin_set_error("align_bwd_packed_strided_ex: bad output strides"); return ALADIN_ERR_ARG; }
   return align_bwd_impl(im, im_sb, im_sr, im_len, s, s_sb, s_st, s_len, geom->Bi, geom->Bc, geom->R, geom->T, geom->D, dS,
                         ld_dS, gscale, (xm && y) ? xm : nullptr, xe, (xm && y) ? y : nullptr, (xm && y) ? geom : nullptr, pairs,

@@ -28,6 +28,14 @@ struct aladin_align_geom;
 int aladin_internal_align_argmax(const aladin_align_geom* g, const void* xm, const void* xe, const void* y, float* E,
                                  const int32_t* im_len, const int32_t* s_len, uint8_t* table, int tstride, uint8_t* flags, hipStream_t stream);
 
+// align_bwd_dense.hip: the row step of the dense-dS backward as two MFMA GEMMs over the arg-max table (see there)
+size_t aladin_internal_dense_rows_bytes(int Bi, int Bc, int R, int T, int D, int x_tail, int y_tail);
+int aladin_internal_dense_rows(const float* im, int64_t im_sb, int64_t im_sr, const int32_t* im_len, const float* s, int64_t s_sb,
+                               int64_t s_st, const int32_t* s_len, int Bi, int Bc, int R, int T, int D, int x_tail, int y_tail,
+                               const float* dS, int64_t ld_dS, const float* gscale, const uint8_t* table, const unsigned* dsmax,
+                               float* d_im, float* d_s, int64_t dim_sb, int64_t dim_sr, int64_t ds_sb, int64_t ds_st, int fp16_only,
+                               void* scratch, hipStream_t st);
+
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 #define GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
 

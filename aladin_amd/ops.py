@@ -216,6 +216,7 @@ def _grad_like(x):
 
 
 DENSE_MIN_PAIRS = 1 << 14    # below: the per-pair kernel is launch-bound and already faster (B = 64: 0.20 vs 0.26 ms)
+DENSE_ROWS_GEMM = True       # False: ALADIN_BWD_DENSE_GATHER -- the dense table with the per-row gather (bit-identical to the list path)
 DENSE_BACKWARD = True        # False: always one workgroup per gradient-carrying pair (the A/B switch of tests/ and tools/bench_dense_ds.py)
 
 
@@ -231,6 +232,8 @@ def _align_backward(im, s, im_len_t, s_len_t, dS, gscale=None, packed=None, pair
     Bc, T, _ = s.shape
     d_im, d_s = _grad_like(im), _grad_like(s)
     dense_flag = _lib.BWD_DENSE if (dense and DENSE_BACKWARD and packed is not None and packed[1] is not None and Bi * Bc >= DENSE_MIN_PAIRS) else 0
+    if dense_flag and not DENSE_ROWS_GEMM:
+        dense_flag |= _lib.BWD_DENSE_GATHER
     ws = _workspace(lib.aladin_align_bwd_workspace_bytes_ex(Bi, Bc, R, T, D, dense_flag), im.device)
     if packed is None:
         if x_tails != (0, 2):

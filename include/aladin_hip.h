@@ -204,6 +204,12 @@ ALADIN_API int aladin_align_bwd_rows(const float* im, int64_t im_stride_b, int64
  *       classes the tile kernel does not cover (more than one region tile per image, small batches) silently take the list
  *       path.  `pairs` / `pair_count` are ignored. */
 #define ALADIN_BWD_DENSE 2
+/*       With the table of all pairs in hand the row step (step 3) runs as two MFMA GEMMs, dXh = P Yh and dYh = P^T Xh with
+ *       P[(i,r),(c,w)] = dS[i,c] [argmax == r] generated in registers from the table (csrc/align_bwd_dense.hip), exact to
+ *       ~2^-22 by hi + lo splitting (one product under ALADIN_BWD_PARTNERS_FP16) -- sums in a different order than the
+ *       gather, so equal to it to rounding, not bit for bit.
+ *   ALADIN_BWD_DENSE_GATHER  (with ALADIN_BWD_DENSE) keep the per-row gather as step 3: bit-identical to the list path. */
+#define ALADIN_BWD_DENSE_GATHER 4
 ALADIN_API size_t aladin_align_bwd_workspace_bytes_ex(int Bi, int Bc, int R, int T, int D, int flags);
 ALADIN_API int aladin_align_bwd_packed_strided_ex(const float* im, int64_t im_stride_b, int64_t im_stride_r, const int32_t* im_len,
                                                   const float* s, int64_t s_stride_b, int64_t s_stride_t, const int32_t* s_len,

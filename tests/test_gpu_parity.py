@@ -1030,19 +1030,26 @@ def test_dense_backward_table_equals_the_per_pair_path(B, kind):
         im[1::2, 9] = im[1::2, 8] * (1 + 1e-7)           # and a near-tie below the fp16 operand resolution
     crit = AlignmentContrastiveLoss(margin=0.2, measure='dot', max_violation=False, aggregation='MrSw')
     grads = {}
-    for dense in (False, True):
+    for dense in (False, True, 'gemm'):
         a, b = T(im).requires_grad_(True), T(s).requires_grad_(True)
-        old, ops.DENSE_BACKWARD = ops.DENSE_BACKWARD, dense
+        old, ops.DENSE_BACKWARD, old_g, ops.DENSE_ROWS_GEMM = ops.DENSE_BACKWARD, bool(dense), ops.DENSE_ROWS_GEMM, dense == 'gemm'
         try:
             loss = crit(a, b, il, sl)
             loss.backward()
         finally:
-            ops.DENSE_BACKWARD = old
+            ops.DENSE_BACKWARD, ops.DENSE_ROWS_GEMM = old, old_g
         grads[dense] = (loss.item(), a.grad.clone(), b.grad.clone())
     assert grads[True][0] == grads[False][0]
     assert torch.equal(grads[True][1], grads[False][1])
     assert torch.equal(grads[True][2], grads[False][2])
     assert grads[True][1].abs().sum() > 0
+    # the row step as two MFMA GEMMs over the same table (csrc/align_bwd_dense.hip): hi + lo split operands, another
+    # summation order -- equal to the fp32 gather to rounding (measured <= 2e-6 of the largest entry)
+    for k in (1, 2):
+        ref, got = grads[True][k], grads['gemm'][k]
+        assert not torch.equal(ref, got)                 # it really took the other path
+        assert torch.equal(ref == 0, got == 0) or (got[(ref == 0) != (got == 0)].abs().max() < 1e-6 * ref.abs().max())
+        assert (ref - got).abs().max() <= 1e-5 * ref.abs().max()
 
 
 def test_dense_backward_through_the_score_matrix():
@@ -1054,17 +1061,19 @@ def test_dense_backward_through_the_score_matrix():
     crit = AlignmentContrastiveLoss(margin=0.2, measure='dot', max_violation=True, aggregation='MrSw')
     w = torch.randn(B, B, device='cuda', generator=torch.Generator('cuda').manual_seed(3))
     grads = {}
-    for dense in (False, True):
+    for dense in (False, True, 'gemm'):
         a, b = T(im).requires_grad_(True), T(s).requires_grad_(True)
-        old, ops.DENSE_BACKWARD = ops.DENSE_BACKWARD, dense
+        old, ops.DENSE_BACKWARD, old_g, ops.DENSE_ROWS_GEMM = ops.DENSE_BACKWARD, bool(dense), ops.DENSE_ROWS_GEMM, dense == 'gemm'
         try:
             loss, S = crit(a, b, il, sl, return_similarity_mat=True)
             (loss + (S * w).sum()).backward()
         finally:
-            ops.DENSE_BACKWARD = old
+            ops.DENSE_BACKWARD, ops.DENSE_ROWS_GEMM = old, old_g
         grads[dense] = (a.grad.clone(), b.grad.clone())
     assert torch.equal(grads[True][0], grads[False][0])
     assert torch.equal(grads[True][1], grads[False][1])
+    for k in (0, 1):                                      # arbitrary real dS through the GEMM row step (dS = hi + lo in fp16)
+        assert (grads[True][k] - grads['gemm'][k]).abs().max() <= 1e-5 * grads[True][k].abs().max()
 
 
 def test_b256_triplet_step_gradient_sparsity():
