@@ -4,6 +4,9 @@
             (N, L, D) tensors and packed stores (bit-equal to each other), random class thresholds;
   partners  the opt-in fp16-partner backward (ops.set_backward_precision('fp16')) vs the oracle's gradients: rtol 1e-3 + 5e-4 of the
             largest entry, and the same zero pattern as the exact path.
+  dense     the dense-dS backward (ALADIN_BWD_DENSE: arg-max table from the split-precision tile kernel; row step as two MFMA
+            GEMMs): table + gather bit-identical to the per-pair list path, the GEMM row step within 1e-5 of the largest entry
+            (5e-4 with fp16 partners), for the sum-of-violations hinge and for arbitrary real dS, random shapes / lengths.
 usage: tests/fuzz/fuzz_round3.py [seconds] [seed]"""
 import os
 import sys
@@ -17,6 +20,7 @@ import torch
 
 import alad_oracle as O
 from aladin_amd import evaluation as E, ops, synth
+from aladin_amd.loss import AlignmentContrastiveLoss
 from aladin_amd.store import PackedSetStore
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
@@ -25,11 +29,11 @@ rng = np.random.RandomState(seed)
 dev = torch.device('cuda:0')
 T = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
 t0 = time.time()
-counts = {'bucket': 0, 'partners': 0}
-worst = {'bucket_split': 0.0, 'partners': 0.0}
+counts = {'bucket': 0, 'partners': 0, 'dense': 0}
+worst = {'bucket_split': 0.0, 'partners': 0.0, 'dense_gemm': 0.0, 'dense_gemm16': 0.0}
 real_plan = ops.bucket_plan
 while time.time() - t0 < budget:
-    kind = ['bucket', 'partners'][int(rng.randint(0, 2))]
+    kind = ['bucket', 'partners', 'dense'][int(rng.randint(0, 3))]
     case_seed = int(rng.randint(1, 1 << 30))
     if kind == 'bucket':
         n_img = int(rng.randint(4, 40))
@@ -68,6 +72,40 @@ while time.time() - t0 < budget:
                 assert d1 <= 1e-5 * scale + 1e-6 and d2 <= 1e-3 * scale, ('bucket fp16', case_seed, d1, d2)
         ops.bucket_plan = real_plan
         ops._PLAN_CACHE.clear()
+    elif kind == 'dense':
+        B = int(rng.choice([128, 136, 160, 200, 256]))
+        R, Tn, D = int(rng.randint(5, 41)), int(rng.randint(6, 51)), int(rng.choice([64, 128, 260, 768]))
+        if B * (R + Tn) * D > 2.2e7:
+            D = 128
+        im, s, il, sl = synth.structured_alignment_batch(B, R, Tn, D, seed=case_seed % 100000, noise=float(rng.choice([1.0, 3.0])), ragged=bool(rng.randint(0, 2)))
+        il = [max(2, v) for v in il]
+        sl = [max(4, v) for v in sl]
+        real_dS = bool(rng.randint(0, 2))
+        w = torch.randn(B, B, device=dev, generator=torch.Generator(dev).manual_seed(case_seed)) * float(10.0 ** rng.randint(-6, 3))
+        grads = {}
+        for mode in ('list', 'gather', 'gemm', 'gemm16'):
+            ops.DENSE_BACKWARD, ops.DENSE_ROWS_GEMM = mode != 'list', mode.startswith('gemm')
+            ops.set_backward_precision('fp16' if mode == 'gemm16' else 'exact')
+            a, b = T(im).requires_grad_(True), T(s).requires_grad_(True)
+            # the fused triplet node knows when dS is dense: sum of violations, or a gradient on the returned score matrix
+            if real_dS:
+                loss, S = AlignmentContrastiveLoss(0.2, 'dot', True, 'MrSw')(a, b, il, sl, return_similarity_mat=True)
+                (loss + (S * w).sum()).backward()
+            else:
+                AlignmentContrastiveLoss(0.2, 'dot', False, 'MrSw')(a, b, il, sl).backward()
+            grads[mode] = (a.grad.clone(), b.grad.clone())
+        ops.DENSE_BACKWARD, ops.DENSE_ROWS_GEMM = True, True
+        ops.set_backward_precision('exact')
+        for k in (0, 1):
+            ref = grads['list'][k]
+            scale = max(1e-30, float(ref.abs().max()))
+            assert torch.equal(ref, grads['gather'][k]), ('dense table != list', case_seed, B, R, Tn, D, real_dS)
+            for mode, tol in (('gemm', 1e-5), ('gemm16', 5e-4)):
+                err = float((grads[mode][k] - ref).abs().max()) / scale
+                worst['dense_' + mode] = max(worst['dense_' + mode], err)
+                # fp16 partners: the opt-in's tolerance (rtol 1e-3 + 5e-4 of the largest entry, as in `partners`)
+                assert bool(((grads[mode][k] - ref).abs() <= (1e-3 * ref.abs() if mode == 'gemm16' else 0) + tol * scale).all()), ('dense ' + mode, case_seed, B, R, Tn, D, real_dS, err)
+                assert torch.isfinite(grads[mode][k]).all()
     else:
         B = int(rng.choice([3, 8, 17, 40, 64, 96]))
         R, Tn, D = int(rng.randint(5, 41)), int(rng.randint(6, 51)), int(rng.choice([64, 128, 768]))
