@@ -79,16 +79,18 @@ static bool dense_supported(int Bi, int Bc, int R, int T, int D, int x_tail, int
 extern "C" size_t aladin_align_bwd_workspace_bytes_ex(int Bi, int Bc, int R, int T, int D, int flags) {
   size_t n = aladin_align_bwd_workspace_bytes(Bi, Bc, R, T, D);
   if (n == 0 || !(flags & ALADIN_BWD_DENSE)) return n;
-  aladin_align_geom gs;
-  // sized for the image / caption convention; the role-swapped poolings have shorter scored axes
-  if (dense_supported(Bi, Bc, R, T, D, 0, 2, &gs) || dense_supported(Bi, Bc, R, T, D, 2, 0, &gs) || dense_supported(Bi, Bc, R, T, D, 0, 0, &gs)) {
-    n += dense_ws_layout(&gs, nullptr, nullptr) + (size_t)Bi * Bc * 16;      // + slack for the other tails' row padding
-    // + the GEMM form of the row step (align_bwd_dense.hip): transposed operands and split-K partial sums
-    size_t rows = 0;
-    const int tails[3][2] = {{0, 2}, {2, 0}, {0, 0}};
-    for (auto& t : tails) { const size_t b = aladin_internal_dense_rows_bytes(Bi, Bc, R, T, D, t[0], t[1]); rows = b > rows ? b : rows; }
-    n += rows + 512;
+  // exact: the largest need over the three tail conventions a caller can pack (image / caption, role-swapped, none) --
+  // [split operands + side scratch + flags | GEMM row step: transposed operands + split-K partial sums], laid out by
+  // align_bwd_impl exactly as here
+  size_t need = 0;
+  const int tails[3][2] = {{0, 2}, {2, 0}, {0, 0}};
+  for (auto& t : tails) {
+    aladin_align_geom gs;
+    if (!dense_supported(Bi, Bc, R, T, D, t[0], t[1], &gs)) continue;
+    const size_t b = dense_ws_layout(&gs, nullptr, nullptr) + aladin_internal_dense_rows_bytes(Bi, Bc, R, T, D, t[0], t[1]);
+    need = b > need ? b : need;
   }
+  n += need;
   return n;
 }
 
@@ -831,8 +833,7 @@ static int align_bwd_impl(const float* im, int64_t im_sb, int64_t im_sr, const i
     if (dense_supported(Bi, Bc, R, T, D, x_tail, y_tail, &gs)) {
       DenseWs dw;
       const size_t dense_bytes = dense_ws_layout(&gs, (char*)workspace + bwd_ws_layout(Bi, Bc, T - 1, nullptr, nullptr), &dw);
-      dense_rows_scratch = (char*)workspace + bwd_ws_layout(Bi, Bc, T - 1, nullptr, nullptr) + dense_bytes + (size_t)Bi * Bc * 16;
-      dense_rows_scratch = (char*)(((uintptr_t)dense_rows_scratch + 255) / 256 * 256);
+      dense_rows_scratch = (char*)workspace + bwd_ws_layout(Bi, Bc, T - 1, nullptr, nullptr) + dense_bytes;      // both 256-multiples
       rc = aladin_align_pack_both(im, im_sb, im_sr, im_len, s, s_sb, s_st, s_len, &gs, dw.xm, dw.xe, dw.y, stream);
       if (rc) return rc;
       rc = aladin_internal_align_argmax(&gs, dw.xm, dw.xe, dw.y, dw.E, im_len, s_len, ws.table, tstride, dw.flags, st);
