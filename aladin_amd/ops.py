@@ -215,9 +215,51 @@ def _grad_like(x):
     return torch.empty(tuple(x.shape), dtype=torch.float32, device=x.device)
 
 
+DENSE_MIN_FRACTION = 0.4     # of the pairs carrying a gradient: below, the list path (cost ~ 3.2 ms x fraction at B = 256) beats the dense one (~1.4 ms)
 DENSE_MIN_PAIRS = 1 << 14    # below: the per-pair kernel is launch-bound and already faster (B = 64: 0.20 vs 0.26 ms)
 DENSE_ROWS_GEMM = True       # False: ALADIN_BWD_DENSE_GATHER -- the dense table with the per-row gather (bit-identical to the list path)
 DENSE_BACKWARD = True        # False: always one workgroup per gradient-carrying pair (the A/B switch of tests/ and tools/bench_dense_ds.py)
+
+
+class _DensityProbe:
+    """How dense is dloss/dS of the sum-of-violations hinge?  Early in training nearly every pair violates the margin, late
+    few do -- and only the device knows (the hinge kernel's pair count).  Reading it would stall the host, so each step's
+    count leaves by ONE asynchronous copy and steers the NEXT steps' choice between the dense and the list backward
+    (the density drifts slowly).  Until a count has arrived: dense."""
+
+    def __init__(self, slots=4):
+        self._slots = [None] * slots
+        self._k = 0
+        self._pending = []
+        self.fraction = None
+
+    def record(self, count, total):
+        if torch.cuda.is_current_stream_capturing():
+            return
+        self.poll()
+        if len(self._pending) >= len(self._slots) - 1:
+            return                                          # the device is far behind: keep what is in flight
+        k = self._k % len(self._slots)
+        self._k += 1
+        if self._slots[k] is None:
+            self._slots[k] = (torch.empty(1, dtype=torch.int32).pin_memory(), torch.cuda.Event())
+        buf, ev = self._slots[k]
+        buf.copy_(count, non_blocking=True)
+        ev.record()
+        self._pending.append((buf, ev, float(total)))
+
+    def poll(self):
+        while self._pending and self._pending[0][1].query():
+            buf, _, total = self._pending.pop(0)
+            self.fraction = int(buf[0]) / total
+        return self.fraction
+
+    def dense(self):
+        f = self.poll()
+        return f is None or f >= DENSE_MIN_FRACTION
+
+
+_density_probe = _DensityProbe()
 
 
 def _align_backward(im, s, im_len_t, s_len_t, dS, gscale=None, packed=None, pairs=None, x_tails=(0, 2), dense=False):
@@ -359,7 +401,11 @@ class _AlignTriplet(torch.autograd.Function):
             ctx.save_for_backward(im, s, im_len_t, s_len_t, packed[1], packed[2], packed[3], dS)
             ctx.geom = geom
             ctx.pairs = pairs
-        ctx.dense = not max_violation                   # sum of violations: dloss/dS is dense
+        # sum of violations: dloss/dS is dense while most pairs violate the margin (the previous steps' pair counts say)
+        ctx.dense = False
+        if need and not max_violation:
+            _density_probe.record(pairs[1], S.shape[0] * S.shape[1])
+            ctx.dense = _density_probe.dense()
         ctx.set_materialize_grads(False)
         return loss, S
 

@@ -32,6 +32,7 @@ t0 = time.time()
 counts = {'bucket': 0, 'partners': 0, 'dense': 0}
 worst = {'bucket_split': 0.0, 'partners': 0.0, 'dense_gemm': 0.0, 'dense_gemm16': 0.0}
 real_plan = ops.bucket_plan
+ops.DENSE_MIN_FRACTION = 0.0        # the dense path whatever the density of a case's dS
 while time.time() - t0 < budget:
     kind = ['bucket', 'partners', 'dense'][int(rng.randint(0, 3))]
     case_seed = int(rng.randint(1, 1 << 30))

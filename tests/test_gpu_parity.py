@@ -1033,11 +1033,12 @@ def test_dense_backward_table_equals_the_per_pair_path(B, kind):
     for dense in (False, True, 'gemm'):
         a, b = T(im).requires_grad_(True), T(s).requires_grad_(True)
         old, ops.DENSE_BACKWARD, old_g, ops.DENSE_ROWS_GEMM = ops.DENSE_BACKWARD, bool(dense), ops.DENSE_ROWS_GEMM, dense == 'gemm'
+        old_f, ops.DENSE_MIN_FRACTION = ops.DENSE_MIN_FRACTION, 0.0      # whatever the density of this batch's dS
         try:
             loss = crit(a, b, il, sl)
             loss.backward()
         finally:
-            ops.DENSE_BACKWARD, ops.DENSE_ROWS_GEMM = old, old_g
+            ops.DENSE_BACKWARD, ops.DENSE_ROWS_GEMM, ops.DENSE_MIN_FRACTION = old, old_g, old_f
         grads[dense] = (loss.item(), a.grad.clone(), b.grad.clone())
     assert grads[True][0] == grads[False][0]
     assert torch.equal(grads[True][1], grads[False][1])
@@ -1050,6 +1051,30 @@ def test_dense_backward_table_equals_the_per_pair_path(B, kind):
         assert not torch.equal(ref, got)                 # it really took the other path
         assert torch.equal(ref == 0, got == 0) or (got[(ref == 0) != (got == 0)].abs().max() < 1e-6 * ref.abs().max())
         assert (ref - got).abs().max() <= 1e-5 * ref.abs().max()
+
+
+def test_dense_backward_follows_the_measured_density():
+    """The dense path is taken while most pairs violate the margin; once the pair counts of earlier steps (copied out
+    asynchronously) say they do not, the sum-of-violations hinge goes back to the list path -- same gradients either way."""
+    from aladin_amd import ops, synth
+    from aladin_amd.loss import AlignmentContrastiveLoss
+    B = 128
+    im, s, il, sl = synth.alignment_batch(B, 34, 50, 768, seed=41, ragged=True)
+    probe = ops._density_probe
+    for margin, dense_expected in ((0.2, True), (-50.0, False)):
+        crit = AlignmentContrastiveLoss(margin=margin, measure='dot', max_violation=False, aggregation='MrSw')
+        probe.__init__()
+        a, b = T(im).requires_grad_(True), T(s).requires_grad_(True)
+        crit(a, b, il, sl).backward()                          # first step: no count yet -> dense
+        torch.cuda.synchronize()
+        frac = probe.poll()
+        assert frac is not None and (frac > 0.5) == dense_expected, frac
+        assert probe.dense() == dense_expected
+        a2, b2 = T(im).requires_grad_(True), T(s).requires_grad_(True)
+        crit(a2, b2, il, sl).backward()                        # second step: steered by the first one's count
+        assert torch.allclose(a.grad, a2.grad, rtol=0, atol=1e-5 * float(a.grad.abs().max()) + 1e-30)
+        assert torch.allclose(b.grad, b2.grad, rtol=0, atol=1e-5 * float(b.grad.abs().max()) + 1e-30)
+    probe.__init__()
 
 
 def test_dense_backward_through_the_score_matrix():
