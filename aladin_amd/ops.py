@@ -255,7 +255,7 @@ class _DensityProbe:
         return self.fraction
 
     def dense(self):
-        f = self.poll()
+        f = self.fraction if torch.cuda.is_current_stream_capturing() else self.poll()
         return f is None or f >= DENSE_MIN_FRACTION
 
 
@@ -1096,6 +1096,7 @@ class _BigHeads(torch.autograd.Function):
         B = img_emb.shape[0]
         terms = torch.empty(3, dtype=torch.float32, device=dev)          # slots of absent heads are never read
         S = packed = dS = pairs = table_ws = None
+        dense = False
         if flags & (HEAD_ALIGN_HINGE | HEAD_LISTNET):
             if need_sets and flags & HEAD_ALIGN_HINGE:
                 _check_backward_supported(im, s, 0, 2)
@@ -1107,6 +1108,9 @@ class _BigHeads(torch.autograd.Function):
                     _, dS, im, s, table_ws = fused
                 else:
                     _, dS, pairs = _hinge_raw(S, margin, max_violation, need_sets, want_pairs=True, loss_out=terms[1:2])
+                    if need_sets and not max_violation:                 # sum of violations: the dense backward while dS is dense
+                        _density_probe.record(pairs[1], B * B)
+                        dense = _density_probe.dense()
         a = b = M = dMh = dMl = None
         if flags & (HEAD_MATCH_HINGE | HEAD_LISTNET):
             a = img_emb if img_emb.stride(1) == 1 else img_emb.contiguous()
@@ -1130,6 +1134,7 @@ class _BigHeads(torch.autograd.Function):
         ctx.flags, ctx.weights = flags, weights
         ctx.geom = packed[0] if packed is not None else None
         ctx.pairs = pairs
+        ctx.dense = dense
         pk = packed[1:] if packed is not None else (None, None, None)
         ctx.save_for_backward(a, b, im, s, im_len_t, s_len_t, pk[0], pk[1], pk[2], dMh, dMl, dS, table_ws)
         ctx.set_materialize_grads(False)
@@ -1165,7 +1170,8 @@ class _BigHeads(torch.autograd.Function):
         if want_a and table_ws is not None:
             d_im, d_s = _align_backward_rows(im, s, im_len_t, s_len_t, dS, scale, ctx.geom, table_ws, (ctx.geom, xm, xe, y))
         elif want_a:
-            d_im, d_s = _align_backward(im, s, im_len_t, s_len_t, dS, gscale=scale, packed=(ctx.geom, xm, xe, y), pairs=ctx.pairs)
+            d_im, d_s = _align_backward(im, s, im_len_t, s_len_t, dS, gscale=scale, packed=(ctx.geom, xm, xe, y), pairs=ctx.pairs,
+                                        dense=ctx.dense)
         return d_a, d_b, d_im, d_s, None, None, None, None, None, None, None, None
 
 

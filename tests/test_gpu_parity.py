@@ -1077,6 +1077,32 @@ def test_dense_backward_follows_the_measured_density():
     probe.__init__()
 
 
+def test_model_heads_take_the_dense_backward_too():
+    """ALADModel's single-node heads (ops._BigHeads, B > 64) with 'max-violation': False: dense and list backward agree."""
+    from aladin_amd import ops, synth
+    from aladin_amd.alad_model import ALADModel
+    B = 128
+    im, s, il, sl = synth.alignment_batch(B, 34, 50, 768, seed=43, ragged=True)
+    gi, gc = synth.global_embeddings(B, 768, seed=44, noise=3.0)
+    model = ALADModel({'training': {'loss-type': 'alignment-distillation-matching', 'loss-weights': [1, 1, 0.5], 'margin': 0.2,
+                                    'measure': 'dot', 'max-violation': False, 'alignment-mode': 'MrSw', 'distillation-mode': 'listnet'}})
+    grads = {}
+    for dense in (False, True):
+        x, y = T(gi).requires_grad_(True), T(gc).requires_grad_(True)
+        a = T(im).permute(1, 0, 2).contiguous().requires_grad_(True)
+        b = T(s).permute(1, 0, 2).contiguous().requires_grad_(True)
+        old, ops.DENSE_BACKWARD, old_f, ops.DENSE_MIN_FRACTION = ops.DENSE_BACKWARD, dense, ops.DENSE_MIN_FRACTION, 0.0
+        try:
+            loss, _ = model.forward_loss_total(x, y, a, b, il, sl, 0, epoch=5)
+            loss.backward()
+        finally:
+            ops.DENSE_BACKWARD, ops.DENSE_MIN_FRACTION = old, old_f
+        grads[dense] = [t.grad.clone() for t in (x, y, a, b)]
+    for g0, g1 in zip(grads[False], grads[True]):
+        assert (g0 - g1).abs().max() <= 1e-5 * g0.abs().max()
+    assert not torch.equal(grads[False][2], grads[True][2])            # the GEMM row step really ran
+
+
 def test_dense_backward_through_the_score_matrix():
     """The other dense caller: a gradient arriving on the returned S (listnet on top of the alignment scores)."""
     from aladin_amd import ops, synth
