@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256) void dense_transpose_kernel(DrSet v, int D, in
     if (lane == 0) inv[kk] = valid ? DR_YS / fmaxf(sqrtf(ss), 1e-12f) : 0.f;
   }
   __syncthreads();
-  for (int dc = 0; dc < Dq / 256; ++dc) {
+  for (int dc = 0; dc * 256 < Dq; ++dc) {                  // Dq: a multiple of 64 (whole 192-row GEMM tiles)
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
       const int kk = wave * 8 + q, d = dc * 256 + lane * 4;
@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256) void dense_transpose_kernel(DrSet v, int D, in
     }
     __syncthreads();
     const int t = threadIdx.x;
-    for (int part = 0; part < parts; ++part) {
+    for (int part = 0; part < parts && dc * 256 + t < Dq; ++part) {
       half_t col[32];
 #pragma unroll
       for (int g = 0; g < 4; ++g)
@@ -519,7 +519,7 @@ static bool dr_plan(int Bi, int Bc, int R, int T, int D, int x_tail, int y_tail,
   if (p->Rq < 8 || p->Tq < 1 || p->Rq > 96 || D % 4 != 0 || D > 1024) return false;      // Rq >= 8: <= 34 images per 256-row tile (AUX slot)
   p->tstride = (p->Tq + 15) / 16 * 16;
   p->RK = (p->Rq + 7) / 8 * 8;
-  p->Dq = (int)up_to(D, 768);                            // whole 192-row tiles and whole 256-column transpose chunks
+  p->Dq = (int)up_to(D, DR_BN);                          // whole 192-row B tiles
   p->KX = up_to((int64_t)Bi * p->RK, 64);
   p->KY = up_to((int64_t)Bc * p->tstride, 64);
   p->MX = Bi * p->Rq; p->MY = Bc * p->tstride;
