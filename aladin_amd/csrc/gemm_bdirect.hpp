@@ -22,6 +22,7 @@
 // so that the counts are the same on every path the LDS-DMA refill is issued UNCONDITIONALLY (in the last two K steps it
 // re-reads the last K step into a stage nobody reads again).
 #pragma once
+#pragma clang diagnostic ignored "-Winline-asm"     // m0 around the LDS-DMA asm (diag build only)
 #include "gemm_core.hpp"
 #ifndef BD_NS
 #define BD_NS 3
