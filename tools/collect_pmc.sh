@@ -17,9 +17,9 @@ for P in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_VALU_MFMA_BUSY
 done
 cd "$R"
 python3 - "$OUT" "$TAG" <<'PY'
-import csv, glob, json, sys, collections, shutil
+import csv, glob, json, os, sys, collections, shutil
 out, tag = sys.argv[1], sys.argv[2]
-stats = sorted(glob.glob(out + '/stats/*/*kernel_stats.csv'))
+stats = sorted(glob.glob(out + '/stats/*/*kernel_stats.csv'), key=os.path.getmtime)       # the newest run's (file names are pids)
 if stats:
     shutil.copy(stats[-1], 'profiles/%s_kernel_stats.csv' % tag)
 agg = collections.defaultdict(lambda: collections.defaultdict(list))

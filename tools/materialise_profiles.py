@@ -14,7 +14,7 @@ tag = sys.argv[1]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = os.path.join(root, 'gpurun_out', tag)
 prof = os.path.join(root, 'profiles')
-stats = sorted(glob.glob(out + '/stats/*/*kernel_stats.csv'))
+stats = sorted(glob.glob(out + '/stats/*/*kernel_stats.csv'), key=os.path.getmtime)       # the newest run's (file names are pids)
 if stats:
     shutil.copy(stats[-1], os.path.join(prof, '%s_kernel_stats.csv' % tag))
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
