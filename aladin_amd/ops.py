@@ -223,43 +223,57 @@ DENSE_BACKWARD = True        # False: always one workgroup per gradient-carrying
 
 class _DensityProbe:
     """How dense is dloss/dS of the sum-of-violations hinge?  Early in training nearly every pair violates the margin, late
-    few do -- and only the device knows (the hinge kernel's pair count).  Reading it would stall the host, so each step's
-    count leaves by ONE asynchronous copy and steers the NEXT steps' choice between the dense and the list backward
-    (the density drifts slowly).  Until a count has arrived: dense."""
+    few do -- and only the device knows (the hinge kernel's pair count).  Reading it at once would stall the host, so each
+    step's count leaves by ONE asynchronous copy and the choice between the dense and the list backward at step n follows
+    the count of step n - LAG (the density drifts slowly).  The lag is FIXED, not "whatever has arrived": the two paths sum
+    in different orders, and which one runs must not depend on timing (bitwise reproducible runs); waiting for a copy
+    issued LAG steps ago costs nothing unless the host is more than LAG steps ahead of the device.
+    Before step LAG: `unknown` (dense for the fused sum-of-violations node, the list path for a generic gradient)."""
+    LAG = 2
 
-    def __init__(self, slots=4):
-        self._slots = [None] * slots
-        self._k = 0
-        self._pending = []
+    def __init__(self, unknown=True):
+        self._hist = []                                     # [buffer, event, total] of the last LAG + 1 recorded steps, oldest first
         self.fraction = None
+        self.unknown = unknown
 
-    def record(self, count, total):
-        if torch.cuda.is_current_stream_capturing():
-            return
-        self.poll()
-        if len(self._pending) >= len(self._slots) - 1:
-            return                                          # the device is far behind: keep what is in flight
-        k = self._k % len(self._slots)
-        self._k += 1
-        if self._slots[k] is None:
-            self._slots[k] = (torch.empty(1, dtype=torch.int32).pin_memory(), torch.cuda.Event())
-        buf, ev = self._slots[k]
-        buf.copy_(count, non_blocking=True)
-        ev.record()
-        self._pending.append((buf, ev, float(total)))
-
-    def poll(self):
-        while self._pending and self._pending[0][1].query():
-            buf, _, total = self._pending.pop(0)
-            self.fraction = int(buf[0]) / total
-        return self.fraction
+    def step(self, count, total):
+        """Record this step's count; -> dense? for this step."""
+        if torch.cuda.is_current_stream_capturing():        # no host copies inside a graph: keep the last answer
+            return self.dense()
+        if len(self._hist) >= self.LAG:
+            buf, ev, tot = self._hist[-self.LAG]
+            ev.synchronize()
+            self.fraction = int(buf[0]) / tot
+        if len(self._hist) > self.LAG:
+            slot = self._hist.pop(0)
+        else:
+            slot = [torch.empty(1, dtype=count.dtype).pin_memory(), torch.cuda.Event(), 1.0]
+        if slot[0].dtype != count.dtype:
+            slot[0] = torch.empty(1, dtype=count.dtype).pin_memory()
+        slot[0].copy_(count.reshape(1), non_blocking=True)
+        slot[1].record()
+        slot[2] = float(total)
+        self._hist.append(slot)
+        return self.dense()
 
     def dense(self):
-        f = self.fraction if torch.cuda.is_current_stream_capturing() else self.poll()
-        return f is None or f >= DENSE_MIN_FRACTION
+        return self.unknown if self.fraction is None else self.fraction >= DENSE_MIN_FRACTION
+
+    def newest(self):
+        """The fraction of the most recent recorded step (waits for it; for tests / tools)."""
+        if not self._hist:
+            return None
+        buf, ev, tot = self._hist[-1]
+        ev.synchronize()
+        return int(buf[0]) / tot
 
 
 _density_probe = _DensityProbe()
+# a gradient arriving on a score matrix from OUTSIDE the fused nodes (ops.alignment_scores + any loss: the 'MwSr' / 'symm'
+# poolings, a caller's own criterion): its non-zeros are counted (one small launch) and, as above, steer the backward of
+# the same shape LAG steps later; until then the list path (the usual dS is the hardest-negative hinge's: <= 3B entries)
+_generic_probes = {}
+_LAST_BWD_FLAGS = [0]
 
 
 def _align_backward(im, s, im_len_t, s_len_t, dS, gscale=None, packed=None, pairs=None, x_tails=(0, 2), dense=False):
@@ -276,6 +290,7 @@ def _align_backward(im, s, im_len_t, s_len_t, dS, gscale=None, packed=None, pair
     dense_flag = _lib.BWD_DENSE if (dense and DENSE_BACKWARD and packed is not None and packed[1] is not None and Bi * Bc >= DENSE_MIN_PAIRS) else 0
     if dense_flag and not DENSE_ROWS_GEMM:
         dense_flag |= _lib.BWD_DENSE_GATHER
+    _LAST_BWD_FLAGS[0] = dense_flag                      # which path the last backward took (tests)
     ws = _workspace(lib.aladin_align_bwd_workspace_bytes_ex(Bi, Bc, R, T, D, dense_flag), im.device)
     if packed is None:
         if x_tails != (0, 2):
@@ -348,7 +363,11 @@ class _AlignScores(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dS):
         im, s, im_len_t, s_len_t, xm, xe, y = ctx.saved_tensors
-        d_im, d_s = _align_backward(im, s, im_len_t, s_len_t, dS, packed=(ctx.geom, xm, xe, y))
+        dense = False
+        if DENSE_BACKWARD and dS.numel() >= DENSE_MIN_PAIRS and not torch.cuda.is_current_stream_capturing():
+            probe = _generic_probes.setdefault((tuple(dS.shape), ctx.geom.x_tail, ctx.geom.y_tail), _DensityProbe(unknown=False))
+            dense = probe.step(torch.count_nonzero(dS), dS.numel())
+        d_im, d_s = _align_backward(im, s, im_len_t, s_len_t, dS, packed=(ctx.geom, xm, xe, y), dense=dense)
         return d_im, d_s, None, None, None, None
 
 
@@ -404,8 +423,7 @@ class _AlignTriplet(torch.autograd.Function):
         # sum of violations: dloss/dS is dense while most pairs violate the margin (the previous steps' pair counts say)
         ctx.dense = False
         if need and not max_violation:
-            _density_probe.record(pairs[1], S.shape[0] * S.shape[1])
-            ctx.dense = _density_probe.dense()
+            ctx.dense = _density_probe.step(pairs[1], S.shape[0] * S.shape[1])
         ctx.set_materialize_grads(False)
         return loss, S
 
@@ -1109,8 +1127,7 @@ class _BigHeads(torch.autograd.Function):
                 else:
                     _, dS, pairs = _hinge_raw(S, margin, max_violation, need_sets, want_pairs=True, loss_out=terms[1:2])
                     if need_sets and not max_violation:                 # sum of violations: the dense backward while dS is dense
-                        _density_probe.record(pairs[1], B * B)
-                        dense = _density_probe.dense()
+                        dense = _density_probe.step(pairs[1], B * B)
         a = b = M = dMh = dMl = None
         if flags & (HEAD_MATCH_HINGE | HEAD_LISTNET):
             a = img_emb if img_emb.stride(1) == 1 else img_emb.contiguous()

@@ -1054,26 +1054,29 @@ def test_dense_backward_table_equals_the_per_pair_path(B, kind):
 
 
 def test_dense_backward_follows_the_measured_density():
-    """The dense path is taken while most pairs violate the margin; once the pair counts of earlier steps (copied out
-    asynchronously) say they do not, the sum-of-violations hinge goes back to the list path -- same gradients either way."""
+    """The dense path is taken while most pairs violate the margin; once the pair count of the step LAG steps earlier (copied
+    out asynchronously) says they do not, the sum-of-violations hinge goes back to the list path -- same gradients either way,
+    and the switch happens at a FIXED step (reproducible runs)."""
     from aladin_amd import ops, synth
     from aladin_amd.loss import AlignmentContrastiveLoss
     B = 128
     im, s, il, sl = synth.alignment_batch(B, 34, 50, 768, seed=41, ragged=True)
     probe = ops._density_probe
+    LAG = probe.LAG
     for margin, dense_expected in ((0.2, True), (-50.0, False)):
         crit = AlignmentContrastiveLoss(margin=margin, measure='dot', max_violation=False, aggregation='MrSw')
         probe.__init__()
-        a, b = T(im).requires_grad_(True), T(s).requires_grad_(True)
-        crit(a, b, il, sl).backward()                          # first step: no count yet -> dense
-        torch.cuda.synchronize()
-        frac = probe.poll()
-        assert frac is not None and (frac > 0.5) == dense_expected, frac
-        assert probe.dense() == dense_expected
-        a2, b2 = T(im).requires_grad_(True), T(s).requires_grad_(True)
-        crit(a2, b2, il, sl).backward()                        # second step: steered by the first one's count
-        assert torch.allclose(a.grad, a2.grad, rtol=0, atol=1e-5 * float(a.grad.abs().max()) + 1e-30)
-        assert torch.allclose(b.grad, b2.grad, rtol=0, atol=1e-5 * float(b.grad.abs().max()) + 1e-30)
+        grads, flags = [], []
+        for step in range(LAG + 2):
+            a, b = T(im).requires_grad_(True), T(s).requires_grad_(True)
+            crit(a, b, il, sl).backward()
+            grads.append((a.grad.clone(), b.grad.clone()))
+            flags.append(ops._LAST_BWD_FLAGS[0] != 0)
+        assert flags == [True] * LAG + [dense_expected] * 2, flags          # unknown -> dense; then the count of step n - LAG decides
+        assert (probe.newest() > 0.5) == dense_expected
+        for g in grads[1:]:
+            assert torch.allclose(grads[0][0], g[0], rtol=0, atol=1e-5 * float(grads[0][0].abs().max()) + 1e-30)
+            assert torch.allclose(grads[0][1], g[1], rtol=0, atol=1e-5 * float(grads[0][1].abs().max()) + 1e-30)
     probe.__init__()
 
 
@@ -1101,6 +1104,33 @@ def test_model_heads_take_the_dense_backward_too():
     for g0, g1 in zip(grads[False], grads[True]):
         assert (g0 - g1).abs().max() <= 1e-5 * g0.abs().max()
     assert not torch.equal(grads[False][2], grads[True][2])            # the GEMM row step really ran
+
+
+def test_generic_score_gradient_learns_its_density():
+    """ops.alignment_scores + a separate loss: the backward counts dS's non-zeros and, LAG steps later, takes the dense path
+    while dS is dense -- and stays on the list path for the hardest-negative hinge's sparse dS."""
+    from aladin_amd import ops, synth
+    B = 128
+    im, s, il, sl = synth.alignment_batch(B, 34, 50, 768, seed=47, ragged=True)
+    LAG = ops._DensityProbe.LAG
+    for mv, dense_expected in ((False, True), (True, False)):
+        ops._generic_probes.clear()
+        grads, flags = [], []
+        for step in range(LAG + 2):
+            a, b = T(im).requires_grad_(True), T(s).requires_grad_(True)
+            ops.hinge_loss(ops.alignment_scores(a, b, il, sl), 0.2, mv).backward()
+            grads.append((a.grad.clone(), b.grad.clone()))
+            flags.append(ops._LAST_BWD_FLAGS[0] != 0)
+        (probe,) = ops._generic_probes.values()
+        assert flags == [False] * LAG + [dense_expected] * 2, flags         # unknown -> list path
+        assert (probe.newest() > 0.5) == dense_expected
+        for k in (0, 1):
+            if dense_expected:
+                assert not torch.equal(grads[0][k], grads[-1][k])          # list path vs dense table + GEMM row step
+                assert (grads[0][k] - grads[-1][k]).abs().max() <= 1e-5 * grads[0][k].abs().max()
+            else:
+                assert torch.equal(grads[0][k], grads[-1][k])
+    ops._generic_probes.clear()
 
 
 def test_dense_backward_through_the_score_matrix():
