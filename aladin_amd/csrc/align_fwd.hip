@@ -720,13 +720,22 @@ __device__ __forceinline__ float xchg16(float v) {          // the value of lane
   return (threadIdx.x & 16) ? a : b;
 }
 
-template <bool HAS_E, int TP16>
+__device__ __forceinline__ float xchg32(float v) {          // the value of lane ^ 32
+  auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  const float a = __uint_as_float(sw[0]), b = __uint_as_float(sw[1]);
+  return (threadIdx.x & 32) ? a : b;
+}
+
+// Q == 1: an image is 32 rows (+ one side row from E): two images per 64-row pair, finished in the two half-waves.
+// Q == 2: an image is all 64 rows of the pair (R' 34..64, no side rows): one more exchange, one result per wave.
+template <bool HAS_E, int TP16, int Q>
 __device__ __forceinline__ void argmax16_epilogue_tall(f32x4 (&acc)[8][6], int mb, int nb, const float* __restrict__ E, int64_t ldE,
                                                        const int32_t* __restrict__ im_len, int x_tail, int Rq,
                                                        const int32_t* __restrict__ s_len, int y_tail, int Tq,
                                                        uint8_t* __restrict__ table, int tstride, uint8_t* __restrict__ flags,
                                                        int Bi, int Bc) {
   using Cfg = GemmCfg<2, 4, 4, 3>;
+  static_assert(Q == 1 || !HAS_E, "two row tiles per image: classes without side rows only");
   constexpr int CT = 6, NC = CT / TP16;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int wm = wave / 4, wn = wave % 4;
@@ -742,18 +751,19 @@ __device__ __forceinline__ void argmax16_epilogue_tall(f32x4 (&acc)[8][6], int m
   }
 #pragma unroll
   for (int p = 0; p < 2; ++p) {
-    // as in scores16_epilogue_tall: the pair's 64 rows are two images; lanes 0-31 finish the first, 32-63 the second
-    const int img = (mb * 2 + wm) * 4 + 2 * p + half;
+    // as in scores16_epilogue_tall: Q == 1: the pair's 64 rows are two images, lanes 0-31 finish the first, 32-63 the second
+    const int img = (Q == 1) ? (mb * 2 + wm) * 4 + 2 * p + half : (mb * 2 + wm) * 2 + p;
     int Li = 0;
     if (img < Bi) { Li = im_len[img] - 1 - x_tail; Li = Li < 0 ? 0 : (Li > Rq ? Rq : Li); }
-    const int Li_a = __shfl(Li, lane & 31, 64), Li_b = __shfl(Li, (lane & 31) + 32, 64);     // lengths of the pair's two images
+    const int Li_a = Q == 1 ? __shfl(Li, lane & 31, 64) : Li, Li_b = Q == 1 ? __shfl(Li, (lane & 31) + 32, 64) : Li;
     const float* e = HAS_E ? E + (int64_t)img * ldE + (int64_t)nb * Cfg::BN + wn * 96 + l4 : nullptr;
     bool pair_flag[NC];
 #pragma unroll
     for (int c = 0; c < NC; ++c) pair_flag[c] = false;
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) {
-      // this lane's 8 values of image A (row tiles 4p, 4p+1) and of image B (4p+2, 4p+3): regions 16 t + 4 q4 + reg
+      // Q == 1: this lane's 8 values of image A (row tiles 4p, 4p+1) and of image B (4p+2, 4p+3): regions 16 t + 4 q4 + reg
+      // Q == 2: 16 values of the one image: regions 16 t + 4 q4 + reg over the four row tiles
       float a1 = NEG, a2 = NEG, b1 = NEG, b2 = NEG;
 #pragma unroll
       for (int t = 0; t < 2; ++t)
@@ -768,19 +778,28 @@ __device__ __forceinline__ void argmax16_epilogue_tall(f32x4 (&acc)[8][6], int m
             top2_merge(a1, a2, v, NEG);
           }
           {
+            const int rb = Q == 1 ? r : r + 32;
             float v = acc[4 * p + 2 + t][ct][reg];
-            unsigned bits = (__float_as_uint(v) & ~63u) | (unsigned)r;
-            if (r >= Li_b) bits = 63u;
-            v = (r >= Rq) ? NEG : __uint_as_float(bits);
+            unsigned bits = (__float_as_uint(v) & ~63u) | (unsigned)rb;
+            if (rb >= Li_b) bits = 63u;
+            v = (rb >= Rq) ? NEG : __uint_as_float(bits);
             top2_merge(b1, b2, v, NEG);
           }
         }
-      // lanes 0-31 take image A's partials of lane + 32, lanes 32-63 image B's of lane - 32
-      auto s1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(a1), __float_as_uint(b1), false, false);
-      auto s2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(a2), __float_as_uint(b2), false, false);
-      float t1 = __uint_as_float(s1[0]), t2 = __uint_as_float(s2[0]);
-      top2_merge(t1, t2, __uint_as_float(s1[1]), __uint_as_float(s2[1]));
-      { const float o1 = xchg16(t1), o2 = xchg16(t2); top2_merge(t1, t2, o1, o2); }
+      float t1, t2;
+      if constexpr (Q == 1) {
+        // lanes 0-31 take image A's partials of lane + 32, lanes 32-63 image B's of lane - 32
+        auto s1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(a1), __float_as_uint(b1), false, false);
+        auto s2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(a2), __float_as_uint(b2), false, false);
+        t1 = __uint_as_float(s1[0]); t2 = __uint_as_float(s2[0]);
+        top2_merge(t1, t2, __uint_as_float(s1[1]), __uint_as_float(s2[1]));
+        { const float o1 = xchg16(t1), o2 = xchg16(t2); top2_merge(t1, t2, o1, o2); }
+      } else {
+        t1 = a1; t2 = a2;
+        top2_merge(t1, t2, b1, b2);
+        { const float o1 = xchg16(t1), o2 = xchg16(t2); top2_merge(t1, t2, o1, o2); }
+        { const float o1 = xchg32(t1), o2 = xchg32(t2); top2_merge(t1, t2, o1, o2); }
+      }
       if constexpr (HAS_E) {
         const float ev = e[ct * 16];
         const float ep = (Rq > 32) ? __uint_as_float((32 >= Li ? 63u : ((__float_as_uint(ev) & ~63u) | 32u))) : NEG;
@@ -791,18 +810,19 @@ __device__ __forceinline__ void argmax16_epilogue_tall(f32x4 (&acc)[8][6], int m
       // NO_GRAD: the zero fill won, or the word is padding (its raw row is not zero: bwd_rows_kernel must skip it)
       const uint8_t res = (idx >= (unsigned)Li || w >= Lc[c]) ? (uint8_t)255 : (uint8_t)idx;
       const bool close = (t1 - t2) < ARGMAX_TAU_ACC;                   // t2 == NEG when there is one candidate only
-      if ((lane & 16) == 0 && img < Bi && cap0 + c < Bc && w < tstride) table[((int64_t)img * Bc + cap0 + c) * tstride + w] = res;
+      if ((lane & (Q == 1 ? 16 : 48)) == 0 && img < Bi && cap0 + c < Bc && w < tstride) table[((int64_t)img * Bc + cap0 + c) * tstride + w] = res;
       pair_flag[c] = pair_flag[c] || (close && w < Lc[c]);
     }
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
-      const bool any = __ballot(pair_flag[c] && img < Bi && cap0 + c < Bc) & (half ? 0xffffffff00000000ull : 0x00000000ffffffffull);
-      if ((lane & 31) == 0 && any) flags[(int64_t)img * Bc + cap0 + c] = 1;
+      const unsigned long long mask = Q == 1 ? (half ? 0xffffffff00000000ull : 0x00000000ffffffffull) : ~0ull;
+      const bool any = (__ballot(pair_flag[c] && img < Bi && cap0 + c < Bc) & mask) != 0;
+      if ((lane & (Q == 1 ? 31 : 63)) == 0 && any) flags[(int64_t)img * Bc + cap0 + c] = 1;
     }
   }
 }
 
-template <bool HAS_E, int TP16>
+template <bool HAS_E, int TP16, int Q>
 __global__ __launch_bounds__(512) void align_argmax16_tall_kernel(const half_t* __restrict__ xm, const half_t* __restrict__ y,
                                                                   const float* __restrict__ E, int64_t ldE,
                                                                   const int32_t* __restrict__ im_len, int x_tail, int Rq,
@@ -819,32 +839,36 @@ __global__ __launch_bounds__(512) void align_argmax16_tall_kernel(const half_t* 
 #pragma unroll
     for (int ct = 0; ct < 6; ++ct) acc[rt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
   gemm_mainloop16_tall<Cfg, true>(xm + (int64_t)mb * Cfg::BM * ldk, y + (int64_t)nb * Cfg::BN * ldk, ldk, ktiles, smem, acc);
-  argmax16_epilogue_tall<HAS_E, TP16>(acc, mb, nb, E, ldE, im_len, x_tail, Rq, s_len, y_tail, Tq, table, tstride, flags, Bi, Bc);
+  argmax16_epilogue_tall<HAS_E, TP16, Q>(acc, mb, nb, E, ldE, im_len, x_tail, Rq, s_len, y_tail, Tq, table, tstride, flags, Bi, Bc);
 }
 
 template <int NT> static int launch_side(const aladin_align_geom* g, const half_t* xe, const half_t* y, float* E, hipStream_t stream);
 
-// g: a SPLIT-precision geometry of the one-region-tile classes (mtiles == 1, rem <= 1, captions tiling a 96-column strip);
+// g: a SPLIT-precision geometry with one region tile per image + at most one side row (R' <= 33) or two region tiles and no
+// side rows (R' 34..64), captions tiling a 96-column strip;
 // xm / xe / y: its packed operands; E: its side scratch (g->e_bytes); flags: Bi * Bc bytes, zeroed here.
 int aladin_internal_align_argmax(const aladin_align_geom* g, const void* xm, const void* xe, const void* y, float* E,
                                  const int32_t* im_len, const int32_t* s_len, uint8_t* table, int tstride, uint8_t* flags,
                                  hipStream_t stream) {
   using Cfg = GemmCfg<2, 4, 4, 3>;
-  if (!g || !g->split || g->mtiles != 1 || g->rem > 1 || 6 % g->tp16 != 0) { aladin_set_error("align_argmax: unsupported tile class (mtiles=%d rem=%d tp16=%d split=%d)", g ? g->mtiles : -1, g ? g->rem : -1, g ? g->tp16 : -1, g ? g->split : -1); return ALADIN_ERR_UNSUPPORTED; }
+  if (!g || !g->split || g->mtiles < 1 || g->mtiles > 2 || (g->mtiles == 1 ? g->rem > 1 : g->rem != 0) || 6 % g->tp16 != 0) { aladin_set_error("align_argmax: unsupported tile class (mtiles=%d rem=%d tp16=%d split=%d)", g ? g->mtiles : -1, g ? g->rem : -1, g ? g->tp16 : -1, g ? g->split : -1); return ALADIN_ERR_UNSUPPORTED; }
   const int n_mblk = (int)(g->xm_rows / Cfg::BM), n_nblk = (int)(g->y_rows / Cfg::BN);
   if ((int64_t)n_mblk * Cfg::BM != g->xm_rows || (int64_t)n_nblk * Cfg::BN != g->y_rows) { aladin_set_error("align_argmax: packed rows do not tile"); return ALADIN_ERR_UNSUPPORTED; }
   if (hipMemsetAsync(flags, 0, (size_t)g->Bi * g->Bc, stream) != hipSuccess) { aladin_set_error("align_argmax: memset failed"); return ALADIN_ERR_HIP; }
   const int n_blocks = n_mblk * n_nblk;
-#define ARGMAX_LAUNCH(HE, TP)                                                                                          \
+#define ARGMAX_LAUNCH_Q(HE, TP, QQ)                                                                                     \
   do {                                                                                                                  \
-    auto kern = align_argmax16_tall_kernel<HE, TP>;                                                                     \
+    auto kern = align_argmax16_tall_kernel<HE, TP, QQ>;                                                                     \
     static unsigned long long lds_reserved = 0;                                                                         \
     if (int rc = aladin_reserve_lds((const void*)kern, Cfg::LDS_BYTES, &lds_reserved, "align_argmax16_tall")) return rc; \
     hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(Cfg::THREADS), Cfg::LDS_BYTES, stream, (const half_t*)xm, (const half_t*)y, \
                        (const float*)E, g->y_rows, im_len, g->x_tail, g->Rq, s_len, g->y_tail, g->Tq, table, tstride, flags, g->Bi, g->Bc,       \
                        (int64_t)g->Dp, g->Dp / 64, n_nblk, n_blocks);                                                   \
   } while (0)
-  if (g->rem) {
+#define ARGMAX_LAUNCH(HE, TP) ARGMAX_LAUNCH_Q(HE, TP, 1)
+  if (g->mtiles == 2) {                              // R' 34..64: an image is two row tiles, no side rows
+    switch (g->tp16) { case 1: ARGMAX_LAUNCH_Q(false, 1, 2); break; case 2: ARGMAX_LAUNCH_Q(false, 2, 2); break; case 3: ARGMAX_LAUNCH_Q(false, 3, 2); break; default: ARGMAX_LAUNCH_Q(false, 6, 2); break; }
+  } else if (g->rem) {
     int rc = ALADIN_OK;
     switch (g->tp16) {
       case 1: rc = launch_side<1>(g, (const half_t*)xe, (const half_t*)y, E, stream); break;
@@ -858,6 +882,7 @@ int aladin_internal_align_argmax(const aladin_align_geom* g, const void* xm, con
     switch (g->tp16) { case 1: ARGMAX_LAUNCH(false, 1); break; case 2: ARGMAX_LAUNCH(false, 2); break; case 3: ARGMAX_LAUNCH(false, 3); break; default: ARGMAX_LAUNCH(false, 6); break; }
   }
 #undef ARGMAX_LAUNCH
+#undef ARGMAX_LAUNCH_Q
   return aladin_check_launch("align_argmax16_tall_kernel");
 }
 

@@ -274,9 +274,32 @@ _density_probe = _DensityProbe()
 # the same shape LAG steps later; until then the list path (the usual dS is the hardest-negative hinge's: <= 3B entries)
 _generic_probes = {}
 _LAST_BWD_FLAGS = [0]
+DENSE_GEMM_FORCE = False     # tests / tools: the GEMM row step whatever the captions' fill
 
 
-def _align_backward(im, s, im_len_t, s_len_t, dS, gscale=None, packed=None, pairs=None, x_tails=(0, 2), dense=False):
+def _caption_fill(s_len, T, y_tail=2):
+    """Mean share of a caption's 16-word tiles that holds real words (None: lengths only on the device).  The gather row
+    step costs ~ real words, the GEMM one the padded tiles: measured crossover (B = 256, tools/debug/dense_fill_sweep.py)
+    at a fill of 0.42 for R' = 33 and 0.50 for R' = 50 -- COCO captions (~12 of 35 tokens) are on the gather side."""
+    if isinstance(s_len, torch.Tensor):
+        return None
+    Tq = T - 1 - y_tail
+    if Tq < 1 or len(s_len) == 0:
+        return None
+    tile = (Tq + 15) // 16 * 16
+    return sum(min(max(int(v) - 1 - y_tail, 0), Tq) for v in s_len) / float(len(s_len) * tile)
+
+
+def _gemm_rows_pay(fill, Rq):
+    if DENSE_GEMM_FORCE or fill is None:
+        return True
+    return fill >= min(0.7, max(0.35, 0.42 + 0.08 * (Rq - 33) / 17.0))
+
+
+_FILL_HINT = [None]          # set by the wrappers just before .apply(), read by the node's forward (same thread, same call)
+
+
+def _align_backward(im, s, im_len_t, s_len_t, dS, gscale=None, packed=None, pairs=None, x_tails=(0, 2), dense=False, fill=None):
     """dense: the caller knows that (almost) every pair carries a gradient (sum-of-violations hinge, a gradient on S):
     ALADIN_BWD_DENSE -- the arg-max table of all pairs from the split-precision tile kernel instead of one workgroup per pair."""
     lib = _lib.load()
@@ -288,7 +311,7 @@ def _align_backward(im, s, im_len_t, s_len_t, dS, gscale=None, packed=None, pair
     Bc, T, _ = s.shape
     d_im, d_s = _grad_like(im), _grad_like(s)
     dense_flag = _lib.BWD_DENSE if (dense and DENSE_BACKWARD and packed is not None and packed[1] is not None and Bi * Bc >= DENSE_MIN_PAIRS) else 0
-    if dense_flag and not DENSE_ROWS_GEMM:
+    if dense_flag and not (DENSE_ROWS_GEMM and _gemm_rows_pay(fill, R - 1 - packed[0].x_tail)):
         dense_flag |= _lib.BWD_DENSE_GATHER
     _LAST_BWD_FLAGS[0] = dense_flag                      # which path the last backward took (tests)
     ws = _workspace(lib.aladin_align_bwd_workspace_bytes_ex(Bi, Bc, R, T, D, dense_flag), im.device)
@@ -398,6 +421,7 @@ class _AlignTriplet(torch.autograd.Function):
     @staticmethod
     def forward(ctx, im, s, im_len_t, s_len_t, margin, max_violation):
         need = any(ctx.needs_input_grad[:2])
+        ctx.fill, _FILL_HINT[0] = _FILL_HINT[0], None
         if need:
             _check_backward_supported(im, s, 0, 2)
         S, packed = _align_forward(im, s, im_len_t, s_len_t)
@@ -445,14 +469,14 @@ class _AlignTriplet(torch.autograd.Function):
             # the training path: only the loss is differentiated; dloss/dS (<= 3B non-zeros with the hardest-negative
             # hinge) never leaves the device and the upstream scalar goes to the kernels as a pointer
             g = g_loss.to(torch.float32).contiguous()
-            d_im, d_s = _align_backward(im, s, im_len_t, s_len_t, dS, gscale=g, packed=packed, pairs=ctx.pairs, dense=ctx.dense)
+            d_im, d_s = _align_backward(im, s, im_len_t, s_len_t, dS, gscale=g, packed=packed, pairs=ctx.pairs, dense=ctx.dense, fill=ctx.fill)
         else:
             # the returned score matrix was used too (the reference's S carries grad, alad/loss.py:151-159):
             # total dS = g_loss * dloss/dS + g_scores, generally dense
             total = g_scores.to(torch.float32)
             if g_loss is not None:
                 total = total + dS * g_loss.to(torch.float32)
-            d_im, d_s = _align_backward(im, s, im_len_t, s_len_t, total.contiguous(), packed=packed, dense=True)
+            d_im, d_s = _align_backward(im, s, im_len_t, s_len_t, total.contiguous(), packed=packed, dense=True, fill=ctx.fill)
         return d_im, d_s, None, None, None, None
 
 
@@ -474,6 +498,7 @@ def alignment_triplet_loss(im_set, s_seq, im_len, s_len, margin, max_violation):
     if im_set.shape[0] != s_seq.shape[0]:
         raise ValueError('aladin_amd: the contrastive loss needs a square score matrix, got (%d, %d) '
                          '(the reference fails in diag/expand_as, alad/loss.py:43-45)' % (im_set.shape[0], s_seq.shape[0]))
+    _FILL_HINT[0] = None if max_violation else _caption_fill(s_len, s_seq.shape[1])
     return _AlignTriplet.apply(im_set, s_seq, im_len_t, s_len_t, margin, max_violation)
 
 
@@ -1115,6 +1140,7 @@ class _BigHeads(torch.autograd.Function):
         terms = torch.empty(3, dtype=torch.float32, device=dev)          # slots of absent heads are never read
         S = packed = dS = pairs = table_ws = None
         dense = False
+        ctx.fill, _FILL_HINT[0] = _FILL_HINT[0], None
         if flags & (HEAD_ALIGN_HINGE | HEAD_LISTNET):
             if need_sets and flags & HEAD_ALIGN_HINGE:
                 _check_backward_supported(im, s, 0, 2)
@@ -1188,7 +1214,7 @@ class _BigHeads(torch.autograd.Function):
             d_im, d_s = _align_backward_rows(im, s, im_len_t, s_len_t, dS, scale, ctx.geom, table_ws, (ctx.geom, xm, xe, y))
         elif want_a:
             d_im, d_s = _align_backward(im, s, im_len_t, s_len_t, dS, gscale=scale, packed=(ctx.geom, xm, xe, y), pairs=ctx.pairs,
-                                        dense=ctx.dense)
+                                        dense=ctx.dense, fill=ctx.fill)
         return d_a, d_b, d_im, d_s, None, None, None, None, None, None, None, None
 
 
@@ -1210,6 +1236,7 @@ def small_batch_loss_heads(img_emb, cap_emb, im_set, s_seq, im_len, s_len, margi
             raise ValueError('aladin_amd: the loss heads need one image set, one caption and one embedding pair per sample')
     w = (float(weights.get('matching', 0.0)), float(weights.get('alignment', 0.0)), float(weights.get('distillation', 0.0)))
     node = _SmallHeads if img_emb.shape[0] <= SMALL_BATCH_MAX else _BigHeads
+    _FILL_HINT[0] = _caption_fill(s_len, s_seq.shape[1]) if (node is _BigHeads and not max_violation and flags & HEAD_ALIGN_HINGE) else None
     return node.apply(img_emb, cap_emb, im_set, s_seq, im_len_t, s_len_t, margin, max_violation, flags, w, temperature, eps)
 
 

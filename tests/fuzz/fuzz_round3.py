@@ -33,6 +33,7 @@ counts = {'bucket': 0, 'partners': 0, 'dense': 0}
 worst = {'bucket_split': 0.0, 'partners': 0.0, 'dense_gemm': 0.0, 'dense_gemm16': 0.0}
 real_plan = ops.bucket_plan
 ops.DENSE_MIN_FRACTION = 0.0        # the dense path whatever the density of a case's dS
+ops.DENSE_GEMM_FORCE = True         # ... and the GEMM row step however full its captions
 while time.time() - t0 < budget:
     kind = ['bucket', 'partners', 'dense'][int(rng.randint(0, 3))]
     case_seed = int(rng.randint(1, 1 << 30))
@@ -75,7 +76,7 @@ while time.time() - t0 < budget:
         ops._PLAN_CACHE.clear()
     elif kind == 'dense':
         B = int(rng.choice([128, 136, 160, 200, 256]))
-        R, Tn, D = int(rng.randint(5, 41)), int(rng.randint(6, 51)), int(rng.choice([64, 128, 260, 768]))
+        R, Tn, D = int(rng.randint(5, 67)), int(rng.randint(6, 51)), int(rng.choice([64, 128, 260, 768]))
         if B * (R + Tn) * D > 2.2e7:
             D = 128
         im, s, il, sl = synth.structured_alignment_batch(B, R, Tn, D, seed=case_seed % 100000, noise=float(rng.choice([1.0, 3.0])), ragged=bool(rng.randint(0, 2)))

@@ -1014,17 +1014,19 @@ def test_b256_triplet_step_gradients_vs_oracle(ragged):
         np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=1e-3, atol=2e-5 * scale)
 
 
-@pytest.mark.parametrize('B,kind', [(128, 'random'), (256, 'random'), (256, 'structured'), (192, 'ties')])
-def test_dense_backward_table_equals_the_per_pair_path(B, kind):
+@pytest.mark.parametrize('B,kind,R,Tn', [(128, 'random', 34, 50), (256, 'random', 34, 50), (256, 'structured', 34, 50), (192, 'ties', 34, 50),
+                                         (128, 'random', 51, 38), (192, 'ties', 51, 38), (160, 'structured', 65, 20)])
+def test_dense_backward_table_equals_the_per_pair_path(B, kind, R, Tn):
     """ALADIN_BWD_DENSE (sum-of-violations hinge: every pair carries a gradient): the arg-max table written by the
     split-precision tile kernel + the per-pair kernel on the flagged near-ties must give EXACTLY the gradients of the
     per-pair kernel on every pair (same winners => same rows kernel input => bit-identical sums)."""
     from aladin_amd import ops, synth
     from aladin_amd.loss import AlignmentContrastiveLoss
+    # (51, 38): VinVL's 50 regions + 35 tokens -- two region tiles per image (R' = 50); (65, 20): R' = 64, the class limit
     if kind == 'random':
-        im, s, il, sl = synth.alignment_batch(B, 34, 50, 768, seed=B + 5, ragged=True)
+        im, s, il, sl = synth.alignment_batch(B, R, Tn, 768, seed=B + 5, ragged=True)
     else:
-        im, s, il, sl = synth.structured_alignment_batch(B, 34, 50, 768, seed=B + 9, noise=3.0, ragged=True)
+        im, s, il, sl = synth.structured_alignment_batch(B, R, Tn, 768, seed=B + 9, noise=3.0, ragged=True)
     if kind == 'ties':
         im[:, 5] = im[:, 3]                               # exact duplicate regions: every word ties between r = 2 and r = 4
         im[1::2, 9] = im[1::2, 8] * (1 + 1e-7)           # and a near-tie below the fp16 operand resolution
@@ -1034,11 +1036,12 @@ def test_dense_backward_table_equals_the_per_pair_path(B, kind):
         a, b = T(im).requires_grad_(True), T(s).requires_grad_(True)
         old, ops.DENSE_BACKWARD, old_g, ops.DENSE_ROWS_GEMM = ops.DENSE_BACKWARD, bool(dense), ops.DENSE_ROWS_GEMM, dense == 'gemm'
         old_f, ops.DENSE_MIN_FRACTION = ops.DENSE_MIN_FRACTION, 0.0      # whatever the density of this batch's dS
+        ops.DENSE_GEMM_FORCE = True                                        # ... and however full its captions
         try:
             loss = crit(a, b, il, sl)
             loss.backward()
         finally:
-            ops.DENSE_BACKWARD, ops.DENSE_ROWS_GEMM, ops.DENSE_MIN_FRACTION = old, old_g, old_f
+            ops.DENSE_BACKWARD, ops.DENSE_ROWS_GEMM, ops.DENSE_MIN_FRACTION, ops.DENSE_GEMM_FORCE = old, old_g, old_f, False
         grads[dense] = (loss.item(), a.grad.clone(), b.grad.clone())
     assert grads[True][0] == grads[False][0]
     assert torch.equal(grads[True][1], grads[False][1])
@@ -1095,11 +1098,12 @@ def test_model_heads_take_the_dense_backward_too():
         a = T(im).permute(1, 0, 2).contiguous().requires_grad_(True)
         b = T(s).permute(1, 0, 2).contiguous().requires_grad_(True)
         old, ops.DENSE_BACKWARD, old_f, ops.DENSE_MIN_FRACTION = ops.DENSE_BACKWARD, dense, ops.DENSE_MIN_FRACTION, 0.0
+        ops.DENSE_GEMM_FORCE = True
         try:
             loss, _ = model.forward_loss_total(x, y, a, b, il, sl, 0, epoch=5)
             loss.backward()
         finally:
-            ops.DENSE_BACKWARD, ops.DENSE_MIN_FRACTION = old, old_f
+            ops.DENSE_BACKWARD, ops.DENSE_MIN_FRACTION, ops.DENSE_GEMM_FORCE = old, old_f, False
         grads[dense] = [t.grad.clone() for t in (x, y, a, b)]
     for g0, g1 in zip(grads[False], grads[True]):
         assert (g0 - g1).abs().max() <= 1e-5 * g0.abs().max()
@@ -1131,6 +1135,27 @@ def test_generic_score_gradient_learns_its_density():
             else:
                 assert torch.equal(grads[0][k], grads[-1][k])
     ops._generic_probes.clear()
+
+
+def test_dense_row_step_follows_the_caption_fill():
+    """Short captions (COCO: ~12 of 35 tokens): the gather row step costs ~ real words, the GEMM one the padded tiles --
+    the choice follows the host-side lengths (ops._caption_fill / _gemm_rows_pay)."""
+    from aladin_amd import _lib, ops, synth
+    from aladin_amd.loss import AlignmentContrastiveLoss
+    B = 128
+    im, s, il, _ = synth.alignment_batch(B, 34, 50, 768, seed=53, ragged=False)
+    crit = AlignmentContrastiveLoss(margin=0.2, measure='dot', max_violation=False, aggregation='MrSw')
+    ops._density_probe.__init__()
+    old_f, ops.DENSE_MIN_FRACTION = ops.DENSE_MIN_FRACTION, 0.0
+    try:
+        for sl, gather in (([50] * B, False), ([13] * B, True)):
+            a, b = T(im).requires_grad_(True), T(s).requires_grad_(True)
+            crit(a, b, il, sl).backward()
+            assert ops._LAST_BWD_FLAGS[0] & _lib.BWD_DENSE
+            assert bool(ops._LAST_BWD_FLAGS[0] & _lib.BWD_DENSE_GATHER) == gather
+    finally:
+        ops.DENSE_MIN_FRACTION = old_f
+        ops._density_probe.__init__()
 
 
 def test_dense_backward_through_the_score_matrix():

@@ -4,7 +4,8 @@ import torch
 from aladin_amd import ops, synth
 from aladin_amd.loss import AlignmentContrastiveLoss
 ops.DENSE_MIN_FRACTION = 0.0
-for B, R, T_, D in ((512, 34, 50, 768), (384, 20, 30, 512), (1024, 34, 50, 256)):
+ops.DENSE_GEMM_FORCE = True
+for B, R, T_, D in ((256, 51, 38, 768), (512, 34, 50, 768), (384, 20, 30, 512), (1024, 34, 50, 256)):
     im, s, il, sl = synth.alignment_batch(B, R, T_, D, seed=B, ragged=True)
     crit = AlignmentContrastiveLoss(0.2, 'dot', False, 'MrSw')
     g = {}

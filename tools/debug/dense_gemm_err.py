@@ -7,6 +7,7 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 im, s, il, sl = synth.alignment_batch(B, 34, 50, 768, seed=B + 5, ragged=True)
 crit = AlignmentContrastiveLoss(0.2, 'dot', False, 'MrSw')
 ops.DENSE_MIN_FRACTION = 0.0
+ops.DENSE_GEMM_FORCE = True
 g = {}
 for mode in ('gather', 'gemm', 'gemm16', 'gather16'):
     a = torch.from_numpy(im).cuda().requires_grad_(True); b = torch.from_numpy(s).cuda().requires_grad_(True)
