@@ -68,8 +68,10 @@ def main():
     dev = torch.device('cuda:0')
     profile = '--profile' in sys.argv
     batches = [int(v) for v in sys.argv[1:] if not v.startswith('--')] or [32, 256]
+    # --shape=R,T: the set lengths (default BASELINE's 34 x 50; the shipped data config is 50 regions + 35 tokens: --shape=51,38)
+    R, Tn = next(([int(x) for x in v.split('=')[1].split(',')] for v in sys.argv[1:] if v.startswith('--shape=')), [34, 50])
     for B in batches:
-        im, s, il, sl = synth.alignment_batch(B, 34, 50, 768, seed=7, ragged=True)
+        im, s, il, sl = synth.alignment_batch(B, R, Tn, 768, seed=7, ragged=True)
         gi, gc = synth.global_embeddings(B, 768, seed=8)
         a = torch.from_numpy(im).to(dev).requires_grad_(True)
         b = torch.from_numpy(s).to(dev).requires_grad_(True)
@@ -144,7 +146,7 @@ def main():
             l1 = float(ac(a, b, il, sl)) + float(dc(ac(a, b, il, sl, return_loss=False, return_similarity_mat=True), x.mm(y.t())))
             Sr = ref_alignment(a, b, il, sl)
             l2 = float(ref_hinge(Sr)) + float(ref_listnet(Sr, x.mm(y.t())))
-        print(json.dumps({'batch': B, 'hip_ms': round(timed(ours, 50), 4), 'hip_graphed_step_ms': round(timed(graphed, 200), 4),
+        print(json.dumps({'batch': B, 'R': R, 'T': Tn, 'hip_ms': round(timed(ours, 50), 4), 'hip_graphed_step_ms': round(timed(graphed, 200), 4),
                           'hip_graphed_step_deferred_log_ms': round(t_logged, 4), 'hip_graphed_step_sync_log_ms': round(t_sync, 4),
                           'hip_graph_replay_only_ms': round(timed(graph_only, 500), 4), 'torch_rocm_eager_ms': round(timed(ref, 10), 3),
                           'loss_hip': round(l1, 5), 'loss_eager': round(l2, 5)}), flush=True)
