@@ -235,7 +235,8 @@ using PairCfg = GemmCfg<2, 2, 1, 1>;      // 64 x 64 block per pair: [32 main re
 // tools/pair_probe.py shows the K loop at 6.5 us of a workgroup's 19).
 #define PAIR_STAGES 3
 
-// Requires mtiles == 1 and 16*tp16 <= 64 (every training shape); other shapes use the fp32 kernel.
+// Requires one region tile per image (+ side rows) or two tiles and no side rows (R' <= 64), and 16*tp16 <= 64 words: every
+// training shape incl. VinVL's 50 regions; other shapes use the fp32 kernel.
 #ifdef ALADIN_DIAG
 // phase stamps of the pair kernel (diagnostic build only; tools/pair_probe.py): 8 words per workgroup =
 // s_memrealtime at entry / after the header loads / after the MFMA phase / after the word scan / after the exact
@@ -338,13 +339,16 @@ __global__ __launch_bounds__(256) void bwd_pair_argmax16_kernel(
     // operand panels: rows [0,32) = the image's 32 main regions, rows [32,64) = 32 consecutive rows
     // of the extra-region operand containing image i's rem rows at offset eo; 64 caption-word rows
     // starting at by (the caption's words sit at column offset co)
-    const int be = rem ? (i * rem < xe_rows - 32 ? i * rem : xe_rows - 32) : 0;     // image i's side rows: [i*rem, i*rem + rem)
-    const int eo = i * rem - be;
+    // rem < 0: TWO region tiles per image (R' 34..64, no side rows): the "side segment" is the image's own second tile
+    const bool two = rem < 0;
+    const int rem_e = two ? 32 : rem;
+    const int be = two ? i * 64 + 32 : (rem ? (i * rem < xe_rows - 32 ? i * rem : xe_rows - 32) : 0);     // image i's side rows: [i*rem, i*rem + rem)
+    const int eo = two ? 0 : i * rem - be;
     const int64_t yrow = (int64_t)j * tpad;
     const int64_t by = yrow < (int64_t)y_rows - 64 ? yrow : (int64_t)y_rows - 64;
     const int co = (int)(yrow - by);
-    const half_t* pa1 = xm + (int64_t)i * 32 * Dp;
-    const half_t* pa2 = rem ? xe + (int64_t)be * Dp : pa1;
+    const half_t* pa1 = xm + (int64_t)i * (two ? 64 : 32) * Dp;
+    const half_t* pa2 = two ? xm + (int64_t)be * Dp : (rem ? xe + (int64_t)be * Dp : pa1);
     f32x16 acc[1][1];
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[0][0][r] = 0.f;
@@ -354,7 +358,7 @@ __global__ __launch_bounds__(256) void bwd_pair_argmax16_kernel(
     uint32_t skip = 0;
     {
       const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-      if (!rem || wv < (eo >> 3) || wv > ((eo + rem - 1) >> 3)) skip |= 2u;
+      if (!rem_e || wv < (eo >> 3) || wv > ((eo + rem_e - 1) >> 3)) skip |= 2u;
       if (8 * wv + 8 <= co || 8 * wv >= co + tpad) skip |= 4u;
       if (32 + 8 * wv + 8 <= co || 32 + 8 * wv >= co + tpad) skip |= 8u;
     }
@@ -373,7 +377,7 @@ __global__ __launch_bounds__(256) void bwd_pair_argmax16_kernel(
     auto region_of = [&](int r) {
       const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
       const int d = row - eo;
-      const int side = ((unsigned)d < (unsigned)rem) ? 32 + d : 255;
+      const int side = ((unsigned)d < (unsigned)rem_e) ? 32 + d : 255;
       return wm == 0 ? row : side;
     };
 #pragma unroll
@@ -786,7 +790,7 @@ static int align_bwd_impl(const float* im, int64_t im_sb, int64_t im_sr, const i
     aladin_set_error("align_bwd: needs D %% 4 == 0, D <= 1024 and 16-byte aligned rows (D=%d)", D);
     return ALADIN_ERR_UNSUPPORTED;
   }
-  const bool packed = xm && y && g && g->mtiles == 1 && g->tp16 <= 4;   // shapes the fp16 pair kernel covers
+  const bool packed = xm && y && g && (g->mtiles == 1 || (g->mtiles == 2 && g->rem == 0)) && g->tp16 <= 4;   // shapes the fp16 pair kernel covers
   if (xm && y && g && (g->Bi != Bi || g->Bc != Bc || g->R != R || g->T != T || g->D != D || (g->rem && !xe))) {
     aladin_set_error("align_bwd: packed operands do not belong to this problem");
     return ALADIN_ERR_ARG;
@@ -798,7 +802,7 @@ static int align_bwd_impl(const float* im, int64_t im_sb, int64_t im_sr, const i
   const int64_t n = (int64_t)Bi * Bc;
   int rc = ALADIN_OK;
   if (phase == BWD_HINGE_ARGMAX) {
-    if (!packed) { aladin_set_error("hinge_argmax: needs the packed fp16 operands of a one-region-tile class (mtiles == 1, <= 64 padded words)"); return ALADIN_ERR_UNSUPPORTED; }
+    if (!packed) { aladin_set_error("hinge_argmax: needs the packed fp16 operands of a class the fp16 pair kernel covers (R' <= 64 without side rows or <= 40 with, <= 64 padded words)"); return ALADIN_ERR_UNSUPPORTED; }
     if (ha->small) {                                      // small-batch heads: their own statistics kernel ran already
       int npb = (3 * Bc + 7) / 8 * 8;
       const PairHinge hfs = {nullptr, 0, 0.f, nullptr, nullptr, nullptr, nullptr, Bc, npb, nullptr};
@@ -806,7 +810,7 @@ static int align_bwd_impl(const float* im, int64_t im_sb, int64_t im_sr, const i
       sfin.dST = (float*)ws.pairs;                        // the list region is free in this mode: it carries dS^T
       hipLaunchKernelGGL(bwd_pair_argmax16_kernel<2>, dim3(npb + cdiv(Bc * Bc, 256)), dim3(256),
                          (size_t)PAIR_STAGES * PairCfg::STAGE_BYTES, st, (const half_t*)xm, (const half_t*)xe, (const half_t*)y,
-                         g->Dp, g->rem, 16 * g->tp16, (int)g->xe_rows, (int)g->y_rows, im, im_sb, im_sr, im_len, s, s_sb, s_st,
+                         g->Dp, (g->mtiles == 2 ? -1 : g->rem), 16 * g->tp16, (int)g->xe_rows, (int)g->y_rows, im, im_sb, im_sr, im_len, s, s_sb, s_st,
                          s_len, Bc, Rq, Tq, D, nullptr, nullptr, ws.table, tstride, x_tail, y_tail, hfs, sfin);
       return aladin_check_launch("bwd_pair_argmax16_kernel<small heads>");
     }
@@ -818,7 +822,7 @@ static int align_bwd_impl(const float* im, int64_t im_sb, int64_t im_sr, const i
     const int nfin = Bc < 1024 ? Bc : 1024;
     const PairHinge hf = {ha->S, ha->ldS, ha->margin, val, arg, ha->loss, ha->dS, Bc, npb, (float*)ws.pairs};
     hipLaunchKernelGGL(bwd_pair_argmax16_kernel<1>, dim3(npb + nfin), dim3(256), (size_t)PAIR_STAGES * PairCfg::STAGE_BYTES, st,
-                       (const half_t*)xm, (const half_t*)xe, (const half_t*)y, g->Dp, g->rem, 16 * g->tp16, (int)g->xe_rows,
+                       (const half_t*)xm, (const half_t*)xe, (const half_t*)y, g->Dp, (g->mtiles == 2 ? -1 : g->rem), 16 * g->tp16, (int)g->xe_rows,
                        (int)g->y_rows, im, im_sb, im_sr, im_len, s, s_sb, s_st, s_len, Bc, Rq, Tq, D, nullptr, nullptr,
                        ws.table, tstride, x_tail, y_tail, hf, SmallFin{});
     return aladin_check_launch("bwd_pair_argmax16_kernel<hinge>");
@@ -865,7 +869,7 @@ static int align_bwd_impl(const float* im, int64_t im_sb, int64_t im_sr, const i
   if (phase == BWD_ROWS) {
   } else if (packed) {
     hipLaunchKernelGGL(bwd_pair_argmax16_kernel<0>, dim3(pgrid), dim3(256), (size_t)PAIR_STAGES * PairCfg::STAGE_BYTES, st,
-                       (const half_t*)xm, (const half_t*)xe, (const half_t*)y, g->Dp, g->rem, 16 * g->tp16, (int)g->xe_rows,
+                       (const half_t*)xm, (const half_t*)xe, (const half_t*)y, g->Dp, (g->mtiles == 2 ? -1 : g->rem), 16 * g->tp16, (int)g->xe_rows,
                        (int)g->y_rows, im, im_sb, im_sr, im_len, s, s_sb, s_st, s_len, Bc, Rq, Tq, D, ws.counter, ws.pairs,
                        ws.table, tstride, x_tail, y_tail, PairHinge{}, SmallFin{});
     rc = aladin_check_launch("bwd_pair_argmax16_kernel");
