@@ -180,6 +180,36 @@ def eval_config3(dev):
             'pairs_per_s': round(5000 * 25000 / (ms * 1e-3), 1), 'tflops_algorithmic': round(2 * 5000 * 25000 * D / (ms * 1e-3) / 1e12, 1)}
 
 
+def shipped_shape_step(dev):
+    """Secondary field: the same triplet step at the shipped DATA shape -- 50 regions + 35 tokens (R = 51, T = 38: two
+    region tiles per image; configs/*.yaml's dataset section) -- eager launches, B = 256, full lengths."""
+    import torch
+    from aladin_amd import synth
+    from aladin_amd.loss import AlignmentContrastiveLoss
+    im, s, il, sl = synth.alignment_batch(B, 51, 38, D, seed=1234, ragged=False)
+    a = torch.from_numpy(im).to(dev).requires_grad_(True)
+    b = torch.from_numpy(s).to(dev).requires_grad_(True)
+    crit = AlignmentContrastiveLoss(margin=0.2, measure='dot', max_violation=True, aggregation='MrSw')
+
+    def step():
+        a.grad = None
+        b.grad = None
+        crit(a, b, il, sl).backward()
+    for _ in range(10):
+        step()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(100):
+        step()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 100
+    return {'workload': 'triplet loss forward+backward at B=256, R=51, T=38, D=768 (50 regions + 35 tokens), eager launches',
+            'ms_per_step': round(ms, 4), 'pairs_per_s': round(B * B / (ms * 1e-3), 1),
+            'flops_per_pair': 2 * 50 * 35 * D, 'tflops_algorithmic_fwd_equiv': round(2 * 50 * 35 * D * B * B / (ms * 1e-3) / 1e12, 1)}
+
+
 def main():
     args = parse()
     # before anything initialises the HIP runtime: the host driver only supports dmabuf IPC
@@ -392,6 +422,10 @@ def main():
                 cfg['eval_config3'] = eval_config3(dev)
             except Exception as exc:
                 cfg['eval_config3'] = {'error': str(exc)}
+            try:
+                cfg['shipped_shape'] = shipped_shape_step(dev)
+            except Exception as exc:
+                cfg['shipped_shape'] = {'error': str(exc)}
         out = {
             'metric': 'alignment image-text pairs/sec (BxB scores, triplet loss fwd+bwd) at B=256/GPU,R=34,T=50,D=768',
             'value': round(value, 1), 'unit': 'pairs/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
