@@ -110,8 +110,8 @@ while time.time() - t0 < budget:
                 assert torch.isfinite(grads[mode][k]).all()
     else:
         B = int(rng.choice([3, 8, 17, 40, 64, 96]))
-        R, Tn, D = int(rng.randint(5, 41)), int(rng.randint(6, 51)), int(rng.choice([64, 128, 768]))
-        if B * (R + Tn) * D > 6e6:
+        R, Tn, D = int(rng.randint(5, 67)), int(rng.randint(6, 51)), int(rng.choice([64, 128, 768]))
+        if B * (R + Tn) * D > 9e6:
             continue
         im, s, il, sl = synth.structured_alignment_batch(B, R, Tn, D, seed=case_seed % 100000, noise=float(rng.choice([1.0, 3.0])), ragged=bool(rng.randint(0, 2)))
         il = [max(2, v) for v in il]
