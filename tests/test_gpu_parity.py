@@ -1225,8 +1225,9 @@ def test_fused_hinge_argmax_equals_the_list_path():
     -> pair list -> aladin_align_bwd_packed_strided) must give the same loss, dS and gradients bit for bit -- including
     when a row's and a column's hardest negative are the same pair, inactive terms and ragged lengths."""
     from aladin_amd import ops, synth
-    for B, seed, noise in ((40, 11, 1.0), (96, 12, 3.0), (256, 13, 1.0)):
-        im, s, il, sl = synth.structured_alignment_batch(B, 34, 50, 768, seed=seed, noise=noise, ragged=True)
+    # (51, 38): the shipped data shape, 50 regions + 35 tokens -- two region tiles per image (the second is the pair kernel's segment)
+    for B, seed, noise, R, Tn in ((40, 11, 1.0, 34, 50), (96, 12, 3.0, 34, 50), (256, 13, 1.0, 34, 50), (72, 14, 3.0, 51, 38), (256, 15, 1.0, 51, 38)):
+        im, s, il, sl = synth.structured_alignment_batch(B, R, Tn, 768, seed=seed, noise=noise, ragged=True)
         a, b = T(im).requires_grad_(True), T(s).requires_grad_(True)
         loss, S = ops.alignment_triplet_loss(a, b, il, sl, 0.2, True)
         loss.backward()
@@ -1468,7 +1469,7 @@ def test_leftover_regions_as_side_rows(R):
 
 
 @pytest.mark.parametrize('shape', [(6, 6, 17, 9, 40), (5, 5, 34, 35, 96), (4, 4, 50, 50, 128), (3, 3, 71, 71, 64),
-                                   (12, 12, 34, 50, 100)])
+                                   (12, 12, 34, 50, 100), (10, 10, 51, 38, 768), (7, 7, 65, 20, 256)])
 @pytest.mark.parametrize('mv', [True, False])
 def test_alignment_backward_shape_sweep(shape, mv):
     """Autograd through the differentiable scores + hinge for every backward code path (fp16 pair
@@ -1988,16 +1989,16 @@ def test_small_batch_fused_heads_equal_the_separate_kernels(eval_precision, B, D
         ops.small_batch_match_distill(T(np.zeros((65, 8), np.float32)), T(np.zeros((65, 8), np.float32)), None, 0.2, True)
 
 
-@pytest.mark.parametrize('B', [32, 96])
+@pytest.mark.parametrize('B,R,Tn', [(32, 34, 50), (96, 34, 50), (32, 51, 38)])
 @pytest.mark.parametrize('heads', [('matching', 'alignment', 'distillation'), ('alignment', 'distillation'), ('alignment',),
                                    ('matching',), ('distillation',), ('matching', 'distillation')])
-def test_small_batch_single_node_step_equals_the_composition(eval_precision, heads, B):
+def test_small_batch_single_node_step_equals_the_composition(eval_precision, heads, B, R, Tn):
     """ops.small_batch_loss_heads (the whole loss-head step of a bs <= 64 batch as one autograd node, weights inside)
     against the same terms composed from the separate differentiable pieces."""
     if eval_precision != 'fp16':
         pytest.skip('training step; run once')
     from aladin_amd import ops, synth
-    R, Tn, D = 34, 50, (768 if B == 32 else 256)              # B = 32: the three-launch heads; B = 96: the general kernels
+    D = 768 if B == 32 else 256                               # B = 32: the three-launch heads; B = 96: the general kernels
     im, s, il, sl = synth.structured_alignment_batch(B, R, Tn, D, seed=321, noise=3.0, ragged=True)
     ge, gc = synth.global_embeddings(B, D, seed=322, noise=1.0)
     weights = {'matching': 0.1, 'alignment': 1.0, 'distillation': 0.75}
