@@ -72,7 +72,7 @@ static size_t dense_ws_layout(const aladin_align_geom* gs, char* base, DenseWs* 
 // the tile classes the arg-max kernel covers; fills the split geometry of the problem
 static bool dense_supported(int Bi, int Bc, int R, int T, int D, int x_tail, int y_tail, aladin_align_geom* gs) {
   if (aladin_align_geometry_mode(Bi, Bc, R, T, D, x_tail, y_tail, ALADIN_PRECISION_SPLIT, gs) != ALADIN_OK) return false;
-  return (gs->mtiles == 1 ? gs->rem <= 1 : (gs->mtiles == 2 && gs->rem == 0)) && 6 % gs->tp16 == 0 && (gs->xm_rows / 256) * (gs->y_rows / 384) > 64 &&
+  return (gs->mtiles == 1 ? gs->rem <= 8 : (gs->mtiles == 2 && gs->rem == 0)) && 6 % gs->tp16 == 0 && (gs->xm_rows / 256) * (gs->y_rows / 384) > 64 &&
          gs->xm_rows % 256 == 0 && gs->y_rows % 384 == 0;
 }
 

@@ -729,7 +729,7 @@ __device__ __forceinline__ float xchg32(float v) {          // the value of lane
 // Q == 1: an image is 32 rows (+ one side row from E): two images per 64-row pair, finished in the two half-waves.
 // Q == 2: an image is all 64 rows of the pair (R' 34..64, no side rows): one more exchange, one result per wave.
 template <bool HAS_E, int TP16, int Q>
-__device__ __forceinline__ void argmax16_epilogue_tall(f32x4 (&acc)[8][6], int mb, int nb, const float* __restrict__ E, int64_t ldE,
+__device__ __forceinline__ void argmax16_epilogue_tall(f32x4 (&acc)[8][6], int mb, int nb, const float* __restrict__ E, int64_t ldE, int rem,
                                                        const int32_t* __restrict__ im_len, int x_tail, int Rq,
                                                        const int32_t* __restrict__ s_len, int y_tail, int Tq,
                                                        uint8_t* __restrict__ table, int tstride, uint8_t* __restrict__ flags,
@@ -756,7 +756,7 @@ __device__ __forceinline__ void argmax16_epilogue_tall(f32x4 (&acc)[8][6], int m
     int Li = 0;
     if (img < Bi) { Li = im_len[img] - 1 - x_tail; Li = Li < 0 ? 0 : (Li > Rq ? Rq : Li); }
     const int Li_a = Q == 1 ? __shfl(Li, lane & 31, 64) : Li, Li_b = Q == 1 ? __shfl(Li, (lane & 31) + 32, 64) : Li;
-    const float* e = HAS_E ? E + (int64_t)img * ldE + (int64_t)nb * Cfg::BN + wn * 96 + l4 : nullptr;
+    const float* e = HAS_E ? E + (int64_t)img * rem * ldE + (int64_t)nb * Cfg::BN + wn * 96 + l4 : nullptr;
     bool pair_flag[NC];
 #pragma unroll
     for (int c = 0; c < NC; ++c) pair_flag[c] = false;
@@ -801,9 +801,21 @@ __device__ __forceinline__ void argmax16_epilogue_tall(f32x4 (&acc)[8][6], int m
         { const float o1 = xchg32(t1), o2 = xchg32(t2); top2_merge(t1, t2, o1, o2); }
       }
       if constexpr (HAS_E) {
-        const float ev = e[ct * 16];
-        const float ep = (Rq > 32) ? __uint_as_float((32 >= Li ? 63u : ((__float_as_uint(ev) & ~63u) | 32u))) : NEG;
-        top2_merge(t1, t2, ep, NEG);
+        if (rem == 1) {                                                 // the headline class: one side row (region 32)
+          const float ev = e[ct * 16];
+          const float ep = (Rq > 32) ? __uint_as_float((32 >= Li ? 63u : ((__float_as_uint(ev) & ~63u) | 32u))) : NEG;
+          top2_merge(t1, t2, ep, NEG);
+        } else {
+          // up to 8 side rows (regions 32 .. 32 + rem - 1); rows past the last repeat it -- the same candidate, merged as one
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            const int kk = k < rem ? k : rem - 1;
+            const unsigned idx = 32u + (unsigned)kk;
+            const float ev = e[(int64_t)kk * ldE + ct * 16];
+            const float ep = ((int)idx < Rq) ? __uint_as_float(((int)idx >= Li ? 63u : ((__float_as_uint(ev) & ~63u) | idx))) : NEG;
+            top2_merge(t1, t2, ep, NEG);
+          }
+        }
       }
       const unsigned idx = __float_as_uint(t1) & 63u;
       const int c = ct / TP16, w = (ct % TP16) * 16 + l4;
@@ -824,7 +836,7 @@ __device__ __forceinline__ void argmax16_epilogue_tall(f32x4 (&acc)[8][6], int m
 
 template <bool HAS_E, int TP16, int Q>
 __global__ __launch_bounds__(512) void align_argmax16_tall_kernel(const half_t* __restrict__ xm, const half_t* __restrict__ y,
-                                                                  const float* __restrict__ E, int64_t ldE,
+                                                                  const float* __restrict__ E, int64_t ldE, int rem,
                                                                   const int32_t* __restrict__ im_len, int x_tail, int Rq,
                                                                   const int32_t* __restrict__ s_len, int y_tail, int Tq,
                                                                   uint8_t* __restrict__ table, int tstride, uint8_t* __restrict__ flags,
@@ -839,19 +851,19 @@ __global__ __launch_bounds__(512) void align_argmax16_tall_kernel(const half_t* 
 #pragma unroll
     for (int ct = 0; ct < 6; ++ct) acc[rt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
   gemm_mainloop16_tall<Cfg, true>(xm + (int64_t)mb * Cfg::BM * ldk, y + (int64_t)nb * Cfg::BN * ldk, ldk, ktiles, smem, acc);
-  argmax16_epilogue_tall<HAS_E, TP16, Q>(acc, mb, nb, E, ldE, im_len, x_tail, Rq, s_len, y_tail, Tq, table, tstride, flags, Bi, Bc);
+  argmax16_epilogue_tall<HAS_E, TP16, Q>(acc, mb, nb, E, ldE, rem, im_len, x_tail, Rq, s_len, y_tail, Tq, table, tstride, flags, Bi, Bc);
 }
 
 template <int NT> static int launch_side(const aladin_align_geom* g, const half_t* xe, const half_t* y, float* E, hipStream_t stream);
 
-// g: a SPLIT-precision geometry with one region tile per image + at most one side row (R' <= 33) or two region tiles and no
-// side rows (R' 34..64), captions tiling a 96-column strip;
+// g: a SPLIT-precision geometry with one region tile per image + up to 8 side rows (R' <= 40) or two region tiles and no
+// side rows (R' 41..64), captions tiling a 96-column strip;
 // xm / xe / y: its packed operands; E: its side scratch (g->e_bytes); flags: Bi * Bc bytes, zeroed here.
 int aladin_internal_align_argmax(const aladin_align_geom* g, const void* xm, const void* xe, const void* y, float* E,
                                  const int32_t* im_len, const int32_t* s_len, uint8_t* table, int tstride, uint8_t* flags,
                                  hipStream_t stream) {
   using Cfg = GemmCfg<2, 4, 4, 3>;
-  if (!g || !g->split || g->mtiles < 1 || g->mtiles > 2 || (g->mtiles == 1 ? g->rem > 1 : g->rem != 0) || 6 % g->tp16 != 0) { aladin_set_error("align_argmax: unsupported tile class (mtiles=%d rem=%d tp16=%d split=%d)", g ? g->mtiles : -1, g ? g->rem : -1, g ? g->tp16 : -1, g ? g->split : -1); return ALADIN_ERR_UNSUPPORTED; }
+  if (!g || !g->split || g->mtiles < 1 || g->mtiles > 2 || (g->mtiles == 1 ? g->rem > 8 : g->rem != 0) || 6 % g->tp16 != 0) { aladin_set_error("align_argmax: unsupported tile class (mtiles=%d rem=%d tp16=%d split=%d)", g ? g->mtiles : -1, g ? g->rem : -1, g ? g->tp16 : -1, g ? g->split : -1); return ALADIN_ERR_UNSUPPORTED; }
   const int n_mblk = (int)(g->xm_rows / Cfg::BM), n_nblk = (int)(g->y_rows / Cfg::BN);
   if ((int64_t)n_mblk * Cfg::BM != g->xm_rows || (int64_t)n_nblk * Cfg::BN != g->y_rows) { aladin_set_error("align_argmax: packed rows do not tile"); return ALADIN_ERR_UNSUPPORTED; }
   if (hipMemsetAsync(flags, 0, (size_t)g->Bi * g->Bc, stream) != hipSuccess) { aladin_set_error("align_argmax: memset failed"); return ALADIN_ERR_HIP; }
@@ -862,7 +874,7 @@ int aladin_internal_align_argmax(const aladin_align_geom* g, const void* xm, con
     static unsigned long long lds_reserved = 0;                                                                         \
     if (int rc = aladin_reserve_lds((const void*)kern, Cfg::LDS_BYTES, &lds_reserved, "align_argmax16_tall")) return rc; \
     hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(Cfg::THREADS), Cfg::LDS_BYTES, stream, (const half_t*)xm, (const half_t*)y, \
-                       (const float*)E, g->y_rows, im_len, g->x_tail, g->Rq, s_len, g->y_tail, g->Tq, table, tstride, flags, g->Bi, g->Bc,       \
+                       (const float*)E, g->y_rows, g->rem, im_len, g->x_tail, g->Rq, s_len, g->y_tail, g->Tq, table, tstride, flags, g->Bi, g->Bc,       \
                        (int64_t)g->Dp, g->Dp / 64, n_nblk, n_blocks);                                                   \
   } while (0)
 #define ARGMAX_LAUNCH(HE, TP) ARGMAX_LAUNCH_Q(HE, TP, 1)

@@ -201,7 +201,7 @@ ALADIN_API int aladin_align_bwd_rows(const float* im, int64_t im_stride_b, int64
  *       precision (64 pairs per workgroup sharing their operand panels) instead of one workgroup per pair; only the pairs with
  *       a word whose two best regions it cannot separate (a few per cent) go through the exact per-pair kernel.  Same table,
  *       same gradients.  Needs the workspace of aladin_align_bwd_workspace_bytes_ex(..., flags) and the packed fp16 operands;
- *       classes the tile kernel does not cover (R' > 64, more than one side row, small batches) silently take the list
+ *       classes the tile kernel does not cover (R' > 64, small batches) silently take the list
  *       path.  `pairs` / `pair_count` are ignored. */
 #define ALADIN_BWD_DENSE 2
 /*       With the table of all pairs in hand the row step (step 3) runs as two MFMA GEMMs, dXh = P Yh and dYh = P^T Xh with

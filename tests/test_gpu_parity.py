@@ -1015,14 +1015,15 @@ def test_b256_triplet_step_gradients_vs_oracle(ragged):
 
 
 @pytest.mark.parametrize('B,kind,R,Tn', [(128, 'random', 34, 50), (256, 'random', 34, 50), (256, 'structured', 34, 50), (192, 'ties', 34, 50),
-                                         (128, 'random', 51, 38), (192, 'ties', 51, 38), (160, 'structured', 65, 20)])
+                                         (128, 'random', 51, 38), (192, 'ties', 51, 38), (160, 'structured', 65, 20), (144, 'random', 38, 30), (128, 'ties', 41, 50)])
 def test_dense_backward_table_equals_the_per_pair_path(B, kind, R, Tn):
     """ALADIN_BWD_DENSE (sum-of-violations hinge: every pair carries a gradient): the arg-max table written by the
     split-precision tile kernel + the per-pair kernel on the flagged near-ties must give EXACTLY the gradients of the
     per-pair kernel on every pair (same winners => same rows kernel input => bit-identical sums)."""
     from aladin_amd import ops, synth
     from aladin_amd.loss import AlignmentContrastiveLoss
-    # (51, 38): VinVL's 50 regions + 35 tokens -- two region tiles per image (R' = 50); (65, 20): R' = 64, the class limit
+    # (51, 38): VinVL's 50 regions + 35 tokens -- two region tiles per image (R' = 50); (65, 20): R' = 64, the class limit;
+    # (38, 30) / (41, 50): one region tile + 5 / 8 side rows
     if kind == 'random':
         im, s, il, sl = synth.alignment_batch(B, R, Tn, 768, seed=B + 5, ragged=True)
     else:
