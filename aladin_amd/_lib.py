@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # ALADIN_LIB points at an alternative build of the same ABI (kernel A/B runs, tools/ab_bench.py)
 LIB_PATH = os.environ.get('ALADIN_LIB') or os.path.join(_HERE, 'lib', 'libaladin_hip.so')
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 PRECISION_FP16, PRECISION_SPLIT = 0, 1      # ALADIN_PRECISION_* of include/aladin_hip.h
 BWD_PARTNERS_FP16, BWD_DENSE, BWD_DENSE_GATHER = 1, 2, 4          # ALADIN_BWD_PARTNERS_FP16, ALADIN_BWD_DENSE
 
@@ -28,7 +28,7 @@ SYMBOLS = [
     'aladin_sim_workspace_bytes', 'aladin_sim_matrix', 'aladin_recall_workspace_bytes',
     'aladin_recall_ranks', 'aladin_normsum_fwd', 'aladin_normsum_bwd',
     'aladin_l2norm_fwd', 'aladin_l2norm_bwd',
-    'aladin_retrieval_workspace_bytes', 'aladin_retrieval_ranks',
+    'aladin_retrieval_workspace_bytes', 'aladin_retrieval_ranks', 'aladin_retrieval_ranks_exact', 'aladin_retrieval_stats_offset',
     'aladin_scan_workspace_bytes', 'aladin_scan_fwd', 'aladin_scan_bwd',
     'aladin_store_row_width', 'aladin_store_append', 'aladin_align_pack_store_x', 'aladin_align_pack_store_y',
     'aladin_store_row_width_mode', 'aladin_store_append_mode', 'aladin_topk',
@@ -95,6 +95,8 @@ def _declare(lib):
         'aladin_l2norm_bwd': (C.c_int, [p, i64, p, i64, i32, i32, p, p]),
         'aladin_retrieval_workspace_bytes': (sz, [i32, i32, i32]),
         'aladin_retrieval_ranks': (C.c_int, [p, i64, p, i64, i32, i32, i32, i32, p, p, p, p, p, p]),
+        'aladin_retrieval_ranks_exact': (C.c_int, [p, i64, p, i64, i32, i32, i32, i32, p, p, p, p, p, p]),
+        'aladin_retrieval_stats_offset': (sz, [i32, i32, i32]),
         'aladin_scan_workspace_bytes': (sz, [i32, i32, i32, i32, i32, i32]),
         'aladin_scan_fwd': (C.c_int, [p, i64, i64, p, p, i64, i64, p, i32, i32, i32, i32, i32, p, i64, p, p]),
         'aladin_scan_bwd': (C.c_int, [p, i64, i64, p, p, i64, i64, p, i32, i32, i32, i32, i32, p, i64, p, p, p, p, p]),

@@ -67,6 +67,26 @@ __device__ __forceinline__ void gemm_stage(const half_t* __restrict__ a_rows, co
   }
 }
 
+// The same staging with the K position given per panel (a_k / b_k, in halfs, wave-uniform): the evaluation similarity GEMM walks
+// operand rows laid out [hi | lo] in the chain order hi.hi, lo.hi, hi.lo (recall.hip), so the two panels sit at different K offsets.
+template <class Cfg, int C0 = 0, int C1 = Cfg::CHUNKS_PER_WAVE>
+__device__ __forceinline__ void gemm_stage_k(const half_t* __restrict__ a_rows, const half_t* __restrict__ b_rows, int64_t ldk,
+                                             int64_t a_k, int64_t b_k, char* stage, int wave, uint32_t lane_off) {
+#pragma unroll
+  for (int c = C0; c < C1; ++c) {
+    const int chunk = wave + c * Cfg::NWAVES;              // wave-uniform
+    const int row0 = chunk * 8;
+    const half_t* base = (row0 < Cfg::BM) ? a_rows + (int64_t)row0 * ldk + a_k : b_rows + (int64_t)(row0 - Cfg::BM) * ldk + b_k;
+    const char* src = reinterpret_cast<const char*>(base) + lane_off;
+    __builtin_amdgcn_global_load_lds(GLOBAL_PTR(src), LDS_PTR(stage + chunk * 1024), 16, 0, 0);
+  }
+}
+// K-step -> K offsets of the two panels.  KMapLinear: both panels walk K together (every caller but the split similarity GEMM).
+struct KMapLinear {
+  __device__ __forceinline__ int64_t a(int kt) const { return (int64_t)kt * 64; }
+  __device__ __forceinline__ int64_t b(int kt) const { return (int64_t)kt * 64; }
+};
+
 __device__ __forceinline__ half8 lds_frag(const char* stage, int row, int kk, int lane) {
   const int logical = kk * 2 + (lane >> 5);
   const int phys = logical ^ ((row >> 1) & 7);
@@ -334,10 +354,10 @@ __device__ __forceinline__ void gemm_mainloop16(const half_t* __restrict__ a_row
 // tile lowers it to 2432.  Three clusters of 16 MFMAs per 32-deep step: 8 row tiles x 2 column tiles; the A fragments
 // stay in registers, the B fragments alternate between two pairs.
 // ================================================================================================
-template <class Cfg, bool SPREAD = true>
+template <class Cfg, bool SPREAD = true, class KMap = KMapLinear>
 __device__ __forceinline__ void gemm_mainloop16_tall(const half_t* __restrict__ a_rows, const half_t* __restrict__ b_rows,
                                                      int64_t ldk, int ktiles, char* smem,
-                                                     f32x4 (&acc)[2 * Cfg::WM][2 * Cfg::WN]) {
+                                                     f32x4 (&acc)[2 * Cfg::WM][2 * Cfg::WN], const KMap km = KMap()) {
   constexpr int RT = 2 * Cfg::WM, CT = 2 * Cfg::WN;
   static_assert(RT == 8 && CT == 6, "written for a 128 x 96 wave tile");
   constexpr int CPW = Cfg::CHUNKS_PER_WAVE;
@@ -348,14 +368,15 @@ __device__ __forceinline__ void gemm_mainloop16_tall(const half_t* __restrict__ 
   const int a_row0 = wm * Cfg::WM * 32 + (lane & 15);
   const int b_row0 = Cfg::BM + wn * Cfg::WN * 32 + (lane & 15);
 
-  gemm_stage<Cfg>(a_rows, nullptr, Cfg::BM, b_rows, ldk, 0, smem, wave, lane_off);
+  gemm_stage_k<Cfg>(a_rows, b_rows, ldk, km.a(0), km.b(0), smem, wave, lane_off);
   for (int kt = 0; kt < ktiles; ++kt) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     const char* cur = smem + (kt & 1) * Cfg::STAGE_BYTES;
     const bool refill = kt + 1 < ktiles;
     char* nxt = smem + ((kt + 1) & 1) * Cfg::STAGE_BYTES;
-    if (!SPREAD && refill) gemm_stage<Cfg>(a_rows, nullptr, Cfg::BM, b_rows, ldk, kt + 1, nxt, wave, lane_off);
+    const int64_t a_k = refill ? km.a(kt + 1) : 0, b_k = refill ? km.b(kt + 1) : 0;      // wave-uniform scalars
+    if (!SPREAD && refill) gemm_stage_k<Cfg>(a_rows, b_rows, ldk, a_k, b_k, nxt, wave, lane_off);
 
     half8 a[RT], bA[2], bB[2];
     // the first MFMAs of the step need a[0], bA[0], bA[1], then a[1] ...: ask in that order (LDS returns in order)
@@ -370,7 +391,7 @@ __device__ __forceinline__ void gemm_mainloop16_tall(const half_t* __restrict__ 
 #pragma unroll
       for (int j = 0; j < 2; ++j) bB[j] = lds_frag16(cur, b_row0 + (2 + j) * 16, k32, lane);
       if (SPREAD && refill) {
-        if (k32 == 1) gemm_stage<Cfg, (6 * CPW) / 10, (8 * CPW) / 10>(a_rows, nullptr, Cfg::BM, b_rows, ldk, kt + 1, nxt, wave, lane_off);
+        if (k32 == 1) gemm_stage_k<Cfg, (6 * CPW) / 10, (8 * CPW) / 10>(a_rows, b_rows, ldk, a_k, b_k, nxt, wave, lane_off);
       }
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_setprio(1);
@@ -385,8 +406,8 @@ __device__ __forceinline__ void gemm_mainloop16_tall(const half_t* __restrict__ 
 #pragma unroll
       for (int j = 0; j < 2; ++j) bA[j] = lds_frag16(cur, b_row0 + (4 + j) * 16, k32, lane);
       if (SPREAD && refill) {
-        if (k32 == 0) gemm_stage<Cfg, 0, (3 * CPW) / 10>(a_rows, nullptr, Cfg::BM, b_rows, ldk, kt + 1, nxt, wave, lane_off);
-        else gemm_stage<Cfg, (8 * CPW) / 10, CPW>(a_rows, nullptr, Cfg::BM, b_rows, ldk, kt + 1, nxt, wave, lane_off);
+        if (k32 == 0) gemm_stage_k<Cfg, 0, (3 * CPW) / 10>(a_rows, b_rows, ldk, a_k, b_k, nxt, wave, lane_off);
+        else gemm_stage_k<Cfg, (8 * CPW) / 10, CPW>(a_rows, b_rows, ldk, a_k, b_k, nxt, wave, lane_off);
       }
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_setprio(1);
@@ -403,7 +424,7 @@ __device__ __forceinline__ void gemm_mainloop16_tall(const half_t* __restrict__ 
         for (int j = 0; j < 2; ++j) bB[j] = lds_frag16(cur, b_row0 + j * 16, 1, lane);
       }
       if (SPREAD && refill) {
-        if (k32 == 0) gemm_stage<Cfg, (3 * CPW) / 10, (6 * CPW) / 10>(a_rows, nullptr, Cfg::BM, b_rows, ldk, kt + 1, nxt, wave, lane_off);
+        if (k32 == 0) gemm_stage_k<Cfg, (3 * CPW) / 10, (6 * CPW) / 10>(a_rows, b_rows, ldk, a_k, b_k, nxt, wave, lane_off);
       }
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_setprio(1);

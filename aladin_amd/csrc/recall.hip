@@ -5,10 +5,18 @@
 // Ranks must agree with the fp32 reference, so the 16-bit MFMA path uses a hi/lo split:
 //   x * 2^e = hi + lo (both fp16),  <a,b> ~ (ah.bh + al.bh + ah.bl) * 2^-(ea+eb)
 // i.e. three fp16 MFMA products accumulated in fp32 (~2^-21 relative operand error, the level of
-// fp32 rounding in the reference's own sgemm).  It is expressed as ONE ordinary GEMM over a
-// K-concatenated operand pair  A'' = [ah | al | ah],  B'' = [bh | bh | bl]  so the LDS-staged
-// main loop of gemm_core.hpp is reused unchanged.  The power-of-two scale 2^e (from the operand's
-// absmax) keeps lo in fp16's normal range; undoing it is exact.
+// fp32 rounding in the reference's own sgemm).  An operand row is stored [hi | lo] (2 Dp halfs) and the
+// EXACT score of a pair is ONE accumulator chain over the 32-deep K blocks of  hi.hi, then lo.hi, then
+// hi.lo  (KMapSplit walks the LDS-staged main loop of gemm_core.hpp through the three segments).  An
+// output element of v_mfma_f32_16x16x32_f16 depends only on its own row / column operands, its
+// accumulator input and that block order, so every kernel below that runs this chain -- the stored
+// matrix, the ground-truth scores, the exact tiles of the fused kernel, the re-scored candidates --
+// produces the same bits for the same pair.  The power-of-two scale 2^e (from the operand's absmax)
+// keeps lo in fp16's normal range; undoing it is exact.
+//
+// Round 4: the fused retrieval (aladin_retrieval_ranks) SCREENS with the hi.hi prefix of that chain
+// (a third of the work) and pays for the other two segments only where a decision needs them; see
+// sim_screen_kernel.
 #include "../../include/aladin_hip.h"
 #include "gemm_core.hpp"
 
@@ -16,10 +24,21 @@ using SimCfg = GemmCfg<2, 4, 4, 3>;       // 256 x 384 tile, 8 waves x (128 x 96
                                           // 14 instead of 16 LDS fragment reads per 32-deep step; an accumulator's bits do not depend on the wave tiling)
 constexpr int SIM_RT = 2 * SimCfg::WM, SIM_CT = 2 * SimCfg::WN;      // 16 x 16 accumulator tiles per wave: 8 x 6
 
+// K step -> K offsets inside [hi | lo] rows for the chain segments 0 = hi.hi, 1 = lo.hi, 2 = hi.lo
+struct KMapSplit {
+  int kps;        // 64-deep K steps per segment (Dp / 64)
+  int seg0;       // segment of K step 0 of this call
+  __device__ __forceinline__ int64_t a(int kt) const { const int q = kt / kps; return (int64_t)((seg0 + q == 1) ? kps : 0) * 64 + (int64_t)(kt - q * kps) * 64; }
+  __device__ __forceinline__ int64_t b(int kt) const { const int q = kt / kps; return (int64_t)((seg0 + q == 2) ? kps : 0) * 64 + (int64_t)(kt - q * kps) * 64; }
+};
+
 struct SimWs {
-  float* scale;      // [0] = 2^ea, [1] = 2^eb, [2] = absmax(img), [3] = absmax(cap)  (256 B block)
-  half_t* a;         // Mp x 3Dp
-  half_t* b;         // Np x 3Dp
+  float* scale;      // [0] = 2^ea, [1] = 2^eb  (256 B block)
+  float* partial;    // 2 x SIM_ABS_BLOCKS per-block absmax partials (images, captions)
+  half_t* a;         // Mp x 2Dp  [hi | lo]
+  half_t* b;         // Np x 2Dp
+  float2* na;        // Mp: (P, R) = (|lo|, |hi|) of the image row, rounded up
+  float2* nb;        // Np: (Q, T) = (|hi|, |lo|) of the caption row, rounded up
 };
 
 static size_t sim_ws_layout(int n_img, int n_cap, int D, char* base, SimWs* ws, int* Mp_, int* Np_, int* Dp_) {
@@ -30,10 +49,16 @@ static size_t sim_ws_layout(int n_img, int n_cap, int D, char* base, SimWs* ws, 
   size_t off = 0;
   if (ws) ws->scale = (float*)(base + off);
   off += 256;
+  if (ws) ws->partial = (float*)(base + off);
+  off += 2 * 1024 * 4;                                     // SIM_ABS_BLOCKS
   if (ws) ws->a = (half_t*)(base + off);
-  off += (size_t)Mp * 3 * Dp * 2;
+  off += (size_t)Mp * 2 * Dp * 2;
   if (ws) ws->b = (half_t*)(base + off);
-  off += (size_t)Np * 3 * Dp * 2;
+  off += (size_t)Np * 2 * Dp * 2;
+  if (ws) ws->na = (float2*)(base + off);
+  off += (size_t)Mp * 8;
+  if (ws) ws->nb = (float2*)(base + off);
+  off += (size_t)Np * 8;
   return off;
 }
 
@@ -42,111 +67,166 @@ extern "C" size_t aladin_sim_workspace_bytes(int n_img, int n_cap, int D) {
   return sim_ws_layout(n_img, n_cap, D, nullptr, nullptr, nullptr, nullptr, nullptr);
 }
 
-// absmax as an integer max on the (non-negative) float bit pattern: order preserving, deterministic
-__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, int64_t rs, int rows, int D,
-                                                     unsigned* __restrict__ out) {
+// ---- operand preparation: two launches --------------------------------------------------------------------------
+// sim_absmax_kernel: per-block partial maxima of |img| and |cap| (plain stores: 2 x SIM_ABS_BLOCKS floats, no same-address
+// atomics -- thousands of them on one line cost more than the matrices take to stream, measured).  One wave per row, every
+// load of a row in flight at once.
+constexpr int SIM_ABS_BLOCKS = 1024;
+__device__ __forceinline__ float row_absmax(const float* __restrict__ row, int D, int lane, bool vec4) {
   float m = 0.f;
-  const int lane = threadIdx.x & 63;
-  const bool vec4 = (D % 4 == 0) && (rs % 4 == 0) && (((uintptr_t)x & 15) == 0);
-  // one wave per row, rows dealt round-robin over all waves of the grid
-  for (int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); r < rows; r += (int64_t)gridDim.x * 4) {
-    const float* row = x + r * rs;
-    if (vec4) {
-      for (int c = lane * 4; c < D; c += 256) {
-        const float4 v = *reinterpret_cast<const float4*>(row + c);
-        const float a = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));   // fmaxf drops NaN
+  if (vec4) {
+    for (int c0 = 0; c0 < D; c0 += 1024) {                 // four float4 per lane in flight
+      float4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int c = c0 + u * 256 + lane * 4;
+        v[u] = (c < D) ? *reinterpret_cast<const float4*>(row + c) : float4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float a = fmaxf(fmaxf(fabsf(v[u].x), fabsf(v[u].y)), fmaxf(fabsf(v[u].z), fabsf(v[u].w)));   // fmaxf drops NaN
         if (a > m) m = a;
       }
+    }
+  } else {
+    for (int c = lane; c < D; c += 64) {
+      const float a = fabsf(row[c]);
+      if (a > m) m = a;                                     // NaN never wins
+    }
+  }
+  return m;
+}
+__global__ __launch_bounds__(256) void sim_absmax_kernel(const float* __restrict__ img, int64_t img_rs, int n_img,
+                                                         const float* __restrict__ cap, int64_t cap_rs, int n_cap, int D,
+                                                         float* __restrict__ partial) {
+  __shared__ float red[2][4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const bool v_img = (D % 4 == 0) && (img_rs % 4 == 0) && (((uintptr_t)img & 15) == 0);
+  const bool v_cap = (D % 4 == 0) && (cap_rs % 4 == 0) && (((uintptr_t)cap & 15) == 0);
+  float mi = 0.f, mc = 0.f;
+  for (int64_t r = (int64_t)blockIdx.x * 4 + wave; r < n_img; r += (int64_t)gridDim.x * 4) mi = fmaxf(mi, row_absmax(img + r * img_rs, D, lane, v_img));
+  for (int64_t r = (int64_t)blockIdx.x * 4 + wave; r < n_cap; r += (int64_t)gridDim.x * 4) mc = fmaxf(mc, row_absmax(cap + r * cap_rs, D, lane, v_cap));
+  mi = wave_max(mi);
+  mc = wave_max(mc);
+  if (lane == 0) { red[0][wave] = mi; red[1][wave] = mc; }
+  __syncthreads();
+  if (threadIdx.x < 2) partial[threadIdx.x * SIM_ABS_BLOCKS + blockIdx.x] = fmaxf(fmaxf(red[threadIdx.x][0], red[threadIdx.x][1]), fmaxf(red[threadIdx.x][2], red[threadIdx.x][3]));
+}
+
+__device__ __forceinline__ float sim_scale_of(float am) {
+  int e = 0;
+  if (am > 0.f && am < INFINITY) {
+    int ex;
+    frexpf(am, &ex);                                        // am = f * 2^ex, f in [0.5, 1)
+    e = 14 - ex;                                            // |x| * 2^e < 2^14
+    e = e > 100 ? 100 : (e < -100 ? -100 : e);
+  }
+  return ldexpf(1.f, e);
+}
+
+// sim_pack_kernel: a block = 4 waves x SIM_PACK_RPW rows, images first, then captions.  Every block reduces the partial
+// maxima to the two power-of-two scales itself (8 KiB from L2; block 0 publishes them in scale[0..1] for the GEMM kernels),
+// then each wave writes its rows [hi | lo] with x * 2^e = hi + lo and the row's two norms for the screening band
+// (sim_screen_kernel): |exact - prefix| <= |lo_a||hi_b| + |hi_a||lo_b| by Cauchy-Schwarz on the two dropped segments.
+// Norms are rounded UP (factor 1 + 2^-10 over an fp32 sum of squares whose own error is < 2^-14 relative).
+//   images: nrm = (P, R) = (|lo|, |hi|)      captions: nrm = (Q, T) = (|hi|, |lo|)
+// The grid also zeroes the fused retrieval's counters (zero0 / zero1 / zero2: int32 words; null for aladin_sim_matrix).
+constexpr int SIM_PACK_RPW = 4;
+__global__ __launch_bounds__(256) void sim_pack_kernel(const float* __restrict__ img, int64_t img_rs, int n_img, int Mp,
+                                                       const float* __restrict__ cap, int64_t cap_rs, int n_cap, int Np, int D, int Dp,
+                                                       const float* __restrict__ partial, float* __restrict__ scale,
+                                                       half_t* __restrict__ a, half_t* __restrict__ b, float2* __restrict__ na,
+                                                       float2* __restrict__ nb, int32_t* __restrict__ zero0, int64_t nz0,
+                                                       int32_t* __restrict__ zero1, int64_t nz1, int32_t* __restrict__ zero2, int64_t nz2) {
+  __shared__ float red[2][4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  {
+    float mi = 0.f, mc = 0.f;
+    for (int e = threadIdx.x; e < SIM_ABS_BLOCKS; e += 256) { mi = fmaxf(mi, partial[e]); mc = fmaxf(mc, partial[SIM_ABS_BLOCKS + e]); }
+    mi = wave_max(mi);
+    mc = wave_max(mc);
+    if (lane == 0) { red[0][wave] = mi; red[1][wave] = mc; }
+    __syncthreads();
+  }
+  const float sc_img = sim_scale_of(fmaxf(fmaxf(red[0][0], red[0][1]), fmaxf(red[0][2], red[0][3])));
+  const float sc_cap = sim_scale_of(fmaxf(fmaxf(red[1][0], red[1][1]), fmaxf(red[1][2], red[1][3])));
+  if (blockIdx.x == 0 && threadIdx.x == 0) { scale[0] = sc_img; scale[1] = sc_cap; }
+  {
+    const int64_t gtid = (int64_t)blockIdx.x * 256 + threadIdx.x, gsz = (int64_t)gridDim.x * 256;
+    for (int64_t e = gtid; e < nz0; e += gsz) zero0[e] = 0;
+    for (int64_t e = gtid; e < nz1; e += gsz) zero1[e] = 0;
+    for (int64_t e = gtid; e < nz2; e += gsz) zero2[e] = 0;
+  }
+  const bool v_img = (D % 4 == 0) && (img_rs % 4 == 0) && (((uintptr_t)img & 15) == 0);      // Dp is a multiple of 64
+  const bool v_cap = (D % 4 == 0) && (cap_rs % 4 == 0) && (((uintptr_t)cap & 15) == 0);
+  const int64_t r_first = ((int64_t)blockIdx.x * 4 + wave) * SIM_PACK_RPW;
+  for (int q = 0; q < SIM_PACK_RPW; ++q) {
+    int64_t r = r_first + q;
+    if (r >= (int64_t)Mp + Np) return;
+    const bool is_cap = r >= Mp;
+    if (is_cap) r -= Mp;
+    const float* x = is_cap ? cap : img;
+    const int64_t rs = is_cap ? cap_rs : img_rs;
+    const int rows = is_cap ? n_cap : n_img;
+    const float sc = is_cap ? sc_cap : sc_img;
+    half_t* d = (is_cap ? b : a) + r * 2 * Dp;
+    float sh = 0.f, sl = 0.f;
+    if (is_cap ? v_cap : v_img) {
+      for (int c = lane * 4; c < Dp; c += 256) {
+        float4 v = {0.f, 0.f, 0.f, 0.f};
+        if (r < rows && c < D) v = *reinterpret_cast<const float4*>(x + r * rs + c);
+        const float w[4] = {v.x * sc, v.y * sc, v.z * sc, v.w * sc};
+        half4 hi, lo;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          hi[k] = (half_t)w[k];
+          lo[k] = (half_t)(w[k] - (float)hi[k]);
+          sh = fmaf((float)hi[k], (float)hi[k], sh);
+          sl = fmaf((float)lo[k], (float)lo[k], sl);
+        }
+        *reinterpret_cast<half4*>(d + c) = hi;
+        *reinterpret_cast<half4*>(d + Dp + c) = lo;
+      }
     } else {
-      for (int c = lane; c < D; c += 64) {
-        const float a = fabsf(row[c]);
-        if (a > m) m = a;                                 // NaN never wins
+      for (int c = lane; c < Dp; c += 64) {
+        float v = 0.f;
+        if (r < rows && c < D) v = x[r * rs + c] * sc;
+        const half_t hi = (half_t)v;
+        const half_t lo = (half_t)(v - (float)hi);
+        d[c] = hi;
+        d[Dp + c] = lo;
+        sh = fmaf((float)hi, (float)hi, sh);
+        sl = fmaf((float)lo, (float)lo, sl);
       }
     }
-  }
-  m = wave_max(m);
-  if (lane == 0) atomicMax(out, __float_as_uint(m));
-}
-
-__global__ void sim_scale_kernel(float* __restrict__ sc) {
-  for (int t = 0; t < 2; ++t) {
-    const float am = sc[2 + t];
-    int e = 0;
-    if (am > 0.f && am < INFINITY) {
-      int ex;
-      frexpf(am, &ex);                                  // am = f * 2^ex, f in [0.5, 1)
-      e = 14 - ex;                                      // |x| * 2^e < 2^14
-      e = e > 100 ? 100 : (e < -100 ? -100 : e);
+    sh = wave_sum(sh);
+    sl = wave_sum(sl);
+    if (lane == 0) {
+      const float up = 1.0f + 0x1p-10f;
+      const float nh = sqrtf(sh) * up, nl = sqrtf(sl) * up;
+      if (is_cap) nb[r] = float2{nh, nl};
+      else na[r] = float2{nl, nh};
     }
-    sc[t] = ldexpf(1.f, e);
   }
 }
 
-// one wave per row: dst row = [hi | lo | hi] (kind 0, images) or [hi | hi | lo] (kind 1, captions)
-__global__ __launch_bounds__(256) void sim_pack_kernel(const float* __restrict__ x, int64_t rs, int rows, int D, int Dp,
-                                                       int rows_p, const float* __restrict__ scale, int kind,
-                                                       half_t* __restrict__ dst) {
-  const int lane = threadIdx.x & 63;
-  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (r >= rows_p) return;
-  const float sc = scale[kind];
-  half_t* d = dst + r * 3 * Dp;
-  const int lo_slot = kind == 0 ? 1 : 2, hi2_slot = kind == 0 ? 2 : 1;
-  const bool vec4 = (D % 4 == 0) && (rs % 4 == 0) && (((uintptr_t)x & 15) == 0);      // Dp is a multiple of 64
-  if (vec4) {
-    for (int c = lane * 4; c < Dp; c += 256) {
-      float4 v = {0.f, 0.f, 0.f, 0.f};
-      if (r < rows && c < D) v = *reinterpret_cast<const float4*>(x + r * rs + c);
-      const float w[4] = {v.x * sc, v.y * sc, v.z * sc, v.w * sc};
-      half4 hi, lo;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) { hi[k] = (half_t)w[k]; lo[k] = (half_t)(w[k] - (float)hi[k]); }
-      *reinterpret_cast<half4*>(d + c) = hi;
-      *reinterpret_cast<half4*>(d + lo_slot * Dp + c) = lo;
-      *reinterpret_cast<half4*>(d + hi2_slot * Dp + c) = hi;
-    }
-    return;
-  }
-  for (int c = lane; c < Dp; c += 64) {
-    float v = 0.f;
-    if (r < rows && c < D) v = x[r * rs + c] * sc;
-    const half_t hi = (half_t)v;
-    const half_t lo = (half_t)(v - (float)hi);
-    d[c] = hi;
-    d[lo_slot * Dp + c] = lo;
-    d[hi2_slot * Dp + c] = hi;
-  }
-}
-
-// order-preserving map float -> uint (NaN excluded by the callers)
+// order-preserving map float -> uint (NaN excluded by the callers) and back
 __device__ __forceinline__ unsigned float_key(float v) {
   const unsigned u = __float_as_uint(v);
   return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
+__device__ __forceinline__ float key_float(unsigned k) { return __uint_as_float((k & 0x80000000u) ? (k ^ 0x80000000u) : ~k); }
 __device__ __forceinline__ unsigned long long pack_best(float v, int idx) {
   return ((unsigned long long)float_key(v) << 32) | (unsigned)(0x7fffffff - idx);      // ties -> the smaller index wins
 }
 
-// What the similarity GEMM does with its tile:
-//   SIM_STORE  writes the scores                                        (aladin_sim_matrix)
-//   SIM_RANK   never writes S: counts, per image row, the scores beating the best of its cpi ground
-//              truths and, per caption column, the scores beating its ground truth (gt[] comes from
-//              sim_gt_kernel, bit-identical to this kernel's own values); tracks both arg-maxima
-struct SimRankArgs {
-  int cpi;
-  const float* gt;                    // n_cap
-  int32_t* cnt_i2t;                   // n_img: scores beating the row's best ground truth = its i2t rank
-  int32_t* cnt_t2i;                   // n_cap
-  unsigned long long* best_i2t;       // n_img
-  unsigned long long* best_t2i;       // n_cap
-};
-enum { SIM_STORE = 0, SIM_RANK = 2 };
-
-template <int MODE>
-__global__ __launch_bounds__(512) void sim_gemm_kernel(const half_t* __restrict__ a, const half_t* __restrict__ b,
-                                                       const float* __restrict__ scale, float* __restrict__ sim,
-                                                       int64_t ld, int n_img, int n_cap, int64_t ldk, int ktiles,
-                                                       int n_nblk, int n_blocks, SimRankArgs ra) {
+// ------------------------------------------------------------------------------------------------
+// sim_gemm_store_kernel: the stored score matrix (aladin_sim_matrix), full chain.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void sim_gemm_store_kernel(const half_t* __restrict__ a, const half_t* __restrict__ b,
+                                                             const float* __restrict__ scale, float* __restrict__ sim,
+                                                             int64_t ld, int n_img, int n_cap, int64_t ldk, int kps,
+                                                             int n_nblk, int n_blocks) {
   using Cfg = SimCfg;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int mb, nb;
@@ -157,153 +237,508 @@ __global__ __launch_bounds__(512) void sim_gemm_kernel(const half_t* __restrict_
   for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) acc[rt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
-  gemm_mainloop16_tall<Cfg>(a + (int64_t)mb * Cfg::BM * ldk, b + (int64_t)nb * Cfg::BN * ldk, ldk, ktiles, smem, acc);
+  gemm_mainloop16_tall<Cfg, true, KMapSplit>(a + (int64_t)mb * Cfg::BM * ldk, b + (int64_t)nb * Cfg::BN * ldk, ldk, 3 * kps, smem, acc,
+                                             KMapSplit{kps, 0});
   const float unscale = 1.0f / (scale[0] * scale[1]);   // exact: powers of two
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int wm = wave / Cfg::WGN, wn = wave % Cfg::WGN;
   // 16x16 C tile: col = lane & 15, row = 4 * (lane >> 4) + reg
   const int row0 = mb * Cfg::BM + wm * (RT * 16) + 4 * (lane >> 4);
   const int col0 = nb * Cfg::BN + wn * (CT * 16) + (lane & 15);
-  if constexpr (MODE == SIM_STORE) {
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt)
+  for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-      for (int reg = 0; reg < 4; ++reg) {
-        const int row = row0 + rt * 16 + reg;
-        if (row >= n_img) continue;
-        float* out = sim + (int64_t)row * ld;
+    for (int reg = 0; reg < 4; ++reg) {
+      const int row = row0 + rt * 16 + reg;
+      if (row >= n_img) continue;
+      float* out = sim + (int64_t)row * ld;
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct) {
-          const int col = col0 + ct * 16;
-          if (col < n_cap) out[col] = acc[rt][ct][reg] * unscale;
-        }
+      for (int ct = 0; ct < CT; ++ct) {
+        const int col = col0 + ct * 16;
+        if (col < n_cap) out[col] = acc[rt][ct][reg] * unscale;
       }
-  } else {
-    // Scores are compared in the accumulators' own scale: unscale is a power of two, so
-    // acc * unscale > gt  <=>  acc > gt * (1 / unscale) exactly, and the arg-maxima do not care.
-    const float rescale = scale[0] * scale[1];
-    // The workgroup's partial results meet in LDS (free after the main loop) so that each row / column
-    // of the tile costs ONE global atomic per counter instead of one per wave.
-    // i2t: the reference's rank is the best of the image's cpi captions (recall_auxiliary.py:38-44);
-    // #(v > t) never grows with t, so that minimum is the count against the LARGEST ground truth.
-    __syncthreads();                                                   // every wave is done with the operand stages
-    int* l_row = reinterpret_cast<int*>(smem);                         // [BM] scores beating the row's best ground truth
-    int* l_col = l_row + Cfg::BM;                                      // [BN]
-    unsigned long long* l_brow = reinterpret_cast<unsigned long long*>(l_col + Cfg::BN);    // [BM]
-    unsigned long long* l_bcol = l_brow + Cfg::BM;                     // [BN]
-    float* l_grow = reinterpret_cast<float*>(l_bcol + Cfg::BN);        // [BM] max of the row's ground truths
-    float* l_gcol = l_grow + Cfg::BM;                                  // [BN]
-    for (int e = threadIdx.x; e < Cfg::BM + Cfg::BN; e += Cfg::THREADS) { l_row[e] = 0; l_brow[e] = 0ull; }
-    for (int e = threadIdx.x; e < Cfg::BM; e += Cfg::THREADS) {
-      const int row = mb * Cfg::BM + e;
-      float g = INFINITY;
-      if (row < n_img) {
-        g = -INFINITY;
-        for (int q = 0; q < ra.cpi; ++q) g = fmaxf(g, ra.gt[row * ra.cpi + q]);
-        g *= rescale;
-      }
-      l_grow[e] = g;
     }
-    for (int e = threadIdx.x; e < Cfg::BN; e += Cfg::THREADS) {
-      const int c = nb * Cfg::BN + e;
-      l_gcol[e] = (c < n_cap) ? ra.gt[c] * rescale : INFINITY;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Fused retrieval (aladin_retrieval_ranks): ranks and arg-maxima of both directions straight from the
+// embeddings; the (n_img x n_cap) score matrix is never written (500 MB at COCO-5k).
+//
+// rank = #(scores strictly above the ground truth G): a DECISION per pair, and most pairs are decided by far
+// less than an exact score.  The fused kernel therefore runs the hi.hi segment only -- s, bit for bit the
+// PREFIX of the pair's exact chain -- and bounds what the two dropped segments can add:
+//     |v - s| <= band = |lo_a||hi_b| + |hi_a||lo_b| + 2^-14 |s|
+// (Cauchy-Schwarz per segment on the actual fp16 operands, norms rounded up by the packer; the last term
+// covers the fp32 rounding of the 48 more accumulator steps, each within a few ulp of the running value,
+// ~16 x what round-to-nearest gives).  Rigorous per pair: no statistics, no tuning to the data.  Then
+//     s - band >  G  : counted          s + band < G : not counted          otherwise: AMBIGUOUS
+// and for the arg-maxima, with L = max(G, tile-local lower bound of the row / column maximum) <= the exact
+// maximum, only pairs with s + band >= L can be the exact arg-max (the true one always is: v >= L).
+// Per 256 x 384 tile:
+//   * at most SIM_LIST_CAP ambiguous / arg-max candidate pairs: they go to the tile's list with their prefix s;
+//     sim_rescore_kernel CONTINUES their chains (16 pairs on the diagonal of one 16 x 16 MFMA tile) and
+//     patches the integer counters / packed maxima with the exact value;
+//   * more than that: the tile itself continues the chain -- the same accumulators run the lo.hi and hi.lo
+//     segments -- and takes the exact epilogue (round 3's kernel, for this tile only).
+// Either way every decision is made on the exact chain's bits or is implied by the band, so the four outputs
+// equal aladin_sim_matrix + aladin_recall_ranks bit for bit (tests), whatever the data; only the COST
+// depends on it: a third of round 3's MFMA work when ground truths stand clear of the bulk, up to all of it
+// when they sit inside.  Ground-truth pairs themselves (exact scores from sim_gt_kernel, which also enters
+// them into the arg-maxima) are masked out of the tiles: they never beat their own threshold.
+// Integer counters and packed-max atomics only: the result does not depend on the tile order.
+// ------------------------------------------------------------------------------------------------
+struct SimEntry { int row, col; float s; int flags; };
+enum { SIM_F_ROWCNT = 1, SIM_F_COLCNT = 2, SIM_F_ROWARG = 4, SIM_F_COLARG = 8 };
+constexpr int SIM_LIST_CAP = 64;
+
+struct SimRankArgs {
+  int cpi;
+  const float* gt;                    // n_cap, in the accumulators' scale
+  const float2* na;                   // Mp  (P, R)
+  const float2* nb;                   // Np  (Q, T)
+  int32_t* cnt_i2t;                   // n_img: scores beating the row's best ground truth = its i2t rank
+  int32_t* cnt_t2i;                   // n_cap
+  unsigned long long* best_i2t;       // n_img
+  unsigned long long* best_t2i;       // n_cap
+  SimEntry* list;                     // n_tiles x SIM_LIST_CAP
+  int* list_cnt;                      // n_tiles
+  int* stats;                         // [0] tiles that went exact, [1] listed pairs
+};
+
+__device__ __forceinline__ unsigned wave_or(unsigned v) {
+  auto s32 = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+  v = s32[0] | s32[1];
+  auto s16 = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+  v = s16[0] | s16[1];
+  v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xF, 0xF, false);
+  v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x124, 0xF, 0xF, false);
+  v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x122, 0xF, 0xF, false);
+  v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x121, 0xF, 0xF, false);
+  return (unsigned)__builtin_amdgcn_readfirstlane((int)v);
+}
+__device__ __forceinline__ int row16_isum(int t) {
+  t += __builtin_amdgcn_update_dpp(0, t, 0x128, 0xF, 0xF, false);
+  t += __builtin_amdgcn_update_dpp(0, t, 0x124, 0xF, 0xF, false);
+  t += __builtin_amdgcn_update_dpp(0, t, 0x122, 0xF, 0xF, false);
+  t += __builtin_amdgcn_update_dpp(0, t, 0x121, 0xF, 0xF, false);
+  return t;
+}
+// threadIdx.x as a value the compiler cannot merge with the copy it computed before a main loop: what the epilogues derive from it
+// is recomputed after the loop instead of living (or spilling) through it
+__device__ __forceinline__ int fresh_tid() { int t = threadIdx.x; asm volatile("" : "+v"(t)); return t; }
+__device__ __forceinline__ float fmax_nc(float a, float b) { return __builtin_elementwise_maximum(a, b); }    // IEEE maximum: no canonicalising v_max x, x, x
+
+// The exact epilogue (round 3): every accumulator holds the full chain.  Scores are compared in the accumulators' own
+// scale (gt[] is kept in it).  The workgroup's partial results meet in LDS (free after the main loop) so that each row /
+// column of the tile costs ONE global atomic per counter instead of one per wave.
+// i2t: the reference's rank is the best of the image's cpi captions (recall_auxiliary.py:38-44);
+// #(v > t) never grows with t, so that minimum is the count against the LARGEST ground truth.
+__device__ __forceinline__ void sim_rank_epilogue_exact(f32x4 (&acc)[SIM_RT][SIM_CT], char* smem, int mb, int nb, int n_img, int n_cap,
+                                                        const SimRankArgs& ra) {
+  using Cfg = SimCfg;
+  constexpr int RT = SIM_RT, CT = SIM_CT;
+  const int tid = fresh_tid();
+  const int wave = tid >> 6, lane = tid & 63;
+  const int wm = wave / Cfg::WGN, wn = wave % Cfg::WGN;
+  const int row0 = mb * Cfg::BM + wm * (RT * 16) + 4 * (lane >> 4);
+  const int col0 = nb * Cfg::BN + wn * (CT * 16) + (lane & 15);
+  __syncthreads();                                                   // every wave is done with the operand stages
+  int* l_row = reinterpret_cast<int*>(smem);                         // [BM] scores beating the row's best ground truth
+  int* l_col = l_row + Cfg::BM;                                      // [BN]
+  unsigned long long* l_brow = reinterpret_cast<unsigned long long*>(l_col + Cfg::BN);    // [BM]
+  unsigned long long* l_bcol = l_brow + Cfg::BM;                     // [BN]
+  float* l_grow = reinterpret_cast<float*>(l_bcol + Cfg::BN);        // [BM] max of the row's ground truths
+  float* l_gcol = l_grow + Cfg::BM;                                  // [BN]
+  for (int e = threadIdx.x; e < Cfg::BM + Cfg::BN; e += Cfg::THREADS) { l_row[e] = 0; l_brow[e] = 0ull; }
+  for (int e = threadIdx.x; e < Cfg::BM; e += Cfg::THREADS) {
+    const int row = mb * Cfg::BM + e;
+    float g = INFINITY;
+    if (row < n_img) {
+      g = -INFINITY;
+      for (int q = 0; q < ra.cpi; ++q) g = fmaxf(g, ra.gt[row * ra.cpi + q]);
     }
-    __syncthreads();
-    const int lrow0 = wm * (RT * 16) + 4 * (lane >> 4), lcol0 = wn * (CT * 16) + (lane & 15);
-    // ---- rows: lanes with the same lane >> 4 share a row; CT columns each
+    l_grow[e] = g;
+  }
+  for (int e = threadIdx.x; e < Cfg::BN; e += Cfg::THREADS) {
+    const int c = nb * Cfg::BN + e;
+    l_gcol[e] = (c < n_cap) ? ra.gt[c] : INFINITY;
+  }
+  __syncthreads();
+  const int lrow0 = wm * (RT * 16) + 4 * (lane >> 4), lcol0 = wn * (CT * 16) + (lane & 15);
+  // ---- rows: lanes with the same lane >> 4 share a row; CT columns each
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt)
+  for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-      for (int reg = 0; reg < 4; ++reg) {
-        const int row = row0 + rt * 16 + reg, lrow = lrow0 + rt * 16 + reg;
-        const float g = l_grow[lrow];
-        int cnt = 0;
-        float best = -INFINITY;
-#pragma unroll
-        for (int ct = 0; ct < CT; ++ct) {
-          const float v = (col0 + ct * 16 < n_cap) ? acc[rt][ct][reg] : -INFINITY;    // pad columns never count, never win
-          cnt += (v > g);
-          best = fmaxf(best, v);
-        }
-#pragma unroll
-        for (int o = 8; o > 0; o >>= 1) {
-          cnt += __shfl_xor(cnt, o, 64);
-          best = fmaxf(best, __shfl_xor(best, o, 64));
-        }
-        // the maximum's first column: this lane's first hit (columns ascend with ct), then the smallest over the 16 lanes
-        int besti = 0x7fffffff;
-#pragma unroll
-        for (int ct = CT - 1; ct >= 0; --ct)
-          if (col0 + ct * 16 < n_cap && acc[rt][ct][reg] == best) besti = col0 + ct * 16;
-#pragma unroll
-        for (int o = 8; o > 0; o >>= 1) { const int oi = __shfl_xor(besti, o, 64); besti = oi < besti ? oi : besti; }
-        if (row < n_img && (lane & 15) == 0) {
-          if (cnt) atomicAdd(&l_row[lrow], cnt);
-          if (besti != 0x7fffffff) atomicMax(&l_brow[lrow], pack_best(best, besti));
-        }
-      }
-    // ---- columns: lanes with the same lane & 15 share a column; 16 rows each
-#pragma unroll
-    for (int ct = 0; ct < CT; ++ct) {
-      const int col = col0 + ct * 16, lcol = lcol0 + ct * 16;
-      const float g = l_gcol[lcol];
+    for (int reg = 0; reg < 4; ++reg) {
+      const int row = row0 + rt * 16 + reg, lrow = lrow0 + rt * 16 + reg;
+      const float g = l_grow[lrow];
       int cnt = 0;
       float best = -INFINITY;
 #pragma unroll
-      for (int rt = 0; rt < RT; ++rt)
+      for (int ct = 0; ct < CT; ++ct) {
+        const float v = (col0 + ct * 16 < n_cap) ? acc[rt][ct][reg] : -INFINITY;    // pad columns never count, never win
+        cnt += (v > g);
+        best = fmaxf(best, v);
+      }
 #pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-          const float v = (row0 + rt * 16 + reg < n_img) ? acc[rt][ct][reg] : -INFINITY;
-          cnt += (v > g);
-          best = fmaxf(best, v);
-        }
-#pragma unroll
-      for (int o = 16; o < 64; o <<= 1) {
+      for (int o = 8; o > 0; o >>= 1) {
         cnt += __shfl_xor(cnt, o, 64);
         best = fmaxf(best, __shfl_xor(best, o, 64));
       }
+      // the maximum's first column: this lane's first hit (columns ascend with ct), then the smallest over the 16 lanes
       int besti = 0x7fffffff;
 #pragma unroll
-      for (int rt = RT - 1; rt >= 0; --rt)
+      for (int ct = CT - 1; ct >= 0; --ct)
+        if (col0 + ct * 16 < n_cap && acc[rt][ct][reg] == best) besti = col0 + ct * 16;
 #pragma unroll
-        for (int reg = 3; reg >= 0; --reg)
-          if (row0 + rt * 16 + reg < n_img && acc[rt][ct][reg] == best) besti = row0 + rt * 16 + reg;     // rows ascend with (rt, reg)
-#pragma unroll
-      for (int o = 16; o < 64; o <<= 1) { const int oi = __shfl_xor(besti, o, 64); besti = oi < besti ? oi : besti; }
-      if (col < n_cap && lane < 16) {
-        if (cnt) atomicAdd(&l_col[lcol], cnt);
-        if (besti != 0x7fffffff) atomicMax(&l_bcol[lcol], pack_best(best, besti));
+      for (int o = 8; o > 0; o >>= 1) { const int oi = __shfl_xor(besti, o, 64); besti = oi < besti ? oi : besti; }
+      if (row < n_img && (lane & 15) == 0) {
+        if (cnt) atomicAdd(&l_row[lrow], cnt);
+        if (besti != 0x7fffffff && best > -INFINITY) atomicMax(&l_brow[lrow], pack_best(best, besti));
       }
     }
-    __syncthreads();
-    // ---- one global atomic per non-zero counter; arg-maxima only when they beat what is already there
-    for (int e = threadIdx.x; e < Cfg::BM; e += Cfg::THREADS) {
-      const int row = mb * Cfg::BM + e;
-      if (row < n_img) {
-        if (l_row[e]) atomicAdd(&ra.cnt_i2t[row], l_row[e]);
-        const unsigned long long p = l_brow[e];
-        if (p > __hip_atomic_load(&ra.best_i2t[row], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&ra.best_i2t[row], p);
+  // ---- columns: lanes with the same lane & 15 share a column; 16 rows each
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct) {
+    const int col = col0 + ct * 16, lcol = lcol0 + ct * 16;
+    const float g = l_gcol[lcol];
+    int cnt = 0;
+    float best = -INFINITY;
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const float v = (row0 + rt * 16 + reg < n_img) ? acc[rt][ct][reg] : -INFINITY;
+        cnt += (v > g);
+        best = fmaxf(best, v);
       }
+#pragma unroll
+    for (int o = 16; o < 64; o <<= 1) {
+      cnt += __shfl_xor(cnt, o, 64);
+      best = fmaxf(best, __shfl_xor(best, o, 64));
     }
-    for (int e = threadIdx.x; e < Cfg::BN; e += Cfg::THREADS) {
-      const int col = nb * Cfg::BN + e;
-      if (col < n_cap) {
-        if (l_col[e]) atomicAdd(&ra.cnt_t2i[col], l_col[e]);
-        const unsigned long long p = l_bcol[e];
-        if (p > __hip_atomic_load(&ra.best_t2i[col], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&ra.best_t2i[col], p);
-      }
+    int besti = 0x7fffffff;
+#pragma unroll
+    for (int rt = RT - 1; rt >= 0; --rt)
+#pragma unroll
+      for (int reg = 3; reg >= 0; --reg)
+        if (row0 + rt * 16 + reg < n_img && acc[rt][ct][reg] == best) besti = row0 + rt * 16 + reg;     // rows ascend with (rt, reg)
+#pragma unroll
+    for (int o = 16; o < 64; o <<= 1) { const int oi = __shfl_xor(besti, o, 64); besti = oi < besti ? oi : besti; }
+    if (col < n_cap && lane < 16) {
+      if (cnt) atomicAdd(&l_col[lcol], cnt);
+      if (besti != 0x7fffffff && best > -INFINITY) atomicMax(&l_bcol[lcol], pack_best(best, besti));
+    }
+  }
+  __syncthreads();
+  // ---- one global atomic per non-zero counter; arg-maxima only when they beat what is already there
+  for (int e = threadIdx.x; e < Cfg::BM; e += Cfg::THREADS) {
+    const int row = mb * Cfg::BM + e;
+    if (row < n_img) {
+      if (l_row[e]) atomicAdd(&ra.cnt_i2t[row], l_row[e]);
+      const unsigned long long p = l_brow[e];
+      if (p > __hip_atomic_load(&ra.best_i2t[row], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&ra.best_i2t[row], p);
+    }
+  }
+  for (int e = threadIdx.x; e < Cfg::BN; e += Cfg::THREADS) {
+    const int col = nb * Cfg::BN + e;
+    if (col < n_cap) {
+      if (l_col[e]) atomicAdd(&ra.cnt_t2i[col], l_col[e]);
+      const unsigned long long p = l_bcol[e];
+      if (p > __hip_atomic_load(&ra.best_t2i[col], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&ra.best_t2i[col], p);
     }
   }
 }
 
-// Ground-truth scores gt[c] = S[c / cpi][c] with the bits the big kernel produces: an output element
-// of v_mfma_f32_16x16x32_f16 depends only on its own row / column operands and on the order of the
-// 32-deep K blocks, which is ascending in both kernels.  For 16 consecutive images the ground truths
-// sit in the 16 x (16 * cpi) block starting at column 16 * cpi * t -- cpi aligned 16 x 16 tiles; one
-// wave per tile, fragments straight from global memory (16 B per lane and K block).
-__global__ __launch_bounds__(256) void sim_gt_kernel(const half_t* __restrict__ a, const half_t* __restrict__ b,
-                                                     const float* __restrict__ scale, int n_img, int n_cap, int cpi,
-                                                     int64_t ldk, int kblocks, float* __restrict__ gt) {
+// FORCE_EXACT: every tile takes the exact path (round 3's behaviour; tests compare the two)
+template <bool FORCE_EXACT>
+__global__ __launch_bounds__(512) void sim_screen_kernel(const half_t* __restrict__ a, const half_t* __restrict__ b,
+                                                         const float* __restrict__ scale, int n_img, int n_cap, int64_t ldk,
+                                                         int kps, int n_nblk, int n_blocks, SimRankArgs ra) {
+  using Cfg = SimCfg;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int mb, nb;
+  tile_coords(blockIdx.x, n_blocks / n_nblk, n_nblk, 4, mb, nb);
+  constexpr int RT = SIM_RT, CT = SIM_CT;
+  f32x4 acc[RT][CT];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) acc[rt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const half_t* a_tile = a + (int64_t)mb * Cfg::BM * ldk;
+  const half_t* b_tile = b + (int64_t)nb * Cfg::BN * ldk;
+  gemm_mainloop16_tall<Cfg>(a_tile, b_tile, ldk, kps, smem, acc);          // hi.hi: the prefix of every pair's chain
+  const int tid = fresh_tid();
+  const int wave = tid >> 6, lane = tid & 63;
+  const int wm = wave / Cfg::WGN, wn = wave % Cfg::WGN;
+  const int row0 = mb * Cfg::BM + wm * (RT * 16) + 4 * (lane >> 4);
+  const int col0 = nb * Cfg::BN + wn * (CT * 16) + (lane & 15);
+  const int lrow0 = wm * (RT * 16) + 4 * (lane >> 4), lcol0 = wn * (CT * 16) + (lane & 15);
+  // ---- phase 0: pad rows / columns and the ground-truth pairs leave the game
+  {
+    const int r_lo = mb * Cfg::BM, c_lo = nb * Cfg::BN;
+    const bool edge = r_lo + Cfg::BM > n_img || c_lo + Cfg::BN > n_cap;
+    const bool gtband = (int64_t)r_lo * ra.cpi < (int64_t)c_lo + Cfg::BN && (int64_t)(r_lo + Cfg::BM) * ra.cpi > c_lo;
+    if (edge || gtband) {
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          const int row = row0 + rt * 16 + reg;
+#pragma unroll
+          for (int ct = 0; ct < CT; ++ct) {
+            const int col = col0 + ct * 16;
+            if (row >= n_img || col >= n_cap || (unsigned)(col - row * ra.cpi) < (unsigned)ra.cpi) acc[rt][ct][reg] = -INFINITY;
+          }
+        }
+    }
+  }
+  if constexpr (!FORCE_EXACT) {
+    __syncthreads();                                                 // every wave is done with the operand stages
+    float* l_thrRow = reinterpret_cast<float*>(smem);                // [BM] s below this cannot reach the row's ground truth
+    float* l_P = l_thrRow + Cfg::BM;
+    float* l_R = l_P + Cfg::BM;
+    float* l_Grow = l_R + Cfg::BM;
+    float* l_bmaxRow = l_Grow + Cfg::BM;
+    unsigned* l_rowmax = reinterpret_cast<unsigned*>(l_bmaxRow + Cfg::BM);     // key of the largest qualifying s of the row in this tile (0: none)
+    int* l_rowcnt = reinterpret_cast<int*>(l_rowmax + Cfg::BM);
+    float* l_thrCol = reinterpret_cast<float*>(l_rowcnt + Cfg::BM);  // [BN] ...
+    float* l_Q = l_thrCol + Cfg::BN;
+    float* l_T = l_Q + Cfg::BN;
+    float* l_Gcol = l_T + Cfg::BN;
+    float* l_bmaxCol = l_Gcol + Cfg::BN;
+    unsigned* l_colmax = reinterpret_cast<unsigned*>(l_bmaxCol + Cfg::BN);
+    int* l_colcnt = reinterpret_cast<int*>(l_colmax + Cfg::BN);
+    SimEntry* l_list = reinterpret_cast<SimEntry*>(l_colcnt + Cfg::BN);        // 7 * (256 + 384) * 4 B = 17920 B: 16-B aligned
+    int* l_listn = reinterpret_cast<int*>(l_list + SIM_LIST_CAP);
+    float* l_wmax = reinterpret_cast<float*>(l_listn + 4);           // [8 waves][4]: per-wave maxima of P, R, Q, T over the tile
+    static_assert(Cfg::BM <= Cfg::THREADS && Cfg::BN <= Cfg::THREADS, "one row / column entry per thread");
+    // the tile's largest band factors bound every pair's band from above: the cheap test of phase 1
+    const int e = tid;
+    float2 pr = {0.f, 0.f}, qt = {0.f, 0.f};
+    if (e < Cfg::BM) pr = ra.na[mb * Cfg::BM + e];                   // padded rows exist and are zero
+    if (e < Cfg::BN) qt = ra.nb[nb * Cfg::BN + e];
+    {
+      const float wP = wave_max(pr.x), wR = wave_max(pr.y), wQ = wave_max(qt.x), wT = wave_max(qt.y);
+      if (lane == 0) { l_wmax[wave * 4 + 0] = wP; l_wmax[wave * 4 + 1] = wR; l_wmax[wave * 4 + 2] = wQ; l_wmax[wave * 4 + 3] = wT; }
+    }
+    __syncthreads();
+    float Pg = 0.f, Rg = 0.f, Qg = 0.f, Tg = 0.f;
+#pragma unroll
+    for (int w = 0; w < Cfg::NWAVES; ++w) {
+      Pg = fmaxf(Pg, l_wmax[w * 4 + 0]); Rg = fmaxf(Rg, l_wmax[w * 4 + 1]); Qg = fmaxf(Qg, l_wmax[w * 4 + 2]); Tg = fmaxf(Tg, l_wmax[w * 4 + 3]);
+    }
+    if (e < Cfg::BM) {
+      const int row = mb * Cfg::BM + e;
+      float g = INFINITY, thr = INFINITY;
+      const float bm = fmaf(pr.x, Qg, pr.y * Tg);                    // >= fmaf(P, Q_j, R * T_j) for every j of the tile: the operations are monotone
+      if (row < n_img) {
+        g = -INFINITY;
+        for (int q = 0; q < ra.cpi; ++q) g = fmaxf(g, ra.gt[row * ra.cpi + q]);
+        const float t = g - bm;
+        thr = t - 0x1p-13f * fabsf(t) - 0x1p-20f * bm;               // s < thr  =>  s + bm + 2^-14 |s| < g, roundings included
+      }
+      l_thrRow[e] = thr; l_P[e] = pr.x; l_R[e] = pr.y; l_Grow[e] = g; l_bmaxRow[e] = bm; l_rowmax[e] = 0u; l_rowcnt[e] = 0;
+    }
+    if (e < Cfg::BN) {
+      const int col = nb * Cfg::BN + e;
+      float g = INFINITY, thr = INFINITY;
+      const float bm = fmaf(Pg, qt.x, Rg * qt.y);
+      if (col < n_cap) {
+        g = ra.gt[col];
+        const float t = g - bm;
+        thr = t - 0x1p-13f * fabsf(t) - 0x1p-20f * bm;
+      }
+      l_thrCol[e] = thr; l_Q[e] = qt.x; l_T[e] = qt.y; l_Gcol[e] = g; l_bmaxCol[e] = bm; l_colmax[e] = 0u; l_colcnt[e] = 0;
+    }
+    if (tid == 0) *l_listn = 0;
+    __syncthreads();
+    // ---- phase 1: which rows / columns of this wave hold a score within reach of their ground truth at all
+    unsigned rowmask = 0u, colmask = 0u;
+    {
+      float cmax[CT];
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) cmax[ct] = -INFINITY;
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) {
+        const float4 thr4 = *reinterpret_cast<const float4*>(l_thrRow + lrow0 + rt * 16);
+        const float thr[4] = {thr4.x, thr4.y, thr4.z, thr4.w};
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          float m = fmax_nc(fmax_nc(fmax_nc(acc[rt][0][reg], acc[rt][1][reg]), fmax_nc(acc[rt][2][reg], acc[rt][3][reg])),
+                            fmax_nc(acc[rt][4][reg], acc[rt][5][reg]));
+#pragma unroll
+          for (int ct = 0; ct < CT; ++ct) cmax[ct] = fmax_nc(cmax[ct], acc[rt][ct][reg]);
+          if (m >= thr[reg]) {
+            rowmask |= 1u << (rt * 4 + reg);
+            atomicMax(&l_rowmax[lrow0 + rt * 16 + reg], float_key(m));
+          }
+        }
+      }
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct)
+        if (cmax[ct] >= l_thrCol[lcol0 + ct * 16]) {
+          colmask |= 1u << ct;
+          atomicMax(&l_colmax[lcol0 + ct * 16], float_key(cmax[ct]));
+        }
+    }
+    const unsigned rowAny = wave_or(rowmask), colAny = wave_or(colmask);      // wave-uniform
+    __syncthreads();
+    // ---- phase 2: the flagged rows / columns element by element
+    if (rowAny | colAny) {
+      float Q[CT], Tt[CT], Gc[CT], Lc[CT];
+      int ccnt[CT];
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) {
+        const int lc = lcol0 + ct * 16;
+        Q[ct] = l_Q[lc]; Tt[ct] = l_T[lc]; Gc[ct] = l_Gcol[lc];
+        const unsigned k = l_colmax[lc];
+        float L = -INFINITY;
+        if (k) { const float m = key_float(k); L = (m - l_bmaxCol[lc]) - 0x1p-13f * fabsf(m); }     // <= lo of that element <= the exact column maximum
+        Lc[ct] = fmaxf(Gc[ct], L);
+        ccnt[ct] = 0;
+      }
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          const bool rowbit = (rowAny >> (rt * 4 + reg)) & 1u;
+          if (!rowbit && !colAny) continue;
+          const int lr = lrow0 + rt * 16 + reg;
+          const float P = l_P[lr], R = l_R[lr], Gr = l_Grow[lr];
+          const unsigned k = l_rowmax[lr];
+          float Lr = -INFINITY;
+          if (k) { const float m = key_float(k); Lr = (m - l_bmaxRow[lr]) - 0x1p-13f * fabsf(m); }
+          Lr = fmaxf(Gr, Lr);
+          int rcnt = 0;
+#pragma unroll
+          for (int ct = 0; ct < CT; ++ct) {
+            const bool colbit = (colAny >> ct) & 1u;
+            if (!rowbit && !colbit) continue;
+            const float s = acc[rt][ct][reg];
+            const float band = fmaf(fabsf(s), 0x1p-14f, fmaf(P, Q[ct], R * Tt[ct]));
+            const float hi = s + band, lo = s - band;
+            int f = 0;
+            const bool gr = lo > Gr;
+            rcnt += gr;
+            if (hi >= Gr) { if (!gr) f |= SIM_F_ROWCNT; if (hi >= Lr) f |= SIM_F_ROWARG; }
+            const bool gc = lo > Gc[ct];
+            ccnt[ct] += gc;
+            if (hi >= Gc[ct]) { if (!gc) f |= SIM_F_COLCNT; if (hi >= Lc[ct]) f |= SIM_F_COLARG; }
+            if (f) {
+              const int idx = atomicAdd(l_listn, 1);
+              if (idx < SIM_LIST_CAP) l_list[idx] = SimEntry{row0 + rt * 16 + reg, col0 + ct * 16, s, f};
+            }
+          }
+          rcnt = row16_isum(rcnt);
+          if ((lane & 15) == 0 && rcnt) atomicAdd(&l_rowcnt[lr], rcnt);
+        }
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) {
+        int c = ccnt[ct];
+        c += lane_xor16(c);
+        c += lane_xor32(c);
+        if (lane < 16 && c) atomicAdd(&l_colcnt[lcol0 + ct * 16], c);
+      }
+    }
+    __syncthreads();
+    const int n_list = *l_listn;
+    const bool exact = n_list > SIM_LIST_CAP;
+    const int tile = mb * n_nblk + nb;
+    if (threadIdx.x == 0) {
+      ra.list_cnt[tile] = exact ? 0 : n_list;
+      if (exact) atomicAdd(&ra.stats[0], 1);
+      else if (n_list) atomicAdd(&ra.stats[1], n_list);
+    }
+    if (!exact) {
+      for (int e = threadIdx.x; e < Cfg::BM; e += Cfg::THREADS)
+        if (l_rowcnt[e]) atomicAdd(&ra.cnt_i2t[mb * Cfg::BM + e], l_rowcnt[e]);       // only valid rows ever count
+      for (int e = threadIdx.x; e < Cfg::BN; e += Cfg::THREADS)
+        if (l_colcnt[e]) atomicAdd(&ra.cnt_t2i[nb * Cfg::BN + e], l_colcnt[e]);
+      for (int e = threadIdx.x; e < n_list; e += Cfg::THREADS) ra.list[(int64_t)tile * SIM_LIST_CAP + e] = l_list[e];
+      return;
+    }
+    __syncthreads();                                                 // the lists are dead: the stages may be refilled
+  } else {
+    if (threadIdx.x == 0) ra.list_cnt[mb * n_nblk + nb] = 0;
+  }
+  gemm_mainloop16_tall<Cfg, true, KMapSplit>(a_tile, b_tile, ldk, 2 * kps, smem, acc, KMapSplit{kps, 1});     // lo.hi, hi.lo
+  sim_rank_epilogue_exact(acc, smem, mb, nb, n_img, n_cap, ra);
+}
+
+// acc (+)= A[16 x K] . B[16 x K]^T over nblk ascending 32-deep K blocks, fragments straight from global memory (16 B per lane
+// and block) with eight blocks of loads in flight: the chain of MFMAs is serial, the loads need not be.
+__device__ __forceinline__ void sim_chain_global(const half_t* __restrict__ ap, const half_t* __restrict__ bp, int nblk, f32x4& acc) {
+  int k = 0;
+  for (; k + 8 <= nblk; k += 8) {
+    half8 af[8], bf[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      af[u] = *reinterpret_cast<const half8*>(ap + (int64_t)(k + u) * 32);
+      bf[u] = *reinterpret_cast<const half8*>(bp + (int64_t)(k + u) * 32);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[u], bf[u], acc, 0, 0, 0);
+  }
+  for (; k < nblk; ++k) {
+    const half8 af = *reinterpret_cast<const half8*>(ap + (int64_t)k * 32);
+    const half8 bf = *reinterpret_cast<const half8*>(bp + (int64_t)k * 32);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf, acc, 0, 0, 0);
+  }
+}
+
+// Continue the chains of the listed pairs: 16 pairs per wave on the DIAGONAL of one 16 x 16 MFMA tile (row m of A = pair
+// m's image, column m of B = pair m's caption, C[m][m] = its prefix s; the off-diagonal products are waste, the loads are
+// what this costs: 4 x 2 Dp bytes per pair), then patch the counters / packed maxima with the exact value.
+__global__ __launch_bounds__(256) void sim_rescore_kernel(const half_t* __restrict__ a, const half_t* __restrict__ b, int64_t ldk,
+                                                          int kps, int n_tiles, SimRankArgs ra) {
+  constexpr int GROUPS = SIM_LIST_CAP / 16;
+  const int lane = threadIdx.x & 63;
+  const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int tile = w / GROUPS, grp = w % GROUPS;
+  if (tile >= n_tiles) return;
+  const int n = ra.list_cnt[tile];
+  if (grp * 16 >= n) return;
+  const int m = lane & 15;
+  const bool live = grp * 16 + m < n;
+  SimEntry e = SimEntry{0, 0, 0.f, 0};
+  if (live) e = ra.list[(int64_t)tile * SIM_LIST_CAP + grp * 16 + m];
+  const half_t* ap = a + (int64_t)e.row * ldk + 8 * (lane >> 4);
+  const half_t* bp = b + (int64_t)e.col * ldk + 8 * (lane >> 4);
+  const bool diag = (lane >> 4) == (m >> 2);                          // C[row][col]: col = lane & 15, row = 4 * (lane >> 4) + reg
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int reg = 0; reg < 4; ++reg)
+    if (diag && reg == (m & 3)) acc[reg] = e.s;
+  const int Dp = kps * 64;
+  sim_chain_global(ap + Dp, bp, 2 * kps, acc);                        // lo.hi
+  sim_chain_global(ap, bp + Dp, 2 * kps, acc);                        // hi.lo
+  if (!(live && diag)) return;
+  float v = acc[0];
+#pragma unroll
+  for (int reg = 1; reg < 4; ++reg)
+    if (reg == (m & 3)) v = acc[reg];
+  if (e.flags & (SIM_F_ROWCNT | SIM_F_ROWARG)) {
+    if (e.flags & SIM_F_ROWCNT) {
+      float g = -INFINITY;
+      for (int q = 0; q < ra.cpi; ++q) g = fmaxf(g, ra.gt[e.row * ra.cpi + q]);
+      if (v > g) atomicAdd(&ra.cnt_i2t[e.row], 1);
+    }
+    if (e.flags & SIM_F_ROWARG) atomicMax(&ra.best_i2t[e.row], pack_best(v, e.col));
+  }
+  if (e.flags & SIM_F_COLCNT) {
+    if (v > ra.gt[e.col]) atomicAdd(&ra.cnt_t2i[e.col], 1);
+  }
+  if (e.flags & SIM_F_COLARG) atomicMax(&ra.best_t2i[e.col], pack_best(v, e.row));
+}
+
+// Ground-truth scores gt[c] = chain(c / cpi, c) in the accumulators' scale, with the bits every other kernel of this file
+// produces for that pair (file header).  For 16 consecutive images the ground truths sit in the 16 x (16 * cpi) block
+// starting at column 16 * cpi * t -- cpi aligned 16 x 16 tiles; one wave per tile, fragments straight from global memory
+// (16 B per lane and K block).  The ground-truth pairs enter the arg-maxima here (the big kernel masks them out).
+__global__ __launch_bounds__(256) void sim_gt_kernel(const half_t* __restrict__ a, const half_t* __restrict__ b, int n_img, int n_cap,
+                                                     int cpi, int64_t ldk, int kps, float* __restrict__ gt,
+                                                     unsigned long long* __restrict__ best_i2t, unsigned long long* __restrict__ best_t2i) {
   const int lane = threadIdx.x & 63;
   const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int t = tile / cpi, c = tile % cpi;
@@ -311,40 +746,35 @@ __global__ __launch_bounds__(256) void sim_gt_kernel(const half_t* __restrict__ 
   const int row_t = t * 16, col_t = t * 16 * cpi + c * 16;
   const half_t* ap = a + (int64_t)(row_t + (lane & 15)) * ldk + 8 * (lane >> 4);     // padded rows exist (Mp, Np)
   const half_t* bp = b + (int64_t)(col_t + (lane & 15)) * ldk + 8 * (lane >> 4);
+  const int Dp = kps * 64;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  for (int k = 0; k < kblocks; ++k) {                                  // the MFMA chain stays in K order
-    const half8 af = *reinterpret_cast<const half8*>(ap + (int64_t)k * 32);
-    const half8 bf = *reinterpret_cast<const half8*>(bp + (int64_t)k * 32);
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf, acc, 0, 0, 0);
-  }
-  const float unscale = 1.0f / (scale[0] * scale[1]);
+  sim_chain_global(ap, bp, 2 * kps, acc);                              // hi.hi   (the MFMA chain stays in K order)
+  sim_chain_global(ap + Dp, bp, 2 * kps, acc);                         // lo.hi
+  sim_chain_global(ap, bp + Dp, 2 * kps, acc);                         // hi.lo
   const int col = col_t + (lane & 15);
 #pragma unroll
   for (int reg = 0; reg < 4; ++reg) {
     const int row = row_t + 4 * (lane >> 4) + reg;
-    if (row < n_img && col < n_cap && col / cpi == row) gt[col] = acc[reg] * unscale;
+    if (row < n_img && col < n_cap && col / cpi == row) {
+      gt[col] = acc[reg];
+      if (best_i2t) {
+        atomicMax(&best_i2t[row], pack_best(acc[reg], col));
+        best_t2i[col] = pack_best(acc[reg], row);                      // one ground truth per column: a plain store, before the big kernel runs
+      }
+    }
   }
 }
 
-// scale search, split-fp16 packing and the LDS reservation shared by the GEMM modes
-template <int MODE>
+// scale search + split-fp16 packing shared by the GEMM modes (zero*: int32 words the pack grid clears on its way)
 static int sim_prepare(const float* img, int64_t img_rs, const float* cap, int64_t cap_rs, int n_img, int n_cap, int D,
-                       void* workspace, SimWs* ws, int* Mp, int* Np, int* Dp, hipStream_t st, bool pack) {
+                       void* workspace, SimWs* ws, int* Mp, int* Np, int* Dp, hipStream_t st, int32_t* zero0 = nullptr, int64_t nz0 = 0,
+                       int32_t* zero1 = nullptr, int64_t nz1 = 0, int32_t* zero2 = nullptr, int64_t nz2 = 0) {
   sim_ws_layout(n_img, n_cap, D, (char*)workspace, ws, Mp, Np, Dp);
-  if (pack) {
-    if (hipMemsetAsync(ws->scale, 0, 256, st) != hipSuccess) { aladin_set_error("sim: memset failed"); return ALADIN_ERR_HIP; }
-    // fixed grids: one same-address atomicMax per wave, so more waves cost more than they stream (measured)
-    hipLaunchKernelGGL(absmax_kernel, dim3(512), dim3(256), 0, st, img, img_rs, n_img, D, (unsigned*)(ws->scale + 2));
-    hipLaunchKernelGGL(absmax_kernel, dim3(1024), dim3(256), 0, st, cap, cap_rs, n_cap, D, (unsigned*)(ws->scale + 3));
-    hipLaunchKernelGGL(sim_scale_kernel, dim3(1), dim3(1), 0, st, ws->scale);
-    hipLaunchKernelGGL(sim_pack_kernel, dim3((*Mp + 3) / 4), dim3(256), 0, st, img, img_rs, n_img, D, *Dp, *Mp, ws->scale, 0, ws->a);
-    hipLaunchKernelGGL(sim_pack_kernel, dim3((*Np + 3) / 4), dim3(256), 0, st, cap, cap_rs, n_cap, D, *Dp, *Np, ws->scale, 1, ws->b);
-    const int rc = aladin_check_launch("sim_pack_kernel");
-    if (rc) return rc;
-  }
-  static unsigned long long lds_reserved = 0;
-  if (int rc = aladin_reserve_lds((const void*)sim_gemm_kernel<MODE>, SimCfg::LDS_BYTES, &lds_reserved, "sim_gemm")) return rc;
-  return ALADIN_OK;
+  hipLaunchKernelGGL(sim_absmax_kernel, dim3(SIM_ABS_BLOCKS), dim3(256), 0, st, img, img_rs, n_img, cap, cap_rs, n_cap, D, ws->partial);
+  const int rows_per_block = 4 * SIM_PACK_RPW;
+  hipLaunchKernelGGL(sim_pack_kernel, dim3((*Mp + *Np + rows_per_block - 1) / rows_per_block), dim3(256), 0, st, img, img_rs, n_img, *Mp, cap,
+                     cap_rs, n_cap, *Np, D, *Dp, ws->partial, ws->scale, ws->a, ws->b, ws->na, ws->nb, zero0, nz0, zero1, nz1, zero2, nz2);
+  return aladin_check_launch("sim_pack_kernel");
 }
 
 extern "C" int aladin_sim_matrix(const float* img, int64_t img_rs, const float* cap, int64_t cap_rs, int n_img, int n_cap,
@@ -356,12 +786,14 @@ extern "C" int aladin_sim_matrix(const float* img, int64_t img_rs, const float* 
   hipStream_t st = (hipStream_t)stream;
   SimWs ws;
   int Mp, Np, Dp;
-  int rc = sim_prepare<SIM_STORE>(img, img_rs, cap, cap_rs, n_img, n_cap, D, workspace, &ws, &Mp, &Np, &Dp, st, true);
+  int rc = sim_prepare(img, img_rs, cap, cap_rs, n_img, n_cap, D, workspace, &ws, &Mp, &Np, &Dp, st);
   if (rc) return rc;
+  static unsigned long long lds_reserved = 0;
+  if ((rc = aladin_reserve_lds((const void*)sim_gemm_store_kernel, SimCfg::LDS_BYTES, &lds_reserved, "sim_gemm_store"))) return rc;
   const int n_mblk = Mp / SimCfg::BM, n_nblk = Np / SimCfg::BN;
-  hipLaunchKernelGGL(sim_gemm_kernel<SIM_STORE>, dim3(n_mblk * n_nblk), dim3(SimCfg::THREADS), SimCfg::LDS_BYTES, st, ws.a, ws.b,
-                     ws.scale, sim, ld_sim, n_img, n_cap, (int64_t)3 * Dp, 3 * Dp / 64, n_nblk, n_mblk * n_nblk, SimRankArgs{});
-  return aladin_check_launch("sim_gemm_kernel");
+  hipLaunchKernelGGL(sim_gemm_store_kernel, dim3(n_mblk * n_nblk), dim3(SimCfg::THREADS), SimCfg::LDS_BYTES, st, ws.a, ws.b,
+                     ws.scale, sim, ld_sim, n_img, n_cap, (int64_t)2 * Dp, Dp / 64, n_nblk, n_mblk * n_nblk);
+  return aladin_check_launch("sim_gemm_store_kernel");
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -463,27 +895,36 @@ extern "C" int aladin_recall_ranks(const float* sim, int64_t ld_sim, int n_img, 
 }
 
 // ------------------------------------------------------------------------------------------------
-// Fused retrieval: ranks and arg-maxima of both directions straight from the embeddings; the
-// (n_img x n_cap) score matrix is never written (500 MB at COCO-5k) nor re-read by rank kernels.
-//   1. ground-truth scores through the GEMM kernel itself on the band of tiles that holds them
-//   2. the full GEMM whose epilogue compares every score with its row's / column's ground truths
-//   3. a small kernel folds the counters into the reference's ranks
-// Integer counters and packed-max atomics only: the result does not depend on the tile order.
+// Fused retrieval, host side.
+//   1. ground-truth scores (exact chain) on the band of 16 x 16 tiles that holds them
+//   2. sim_screen_kernel: prefix + band per tile, lists or exact continuation
+//   3. sim_rescore_kernel: the listed pairs, exactly
+//   4. a small kernel unpacks the arg-maxima
 // ------------------------------------------------------------------------------------------------
 struct RetrWs {
   float* gt;
   unsigned long long *best_i2t, *best_t2i;
+  int* stats;
+  int* list_cnt;
+  SimEntry* list;
 };
-static size_t retr_layout(int n_img, int n_cap, int D, char* base, RetrWs* w, size_t* counters_off, size_t* counters_bytes) {
+static size_t retr_layout(int n_img, int n_cap, int D, char* base, RetrWs* w, size_t* counters_off, size_t* counters_bytes,
+                          size_t* stats_off) {
   size_t off = (sim_ws_layout(n_img, n_cap, D, nullptr, nullptr, nullptr, nullptr, nullptr) + 255) / 256 * 256;
   auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off += (bytes + 255) / 256 * 256; return p; };
+  const int n_tiles = (round_up(n_img, SimCfg::BM) / SimCfg::BM) * (round_up(n_cap, SimCfg::BN) / SimCfg::BN);
   float* gt = (float*)take((size_t)n_cap * 4);
   const size_t c0 = off;
   unsigned long long* bi = (unsigned long long*)take((size_t)n_img * 8);
   unsigned long long* bt = (unsigned long long*)take((size_t)n_cap * 8);
-  if (w) *w = RetrWs{gt, bi, bt};
+  if (stats_off) *stats_off = off;
+  int* stats = (int*)take(256);
+  const size_t c1 = off;
+  int* lc = (int*)take((size_t)n_tiles * 4);
+  SimEntry* list = (SimEntry*)take((size_t)n_tiles * SIM_LIST_CAP * sizeof(SimEntry));
+  if (w) *w = RetrWs{gt, bi, bt, stats, lc, list};
   if (counters_off) *counters_off = c0;
-  if (counters_bytes) *counters_bytes = off - c0;
+  if (counters_bytes) *counters_bytes = c1 - c0;
   return off;
 }
 
@@ -498,12 +939,19 @@ __global__ __launch_bounds__(256) void retrieval_finish_kernel(const unsigned lo
 
 extern "C" size_t aladin_retrieval_workspace_bytes(int n_img, int n_cap, int D) {
   if (n_img < 1 || n_cap < 1 || D < 1) return 0;
-  return retr_layout(n_img, n_cap, D, nullptr, nullptr, nullptr, nullptr);
+  return retr_layout(n_img, n_cap, D, nullptr, nullptr, nullptr, nullptr, nullptr);
 }
 
-extern "C" int aladin_retrieval_ranks(const float* img, int64_t img_rs, const float* cap, int64_t cap_rs, int n_img, int n_cap,
-                                      int D, int caps_per_img, int32_t* rank_i2t, int32_t* top1_i2t, int32_t* rank_t2i,
-                                      int32_t* top1_t2i, void* workspace, void* stream) {
+extern "C" size_t aladin_retrieval_stats_offset(int n_img, int n_cap, int D) {
+  if (n_img < 1 || n_cap < 1 || D < 1) return 0;
+  size_t so = 0;
+  retr_layout(n_img, n_cap, D, nullptr, nullptr, nullptr, nullptr, &so);
+  return so;
+}
+
+static int retrieval_ranks_impl(const float* img, int64_t img_rs, const float* cap, int64_t cap_rs, int n_img, int n_cap,
+                                int D, int caps_per_img, int32_t* rank_i2t, int32_t* top1_i2t, int32_t* rank_t2i,
+                                int32_t* top1_t2i, void* workspace, void* stream, bool force_exact) {
   if (!img || !cap || !rank_i2t || !top1_i2t || !rank_t2i || !top1_t2i || !workspace || D < 1 || img_rs < D || cap_rs < D) {
     aladin_set_error("retrieval_ranks: bad argument");
     return ALADIN_ERR_ARG;
@@ -516,35 +964,64 @@ extern "C" int aladin_retrieval_ranks(const float* img, int64_t img_rs, const fl
   SimWs ws;
   RetrWs rw;
   size_t c_off, c_bytes;
-  retr_layout(n_img, n_cap, D, (char*)workspace, &rw, &c_off, &c_bytes);
+  retr_layout(n_img, n_cap, D, (char*)workspace, &rw, &c_off, &c_bytes, nullptr);
   int Mp, Np, Dp;
-  int rc = sim_prepare<SIM_RANK>(img, img_rs, cap, cap_rs, n_img, n_cap, D, workspace, &ws, &Mp, &Np, &Dp, st, true);
+  int rc = sim_prepare(img, img_rs, cap, cap_rs, n_img, n_cap, D, workspace, &ws, &Mp, &Np, &Dp, st, (int32_t*)((char*)workspace + c_off),
+                       (int64_t)(c_bytes / 4), rank_i2t, n_img, rank_t2i, n_cap);
   if (rc) return rc;
-  if (hipMemsetAsync((char*)workspace + c_off, 0, c_bytes, st) != hipSuccess || hipMemsetAsync(rank_t2i, 0, (size_t)n_cap * 4, st) != hipSuccess ||
-      hipMemsetAsync(rank_i2t, 0, (size_t)n_img * 4, st) != hipSuccess) {
-    aladin_set_error("retrieval_ranks: memset failed");
-    return ALADIN_ERR_HIP;
-  }
-  const int n_mblk = Mp / SimCfg::BM, n_nblk = Np / SimCfg::BN;
+  static unsigned long long lds_reserved[2] = {0, 0};
+  const void* kern = force_exact ? (const void*)sim_screen_kernel<true> : (const void*)sim_screen_kernel<false>;
+  if ((rc = aladin_reserve_lds(kern, SimCfg::LDS_BYTES, &lds_reserved[force_exact ? 1 : 0], "sim_screen"))) return rc;
+  const int n_mblk = Mp / SimCfg::BM, n_nblk = Np / SimCfg::BN, n_tiles = n_mblk * n_nblk;
+  const int64_t ldk = (int64_t)2 * Dp;
+  const int kps = Dp / 64;
   SimRankArgs ra{};
   ra.cpi = caps_per_img;
   ra.gt = rw.gt;
+  ra.na = ws.na;
+  ra.nb = ws.nb;
   ra.cnt_i2t = rank_i2t;                                 // the row counters ARE the i2t ranks
   ra.cnt_t2i = rank_t2i;                                 // the column counters ARE the t2i ranks
   ra.best_i2t = rw.best_i2t;
   ra.best_t2i = rw.best_t2i;
+  ra.list = rw.list;
+  ra.list_cnt = rw.list_cnt;
+  ra.stats = rw.stats;
   {
     const int tiles = cdiv(n_img, 16) * caps_per_img;
-    hipLaunchKernelGGL(sim_gt_kernel, dim3(cdiv(tiles, 4)), dim3(256), 0, st, ws.a, ws.b, ws.scale, n_img, n_cap, caps_per_img,
-                       (int64_t)3 * Dp, 3 * Dp / 32, rw.gt);
+    hipLaunchKernelGGL(sim_gt_kernel, dim3(cdiv(tiles, 4)), dim3(256), 0, st, ws.a, ws.b, n_img, n_cap, caps_per_img, ldk, kps, rw.gt,
+                       rw.best_i2t, rw.best_t2i);
   }
-  hipLaunchKernelGGL(sim_gemm_kernel<SIM_RANK>, dim3(n_mblk * n_nblk), dim3(SimCfg::THREADS), SimCfg::LDS_BYTES, st, ws.a, ws.b,
-                     ws.scale, nullptr, 0, n_img, n_cap, (int64_t)3 * Dp, 3 * Dp / 64, n_nblk, n_mblk * n_nblk, ra);
-  rc = aladin_check_launch("sim_gemm_kernel<rank>");
+  if (force_exact)
+    hipLaunchKernelGGL(sim_screen_kernel<true>, dim3(n_tiles), dim3(SimCfg::THREADS), SimCfg::LDS_BYTES, st, ws.a, ws.b, ws.scale, n_img, n_cap,
+                       ldk, kps, n_nblk, n_tiles, ra);
+  else
+    hipLaunchKernelGGL(sim_screen_kernel<false>, dim3(n_tiles), dim3(SimCfg::THREADS), SimCfg::LDS_BYTES, st, ws.a, ws.b, ws.scale, n_img, n_cap,
+                       ldk, kps, n_nblk, n_tiles, ra);
+  rc = aladin_check_launch("sim_screen_kernel");
   if (rc) return rc;
+  if (!force_exact) {
+    hipLaunchKernelGGL(sim_rescore_kernel, dim3(cdiv(n_tiles * (SIM_LIST_CAP / 16), 4)), dim3(256), 0, st, ws.a, ws.b, ldk, kps, n_tiles, ra);
+    rc = aladin_check_launch("sim_rescore_kernel");
+    if (rc) return rc;
+  }
   hipLaunchKernelGGL(retrieval_finish_kernel, dim3(cdiv(n_cap, 256)), dim3(256), 0, st, rw.best_i2t, rw.best_t2i, n_img, n_cap,
                      top1_i2t, top1_t2i);
   return aladin_check_launch("retrieval_finish_kernel");
+}
+
+extern "C" int aladin_retrieval_ranks(const float* img, int64_t img_rs, const float* cap, int64_t cap_rs, int n_img, int n_cap,
+                                      int D, int caps_per_img, int32_t* rank_i2t, int32_t* top1_i2t, int32_t* rank_t2i,
+                                      int32_t* top1_t2i, void* workspace, void* stream) {
+  return retrieval_ranks_impl(img, img_rs, cap, cap_rs, n_img, n_cap, D, caps_per_img, rank_i2t, top1_i2t, rank_t2i, top1_t2i, workspace,
+                              stream, false);
+}
+
+extern "C" int aladin_retrieval_ranks_exact(const float* img, int64_t img_rs, const float* cap, int64_t cap_rs, int n_img, int n_cap,
+                                            int D, int caps_per_img, int32_t* rank_i2t, int32_t* top1_i2t, int32_t* rank_t2i,
+                                            int32_t* top1_t2i, void* workspace, void* stream) {
+  return retrieval_ranks_impl(img, img_rs, cap, cap_rs, n_img, n_cap, D, caps_per_img, rank_i2t, top1_i2t, rank_t2i, top1_t2i, workspace,
+                              stream, true);
 }
 
 // ------------------------------------------------------------------------------------------------

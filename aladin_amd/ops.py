@@ -1299,10 +1299,13 @@ def recall_ranks(sim, caps_per_img=5):
     return r_i2t, t_i2t, r_t2i, t_t2i
 
 
-def retrieval_ranks(img, cap, caps_per_img=5):
+def retrieval_ranks(img, cap, caps_per_img=5, exact=False, return_stats=False):
     """(rank_i2t, top1_i2t, rank_t2i, top1_t2i) straight from the (n_img, D) / (n_cap, D) embeddings:
     sim_matrix + recall_ranks fused, the (n_img, n_cap) score matrix is never written.  Same bits as
-    the two-step path; replaces reference alad/recall_auxiliary.py:30-56 in one pass."""
+    the two-step path; replaces reference alad/recall_auxiliary.py:30-56 in one pass.
+    The kernel screens with the hi.hi third of the split product and continues to the exact score only the pairs a
+    rigorous per-pair bound leaves undecided (include/aladin_hip.h); exact=True forces the three-product path on
+    every tile (same outputs).  return_stats=True appends {'exact_tiles', 'listed_pairs', 'tiles'} (one D2H copy)."""
     _require_gpu(img, cap)
     if img.dim() != 2 or cap.dim() != 2 or img.shape[1] != cap.shape[1]:
         raise ValueError('aladin_amd: (n_img,D) and (n_cap,D) embeddings expected')
@@ -1316,9 +1319,14 @@ def retrieval_ranks(img, cap, caps_per_img=5):
     r_t2i = torch.empty(n_cap, dtype=torch.int32, device=dev)
     t_t2i = torch.empty(n_cap, dtype=torch.int32, device=dev)
     ws = _workspace(lib.aladin_retrieval_workspace_bytes(n_img, n_cap, D), dev)
-    _lib.check(lib.aladin_retrieval_ranks(_ptr(img), img.stride(0), _ptr(cap), cap.stride(0), n_img, n_cap, D, caps_per_img,
-                                          _ptr(r_i2t), _ptr(t_i2t), _ptr(r_t2i), _ptr(t_t2i), _ptr(ws), _stream()),
-               'retrieval_ranks')
+    fn = lib.aladin_retrieval_ranks_exact if exact else lib.aladin_retrieval_ranks
+    _lib.check(fn(_ptr(img), img.stride(0), _ptr(cap), cap.stride(0), n_img, n_cap, D, caps_per_img,
+                  _ptr(r_i2t), _ptr(t_i2t), _ptr(r_t2i), _ptr(t_t2i), _ptr(ws), _stream()), 'retrieval_ranks')
+    if return_stats:
+        off = lib.aladin_retrieval_stats_offset(n_img, n_cap, D)
+        st = ws[off:off + 8].view(torch.int32).cpu().tolist()
+        tiles = -(-n_img // 256) * -(-n_cap // 384)
+        return r_i2t, t_i2t, r_t2i, t_t2i, {'exact_tiles': st[0], 'listed_pairs': st[1], 'tiles': tiles}
     return r_i2t, t_i2t, r_t2i, t_t2i
 
 

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define ALADIN_ABI_VERSION 8
+#define ALADIN_ABI_VERSION 9
 
 /* The library is built with -fvisibility=hidden: the entry points declared here are its ONLY exports. */
 #if defined(__GNUC__)
@@ -392,7 +392,7 @@ ALADIN_API int aladin_sgemm_strided(int M, int N, int K, const float* A, int64_t
 /* ---------------------------------------------------------------------------------------------
  * Retrieval similarity matrix  sim = img @ cap.T  at evaluation scale (5000 x 25000 x 768) on the
  * 16-bit MFMA path with a hi/lo fp16 split (3 MFMAs per product, ~fp32 accuracy so that ranks
- * agree with the reference).  Replaces ims.mm(caps.t()), reference alad/recall_auxiliary.py:30,51
+ * agree with the reference; operand rows are kept [hi | lo] and one accumulator chain runs hi.hi, lo.hi, hi.lo).  Replaces ims.mm(caps.t()), reference alad/recall_auxiliary.py:30,51
  * and torch.mm at alad/evaluation.py:196,285.
  * workspace: aladin_sim_workspace_bytes(n_img, n_cap, D).
  * ------------------------------------------------------------------------------------------- */
@@ -421,12 +421,24 @@ ALADIN_API int aladin_topk(const float* M, int64_t q_stride, int64_t c_stride, i
 
 /* Fused retrieval: the same four outputs as aladin_sim_matrix + aladin_recall_ranks straight from the
  * embeddings, without ever writing the (n_img x n_cap) score matrix (reference
- * alad/recall_auxiliary.py:30-56 / alad/evaluation.py:196-223,285-308 in one pass): the ground-truth
- * scores come from the GEMM kernel itself run on the band of tiles that holds them, and the full GEMM's
- * epilogue counts, per image row and per caption column, the scores that beat them (integer and
- * packed-max atomics: independent of the tile order, bit-identical to the two-step path). */
+ * alad/recall_auxiliary.py:30-56 / alad/evaluation.py:196-223,285-308 in one pass), bit-identical to the
+ * two-step path whatever the data (integer and packed-max atomics: independent of the tile order).
+ * A rank is a count of DECISIONS "score > ground truth", so the GEMM runs the hi.hi third of the split
+ * product only and bounds, per pair and rigorously (Cauchy-Schwarz on the two dropped segments of the
+ * actual fp16 operands + the fp32 rounding of their accumulation), what the rest can add; pairs the
+ * bound does not decide are continued to the exact score -- a handful per 256 x 384 tile through a list
+ * (aladin_retrieval_stats: how many), a whole tile in place when there are more than 64.  Cost: a third
+ * of the three-product GEMM when ground truths stand clear of the bulk of the scores, up to all of it
+ * when they sit inside; the result never depends on it.
+ * aladin_retrieval_ranks_exact: every tile takes the three-product path (the round-3 kernel; for A/B
+ * runs and tests).  aladin_retrieval_stats_offset: byte offset, inside the workspace of the last call,
+ * of int32[2] = {tiles continued in place, pairs continued through lists}. */
 ALADIN_API size_t aladin_retrieval_workspace_bytes(int n_img, int n_cap, int D);
+ALADIN_API size_t aladin_retrieval_stats_offset(int n_img, int n_cap, int D);
 ALADIN_API int aladin_retrieval_ranks(const float* img, int64_t img_row_stride, const float* cap, int64_t cap_row_stride, int n_img,
+                           int n_cap, int D, int caps_per_img, int32_t* rank_i2t, int32_t* top1_i2t, int32_t* rank_t2i,
+                           int32_t* top1_t2i, void* workspace, void* stream);
+ALADIN_API int aladin_retrieval_ranks_exact(const float* img, int64_t img_row_stride, const float* cap, int64_t cap_row_stride, int n_img,
                            int n_cap, int D, int caps_per_img, int32_t* rank_i2t, int32_t* top1_i2t, int32_t* rank_t2i,
                            int32_t* top1_t2i, void* workspace, void* stream);
 

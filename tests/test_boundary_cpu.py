@@ -64,7 +64,7 @@ def test_workspace_queries():
     assert lib.aladin_hinge_workspace_bytes(256) >= 256 * 16
     assert lib.aladin_listnet_workspace_bytes(256) >= 256 * 48
     assert lib.aladin_align_bwd_workspace_bytes(256, 256, 34, 50, 768) >= 256 * 256 * (4 + 47)
-    assert lib.aladin_sim_workspace_bytes(5000, 25000, 768) >= (5000 + 25000) * 3 * 768 * 2
+    assert lib.aladin_sim_workspace_bytes(5000, 25000, 768) >= (5000 + 25000) * 2 * 768 * 2      # [hi | lo] rows
     assert lib.aladin_recall_workspace_bytes(25000) == 25000 * 8
 
 

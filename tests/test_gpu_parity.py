@@ -1308,8 +1308,9 @@ def test_error_behaviour():
 
 @pytest.mark.parametrize('n_img,cpi,D', [(1, 5, 8), (7, 1, 33), (77, 3, 100), (300, 5, 64), (1000, 5, 768), (257, 8, 50), (40, 13, 24)])
 def test_fused_retrieval_ranks_equal_two_step(n_img, cpi, D):
-    """aladin_retrieval_ranks (ranks inside the GEMM epilogue, no score matrix) must give the very ints of
-    aladin_sim_matrix + aladin_recall_ranks: ragged tile edges, every captions-per-image count, odd D."""
+    """aladin_retrieval_ranks (prefix screening + exact continuation, no score matrix) must give the very ints of
+    aladin_sim_matrix + aladin_recall_ranks: ragged tile edges, every captions-per-image count, odd D; so must the
+    all-exact variant (every tile on the three-product path)."""
     from aladin_amd import ops
     rng = np.random.default_rng(n_img * 31 + cpi)
     img = rng.standard_normal((n_img, D)).astype(np.float32)
@@ -1321,11 +1322,97 @@ def test_fused_retrieval_ranks_equal_two_step(n_img, cpi, D):
     one = ops.retrieval_ranks(a, b, cpi)
     for x, y in zip(one, two):
         assert torch.equal(x, y)
+    for x, y in zip(ops.retrieval_ranks(a, b, cpi, exact=True), two):
+        assert torch.equal(x, y)
     # and against the oracle's argsort-free definition
     if n_img <= 300:
         r_i2t, _, r_t2i, _ = O.ranks_from_scores(img.astype(np.float64) @ cap.astype(np.float64).T, cpi)
         # fp64 vs device near-ties may swap neighbours
         assert np.mean(one[0].cpu().numpy() == r_i2t) >= 0.99 and np.mean(one[2].cpu().numpy() == r_t2i) >= 0.99
+
+
+def _adversarial_retrieval(case, n_img, cpi, D, seed):
+    """Inputs built to sit ON the screening kernel's decision boundaries (ops.retrieval_ranks)."""
+    rng = np.random.default_rng(seed)
+    img = rng.standard_normal((n_img, D)).astype(np.float32)
+    img /= np.linalg.norm(img, axis=1, keepdims=True)
+    if case == 'bulk':                   # ground truths inside the bulk of the scores: captions unrelated to their images
+        cap = rng.standard_normal((n_img * cpi, D)).astype(np.float32)
+        cap /= np.linalg.norm(cap, axis=1, keepdims=True)
+    elif case == 'near_duplicates':      # every caption has near-copies (relative 1e-4 .. 1e-7) filed under OTHER images
+        base = np.repeat(img, cpi, axis=0) + 0.6 * rng.standard_normal((n_img * cpi, D)).astype(np.float32)
+        cap = base.copy()
+        src = rng.integers(0, n_img * cpi, size=n_img * cpi // 2)
+        dst = rng.permutation(n_img * cpi)[:src.size]
+        eps = (10.0 ** rng.uniform(-7, -4, size=(src.size, 1))).astype(np.float32)
+        cap[dst] = base[src] * (1 + eps * rng.standard_normal((src.size, D)).astype(np.float32))
+        cap /= np.linalg.norm(cap, axis=1, keepdims=True)
+    elif case == 'exact_ties':           # bit-identical caption rows under different images, duplicated images too
+        cap = np.repeat(img, cpi, axis=0) + 0.8 * rng.standard_normal((n_img * cpi, D)).astype(np.float32)
+        cap /= np.linalg.norm(cap, axis=1, keepdims=True)
+        k = n_img * cpi
+        src = rng.integers(0, k, size=k // 3)
+        dst = rng.permutation(k)[:src.size]
+        cap[dst] = cap[src]
+        isrc = rng.integers(0, n_img, size=n_img // 4)
+        idst = rng.permutation(n_img)[:isrc.size]
+        img[idst] = img[isrc]
+    elif case == 'norms':                # wildly different row norms (the band is per pair, not per matrix), some tiny rows
+        cap = np.repeat(img, cpi, axis=0) + 1.2 * rng.standard_normal((n_img * cpi, D)).astype(np.float32)
+        cap *= (10.0 ** rng.uniform(-3, 1, size=(n_img * cpi, 1))).astype(np.float32)
+        img *= (10.0 ** rng.uniform(-3, 1, size=(n_img, 1))).astype(np.float32)
+        img[::17] = 0.0
+        cap[::29] = 0.0
+    elif case == 'mixed':                # half the images retrieve cleanly, half have their ground truths in the bulk
+        cap = np.repeat(img, cpi, axis=0) + 0.3 * rng.standard_normal((n_img * cpi, D)).astype(np.float32)
+        bad = np.repeat(rng.random(n_img) < 0.5, cpi)
+        cap[bad] = rng.standard_normal((int(bad.sum()), D)).astype(np.float32)
+        cap /= np.linalg.norm(cap, axis=1, keepdims=True)
+    else:
+        raise ValueError(case)
+    return img, cap.astype(np.float32)
+
+
+@pytest.mark.parametrize('case', ['bulk', 'near_duplicates', 'exact_ties', 'norms', 'mixed'])
+@pytest.mark.parametrize('n_img,cpi,D', [(700, 5, 768), (1300, 3, 96), (520, 1, 40)])
+def test_fused_retrieval_adversarial_equals_two_step(case, n_img, cpi, D):
+    """ground truths in the bulk, near-duplicate captions, exact ties, mixed norms -- the screened
+    retrieval equals the two-step split path (stored scores + rank kernels) int for int, and so does the all-exact
+    variant; the statistics say which mechanism ran (lists vs tiles continued in place)."""
+    from aladin_amd import ops
+    img, cap = _adversarial_retrieval(case, n_img, cpi, D, seed=n_img + 7 * cpi)
+    a, b = T(img), T(cap)
+    two = ops.recall_ranks(ops.sim_matrix(a, b), cpi)
+    *one, stats = ops.retrieval_ranks(a, b, cpi, return_stats=True)
+    for x, y in zip(one, two):
+        assert torch.equal(x, y), (case, stats)
+    for x, y in zip(ops.retrieval_ranks(a, b, cpi, exact=True), two):
+        assert torch.equal(x, y)
+    assert 0 <= stats['exact_tiles'] <= stats['tiles']
+    if case == 'bulk' and D >= 96 and cpi > 1:
+        assert stats['exact_tiles'] > 0                  # thousands of undecided pairs per tile: continued in place
+    # ranks against float64 on the host: only near-ties may differ
+    r_i2t, _, r_t2i, _ = O.ranks_from_scores(img.astype(np.float64) @ cap.astype(np.float64).T, cpi)
+    if case in ('bulk', 'mixed'):
+        assert np.mean(one[0].cpu().numpy() == r_i2t) >= 0.98 and np.mean(one[2].cpu().numpy() == r_t2i) >= 0.98
+
+
+def test_fused_retrieval_clean_data_uses_the_screen():
+    """Ground truths clear of the bulk (what a trained matching head produces): no tile needs the exact path and only a
+    few pairs are continued through lists."""
+    from aladin_amd import ops
+    rng = np.random.default_rng(5)
+    n_img, cpi, D = 1500, 5, 768
+    img = rng.standard_normal((n_img, D)).astype(np.float32)
+    cap = np.repeat(img, cpi, axis=0) + 0.7 * rng.standard_normal((n_img * cpi, D)).astype(np.float32)
+    img /= np.linalg.norm(img, axis=1, keepdims=True)
+    cap /= np.linalg.norm(cap, axis=1, keepdims=True)
+    a, b = T(img), T(cap)
+    *one, stats = ops.retrieval_ranks(a, b, cpi, return_stats=True)
+    two = ops.recall_ranks(ops.sim_matrix(a, b), cpi)
+    for x, y in zip(one, two):
+        assert torch.equal(x, y)
+    assert stats['exact_tiles'] == 0 and stats['listed_pairs'] < 2000, stats
 
 
 def test_config3_full_size_retrieval_ranks():

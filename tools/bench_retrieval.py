@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""configs[2] (5000 x 25000 x 768 matching-head retrieval, aladin_retrieval_ranks) over data of different difficulty:
+the cost of the screened kernel depends on where the ground-truth scores sit relative to the bulk of the scores
+(the RESULT never does: every run is checked against the two-step split path).  Prints one JSON line per data set:
+Recall@1 of both directions, fused ms (screened / all-exact), tiles continued in place, pairs continued through lists.
+usage: tools/bench_retrieval.py [--profile]   (--profile: a few calls only, for rocprofv3)"""
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+from aladin_amd import ops, synth
+
+
+def ev_ms(fn, iters=20, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def datasets(dev):
+    n_img, D = 5000, 768
+    g = torch.Generator(device='cpu').manual_seed(7)
+    img = torch.nn.functional.normalize(torch.randn(n_img, D, generator=g), dim=1)
+    noise = torch.randn(5 * n_img, D, generator=g)
+    # captions = normalize(image + t * noise): t = 0.05 is bench.py's round-1..3 timing input (every R@1 = 100)
+    for t in (0.05, 0.5, 0.8, 1.0):
+        cap = torch.nn.functional.normalize(img.repeat_interleave(5, 0) + t * noise / D ** 0.5 * (D ** 0.5), dim=1)
+        yield 'caption = image + %.2f * N(0, I)' % t, img.to(dev), cap.to(dev)
+    for sigma in (3.0, 6.0, 12.0):
+        i, c = synth.retrieval_embeddings(n_img, D, seed=303, sigma=sigma)
+        yield 'synth.retrieval_embeddings(sigma=%g)%s' % (sigma, ' = tests/config 3 full size' if sigma == 12.0 else ''), \
+            torch.from_numpy(i[0::5]).to(dev), torch.from_numpy(c).to(dev)
+
+
+def main():
+    dev = torch.device('cuda:0')
+    profile = '--profile' in sys.argv
+    for name, a, b in datasets(dev):
+        *one, st = ops.retrieval_ranks(a, b, return_stats=True)
+        if not profile:
+            two = ops.recall_ranks(ops.sim_matrix(a, b))
+            assert all(torch.equal(x, y) for x, y in zip(one, two)), name
+            assert all(torch.equal(x, y) for x, y in zip(ops.retrieval_ranks(a, b, exact=True), two)), name
+        r1_i = float((one[0] == 0).float().mean()) * 100
+        r1_t = float((one[2] == 0).float().mean()) * 100
+        it = 3 if profile else 20
+        ms = ev_ms(lambda: ops.retrieval_ranks(a, b), iters=it)
+        ms_x = ev_ms(lambda: ops.retrieval_ranks(a, b, exact=True), iters=it)
+        print(json.dumps({'data': name, 'R@1_i2t': round(r1_i, 1), 'R@1_t2i': round(r1_t, 1), 'fused_ms': round(ms, 4),
+                          'fused_all_exact_ms': round(ms_x, 4), 'exact_tiles': st['exact_tiles'], 'tiles': st['tiles'],
+                          'listed_pairs': st['listed_pairs'], 'equal_to_two_step': not profile}), flush=True)
+
+
+if __name__ == '__main__':
+    main()
