@@ -345,12 +345,25 @@ class ImageBertForSequenceClassification(nn.Module):
     @classmethod
     def from_pretrained(cls, path, config=None, map_location='cpu'):
         """`path`: the checkpoint directory of the VinVL model zoo (config.json + pytorch_model.bin), as the reference
-        passes it (alad_model.py:40-43, train.py --eval_model_dir).  Loads with strict=True."""
+        passes it (alad_model.py:40-43, train.py --eval_model_dir).  Like pytorch_transformers' loader the reference goes
+        through, keys outside the backbone are tolerated: a pre-training checkpoint carries `cls.*` and no `classifier.*`,
+        newer exports add buffers such as `bert.embeddings.position_ids` -- those are reported with a warning.  A MISSING
+        `bert.*` parameter is an error (the encoder would silently run on random weights)."""
+        import warnings
         config = config or BertConfig.from_pretrained(path)
         model = cls(config)
         weights = os.path.join(path, 'pytorch_model.bin') if os.path.isdir(path) else path
         state = torch.load(weights, map_location=map_location)
-        model.load_state_dict(state, strict=True)
+        missing, unexpected = model.load_state_dict(state, strict=False)
+        bad = [k for k in missing if k.startswith('bert.')]
+        if bad:
+            raise RuntimeError('aladin_amd.backbone: checkpoint %s lacks backbone parameters: %s%s'
+                               % (weights, ', '.join(bad[:8]), ' ...' if len(bad) > 8 else ''))
+        if missing:
+            warnings.warn('aladin_amd.backbone: not in the checkpoint, left at their initial values: %s' % ', '.join(missing))
+        if unexpected:
+            warnings.warn('aladin_amd.backbone: checkpoint keys this model does not use: %s%s'
+                          % (', '.join(unexpected[:8]), ' ...' if len(unexpected) > 8 else ''))
         return model
 
     def forward(self, input_ids, token_type_ids=None, attention_mask=None, labels=None, position_ids=None, head_mask=None,

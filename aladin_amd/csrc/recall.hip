@@ -18,6 +18,8 @@
 // (a third of the work) and pays for the other two segments only where a decision needs them; see
 // sim_screen_kernel.
 #include "../../include/aladin_hip.h"
+#include <utility>
+
 #include "gemm_core.hpp"
 
 using SimCfg = GemmCfg<2, 4, 4, 3>;       // 256 x 384 tile, 8 waves x (128 x 96), v_mfma_f32_16x16x32_f16 body (gemm_mainloop16_tall, gemm_core.hpp:
@@ -305,6 +307,11 @@ struct SimRankArgs {
   int* stats;                         // [0] tiles that went exact, [1] listed pairs
 };
 
+template <int... I, class F>
+__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>, F&& f) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) { static_for_impl(std::make_integer_sequence<int, N>{}, f); }
+
 __device__ __forceinline__ unsigned wave_or(unsigned v) {
   auto s32 = __builtin_amdgcn_permlane32_swap(v, v, false, false);
   v = s32[0] | s32[1];
@@ -327,14 +334,36 @@ __device__ __forceinline__ int row16_isum(int t) {
 // is recomputed after the loop instead of living (or spilling) through it
 __device__ __forceinline__ int fresh_tid() { int t = threadIdx.x; asm volatile("" : "+v"(t)); return t; }
 __device__ __forceinline__ float fmax_nc(float a, float b) { return __builtin_elementwise_maximum(a, b); }    // IEEE maximum: no canonicalising v_max x, x, x
+__device__ __forceinline__ float row16_max(float v) {
+  v = fmax_nc(v, ALADIN_ROW_ROR(v, 8));
+  v = fmax_nc(v, ALADIN_ROW_ROR(v, 4));
+  v = fmax_nc(v, ALADIN_ROW_ROR(v, 2));
+  v = fmax_nc(v, ALADIN_ROW_ROR(v, 1));
+  return v;
+}
+__device__ __forceinline__ int row16_imin(int t) {
+  int o;
+  o = __builtin_amdgcn_update_dpp(0, t, 0x128, 0xF, 0xF, false); t = o < t ? o : t;
+  o = __builtin_amdgcn_update_dpp(0, t, 0x124, 0xF, 0xF, false); t = o < t ? o : t;
+  o = __builtin_amdgcn_update_dpp(0, t, 0x122, 0xF, 0xF, false); t = o < t ? o : t;
+  o = __builtin_amdgcn_update_dpp(0, t, 0x121, 0xF, 0xF, false); t = o < t ? o : t;
+  return t;
+}
 
+// ALADIN_DIAG build (make diag): thread 0 of every tile leaves wall-clock stamps of its phases in the tile's list segment
+// (tools/retrieval_stamps.py reads them; a tile that lists pairs overwrites them -- the tool looks at the others)
+#ifdef ALADIN_DIAG
+#define SIM_STAMP(k) do { if (threadIdx.x == 0) reinterpret_cast<long long*>(ra.list + (int64_t)(mb * n_nblk + nb) * SIM_LIST_CAP)[k] = wall_clock64(); } while (0)
+#else
+#define SIM_STAMP(k) do { } while (0)
+#endif
 // The exact epilogue (round 3): every accumulator holds the full chain.  Scores are compared in the accumulators' own
 // scale (gt[] is kept in it).  The workgroup's partial results meet in LDS (free after the main loop) so that each row /
 // column of the tile costs ONE global atomic per counter instead of one per wave.
 // i2t: the reference's rank is the best of the image's cpi captions (recall_auxiliary.py:38-44);
 // #(v > t) never grows with t, so that minimum is the count against the LARGEST ground truth.
 __device__ __forceinline__ void sim_rank_epilogue_exact(f32x4 (&acc)[SIM_RT][SIM_CT], char* smem, int mb, int nb, int n_img, int n_cap,
-                                                        const SimRankArgs& ra) {
+                                                        const SimRankArgs& ra, int n_nblk) {
   using Cfg = SimCfg;
   constexpr int RT = SIM_RT, CT = SIM_CT;
   const int tid = fresh_tid();
@@ -364,7 +393,11 @@ __device__ __forceinline__ void sim_rank_epilogue_exact(f32x4 (&acc)[SIM_RT][SIM
     l_gcol[e] = (c < n_cap) ? ra.gt[c] : INFINITY;
   }
   __syncthreads();
+  SIM_STAMP(8);
   const int lrow0 = wm * (RT * 16) + 4 * (lane >> 4), lcol0 = wn * (CT * 16) + (lane & 15);
+  // Reductions by DPP row rotations (the 16 lanes of a row) and permlane swaps (the 4 lane groups of a column): round 3
+  // used __shfl_xor (ds_bpermute through the LDS crossbar, ~400 of them per wave) and this epilogue took as long as a
+  // K = 768 main loop (26 us per tile, phase stamps).
   // ---- rows: lanes with the same lane >> 4 share a row; CT columns each
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt)
@@ -376,27 +409,24 @@ __device__ __forceinline__ void sim_rank_epilogue_exact(f32x4 (&acc)[SIM_RT][SIM
       float best = -INFINITY;
 #pragma unroll
       for (int ct = 0; ct < CT; ++ct) {
-        const float v = (col0 + ct * 16 < n_cap) ? acc[rt][ct][reg] : -INFINITY;    // pad columns never count, never win
+        const float v = acc[rt][ct][reg];               // pad rows / columns and ground-truth pairs are -inf since phase 0: never count, never win
         cnt += (v > g);
-        best = fmaxf(best, v);
+        best = fmax_nc(best, v);
       }
-#pragma unroll
-      for (int o = 8; o > 0; o >>= 1) {
-        cnt += __shfl_xor(cnt, o, 64);
-        best = fmaxf(best, __shfl_xor(best, o, 64));
-      }
+      cnt = row16_isum(cnt);
+      best = row16_max(best);
       // the maximum's first column: this lane's first hit (columns ascend with ct), then the smallest over the 16 lanes
       int besti = 0x7fffffff;
 #pragma unroll
       for (int ct = CT - 1; ct >= 0; --ct)
-        if (col0 + ct * 16 < n_cap && acc[rt][ct][reg] == best) besti = col0 + ct * 16;
-#pragma unroll
-      for (int o = 8; o > 0; o >>= 1) { const int oi = __shfl_xor(besti, o, 64); besti = oi < besti ? oi : besti; }
+        if (acc[rt][ct][reg] == best) besti = col0 + ct * 16;
+      besti = row16_imin(besti);
       if (row < n_img && (lane & 15) == 0) {
         if (cnt) atomicAdd(&l_row[lrow], cnt);
         if (besti != 0x7fffffff && best > -INFINITY) atomicMax(&l_brow[lrow], pack_best(best, besti));
       }
     }
+  SIM_STAMP(9);
   // ---- columns: lanes with the same lane & 15 share a column; 16 rows each
 #pragma unroll
   for (int ct = 0; ct < CT; ++ct) {
@@ -408,29 +438,30 @@ __device__ __forceinline__ void sim_rank_epilogue_exact(f32x4 (&acc)[SIM_RT][SIM
     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg) {
-        const float v = (row0 + rt * 16 + reg < n_img) ? acc[rt][ct][reg] : -INFINITY;
+        const float v = acc[rt][ct][reg];
         cnt += (v > g);
-        best = fmaxf(best, v);
+        best = fmax_nc(best, v);
       }
-#pragma unroll
-    for (int o = 16; o < 64; o <<= 1) {
-      cnt += __shfl_xor(cnt, o, 64);
-      best = fmaxf(best, __shfl_xor(best, o, 64));
-    }
+    cnt += lane_xor16(cnt);
+    cnt += lane_xor32(cnt);
+    best = fmax_nc(best, lane_xor16(best));
+    best = fmax_nc(best, lane_xor32(best));
     int besti = 0x7fffffff;
 #pragma unroll
     for (int rt = RT - 1; rt >= 0; --rt)
 #pragma unroll
       for (int reg = 3; reg >= 0; --reg)
-        if (row0 + rt * 16 + reg < n_img && acc[rt][ct][reg] == best) besti = row0 + rt * 16 + reg;     // rows ascend with (rt, reg)
-#pragma unroll
-    for (int o = 16; o < 64; o <<= 1) { const int oi = __shfl_xor(besti, o, 64); besti = oi < besti ? oi : besti; }
+        if (acc[rt][ct][reg] == best) besti = row0 + rt * 16 + reg;     // rows ascend with (rt, reg)
+    { const int o = lane_xor16(besti); besti = o < besti ? o : besti; }
+    { const int o = lane_xor32(besti); besti = o < besti ? o : besti; }
     if (col < n_cap && lane < 16) {
       if (cnt) atomicAdd(&l_col[lcol], cnt);
       if (besti != 0x7fffffff && best > -INFINITY) atomicMax(&l_bcol[lcol], pack_best(best, besti));
     }
   }
+  SIM_STAMP(10);
   __syncthreads();
+  SIM_STAMP(11);
   // ---- one global atomic per non-zero counter; arg-maxima only when they beat what is already there
   for (int e = threadIdx.x; e < Cfg::BM; e += Cfg::THREADS) {
     const int row = mb * Cfg::BM + e;
@@ -467,7 +498,9 @@ __global__ __launch_bounds__(512) void sim_screen_kernel(const half_t* __restric
     for (int ct = 0; ct < CT; ++ct) acc[rt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
   const half_t* a_tile = a + (int64_t)mb * Cfg::BM * ldk;
   const half_t* b_tile = b + (int64_t)nb * Cfg::BN * ldk;
+  SIM_STAMP(0);
   gemm_mainloop16_tall<Cfg>(a_tile, b_tile, ldk, kps, smem, acc);          // hi.hi: the prefix of every pair's chain
+  SIM_STAMP(1);
   const int tid = fresh_tid();
   const int wave = tid >> 6, lane = tid & 63;
   const int wm = wave / Cfg::WGN, wn = wave % Cfg::WGN;
@@ -494,8 +527,10 @@ __global__ __launch_bounds__(512) void sim_screen_kernel(const half_t* __restric
     }
   }
   if constexpr (!FORCE_EXACT) {
-    __syncthreads();                                                 // every wave is done with the operand stages
-    float* l_thrRow = reinterpret_cast<float*>(smem);                // [BM] s below this cannot reach the row's ground truth
+    // The analysis arrays live in the stage the LAST K step did not use: every wave left that stage before the last step's
+    // barrier and nothing refills it any more, so no barrier is needed before writing them.
+    char* ep = smem + ((kps & 1) ? Cfg::STAGE_BYTES : 0);
+    float* l_thrRow = reinterpret_cast<float*>(ep);                  // [BM] s below this cannot reach the row's ground truth
     float* l_P = l_thrRow + Cfg::BM;
     float* l_R = l_P + Cfg::BM;
     float* l_Grow = l_R + Cfg::BM;
@@ -516,8 +551,20 @@ __global__ __launch_bounds__(512) void sim_screen_kernel(const half_t* __restric
     // the tile's largest band factors bound every pair's band from above: the cheap test of phase 1
     const int e = tid;
     float2 pr = {0.f, 0.f}, qt = {0.f, 0.f};
-    if (e < Cfg::BM) pr = ra.na[mb * Cfg::BM + e];                   // padded rows exist and are zero
-    if (e < Cfg::BN) qt = ra.nb[nb * Cfg::BN + e];
+    float g_row = INFINITY, g_col = INFINITY;                        // every global load of the analysis goes out here, in one latency
+    if (e < Cfg::BM) {
+      const int row = mb * Cfg::BM + e;
+      pr = ra.na[row];                                               // padded rows exist and are zero
+      if (row < n_img) {
+        g_row = -INFINITY;
+        for (int q = 0; q < ra.cpi; ++q) g_row = fmaxf(g_row, ra.gt[row * ra.cpi + q]);
+      }
+    }
+    if (e < Cfg::BN) {
+      const int col = nb * Cfg::BN + e;
+      qt = ra.nb[col];
+      if (col < n_cap) g_col = ra.gt[col];
+    }
     {
       const float wP = wave_max(pr.x), wR = wave_max(pr.y), wQ = wave_max(qt.x), wT = wave_max(qt.y);
       if (lane == 0) { l_wmax[wave * 4 + 0] = wP; l_wmax[wave * 4 + 1] = wR; l_wmax[wave * 4 + 2] = wQ; l_wmax[wave * 4 + 3] = wT; }
@@ -529,23 +576,20 @@ __global__ __launch_bounds__(512) void sim_screen_kernel(const half_t* __restric
       Pg = fmaxf(Pg, l_wmax[w * 4 + 0]); Rg = fmaxf(Rg, l_wmax[w * 4 + 1]); Qg = fmaxf(Qg, l_wmax[w * 4 + 2]); Tg = fmaxf(Tg, l_wmax[w * 4 + 3]);
     }
     if (e < Cfg::BM) {
-      const int row = mb * Cfg::BM + e;
-      float g = INFINITY, thr = INFINITY;
+      const float g = g_row;
+      float thr = INFINITY;
       const float bm = fmaf(pr.x, Qg, pr.y * Tg);                    // >= fmaf(P, Q_j, R * T_j) for every j of the tile: the operations are monotone
-      if (row < n_img) {
-        g = -INFINITY;
-        for (int q = 0; q < ra.cpi; ++q) g = fmaxf(g, ra.gt[row * ra.cpi + q]);
+      if (g < INFINITY) {
         const float t = g - bm;
         thr = t - 0x1p-13f * fabsf(t) - 0x1p-20f * bm;               // s < thr  =>  s + bm + 2^-14 |s| < g, roundings included
       }
       l_thrRow[e] = thr; l_P[e] = pr.x; l_R[e] = pr.y; l_Grow[e] = g; l_bmaxRow[e] = bm; l_rowmax[e] = 0u; l_rowcnt[e] = 0;
     }
     if (e < Cfg::BN) {
-      const int col = nb * Cfg::BN + e;
-      float g = INFINITY, thr = INFINITY;
+      const float g = g_col;
+      float thr = INFINITY;
       const float bm = fmaf(Pg, qt.x, Rg * qt.y);
-      if (col < n_cap) {
-        g = ra.gt[col];
+      if (g < INFINITY) {
         const float t = g - bm;
         thr = t - 0x1p-13f * fabsf(t) - 0x1p-20f * bm;
       }
@@ -553,6 +597,7 @@ __global__ __launch_bounds__(512) void sim_screen_kernel(const half_t* __restric
     }
     if (tid == 0) *l_listn = 0;
     __syncthreads();
+    SIM_STAMP(2);
     // ---- phase 1: which rows / columns of this wave hold a score within reach of their ground truth at all
     unsigned rowmask = 0u, colmask = 0u;
     {
@@ -584,38 +629,55 @@ __global__ __launch_bounds__(512) void sim_screen_kernel(const half_t* __restric
     }
     const unsigned rowAny = wave_or(rowmask), colAny = wave_or(colmask);      // wave-uniform
     __syncthreads();
-    // ---- phase 2: the flagged rows / columns element by element
+    SIM_STAMP(3);
+    // ---- phase 2: the flagged rows / columns, one group of 4 rows x 16 columns (an accumulator register across the wave) at a
+    // time.  A group is looked at closely only if one of its 64 scores passes the cheap test of phase 1 against ITS row or
+    // column; pushes are aggregated per wave (one LDS atomic per group); once the list has overflowed the tile is going to
+    // continue its chains anyway and the rest of the analysis is skipped.
     if (rowAny | colAny) {
-      float Q[CT], Tt[CT], Gc[CT], Lc[CT];
+      float Q[CT], Tt[CT], Gc[CT], Lc[CT], thrC[CT];
       int ccnt[CT];
 #pragma unroll
       for (int ct = 0; ct < CT; ++ct) {
         const int lc = lcol0 + ct * 16;
-        Q[ct] = l_Q[lc]; Tt[ct] = l_T[lc]; Gc[ct] = l_Gcol[lc];
+        Q[ct] = l_Q[lc]; Tt[ct] = l_T[lc]; Gc[ct] = l_Gcol[lc]; thrC[ct] = l_thrCol[lc];
         const unsigned k = l_colmax[lc];
         float L = -INFINITY;
         if (k) { const float m = key_float(k); L = (m - l_bmaxCol[lc]) - 0x1p-13f * fabsf(m); }     // <= lo of that element <= the exact column maximum
         Lc[ct] = fmaxf(Gc[ct], L);
         ccnt[ct] = 0;
       }
-#pragma unroll
-      for (int rt = 0; rt < RT; ++rt)
+      bool overflow = false;
+      // (a compile-time loop: the body is past the size up to which `#pragma unroll` is honoured, and an rt that is not a
+      // constant would put the accumulators in scratch)
+      static_for<RT>([&](auto rt_) {
+        constexpr int rt = decltype(rt_)::value;
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
+          if (overflow) continue;
+          overflow = *reinterpret_cast<volatile int*>(l_listn) > SIM_LIST_CAP;    // wave-uniform (one LDS address)
+          if (overflow) continue;
           const bool rowbit = (rowAny >> (rt * 4 + reg)) & 1u;
           if (!rowbit && !colAny) continue;
           const int lr = lrow0 + rt * 16 + reg;
-          const float P = l_P[lr], R = l_R[lr], Gr = l_Grow[lr];
-          const unsigned k = l_rowmax[lr];
-          float Lr = -INFINITY;
-          if (k) { const float m = key_float(k); Lr = (m - l_bmaxRow[lr]) - 0x1p-13f * fabsf(m); }
-          Lr = fmaxf(Gr, Lr);
+          const float thrR = l_thrRow[lr];
+          float P = 0.f, R = 0.f, Gr = INFINITY, Lr = INFINITY;
+          bool loaded = false;
           int rcnt = 0;
 #pragma unroll
           for (int ct = 0; ct < CT; ++ct) {
             const bool colbit = (colAny >> ct) & 1u;
             if (!rowbit && !colbit) continue;
             const float s = acc[rt][ct][reg];
+            if (!__any((s >= thrR) | (s >= thrC[ct]))) continue;      // nobody in this group is within reach of its row's or column's ground truth
+            if (!loaded) {
+              loaded = true;
+              P = l_P[lr]; R = l_R[lr]; Gr = l_Grow[lr];
+              const unsigned k = l_rowmax[lr];
+              Lr = -INFINITY;
+              if (k) { const float m = key_float(k); Lr = (m - l_bmaxRow[lr]) - 0x1p-13f * fabsf(m); }
+              Lr = fmaxf(Gr, Lr);
+            }
             const float band = fmaf(fabsf(s), 0x1p-14f, fmaf(P, Q[ct], R * Tt[ct]));
             const float hi = s + band, lo = s - band;
             int f = 0;
@@ -625,14 +687,21 @@ __global__ __launch_bounds__(512) void sim_screen_kernel(const half_t* __restric
             const bool gc = lo > Gc[ct];
             ccnt[ct] += gc;
             if (hi >= Gc[ct]) { if (!gc) f |= SIM_F_COLCNT; if (hi >= Lc[ct]) f |= SIM_F_COLARG; }
-            if (f) {
-              const int idx = atomicAdd(l_listn, 1);
-              if (idx < SIM_LIST_CAP) l_list[idx] = SimEntry{row0 + rt * 16 + reg, col0 + ct * 16, s, f};
+            const unsigned long long pm = __ballot(f != 0);
+            if (pm) {
+              int base = 0;
+              if (lane == 0) base = atomicAdd(l_listn, __popcll(pm));
+              base = lane_bcast(base, 0);
+              const int idx = base + __popcll(pm & ((1ull << lane) - 1ull));
+              if (f && idx < SIM_LIST_CAP) l_list[idx] = SimEntry{row0 + rt * 16 + reg, col0 + ct * 16, s, f};
             }
           }
-          rcnt = row16_isum(rcnt);
-          if ((lane & 15) == 0 && rcnt) atomicAdd(&l_rowcnt[lr], rcnt);
+          if (loaded) {
+            rcnt = row16_isum(rcnt);
+            if ((lane & 15) == 0 && rcnt) atomicAdd(&l_rowcnt[lr], rcnt);
+          }
         }
+      });
 #pragma unroll
       for (int ct = 0; ct < CT; ++ct) {
         int c = ccnt[ct];
@@ -642,6 +711,7 @@ __global__ __launch_bounds__(512) void sim_screen_kernel(const half_t* __restric
       }
     }
     __syncthreads();
+    SIM_STAMP(4);
     const int n_list = *l_listn;
     const bool exact = n_list > SIM_LIST_CAP;
     const int tile = mb * n_nblk + nb;
@@ -661,24 +731,33 @@ __global__ __launch_bounds__(512) void sim_screen_kernel(const half_t* __restric
     __syncthreads();                                                 // the lists are dead: the stages may be refilled
   } else {
     if (threadIdx.x == 0) ra.list_cnt[mb * n_nblk + nb] = 0;
+    __syncthreads();                                                 // the last K step's stage may be stage 0, which the continuation refills first
   }
+  SIM_STAMP(5);
   gemm_mainloop16_tall<Cfg, true, KMapSplit>(a_tile, b_tile, ldk, 2 * kps, smem, acc, KMapSplit{kps, 1});     // lo.hi, hi.lo
-  sim_rank_epilogue_exact(acc, smem, mb, nb, n_img, n_cap, ra);
+  SIM_STAMP(6);
+  sim_rank_epilogue_exact(acc, smem, mb, nb, n_img, n_cap, ra, n_nblk);
+  SIM_STAMP(7);
 }
 
 // acc (+)= A[16 x K] . B[16 x K]^T over nblk ascending 32-deep K blocks, fragments straight from global memory (16 B per lane
-// and block) with eight blocks of loads in flight: the chain of MFMAs is serial, the loads need not be.
+// and block) with NB blocks of loads in flight: the chain of MFMAs is serial, the loads need not be.
+template <int NB = 8>
 __device__ __forceinline__ void sim_chain_global(const half_t* __restrict__ ap, const half_t* __restrict__ bp, int nblk, f32x4& acc) {
   int k = 0;
-  for (; k + 8 <= nblk; k += 8) {
-    half8 af[8], bf[8];
+  for (; k + NB <= nblk; k += NB) {
+    half8 af[NB], bf[NB];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
+    for (int u = 0; u < NB; ++u) {
       af[u] = *reinterpret_cast<const half8*>(ap + (int64_t)(k + u) * 32);
       bf[u] = *reinterpret_cast<const half8*>(bp + (int64_t)(k + u) * 32);
     }
 #pragma unroll
-    for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[u], bf[u], acc, 0, 0, 0);
+    for (int u = 0; u < NB; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[u], bf[u], acc, 0, 0, 0);
+  }
+  if constexpr (NB > 8) {
+    sim_chain_global<8>(ap + (int64_t)k * 32, bp + (int64_t)k * 32, nblk - k, acc);
+    return;
   }
   for (; k < nblk; ++k) {
     const half8 af = *reinterpret_cast<const half8*>(ap + (int64_t)k * 32);
@@ -748,9 +827,11 @@ __global__ __launch_bounds__(256) void sim_gt_kernel(const half_t* __restrict__ 
   const half_t* bp = b + (int64_t)(col_t + (lane & 15)) * ldk + 8 * (lane >> 4);
   const int Dp = kps * 64;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  sim_chain_global(ap, bp, 2 * kps, acc);                              // hi.hi   (the MFMA chain stays in K order)
-  sim_chain_global(ap + Dp, bp, 2 * kps, acc);                         // lo.hi
-  sim_chain_global(ap, bp + Dp, 2 * kps, acc);                         // hi.lo
+  // 1565 waves at configs[2] size, a wave and a half per SIMD: the kernel is a chain of load latencies, so a whole
+  // segment's loads (24 blocks at D = 768) go out at once
+  sim_chain_global<24>(ap, bp, 2 * kps, acc);                          // hi.hi   (the MFMA chain stays in K order)
+  sim_chain_global<24>(ap + Dp, bp, 2 * kps, acc);                     // lo.hi
+  sim_chain_global<24>(ap, bp + Dp, 2 * kps, acc);                     // hi.lo
   const int col = col_t + (lane & 15);
 #pragma unroll
   for (int reg = 0; reg < 4; ++reg) {

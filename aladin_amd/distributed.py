@@ -194,23 +194,29 @@ def rank_backward_block(im_all, il_all_t, s_local, s_len_t, dS_full, rank, g_glo
 
 
 class _PinnedPool:
-    """A few pinned host buffers handed out in rotation for asynchronous device->host copies: a buffer comes back
-    only after the copy last issued into it has completed (event), so a plan that is never resolved cannot be
-    overwritten mid-copy and no step allocates pinned memory."""
+    """Pinned host buffers for asynchronous device->host copies, OWNED by whoever took them until handed back:
+    `get` hands out a free buffer (allocating one when none is free -- a step in steady state allocates nothing),
+    `put` returns it.  A buffer is reused only after its owner returned it AND the copy last issued into it has
+    completed (event), so any number of plans may be outstanding at once -- e.g. several micro-batch forwards before
+    one backward -- without one reading another's counts.  (Round 3 rotated 8 slots guarded by the copy event alone:
+    the ninth forward before the first backward overwrote the first plan's counts.)"""
 
-    def __init__(self, n=8):
-        self.slots, self.n, self.k = {}, n, 0
+    def __init__(self, alloc=None):
+        self.free = {}
+        self.allocated = 0
+        self._alloc = alloc or (lambda n: (torch.empty(n, dtype=torch.int64).pin_memory(), torch.cuda.Event()))
 
     def get(self, numel):
-        key = (self.k % self.n, int(numel))
-        self.k += 1
-        buf, ev = self.slots.get(key, (None, None))
-        if buf is None:
-            buf, ev = torch.empty(int(numel), dtype=torch.int64).pin_memory(), torch.cuda.Event()
-            self.slots[key] = (buf, ev)
-        else:
-            ev.synchronize()
-        return buf, ev
+        lst = self.free.setdefault(int(numel), [])
+        if lst:
+            buf, ev = lst.pop()
+            ev.synchronize()                     # an owner that died unresolved may have left its copy in flight
+            return buf, ev
+        self.allocated += 1
+        return self._alloc(int(numel))
+
+    def put(self, buf, ev):
+        self.free.setdefault(int(buf.numel()), []).append((buf, ev))
 
 
 _PINNED = _PinnedPool()
@@ -236,15 +242,16 @@ class SparseImageExchange:
     per sample), so ~45 MB travel each way instead of the 214 MB all-gather + 214 MB reduce-scatter of
     the dense form.  Pure torch + torch.distributed: runs under gloo on CPU for the tests."""
 
-    def __init__(self, dS_full, B, group=None):
+    def __init__(self, dS_full, B, group=None, pool=None):
         self.group = group
         W, r = _world(group)
         self.W, self.r, self.B = W, r, B
         nz = (dS_full.view(W * B, W, B) != 0).any(dim=2).t().contiguous()          # nz[b, i]
         counts = nz.view(W, W, B).sum(dim=2).reshape(-1)                           # counts[b * W + a]
         self._event = None
-        if counts.is_cuda:
-            self._counts, self._event = _PINNED.get(W * W)
+        self._pool = pool if pool is not None else (_PINNED if counts.is_cuda else None)       # `pool`: tests drive the ownership logic on CPU
+        if self._pool is not None:
+            self._counts, self._event = self._pool.get(W * W)          # ours until _resolve() (or __del__) hands it back
             self._counts.copy_(counts, non_blocking=True)
             self._event.record()
         else:
@@ -263,12 +270,23 @@ class SparseImageExchange:
             self._event.synchronize()
         W, r, B = self.W, self.r, self.B
         counts = self._counts.view(W, W).tolist()                                  # counts[b][a]
-        self._counts = None
+        self._release()
         self.recv_splits = [int(counts[r][a]) for a in range(W)]
         self.send_splits = [int(counts[b][r]) for b in range(W)]
         self._need_idx = self._need_order[:sum(self.recv_splits)]
         self.send_rows = self._send_order[:sum(self.send_splits)] % B
         self._resolved = True
+
+    def _release(self):
+        if self._pool is not None and self._counts is not None:
+            self._pool.put(self._counts, self._event)
+        self._counts, self._pool = None, None
+
+    def __del__(self):                               # a plan whose backward never ran: the buffer goes back (get() waits for its copy)
+        try:
+            self._release()
+        except Exception:
+            pass
 
     @property
     def need_idx(self):

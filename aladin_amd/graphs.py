@@ -186,7 +186,10 @@ class GraphedLossStep:
                 self._cache.popitem(last=False)
         else:
             self._cache.move_to_end(key)
-        lk = (tuple(img_lengths), tuple(cap_lengths))
+        # plain ints, whatever the caller holds them in (lists, numpy, CPU or device tensors: one .tolist() each, never a
+        # per-element tensor comparison)
+        lk = (tuple(int(v) for v in (img_lengths.tolist() if torch.is_tensor(img_lengths) else img_lengths)),
+              tuple(int(v) for v in (cap_lengths.tolist() if torch.is_tensor(cap_lengths) else cap_lengths)))
         if lk != e.lens_key:
             # one pinned buffer per in-flight copy (rotation + event): the host may run ahead of the device by several
             # steps, and a staging buffer must not be rewritten before its host->device copy has executed

@@ -45,16 +45,40 @@ def _is_result_line(line):
         return False
 
 
+_BIND_FAILURES = ('Address already in use', 'EADDRINUSE', 'address already in use', 'failed to bind')
+
+
 def run_ranks(script, argv, nproc, env=None, python=None, out=None, err=None, timeout=None):
     """Start `nproc` ranks of `script argv...` as children and wait for them.
 
     stdout of the children is relayed line by line, except that the LAST JSON-object line is held back and
     written after everything else (RCCL and the launcher print banners of their own; the driver reads the last
-    line).  stderr is relayed as it comes.  Returns (return code, result line or None): the children's return code,
-    or 1 when they all succeeded without printing a result line; on `timeout` seconds the whole process group of
-    the launcher is ended and 124 returned."""
+    line) -- and only when the ranks SUCCEEDED: the result line of a failed run goes to stderr, marked, so that a
+    reader of stdout's last line cannot take a partial result for a valid one.  stderr is relayed as it comes.
+    Returns (return code, result line or None): the children's return code, or 1 when they all succeeded without
+    printing a result line; on `timeout` seconds the whole process group of the launcher is ended and 124 returned.
+    The rendezvous port is found by bind-and-release, which another job can win before torch.distributed.run binds it:
+    a launch that dies on the bind is repeated once on a fresh port."""
     out = sys.stdout if out is None else out
     err = sys.stderr if err is None else err
+    rc, result, err_tail = _run_ranks_once(script, argv, nproc, env, python, out, err, timeout)
+    if rc not in (0, 124) and result is None and any(sig in err_tail for sig in _BIND_FAILURES):
+        err.write('aladin_amd.launch: rendezvous port was taken, retrying once on a fresh port\n')
+        rc, result, err_tail = _run_ranks_once(script, argv, nproc, env, python, out, err, timeout)
+    if result is not None:
+        if rc == 0:
+            out.write(result)
+            out.flush()
+        else:
+            err.write('aladin_amd.launch: ranks FAILED (rc %d); their result line is withheld from stdout: %s' % (rc, result))
+            err.flush()
+    elif rc == 0:
+        err.write('aladin_amd.launch: %d ranks exited 0 without printing a result line\n' % int(nproc))
+        rc = 1
+    return rc, (result.strip() if result and rc == 0 else None)
+
+
+def _run_ranks_once(script, argv, nproc, env, python, out, err, timeout):
     child_env = dict(os.environ if env is None else env)
     for k in RANK_ENV + ('MASTER_ADDR', 'MASTER_PORT', 'GROUP_RANK', 'LOCAL_WORLD_SIZE', 'ROLE_RANK'):
         child_env.pop(k, None)
@@ -65,6 +89,7 @@ def run_ranks(script, argv, nproc, env=None, python=None, out=None, err=None, ti
     proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=child_env, text=True, bufsize=1,
                             start_new_session=True)
     result = [None]
+    err_tail = []
 
     def pump_out():
         for line in proc.stdout:
@@ -80,6 +105,8 @@ def run_ranks(script, argv, nproc, env=None, python=None, out=None, err=None, ti
         for line in proc.stderr:
             err.write(line)
             err.flush()
+            err_tail.append(line)
+            del err_tail[:-200]
 
     threads = [threading.Thread(target=pump_out, daemon=True), threading.Thread(target=pump_err, daemon=True)]
     for th in threads:
@@ -95,15 +122,12 @@ def run_ranks(script, argv, nproc, env=None, python=None, out=None, err=None, ti
         try:
             proc.wait(timeout=20)
         except subprocess.TimeoutExpired:
-            os.killpg(proc.pid, signal.SIGKILL)
+            try:
+                os.killpg(proc.pid, signal.SIGKILL)
+            except ProcessLookupError:
+                pass
             proc.wait()
         rc = 124
     for th in threads:
         th.join(timeout=10)
-    if result[0] is not None:
-        out.write(result[0])
-        out.flush()
-    elif rc == 0:
-        err.write('aladin_amd.launch: %d ranks exited 0 without printing a result line\n' % int(nproc))
-        rc = 1
-    return rc, (result[0].strip() if result[0] else None)
+    return rc, result[0], ''.join(err_tail)

@@ -102,6 +102,27 @@ def _exchange_worker(rank, world, port, ret):
         d_need = _contribution(need, rank, R, D)
         d_local = ex.give_back(torch.from_numpy(d_need), (B, R, D))
         out[seed] = (need, got.numpy(), d_local.numpy())
+    # MANY plans outstanding before the first one is used (micro-batch losses summed, one backward): every plan
+    # owns its host counts buffer until it is resolved.  The pool is driven with host buffers here (no GPU in this tier).
+    from aladin_amd.distributed import _PinnedPool
+
+    class _Ev:
+        def record(self): pass
+        def synchronize(self): pass
+    pool = _PinnedPool(alloc=lambda n: (torch.empty(n, dtype=torch.int64), _Ev()))
+    seeds = list(range(10, 21))
+    plans = [SparseImageExchange(torch.from_numpy(_sparse_pattern(world, B, sd)), B, pool=pool) for sd in seeds]
+    many = {}
+    for sd, ex in zip(seeds, plans):
+        im_all = np.arange(world * B * R * D, dtype=np.float32).reshape(world * B, R, D) + sd
+        got = ex.fetch(torch.from_numpy(im_all[rank * B:(rank + 1) * B]))
+        many[sd] = (ex.need_idx.numpy(), got.numpy())
+    out['many'] = many
+    out['pool'] = (pool.allocated, sum(len(v) for v in pool.free.values()))
+    del plans, ex
+    again = SparseImageExchange(torch.from_numpy(_sparse_pattern(world, B, 3)), B, pool=pool)      # steady state: nothing new is allocated
+    out['pool_after'] = pool.allocated
+    del again
     ret[rank] = out
     dist.barrier()
     dist.destroy_process_group()
@@ -127,6 +148,14 @@ def test_sparse_image_exchange_world3():
                 used = np.nonzero((dS[r * B:(r + 1) * B, b * B:(b + 1) * B] != 0).any(axis=1))[0]
                 want[used] += _contribution(used + r * B, b, R, D)
             np.testing.assert_allclose(d_local, want, rtol=1e-6)
+    for r in range(world):
+        for sd, (need, got) in ret[r]['many'].items():                           # 11 plans built before any was resolved
+            dS = _sparse_pattern(world, B, sd)
+            want_need = np.nonzero((dS[:, r * B:(r + 1) * B] != 0).any(axis=1))[0]
+            np.testing.assert_array_equal(need, want_need)
+            np.testing.assert_array_equal(got, (im_all + sd)[want_need])
+        assert ret[r]['pool'] == (11, 11)            # one buffer per outstanding plan, all handed back on resolve
+        assert ret[r]['pool_after'] == 11            # and reused afterwards
 
 
 # ------------------------------------------------------------------------------------------------

@@ -42,6 +42,7 @@ def eval_precision(request):
     E.clear_eval_cache()
 
 
+SCORE_HEADROOM = 0.5       # assert_scores_close fails when an error exceeds this fraction of its tolerance
 SCORE_ERR_LOG = []          # (test id, worst |S - ref| / (rtol |ref| + atol)) per call; conftest writes it out on the GPU box
 
 
@@ -63,6 +64,10 @@ def assert_scores_close(S, ref, rtol=RTOL, atol_rel=3e-4, scale='max'):
             'mean_abs_ref': float('%.3g' % np.abs(ref).mean()),
             'max_err_over_max_ref': float('%.3g' % (err.max() / max(1e-30, np.abs(ref).max()))),
             'max_rel_err_where_ref_ge_tenth_of_max': float('%.3g' % (err / np.maximum(np.abs(ref), 1e-30))[np.abs(ref) >= 0.1 * np.abs(ref).max()].max())}))
+        # the bar above was re-stated in round 3 (max- instead of mean-scaled absolute term); the measured worst
+        # case of the whole suite is 0.10 of it (profiles/r03_score_err_stats.json).  A regression has to surface long before
+        # it eats the tolerance: fail at HALF of it.
+        assert SCORE_ERR_LOG[-1][1]['frac_of_tol'] <= SCORE_HEADROOM, SCORE_ERR_LOG[-1]
     np.testing.assert_allclose(S, ref, rtol=rtol, atol=atol)
 
 

@@ -3,7 +3,8 @@
 the cost of the screened kernel depends on where the ground-truth scores sit relative to the bulk of the scores
 (the RESULT never does: every run is checked against the two-step split path).  Prints one JSON line per data set:
 Recall@1 of both directions, fused ms (screened / all-exact), tiles continued in place, pairs continued through lists.
-usage: tools/bench_retrieval.py [--profile]   (--profile: a few calls only, for rocprofv3)"""
+usage: tools/bench_retrieval.py [--profile] [--only SUBSTRING]
+       --profile: a few calls only and no two-step check (for rocprofv3); --only: the data sets whose name contains SUBSTRING"""
 import json
 import os
 import sys
@@ -35,7 +36,7 @@ def datasets(dev):
     noise = torch.randn(5 * n_img, D, generator=g)
     # captions = normalize(image + t * noise): t = 0.05 is bench.py's round-1..3 timing input (every R@1 = 100)
     for t in (0.05, 0.5, 0.8, 1.0):
-        cap = torch.nn.functional.normalize(img.repeat_interleave(5, 0) + t * noise / D ** 0.5 * (D ** 0.5), dim=1)
+        cap = torch.nn.functional.normalize(img.repeat_interleave(5, 0) + t * noise, dim=1)
         yield 'caption = image + %.2f * N(0, I)' % t, img.to(dev), cap.to(dev)
     for sigma in (3.0, 6.0, 12.0):
         i, c = synth.retrieval_embeddings(n_img, D, seed=303, sigma=sigma)
@@ -46,7 +47,10 @@ def datasets(dev):
 def main():
     dev = torch.device('cuda:0')
     profile = '--profile' in sys.argv
+    only = sys.argv[sys.argv.index('--only') + 1] if '--only' in sys.argv else ''
     for name, a, b in datasets(dev):
+        if only not in name:
+            continue
         *one, st = ops.retrieval_ranks(a, b, return_stats=True)
         if not profile:
             two = ops.recall_ranks(ops.sim_matrix(a, b))
