@@ -39,7 +39,7 @@ SYMBOLS = [
 
 class AlignGeom(C.Structure):
     """struct aladin_align_geom."""
-    _fields_ = [(n, C.c_int32) for n in ('Bi', 'Bc', 'R', 'T', 'D', 'Rq', 'Tq', 'mtiles', 'rem', 'tp16', 'Dp',
+    _fields_ = [(n, C.c_int32) for n in ('Bi', 'Bc', 'R', 'T', 'D', 'Rq', 'Tq', 'mrows', 'rem', 'tp16', 'Dp',
                                          'img_unit', 'cap_unit', 'Bi_pad', 'Bc_pad', 'x_tail', 'y_tail', 'split')] + \
                [(n, C.c_int64) for n in ('xm_rows', 'xe_rows', 'y_rows', 'xm_bytes', 'xe_bytes', 'y_bytes',
                                          'e_bytes')]

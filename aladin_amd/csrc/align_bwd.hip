@@ -72,8 +72,9 @@ static size_t dense_ws_layout(const aladin_align_geom* gs, char* base, DenseWs* 
 // the tile classes the arg-max kernel covers; fills the split geometry of the problem
 static bool dense_supported(int Bi, int Bc, int R, int T, int D, int x_tail, int y_tail, aladin_align_geom* gs) {
   if (aladin_align_geometry_mode(Bi, Bc, R, T, D, x_tail, y_tail, ALADIN_PRECISION_SPLIT, gs) != ALADIN_OK) return false;
-  return (gs->mtiles == 1 ? gs->rem <= 8 : (gs->mtiles == 2 && gs->rem == 0)) && 6 % gs->tp16 == 0 && (gs->xm_rows / 256) * (gs->y_rows / 384) > 64 &&
-         gs->xm_rows % 256 == 0 && gs->y_rows % 384 == 0;
+  const int bm = gs->mrows == 48 ? 192 : 256;                  // the tile kernel's workgroup rows for the class
+  return ((gs->mrows == 32 || gs->mrows == 48) ? gs->rem <= 8 : (gs->mrows == 64 && gs->rem == 0)) && 6 % gs->tp16 == 0 &&
+         (gs->xm_rows / bm) * (gs->y_rows / 384) > 64 && gs->xm_rows % bm == 0 && gs->y_rows % 384 == 0;
 }
 
 extern "C" size_t aladin_align_bwd_workspace_bytes_ex(int Bi, int Bc, int R, int T, int D, int flags) {
@@ -229,13 +230,13 @@ __global__ __launch_bounds__(256) void bwd_pair_argmax_kernel(
 #define CAND_MAX 4096             // 64 x 64 accumulator elements per pair: every one of them may be a close call
 #define AMBIG_MARGIN 2.2e-3f      // > 2 * 2^-10: two fp16-operand cosines of unit vectors
 
-using PairCfg = GemmCfg<2, 2, 1, 1>;      // 64 x 64 block per pair: [32 main regions | extra-region segment] x 64 word rows
+using PairCfg = GemmCfg<2, 2, 1, 1>;      // 64 x 64 block per pair: [32 / 48 / 64 main rows | window on the extra-region operand] x 64 word rows
 // LDS ring depth of the pair kernel: 3 stages (48 KB: three workgroups per CU, the <= 3B pairs of a B = 256 step run in one
 // round).  Measured and not kept: 4 stages at B = 256 (+14 us: only two workgroups per CU), 6 stages for bs <= 85 (no change:
 // tools/pair_probe.py shows the K loop at 6.5 us of a workgroup's 19).
 #define PAIR_STAGES 3
 
-// Requires one region tile per image (+ side rows) or two tiles and no side rows (R' <= 64), and 16*tp16 <= 64 words: every
+// Requires 32 or 48 main rows per image (+ side rows) or 64 and no side rows (R' <= 64), and 16*tp16 <= 64 words: every
 // training shape incl. VinVL's 50 regions; other shapes use the fp32 kernel.
 #ifdef ALADIN_DIAG
 // phase stamps of the pair kernel (diagnostic build only; tools/pair_probe.py): 8 words per workgroup =
@@ -266,7 +267,7 @@ struct PairHinge {
 //   (st[v][8..9] = value, arg of the alignment hinge), element-wise pass = heads_small_finish_body.
 template <int SRC>
 __global__ __launch_bounds__(256) void bwd_pair_argmax16_kernel(
-    const half_t* __restrict__ xm, const half_t* __restrict__ xe, const half_t* __restrict__ y, int Dp, int rem,
+    const half_t* __restrict__ xm, const half_t* __restrict__ xe, const half_t* __restrict__ y, int Dp, int mrows, int rem,
     int tpad, int xe_rows, int y_rows, const float* __restrict__ im, int64_t im_sb, int64_t im_sr,
     const int32_t* __restrict__ im_len, const float* __restrict__ s, int64_t s_sb, int64_t s_st,
     const int32_t* __restrict__ s_len, int Bc, int Rq, int Tq, int D, const int* __restrict__ counter,
@@ -336,19 +337,20 @@ __global__ __launch_bounds__(256) void bwd_pair_argmax16_kernel(
     if (Li + Lj >= 0) PAIR_STAMP(1);
     if (threadIdx.x == 0) ncand = 0;
     if (threadIdx.x < 64) { word_amb[threadIdx.x] = 0; word_res[threadIdx.x] = NO_GRAD; word_key[threadIdx.x] = 0ull; }
-    // operand panels: rows [0,32) = the image's 32 main regions, rows [32,64) = 32 consecutive rows
-    // of the extra-region operand containing image i's rem rows at offset eo; 64 caption-word rows
-    // starting at by (the caption's words sit at column offset co)
-    // rem < 0: TWO region tiles per image (R' 34..64, no side rows): the "side segment" is the image's own second tile
-    const bool two = rem < 0;
-    const int rem_e = two ? 32 : rem;
-    const int be = two ? i * 64 + 32 : (rem ? (i * rem < xe_rows - 32 ? i * rem : xe_rows - 32) : 0);     // image i's side rows: [i*rem, i*rem + rem)
-    const int eo = two ? 0 : i * rem - be;
+    // operand panel of 64 region rows: rows [0, M) = the image's M = mrows main rows (32, 48 or 64: regions 0 .. M-1; rows past
+    // R' repeat region 0 and are never looked at), rows [M, 64) = a window of 64 - M consecutive rows of the extra-region
+    // operand containing image i's rem side rows at offset eo (regions M .. M + rem - 1); 64 caption-word rows starting at
+    // by (the caption's words sit at column offset co)
+    const int M = mrows, win = 64 - M;
+    const bool side = rem > 0 && win > 0;
+    int be = 0;
+    if (side) be = i * rem < xe_rows - win ? i * rem : xe_rows - win;      // image i's side rows: [i*rem, i*rem + rem); xe_rows is a multiple of 64
+    const int eo = side ? i * rem - be : 0;
     const int64_t yrow = (int64_t)j * tpad;
     const int64_t by = yrow < (int64_t)y_rows - 64 ? yrow : (int64_t)y_rows - 64;
     const int co = (int)(yrow - by);
-    const half_t* pa1 = xm + (int64_t)i * (two ? 64 : 32) * Dp;
-    const half_t* pa2 = two ? xm + (int64_t)be * Dp : (rem ? xe + (int64_t)be * Dp : pa1);
+    const half_t* pa1 = xm + (int64_t)i * M * Dp;
+    const half_t* pa2 = side ? xe + (int64_t)be * Dp : pa1;
     f32x16 acc[1][1];
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[0][0][r] = 0.f;
@@ -358,11 +360,12 @@ __global__ __launch_bounds__(256) void bwd_pair_argmax16_kernel(
     uint32_t skip = 0;
     {
       const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-      if (!rem_e || wv < (eo >> 3) || wv > ((eo + rem_e - 1) >> 3)) skip |= 2u;
+      const int w0 = 32 + 8 * wv - M;                    // first window row of this wave's piece of rows [32, 64) (< 0: main rows)
+      if (w0 >= 0 && (!side || w0 + 8 <= eo || w0 >= eo + rem)) skip |= 2u;
       if (8 * wv + 8 <= co || 8 * wv >= co + tpad) skip |= 4u;
       if (32 + 8 * wv + 8 <= co || 32 + 8 * wv >= co + tpad) skip |= 8u;
     }
-    gemm_mainloop<PairCfg, PAIR_STAGES>(pa1, y + by * Dp, Dp, Dp / 64, pair_smem, acc, pa2, 32, skip);
+    gemm_mainloop<PairCfg, PAIR_STAGES>(pa1, y + by * Dp, Dp, Dp / 64, pair_smem, acc, pa2, M, skip);
     PAIR_STAMP(2);
     // Per word: approximate winner, runner-up and the candidates that need an exact look — straight from the
     // accumulators.  A lane holds 16 regions of ONE word (column l5 of its wave's 32 x 32 block): top-2 in registers,
@@ -375,10 +378,10 @@ __global__ __launch_bounds__(256) void bwd_pair_argmax16_kernel(
     // region index of accumulator register r of this lane (255: not a region of this pair), branch-free: written with
     // if / else the compiler built 66 exec-mask branches and parked b1 / b2 in AccVGPRs (1.6 us for this loop)
     auto region_of = [&](int r) {
-      const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-      const int d = row - eo;
-      const int side = ((unsigned)d < (unsigned)rem_e) ? 32 + d : 255;
-      return wm == 0 ? row : side;
+      const int gr = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;          // row of the 64-row panel
+      const int d = gr - M - eo;
+      const int sreg = ((unsigned)d < (unsigned)rem) ? M + d : 255;
+      return gr < M ? gr : sreg;
     };
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -790,7 +793,7 @@ static int align_bwd_impl(const float* im, int64_t im_sb, int64_t im_sr, const i
     aladin_set_error("align_bwd: needs D %% 4 == 0, D <= 1024 and 16-byte aligned rows (D=%d)", D);
     return ALADIN_ERR_UNSUPPORTED;
   }
-  const bool packed = xm && y && g && (g->mtiles == 1 || (g->mtiles == 2 && g->rem == 0)) && g->tp16 <= 4;   // shapes the fp16 pair kernel covers
+  const bool packed = xm && y && g && (g->mrows == 32 || g->mrows == 48 || (g->mrows == 64 && g->rem == 0)) && g->tp16 <= 4;   // shapes the fp16 pair kernel covers
   if (xm && y && g && (g->Bi != Bi || g->Bc != Bc || g->R != R || g->T != T || g->D != D || (g->rem && !xe))) {
     aladin_set_error("align_bwd: packed operands do not belong to this problem");
     return ALADIN_ERR_ARG;
@@ -802,7 +805,7 @@ static int align_bwd_impl(const float* im, int64_t im_sb, int64_t im_sr, const i
   const int64_t n = (int64_t)Bi * Bc;
   int rc = ALADIN_OK;
   if (phase == BWD_HINGE_ARGMAX) {
-    if (!packed) { aladin_set_error("hinge_argmax: needs the packed fp16 operands of a class the fp16 pair kernel covers (R' <= 64 without side rows or <= 40 with, <= 64 padded words)"); return ALADIN_ERR_UNSUPPORTED; }
+    if (!packed) { aladin_set_error("hinge_argmax: needs the packed fp16 operands of a class the fp16 pair kernel covers (R' <= 64, <= 64 padded words)"); return ALADIN_ERR_UNSUPPORTED; }
     if (ha->small) {                                      // small-batch heads: their own statistics kernel ran already
       int npb = (3 * Bc + 7) / 8 * 8;
       const PairHinge hfs = {nullptr, 0, 0.f, nullptr, nullptr, nullptr, nullptr, Bc, npb, nullptr};
@@ -810,7 +813,7 @@ static int align_bwd_impl(const float* im, int64_t im_sb, int64_t im_sr, const i
       sfin.dST = (float*)ws.pairs;                        // the list region is free in this mode: it carries dS^T
       hipLaunchKernelGGL(bwd_pair_argmax16_kernel<2>, dim3(npb + cdiv(Bc * Bc, 256)), dim3(256),
                          (size_t)PAIR_STAGES * PairCfg::STAGE_BYTES, st, (const half_t*)xm, (const half_t*)xe, (const half_t*)y,
-                         g->Dp, (g->mtiles == 2 ? -1 : g->rem), 16 * g->tp16, (int)g->xe_rows, (int)g->y_rows, im, im_sb, im_sr, im_len, s, s_sb, s_st,
+                         g->Dp, g->mrows, g->rem, 16 * g->tp16, (int)g->xe_rows, (int)g->y_rows, im, im_sb, im_sr, im_len, s, s_sb, s_st,
                          s_len, Bc, Rq, Tq, D, nullptr, nullptr, ws.table, tstride, x_tail, y_tail, hfs, sfin);
       return aladin_check_launch("bwd_pair_argmax16_kernel<small heads>");
     }
@@ -822,7 +825,7 @@ static int align_bwd_impl(const float* im, int64_t im_sb, int64_t im_sr, const i
     const int nfin = Bc < 1024 ? Bc : 1024;
     const PairHinge hf = {ha->S, ha->ldS, ha->margin, val, arg, ha->loss, ha->dS, Bc, npb, (float*)ws.pairs};
     hipLaunchKernelGGL(bwd_pair_argmax16_kernel<1>, dim3(npb + nfin), dim3(256), (size_t)PAIR_STAGES * PairCfg::STAGE_BYTES, st,
-                       (const half_t*)xm, (const half_t*)xe, (const half_t*)y, g->Dp, (g->mtiles == 2 ? -1 : g->rem), 16 * g->tp16, (int)g->xe_rows,
+                       (const half_t*)xm, (const half_t*)xe, (const half_t*)y, g->Dp, g->mrows, g->rem, 16 * g->tp16, (int)g->xe_rows,
                        (int)g->y_rows, im, im_sb, im_sr, im_len, s, s_sb, s_st, s_len, Bc, Rq, Tq, D, nullptr, nullptr,
                        ws.table, tstride, x_tail, y_tail, hf, SmallFin{});
     return aladin_check_launch("bwd_pair_argmax16_kernel<hinge>");
@@ -869,7 +872,7 @@ static int align_bwd_impl(const float* im, int64_t im_sb, int64_t im_sr, const i
   if (phase == BWD_ROWS) {
   } else if (packed) {
     hipLaunchKernelGGL(bwd_pair_argmax16_kernel<0>, dim3(pgrid), dim3(256), (size_t)PAIR_STAGES * PairCfg::STAGE_BYTES, st,
-                       (const half_t*)xm, (const half_t*)xe, (const half_t*)y, g->Dp, (g->mtiles == 2 ? -1 : g->rem), 16 * g->tp16, (int)g->xe_rows,
+                       (const half_t*)xm, (const half_t*)xe, (const half_t*)y, g->Dp, g->mrows, g->rem, 16 * g->tp16, (int)g->xe_rows,
                        (int)g->y_rows, im, im_sb, im_sr, im_len, s, s_sb, s_st, s_len, Bc, Rq, Tq, D, ws.counter, ws.pairs,
                        ws.table, tstride, x_tail, y_tail, PairHinge{}, SmallFin{});
     rc = aladin_check_launch("bwd_pair_argmax16_kernel");
@@ -897,7 +900,7 @@ static int align_bwd_impl(const float* im, int64_t im_sb, int64_t im_sr, const i
       aladin_set_error("align_bwd: ALADIN_BWD_PARTNERS_FP16 needs the forward's fp16 packed operands and their geometry");
       return ALADIN_ERR_ARG;
     }
-    pk = PackedRows{(const half_t*)xm, (const half_t*)xe, (const half_t*)y, g->Dp, 32 * g->mtiles, g->rem, 16 * g->tp16};
+    pk = PackedRows{(const half_t*)xm, (const half_t*)xe, (const half_t*)y, g->Dp, g->mrows, g->rem, 16 * g->tp16};
   }
 #define LAUNCH_ROWS_FP(N, F, P)                                                                                         \
   hipLaunchKernelGGL((bwd_rows_kernel<N, F, P>), dim3(rgrid), dim3(256), 0, st, im, im_sb, im_sr, im_len, s, s_sb, s_st, s_len, \

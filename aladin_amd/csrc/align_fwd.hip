@@ -30,9 +30,6 @@
 
 #include "../../include/aladin_hip.h"
 #include "gemm_core.hpp"
-#ifdef ALADIN_DIAG
-#include "gemm_bdirect.hpp"
-#endif
 
 // ------------------------------------------------------------------------------------------------
 // geometry
@@ -47,21 +44,27 @@ static int diag_env(const char* name, int dflt) { const char* e = getenv(name); 
 static constexpr int diag_env(const char*, int dflt) { return dflt; }
 #endif
 
-static int scores_strip_mult(int tp16, int mtiles) {
+static int scores_strip_mult(int tp16, int mrows) {
   static const int env = diag_env("ALADIN_ALIGN_STRIP", 2);
-  return (env == 2 && mtiles <= 2 && tp16 <= 6) ? 2 : 1;       // tp16 in {1,2,3,4,6}: 24 / tp16 captions per 384-row tile
+  return (env == 2 && mrows <= 64 && tp16 <= 6) ? 2 : 1;       // tp16 in {1,2,3,4,6}: 24 / tp16 captions per 384-row tile
 }
 
 // Largest leftover handled as side rows (ALADIN_ALIGN_SIDE_MAX, default and maximum 8; 1 when the 32x32x16
 // kernels are forced by ALADIN_ALIGN_STRIP).  Measured at B=256, T=50, D=768 (forward incl. packing): R'=34
 // 0.183 vs 0.271 ms with a second region tile, R'=36 0.200 vs 0.273, R'=38 0.215 vs 0.277, R'=40 0.236 vs 0.276.
+// the 48-row region class (R' 41..56); ALADIN_ALIGN_CLASS48=0 in the diagnostic build falls back to two 32-row tiles (A/B runs)
+static int scores_class48() {
+  static const int v = diag_env("ALADIN_ALIGN_CLASS48", 1);
+  return v != 0;
+}
+
 static int scores_side_max() {
   static int v = -1;
   if (v < 0) {
     v = diag_env("ALADIN_ALIGN_SIDE_MAX", 8);
     if (v < 1) v = 1;
     if (v > 8) v = 8;
-    if (scores_strip_mult(3, 1) != 2) v = 1;
+    if (scores_strip_mult(3, 32) != 2) v = 1;
   }
   return v;
 }
@@ -86,23 +89,26 @@ extern "C" int aladin_align_geometry_mode(int Bi, int Bc, int R, int T, int D, i
   g->split = precision == ALADIN_PRECISION_SPLIT;
   g->Rq = R - 1 - x_tail; g->Tq = T - 1 - y_tail;
   if (g->Rq > 96 || g->Tq > 96) { aladin_set_error("align_geometry: at most 97 regions / 99 tokens supported (got R=%d T=%d)", R, T); return ALADIN_ERR_UNSUPPORTED; }
-  // R' = 32*mtiles + rem: `rem` leftover regions per image go through the side GEMM instead of opening
-  // another 32-row MFMA tile.  33..32+SIDE_MAX regions: one tile + rem side rows (the 16x16x32 kernel's
-  // epilogue takes any rem; the older 32x32x16 kernels only rem == 1); 65: two tiles + one side row.
-  if (g->Rq > 32 && g->Rq <= 32 + scores_side_max()) { g->mtiles = 1; g->rem = g->Rq - 32; }
-  else if (g->Rq > 64 && g->Rq % 32 == 1 && g->Rq < 96) { g->mtiles = g->Rq / 32; g->rem = 1; }
-  else { g->mtiles = cdiv(g->Rq, 32); g->rem = 0; }
+  // R' = mrows + rem: `mrows` rows per image in the main operand (16-row MFMA tiles; rows past R' repeat region 0), `rem`
+  // leftover regions per image go through the side GEMM instead of opening another tile.
+  //   33..40  : 32 rows + rem side rows (the 16x16x32 kernel's epilogue takes any rem <= 8; the older 32x32x16 kernels only 1)
+  //   41..56  : 48 rows (three 16-row tiles) + up to 8 side rows -- VinVL's 50 regions, the shape every shipped YAML trains
+  //             on, pays for 48 + 2 rows instead of 64 (round 4; captions must tile a 96-column strip: tp16 in {1, 2, 3, 6})
+  //   65      : 64 rows + one side row;   everything else: the next multiple of 32, no side rows
   g->tp16 = cdiv(g->Tq, 16);
   if (g->tp16 == 5) g->tp16 = 6;
+  if (g->Rq > 32 && g->Rq <= 32 + scores_side_max()) { g->mrows = 32; g->rem = g->Rq - 32; }
+  else if (g->Rq > 40 && g->Rq <= 48 + scores_side_max() && scores_side_max() == 8 && 6 % g->tp16 == 0 && scores_class48()) { g->mrows = 48; g->rem = g->Rq > 48 ? g->Rq - 48 : 0; }
+  else if (g->Rq > 64 && g->Rq % 32 == 1 && g->Rq < 96) { g->mrows = 32 * (g->Rq / 32); g->rem = 1; }
+  else { g->mrows = 32 * cdiv(g->Rq, 32); g->rem = 0; }
   // split precision: every packed row is three K segments of round_up(D, 64) halfs -- [hi | lo | hi] on the max
   // side, [hi | hi | lo] on the sum side -- so the unchanged main loops contract hi.hi + lo.hi + hi.lo
   g->Dp = round_up(D, 64) * (g->split ? 3 : 1);
-  const int imgs_per_wave = (g->mtiles == 1) ? 2 : 1;
-  g->img_unit = 4 * imgs_per_wave;
-  g->cap_unit = (scores_strip_mult(g->tp16, g->mtiles) == 2) ? 24 / g->tp16 : 2 * ((g->tp16 & 1) ? 2 : 1);
+  g->img_unit = (g->mrows == 32) ? 8 : 4;                     // images per workgroup tile: 256 rows (192 in the 48-row class, 384 at 96)
+  g->cap_unit = (scores_strip_mult(g->tp16, g->mrows) == 2) ? 24 / g->tp16 : 2 * ((g->tp16 & 1) ? 2 : 1);
   g->Bi_pad = round_up(Bi, g->img_unit);
   g->Bc_pad = round_up(Bc, g->cap_unit);
-  g->xm_rows = (int64_t)g->Bi_pad * 32 * g->mtiles;
+  g->xm_rows = (int64_t)g->Bi_pad * g->mrows;
   g->xe_rows = g->rem ? round_up(g->Bi_pad * g->rem, 64) : 0;      // image i: rows [i*rem, i*rem + rem)
   g->y_rows = (int64_t)g->Bc_pad * 16 * g->tp16;
   g->xm_bytes = g->xm_rows * g->Dp * 2;
@@ -209,7 +215,7 @@ __device__ __forceinline__ void pack_row(const float* __restrict__ src, half_t* 
 
 __global__ __launch_bounds__(256) void pack_images_kernel(const float* __restrict__ im, int64_t sb, int64_t sr,
                                                           const int32_t* __restrict__ im_len, int Bi, int Rq, int x_tail, int D,
-                                                          int Dp, int mtiles, int rem, int64_t xm_rows,
+                                                          int Dp, int mrows, int rem, int64_t xm_rows,
                                                           int64_t total_rows, half_t* __restrict__ xm,
                                                           half_t* __restrict__ xe, int vec4, int split) {
   const int lane = threadIdx.x & 63;
@@ -218,14 +224,14 @@ __global__ __launch_bounds__(256) void pack_images_kernel(const float* __restric
   int i, rho;
   half_t* dst;
   if (d < xm_rows) {
-    const int rows_per_img = 32 * mtiles;
+    const int rows_per_img = mrows;
     i = (int)(d / rows_per_img);
     rho = (int)(d % rows_per_img);
     if (rho >= Rq) rho = 0;                       // tile-filling copy of the first region
     dst = xm + d * Dp;
   } else {
     i = (int)((d - xm_rows) / rem);
-    rho = 32 * mtiles + (int)((d - xm_rows) % rem);   // the leftover region(s)
+    rho = mrows + (int)((d - xm_rows) % rem);     // the leftover region(s)
     dst = xe + (d - xm_rows) * Dp;
   }
   const float* src = nullptr;
@@ -258,7 +264,7 @@ __global__ __launch_bounds__(256) void pack_captions_kernel(const float* __restr
 __global__ __launch_bounds__(256) void pack_both_kernel(const float* __restrict__ im, int64_t isb, int64_t isr,
                                                         const int32_t* __restrict__ im_len, const float* __restrict__ s,
                                                         int64_t ssb, int64_t sst, const int32_t* __restrict__ s_len, int Bi,
-                                                        int Bc, int Rq, int Tq, int x_tail, int y_tail, int D, int Dp, int mtiles, int rem, int64_t xm_rows,
+                                                        int Bc, int Rq, int Tq, int x_tail, int y_tail, int D, int Dp, int mrows, int rem, int64_t xm_rows,
                                                         int64_t img_rows, int64_t total_rows, int tpad,
                                                         half_t* __restrict__ xm, half_t* __restrict__ xe,
                                                         half_t* __restrict__ y, int vec_i, int vec_s, int split) {
@@ -275,14 +281,14 @@ __global__ __launch_bounds__(256) void pack_both_kernel(const float* __restrict_
     seg = split ? 1 : 0;
     int i, rho;
     if (d < xm_rows) {
-      const int rows_per_img = 32 * mtiles;
+      const int rows_per_img = mrows;
       i = (int)(d / rows_per_img);
       rho = (int)(d % rows_per_img);
       if (rho >= Rq) rho = 0;
       dst = xm + d * Dp;
     } else {
       i = (int)((d - xm_rows) / rem);
-      rho = 32 * mtiles + (int)((d - xm_rows) % rem);
+      rho = mrows + (int)((d - xm_rows) % rem);
       dst = xe + (d - xm_rows) * Dp;
     }
     if (i < Bi && rho < Rq) { src = im + i * isb + (int64_t)(rho + 1) * isr; len_ptr = im_len + i; pos = rho; tail = x_tail; cap = Rq; }
@@ -308,7 +314,7 @@ extern "C" int aladin_align_pack_images(const float* im, int64_t stride_b, int64
   const int64_t total = g->xm_rows + g->xe_rows;
   const unsigned grid = (unsigned)((total + 3) / 4);
   hipLaunchKernelGGL(pack_images_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, im, stride_b, stride_r, im_len,
-                     g->Bi, g->Rq, g->x_tail, g->D, g->Dp, g->mtiles, g->rem > 0 ? g->rem : 1, g->xm_rows, total, (half_t*)xm, (half_t*)xe,
+                     g->Bi, g->Rq, g->x_tail, g->D, g->Dp, g->mrows, g->rem > 0 ? g->rem : 1, g->xm_rows, total, (half_t*)xm, (half_t*)xe,
                      is_vec4_ok(im, stride_b, stride_r, g->D), g->split);
   return aladin_check_launch("pack_images_kernel");
 }
@@ -329,7 +335,7 @@ extern "C" int aladin_align_pack_both(const float* im, int64_t im_stride_b, int6
   if (!im || !im_len || !s || !s_len || !g || !xm || !y || (g->rem && !xe)) { aladin_set_error("align_pack_both: null argument"); return ALADIN_ERR_ARG; }
   const int64_t img_rows = g->xm_rows + g->xe_rows, total = img_rows + g->y_rows;
   hipLaunchKernelGGL(pack_both_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, (hipStream_t)stream, im, im_stride_b,
-                     im_stride_r, im_len, s, s_stride_b, s_stride_t, s_len, g->Bi, g->Bc, g->Rq, g->Tq, g->x_tail, g->y_tail, g->D, g->Dp, g->mtiles,
+                     im_stride_r, im_len, s, s_stride_b, s_stride_t, s_len, g->Bi, g->Bc, g->Rq, g->Tq, g->x_tail, g->y_tail, g->D, g->Dp, g->mrows,
                      g->rem > 0 ? g->rem : 1, g->xm_rows, img_rows, total, 16 * g->tp16, (half_t*)xm, (half_t*)xe, (half_t*)y,
                      is_vec4_ok(im, im_stride_b, im_stride_r, g->D), is_vec4_ok(s, s_stride_b, s_stride_t, g->D), g->split);
   return aladin_check_launch("pack_both_kernel");
@@ -691,6 +697,113 @@ static int launch_scores16_tall(const aladin_align_geom* g, const half_t* xm, co
 }
 
 // ------------------------------------------------------------------------------------------------
+// The 48-row region class (R' 41..56: three 16-row tiles per image + up to 8 side rows; round 4).  VinVL's 50 regions -- the
+// shape of every shipped YAML -- used to pay for two 32-row tiles (64 rows, 22 % of the MFMA rows padding).  Wave tile
+// 96 x 96 = two images x 96 / (16 TP16) captions (6 x 6 accumulator tiles: 144 registers), workgroup 2 x 4 waves = 192 x 384
+// (4 images x 8 captions at 48 padded words), same LDS image and main loop (gemm_mainloop16_tall with six row tiles: 12
+// fragment reads per 36 MFMAs).  Epilogue: in-lane max over an image's 3 row tiles x 4 registers, v_permlane32_swap pairs
+// the wave's two images into the half-waves, one 16-lane exchange; the side rows join from E; in-lane adds over a caption's
+// column tiles, then the 16-lane sum.  WGM x WGN = 1 x 2 (96 x 192, two waves) is the small-grid variant: same operations
+// in the same order per score, so a score is bit-identical whichever variant computed it.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float max12(const f32x4& a, const f32x4& b, const f32x4& c) {
+  float t = vmax(vmax(a[0], a[1]), a[2]);
+  t = vmax(vmax(t, a[3]), b[0]);
+  t = vmax(vmax(t, b[1]), b[2]);
+  t = vmax(vmax(t, b[3]), c[0]);
+  t = vmax(vmax(t, c[1]), c[2]);
+  return vmax(t, c[3]);
+}
+
+template <bool HAS_E, int TP16, int REMC, int WGM, int WGN>
+__device__ __forceinline__ void scores16_epilogue_r48(f32x4 (&acc)[6][6], int mb, int nb, const float* __restrict__ E, int64_t ldE,
+                                                      int rem, float* __restrict__ S, int64_t ldS, int Bi, int Bc) {
+  using Cfg = GemmCfg<WGM, WGN, 3, 3>;
+  constexpr int CT = 6;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int half = lane >> 5, l4 = lane & 15;
+  if constexpr (REMC == 1) rem = 1;
+  constexpr int NC = CT / TP16;
+  static_assert(CT % TP16 == 0, "a caption must be a whole number of 16-word column tiles of the strip");
+  const int cap = (nb * WGN + wn) * NC;
+  const int img = (mb * WGM + wm) * 2 + half;                      // lanes 0-31 finish the wave's first image, 32-63 the second
+  const float* e = HAS_E ? E + (int64_t)img * rem * ldE + (int64_t)nb * Cfg::BN + wn * 96 + l4 : nullptr;
+  float v[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) v[c] = 0.f;
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct) {
+    const float p0 = max12(acc[0][ct], acc[1][ct], acc[2][ct]);
+    const float p1 = max12(acc[3][ct], acc[4][ct], acc[5][ct]);
+    auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(p0), __float_as_uint(p1), false, false);
+    float m = vmax(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+    m = max_xor16(m);
+    if constexpr (HAS_E && REMC == 1) m = vmax(m, e[ct * 16]);
+    if constexpr (HAS_E && REMC != 1) {
+      // branch-free: max is idempotent, so rows past the last side row re-read it (k clamped to rem - 1)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) m = vmax(m, e[(int64_t)(k < rem ? k : rem - 1) * ldE + ct * 16]);
+    }
+    v[ct / TP16] += m;
+  }
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const float t = row16_sum(v[c]);
+    if ((lane & 31) == 0 && img < Bi && cap + c < Bc) S[(int64_t)img * ldS + cap + c] = t;
+  }
+}
+
+template <bool HAS_E, int TP16, int REMC, int WGM, int WGN>
+__global__ __launch_bounds__(WGM * WGN * 64) void align_scores16_r48_kernel(const half_t* __restrict__ xm, const half_t* __restrict__ y,
+                                                                            const float* __restrict__ E, int64_t ldE,
+                                                                            float* __restrict__ S, int64_t ldS, int Bi, int Bc,
+                                                                            int64_t ldk, int ktiles, int n_nblk, int n_blocks, int rem) {
+  using Cfg = GemmCfg<WGM, WGN, 3, 3>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int mb, nb;
+  tile_coords(blockIdx.x, n_blocks / n_nblk, n_nblk, 8, mb, nb);
+  f32x4 acc[6][6];
+#pragma unroll
+  for (int rt = 0; rt < 6; ++rt)
+#pragma unroll
+    for (int ct = 0; ct < 6; ++ct) acc[rt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+  gemm_mainloop16_tall<Cfg, true>(xm + (int64_t)mb * Cfg::BM * ldk, y + (int64_t)nb * Cfg::BN * ldk, ldk, ktiles, smem, acc);
+  scores16_epilogue_r48<HAS_E, TP16, REMC, WGM, WGN>(acc, mb, nb, E, ldE, rem, S, ldS, Bi, Bc);
+}
+
+template <bool HAS_E, int TP16, int REMC, int WGM, int WGN>
+static int launch_scores16_r48_cfg(const aladin_align_geom* g, const half_t* xm, const half_t* y, const float* E, float* S,
+                                   int64_t ldS, hipStream_t stream) {
+  using Cfg = GemmCfg<WGM, WGN, 3, 3>;
+  const int n_mblk = (int)(g->xm_rows / Cfg::BM), n_nblk = (int)(g->y_rows / Cfg::BN);
+  if ((int64_t)n_mblk * Cfg::BM != g->xm_rows || (int64_t)n_nblk * Cfg::BN != g->y_rows) {
+    aladin_set_error("align_scores16_r48: packed rows do not tile");
+    return ALADIN_ERR_ARG;
+  }
+  auto kern = align_scores16_r48_kernel<HAS_E, TP16, REMC, WGM, WGN>;
+  static unsigned long long lds_reserved = 0;
+  if (int rc = aladin_reserve_lds((const void*)kern, Cfg::LDS_BYTES, &lds_reserved, "align_scores16_r48")) return rc;
+  const int n_blocks = n_mblk * n_nblk;
+  hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(Cfg::THREADS), Cfg::LDS_BYTES, stream, xm, y, E, g->y_rows, S, ldS, g->Bi,
+                     g->Bc, (int64_t)g->Dp, g->Dp / 64, n_nblk, n_blocks, g->rem);
+  return aladin_check_launch("align_scores16_r48_kernel");
+}
+
+template <bool HAS_E, int TP16>
+static int launch_scores16_r48(const aladin_align_geom* g, const half_t* xm, const half_t* y, const float* E, float* S, int64_t ldS,
+                               hipStream_t stream) {
+  // small grids (<= 64 tiles of 192 x 384, e.g. the shipped batch size 32): 96 x 192 tiles of two waves, four times the workgroups
+  const bool small = (g->xm_rows / 192) * (g->y_rows / 384) <= 64;
+  if constexpr (HAS_E) {
+    if (g->rem > 1) return small ? launch_scores16_r48_cfg<true, TP16, 0, 1, 2>(g, xm, y, E, S, ldS, stream)
+                                 : launch_scores16_r48_cfg<true, TP16, 0, 2, 4>(g, xm, y, E, S, ldS, stream);
+  }
+  return small ? launch_scores16_r48_cfg<HAS_E, TP16, 1, 1, 2>(g, xm, y, E, S, ldS, stream)
+               : launch_scores16_r48_cfg<HAS_E, TP16, 1, 2, 4>(g, xm, y, E, S, ldS, stream);
+}
+
+// ------------------------------------------------------------------------------------------------
 // Arg-max table for EVERY pair of a batch from the forward's own tile kernel (dense dS: max_violation = False, or a
 // gradient arriving on the score matrix).  The one-workgroup-per-pair kernel of align_bwd.hip pays a ~22 us latency chain and
 // 132 KB of operand traffic per pair: 1.88 ms for the 65 536 pairs of B = 256.  Here the split-precision operands
@@ -854,20 +967,151 @@ __global__ __launch_bounds__(512) void align_argmax16_tall_kernel(const half_t* 
   argmax16_epilogue_tall<HAS_E, TP16, Q>(acc, mb, nb, E, ldE, rem, im_len, x_tail, Rq, s_len, y_tail, Tq, table, tstride, flags, Bi, Bc);
 }
 
+// The 48-row region class (see align_scores16_r48_kernel): a wave's 96 rows are two images of three row tiles each; side rows
+// (regions 48 .. 48 + rem - 1) join from E.  Same packing of the region index into the 6 low mantissa bits (regions < 56).
+template <bool HAS_E, int TP16>
+__device__ __forceinline__ void argmax16_epilogue_r48(f32x4 (&acc)[6][6], int mb, int nb, const float* __restrict__ E, int64_t ldE, int rem,
+                                                      const int32_t* __restrict__ im_len, int x_tail, int Rq,
+                                                      const int32_t* __restrict__ s_len, int y_tail, int Tq,
+                                                      uint8_t* __restrict__ table, int tstride, uint8_t* __restrict__ flags,
+                                                      int Bi, int Bc) {
+  using Cfg = GemmCfg<2, 4, 3, 3>;
+  constexpr int CT = 6, NC = CT / TP16;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wm = wave / 4, wn = wave % 4;
+  const int half = lane >> 5, l4 = lane & 15, q4 = lane >> 4;
+  const int cap0 = (nb * 4 + wn) * NC;
+  const float NEG = -3.0e38f;
+  int Lc[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    Lc[c] = 0;
+    if (cap0 + c < Bc) { int l = s_len[cap0 + c] - 1 - y_tail; Lc[c] = l < 0 ? 0 : (l > Tq ? Tq : l); }
+  }
+  const int img = (mb * 2 + wm) * 2 + half;
+  int Li = 0;
+  if (img < Bi) { Li = im_len[img] - 1 - x_tail; Li = Li < 0 ? 0 : (Li > Rq ? Rq : Li); }
+  const int Li_a = __shfl(Li, lane & 31, 64), Li_b = __shfl(Li, (lane & 31) + 32, 64);
+  const float* e = HAS_E ? E + (int64_t)img * rem * ldE + (int64_t)nb * Cfg::BN + wn * 96 + l4 : nullptr;
+  bool pair_flag[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) pair_flag[c] = false;
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct) {
+    float a1 = NEG, a2 = NEG, b1 = NEG, b2 = NEG;
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int r = 16 * t + 4 * q4 + reg;
+        {
+          float v = acc[t][ct][reg];
+          unsigned bits = (__float_as_uint(v) & ~63u) | (unsigned)r;
+          if (r >= Li_a) bits = 63u;                               // every masked region is the one zero-fill candidate
+          v = (r >= Rq) ? NEG : __uint_as_float(bits);               // rows past R' only fill the tile
+          top2_merge(a1, a2, v, NEG);
+        }
+        {
+          float v = acc[3 + t][ct][reg];
+          unsigned bits = (__float_as_uint(v) & ~63u) | (unsigned)r;
+          if (r >= Li_b) bits = 63u;
+          v = (r >= Rq) ? NEG : __uint_as_float(bits);
+          top2_merge(b1, b2, v, NEG);
+        }
+      }
+    // lanes 0-31 take the first image's partials of lane + 32, lanes 32-63 the second image's of lane - 32
+    auto s1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(a1), __float_as_uint(b1), false, false);
+    auto s2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(a2), __float_as_uint(b2), false, false);
+    float t1 = __uint_as_float(s1[0]), t2 = __uint_as_float(s2[0]);
+    top2_merge(t1, t2, __uint_as_float(s1[1]), __uint_as_float(s2[1]));
+    { const float o1 = xchg16(t1), o2 = xchg16(t2); top2_merge(t1, t2, o1, o2); }
+    if constexpr (HAS_E) {
+      // up to 8 side rows (regions 48 .. 48 + rem - 1); rows past the last repeat it -- the same candidate, merged as one
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int kk = k < rem ? k : rem - 1;
+        const unsigned idx = 48u + (unsigned)kk;
+        const float ev = e[(int64_t)kk * ldE + ct * 16];
+        const float ep = ((int)idx < Rq) ? __uint_as_float(((int)idx >= Li ? 63u : ((__float_as_uint(ev) & ~63u) | idx))) : NEG;
+        top2_merge(t1, t2, ep, NEG);
+      }
+    }
+    const unsigned idx = __float_as_uint(t1) & 63u;
+    const int c = ct / TP16, w = (ct % TP16) * 16 + l4;
+    const uint8_t res = (idx >= (unsigned)Li || w >= Lc[c]) ? (uint8_t)255 : (uint8_t)idx;
+    const bool close = (t1 - t2) < ARGMAX_TAU_ACC;
+    if ((lane & 16) == 0 && img < Bi && cap0 + c < Bc && w < tstride) table[((int64_t)img * Bc + cap0 + c) * tstride + w] = res;
+    pair_flag[c] = pair_flag[c] || (close && w < Lc[c]);
+  }
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const unsigned long long mask = half ? 0xffffffff00000000ull : 0x00000000ffffffffull;
+    const bool any = (__ballot(pair_flag[c] && img < Bi && cap0 + c < Bc) & mask) != 0;
+    if ((lane & 31) == 0 && any) flags[(int64_t)img * Bc + cap0 + c] = 1;
+  }
+}
+
+template <bool HAS_E, int TP16>
+__global__ __launch_bounds__(512) void align_argmax16_r48_kernel(const half_t* __restrict__ xm, const half_t* __restrict__ y,
+                                                                 const float* __restrict__ E, int64_t ldE, int rem,
+                                                                 const int32_t* __restrict__ im_len, int x_tail, int Rq,
+                                                                 const int32_t* __restrict__ s_len, int y_tail, int Tq,
+                                                                 uint8_t* __restrict__ table, int tstride, uint8_t* __restrict__ flags,
+                                                                 int Bi, int Bc, int64_t ldk, int ktiles, int n_nblk, int n_blocks) {
+  using Cfg = GemmCfg<2, 4, 3, 3>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int mb, nb;
+  tile_coords(blockIdx.x, n_blocks / n_nblk, n_nblk, 8, mb, nb);
+  f32x4 acc[6][6];
+#pragma unroll
+  for (int rt = 0; rt < 6; ++rt)
+#pragma unroll
+    for (int ct = 0; ct < 6; ++ct) acc[rt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+  gemm_mainloop16_tall<Cfg, true>(xm + (int64_t)mb * Cfg::BM * ldk, y + (int64_t)nb * Cfg::BN * ldk, ldk, ktiles, smem, acc);
+  argmax16_epilogue_r48<HAS_E, TP16>(acc, mb, nb, E, ldE, rem, im_len, x_tail, Rq, s_len, y_tail, Tq, table, tstride, flags, Bi, Bc);
+}
+
 template <int NT> static int launch_side(const aladin_align_geom* g, const half_t* xe, const half_t* y, float* E, hipStream_t stream);
 
-// g: a SPLIT-precision geometry with one region tile per image + up to 8 side rows (R' <= 40) or two region tiles and no
-// side rows (R' 41..64), captions tiling a 96-column strip;
+// g: a SPLIT-precision geometry with 32 or 48 rows per image + up to 8 side rows (R' <= 40, 41..56) or 64 rows and no
+// side rows (R' 57..64), captions tiling a 96-column strip;
 // xm / xe / y: its packed operands; E: its side scratch (g->e_bytes); flags: Bi * Bc bytes, zeroed here.
 int aladin_internal_align_argmax(const aladin_align_geom* g, const void* xm, const void* xe, const void* y, float* E,
                                  const int32_t* im_len, const int32_t* s_len, uint8_t* table, int tstride, uint8_t* flags,
                                  hipStream_t stream) {
   using Cfg = GemmCfg<2, 4, 4, 3>;
-  if (!g || !g->split || g->mtiles < 1 || g->mtiles > 2 || (g->mtiles == 1 ? g->rem > 8 : g->rem != 0) || 6 % g->tp16 != 0) { aladin_set_error("align_argmax: unsupported tile class (mtiles=%d rem=%d tp16=%d split=%d)", g ? g->mtiles : -1, g ? g->rem : -1, g ? g->tp16 : -1, g ? g->split : -1); return ALADIN_ERR_UNSUPPORTED; }
-  const int n_mblk = (int)(g->xm_rows / Cfg::BM), n_nblk = (int)(g->y_rows / Cfg::BN);
-  if ((int64_t)n_mblk * Cfg::BM != g->xm_rows || (int64_t)n_nblk * Cfg::BN != g->y_rows) { aladin_set_error("align_argmax: packed rows do not tile"); return ALADIN_ERR_UNSUPPORTED; }
+  const bool ok_class = g && g->split && 6 % g->tp16 == 0 &&
+                        ((g->mrows == 32 && g->rem <= 8) || (g->mrows == 48 && g->rem <= 8) || (g->mrows == 64 && g->rem == 0));
+  if (!ok_class) { aladin_set_error("align_argmax: unsupported tile class (mrows=%d rem=%d tp16=%d split=%d)", g ? g->mrows : -1, g ? g->rem : -1, g ? g->tp16 : -1, g ? g->split : -1); return ALADIN_ERR_UNSUPPORTED; }
+  const int BMc = g->mrows == 48 ? 192 : Cfg::BM;
+  const int n_mblk = (int)(g->xm_rows / BMc), n_nblk = (int)(g->y_rows / Cfg::BN);
+  if ((int64_t)n_mblk * BMc != g->xm_rows || (int64_t)n_nblk * Cfg::BN != g->y_rows) { aladin_set_error("align_argmax: packed rows do not tile"); return ALADIN_ERR_UNSUPPORTED; }
   if (hipMemsetAsync(flags, 0, (size_t)g->Bi * g->Bc, stream) != hipSuccess) { aladin_set_error("align_argmax: memset failed"); return ALADIN_ERR_HIP; }
   const int n_blocks = n_mblk * n_nblk;
+  if (g->mrows == 48) {
+    using Cfg48 = GemmCfg<2, 4, 3, 3>;
+    int rc = ALADIN_OK;
+    if (g->rem) {
+      switch (g->tp16) {
+        case 1: case 2: rc = launch_side<1>(g, (const half_t*)xe, (const half_t*)y, E, stream); break;
+        default: rc = launch_side<3>(g, (const half_t*)xe, (const half_t*)y, E, stream); break;
+      }
+      if (rc) return rc;
+    }
+#define ARGMAX48_LAUNCH(HE, TP)                                                                                           \
+  do {                                                                                                                    \
+    auto kern = align_argmax16_r48_kernel<HE, TP>;                                                                        \
+    static unsigned long long lds_reserved = 0;                                                                           \
+    if (int rc2 = aladin_reserve_lds((const void*)kern, Cfg48::LDS_BYTES, &lds_reserved, "align_argmax16_r48")) return rc2; \
+    hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(Cfg48::THREADS), Cfg48::LDS_BYTES, stream, (const half_t*)xm, (const half_t*)y, \
+                       (const float*)E, g->y_rows, g->rem, im_len, g->x_tail, g->Rq, s_len, g->y_tail, g->Tq, table, tstride, flags, g->Bi, g->Bc, \
+                       (int64_t)g->Dp, g->Dp / 64, n_nblk, n_blocks);                                                     \
+  } while (0)
+    if (g->rem) { switch (g->tp16) { case 1: ARGMAX48_LAUNCH(true, 1); break; case 2: ARGMAX48_LAUNCH(true, 2); break; case 3: ARGMAX48_LAUNCH(true, 3); break; default: ARGMAX48_LAUNCH(true, 6); break; } }
+    else { switch (g->tp16) { case 1: ARGMAX48_LAUNCH(false, 1); break; case 2: ARGMAX48_LAUNCH(false, 2); break; case 3: ARGMAX48_LAUNCH(false, 3); break; default: ARGMAX48_LAUNCH(false, 6); break; } }
+#undef ARGMAX48_LAUNCH
+    return aladin_check_launch("align_argmax16_r48_kernel");
+  }
 #define ARGMAX_LAUNCH_Q(HE, TP, QQ)                                                                                     \
   do {                                                                                                                  \
     auto kern = align_argmax16_tall_kernel<HE, TP, QQ>;                                                                     \
@@ -878,7 +1122,7 @@ int aladin_internal_align_argmax(const aladin_align_geom* g, const void* xm, con
                        (int64_t)g->Dp, g->Dp / 64, n_nblk, n_blocks);                                                   \
   } while (0)
 #define ARGMAX_LAUNCH(HE, TP) ARGMAX_LAUNCH_Q(HE, TP, 1)
-  if (g->mtiles == 2) {                              // R' 34..64: an image is two row tiles, no side rows
+  if (g->mrows == 64) {                              // R' 57..64 (or 41..64 without the 48-row class): an image is two row tiles, no side rows
     switch (g->tp16) { case 1: ARGMAX_LAUNCH_Q(false, 1, 2); break; case 2: ARGMAX_LAUNCH_Q(false, 2, 2); break; case 3: ARGMAX_LAUNCH_Q(false, 3, 2); break; default: ARGMAX_LAUNCH_Q(false, 6, 2); break; }
   } else if (g->rem) {
     int rc = ALADIN_OK;
@@ -897,88 +1141,6 @@ int aladin_internal_align_argmax(const aladin_align_geom* g, const void* xm, con
 #undef ARGMAX_LAUNCH_Q
   return aladin_check_launch("align_argmax16_tall_kernel");
 }
-
-#ifdef ALADIN_DIAG
-// ---- EXPERIMENT (ALADIN_SCORE_VARIANT=8): B fragments straight from L2, only the A panel through the LDS (gemm_bdirect.hpp)
-static int g_scores_flags = 0;                   // flags of the aladin_align_scores_ex call being dispatched (diag build only)
-
-// y (rows x ldk halfs, row-major) -> fragment-major copy: block ((strip * KB + kb) * 6 + j) of 1 KiB holds, lane by lane,
-// the 16 B that lane l = (row & 15) + 16 * kgroup of a v_mfma_f32_16x16x32_f16 B fragment reads: y[(strip*6 + j)*16 + (l&15)][kb*32 + 8*(l>>4) ..]
-__global__ __launch_bounds__(256) void y_fragment_major_kernel(const half_t* __restrict__ y, char* __restrict__ yf, int64_t ldk,
-                                                               int KB, int64_t n_chunks) {
-  for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < n_chunks; c += (int64_t)gridDim.x * blockDim.x) {
-    const int l = (int)(c & 63);
-    const int64_t blk = c >> 6;
-    const int j = (int)(blk % 6);
-    const int64_t sk = blk / 6;
-    const int kb = (int)(sk % KB);
-    const int64_t strip = sk / KB;
-    const int64_t row = (strip * 6 + j) * 16 + (l & 15);
-    const uint4 v = *reinterpret_cast<const uint4*>(y + row * ldk + kb * 32 + 8 * (l >> 4));
-    *reinterpret_cast<uint4*>(yf + c * 16) = v;
-  }
-}
-
-template <bool HAS_E, int TP16, int REMC, int Q = 1>
-__global__ __launch_bounds__(512) void align_scores16_tall_bdirect_kernel(const half_t* __restrict__ xm, const char* __restrict__ yf,
-                                                                          const float* __restrict__ E, int64_t ldE,
-                                                                          float* __restrict__ S, int64_t ldS, int Bi, int Bc,
-                                                                          int64_t ldk, int ktiles, int n_nblk, int n_blocks, int rem) {
-  using Cfg = GemmCfg<2, 4, 4, 3>;                // the workgroup tile (epilogue, tile order)
-  using ACfg = GemmCfg<2, 4, 4, 0>;               // what is staged: the 256 A rows only
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  int mb, nb;
-  tile_coords(blockIdx.x, n_blocks / n_nblk, n_nblk, 8, mb, nb);
-  f32x4 acc[8][6];
-#pragma unroll
-  for (int rt = 0; rt < 8; ++rt)
-#pragma unroll
-    for (int ct = 0; ct < 6; ++ct) acc[rt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const int wave_u = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  if constexpr (HAS_E && REMC == 1 && Q == 1) {
-    // side-row values into this XCD's L2 (as in align_scores16_tall_kernel), parked in stage 2, which this wave's own
-    // refill overwrites later (same wave, same piece: in order)
-    const int lane_p = threadIdx.x & 63;
-    const int img_p = (mb * 2 + wave_u / 4) * 4 + ((lane_p % 12) / 3);
-    const float* src = E + (int64_t)img_p * ldE + (int64_t)nb * Cfg::BN + (wave_u % 4) * 96 + (lane_p % 3) * 32;
-    __builtin_amdgcn_global_load_lds(GLOBAL_PTR(src), LDS_PTR(smem + (BD_NS - 1) * ACfg::STAGE_BYTES + wave_u * 1024), 4, 0, 0);
-  }
-  const int64_t strip = (int64_t)nb * 4 + (wave_u % 4);            // 96-row strips of y
-  const char* yf_strip = yf + strip * (2 * ktiles) * 6 * 1024;
-  gemm_mainloop16_tall_bdirect<ACfg>(xm + (int64_t)mb * Cfg::BM * ldk, yf_strip, ldk, ktiles, smem, acc);
-  scores16_epilogue_tall<HAS_E, TP16, REMC, Q>(acc, mb, nb, E, ldE, rem, S, ldS, Bi, Bc);
-}
-
-template <bool HAS_E, int TP16, int REMC, int Q = 1>
-static int launch_scores16_tall_bdirect(const aladin_align_geom* g, const half_t* xm, const half_t* y, const float* E, float* S,
-                                        int64_t ldS, hipStream_t stream) {
-  using Cfg = GemmCfg<2, 4, 4, 3>;
-  using ACfg = GemmCfg<2, 4, 4, 0>;
-  const int n_mblk = (int)(g->xm_rows / Cfg::BM), n_nblk = (int)(g->y_rows / Cfg::BN);
-  if ((int64_t)n_mblk * Cfg::BM != g->xm_rows || (int64_t)n_nblk * Cfg::BN != g->y_rows) { aladin_set_error("align_scores16 bdirect: packed rows do not tile"); return ALADIN_ERR_ARG; }
-  static char* yf = nullptr;
-  static size_t yf_bytes = 0;
-  if ((size_t)g->y_bytes > yf_bytes) {            // experiment only: the library proper never allocates
-    if (yf) (void)hipFree(yf);
-    if (hipMalloc((void**)&yf, (size_t)g->y_bytes + 8192) != hipSuccess)   /* + one block: the loop's last prefetch */ { yf = nullptr; yf_bytes = 0; aladin_set_error("bdirect: hipMalloc failed"); return ALADIN_ERR_HIP; }
-    yf_bytes = (size_t)g->y_bytes;
-  }
-  if (!(g_scores_flags & ALADIN_SCORES_REUSE_SIDE)) {
-    const int64_t n_chunks = g->y_bytes / 16;
-    hipLaunchKernelGGL(y_fragment_major_kernel, dim3(2048), dim3(256), 0, stream, y, yf, (int64_t)g->Dp, g->Dp / 32, n_chunks);
-    if (int rc = aladin_check_launch("y_fragment_major_kernel")) return rc;
-    if (diag_env("ALADIN_BD_SYNC", 0)) { hipError_t e = hipStreamSynchronize(stream); fprintf(stderr, "bdirect: repack done (%s) yf=%p bytes=%zu KB=%d chunks=%lld\n", hipGetErrorString(e), (void*)yf, yf_bytes, g->Dp / 32, (long long)n_chunks); }
-  }
-  auto kern = align_scores16_tall_bdirect_kernel<HAS_E, TP16, REMC, Q>;
-  static unsigned long long lds_reserved = 0;
-  if (int rc = aladin_reserve_lds((const void*)kern, BD_NS * ACfg::STAGE_BYTES, &lds_reserved, "align_scores16_tall_bdirect")) return rc;
-  const int n_blocks = n_mblk * n_nblk;
-  hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(Cfg::THREADS), BD_NS * ACfg::STAGE_BYTES, stream, xm, (const char*)yf, E, g->y_rows, S, ldS,
-                     g->Bi, g->Bc, (int64_t)g->Dp, g->Dp / 64, n_nblk, n_blocks, g->rem);
-  if (diag_env("ALADIN_BD_SYNC", 0)) { hipError_t e = hipStreamSynchronize(stream); fprintf(stderr, "bdirect: score kernel done (%s) blocks=%d ktiles=%d\n", hipGetErrorString(e), n_blocks, g->Dp / 64); }
-  return aladin_check_launch("align_scores16_tall_bdirect_kernel");
-}
-#endif
 
 // WGM x WGN waves of 64 x 192 each: 4 x 2 with a double buffer is the kernel above; 2 x 1 (128 x 192, two waves) with a
 // three-stage ring is the SMALL-GRID variant: when the 256 x 384 tiling leaves most CUs idle (B <= 64: at most 64
@@ -1064,8 +1226,6 @@ static int launch_scores16(const aladin_align_geom* g, const half_t* xm, const h
     if (variant == 1) return launch_scores16_cfg<HAS_E, TP16, false, Q, REMC, 2, 1, 2>(g, xm, y, E, S, ldS, stream);
     if (variant == 2) return launch_scores16_cfg<HAS_E, TP16, false, Q, REMC, 2, 1, 3>(g, xm, y, E, S, ldS, stream);
     if (variant == 4) return launch_scores16_cfg<HAS_E, TP16, false, Q, REMC, 4, 2, 2>(g, xm, y, E, S, ldS, stream);   // 64 x 192 wave tiles
-    if constexpr (6 % TP16 == 0)
-      if (variant == 8 && !g->split) return launch_scores16_tall_bdirect<HAS_E, TP16, REMC, Q>(g, xm, y, E, S, ldS, stream);   // B straight from L2
 #endif
     if ((g->xm_rows / 256) * (g->y_rows / 384) <= 64)
       return launch_scores16_cfg<HAS_E, TP16, false, Q, REMC, 2, 1, 3>(g, xm, y, E, S, ldS, stream);
@@ -1100,7 +1260,7 @@ template <int WM, int Q, int TP16, bool HAS_E>
 static int launch_scores(const aladin_align_geom* g, const half_t* xm, const half_t* y, const float* E, float* S,
                          int64_t ldS, hipStream_t stream) {
   if constexpr (Q <= 2 && TP16 <= 6)
-    if (scores_strip_mult(TP16, g->mtiles) == 2) {
+    if (scores_strip_mult(TP16, g->mrows) == 2) {
       // ALADIN_ALIGN_SPREAD: 16 (default) = v_mfma_f32_16x16x32_f16 body; 26 = the same + clock probe
       // (diagnostic); 3 / 6 = the earlier 32x32x16 body and its clock probe, 7 / 9 = its ablations
       // (headline class only)
@@ -1157,14 +1317,18 @@ static int dispatch_tp(const aladin_align_geom* g, const half_t* xm, const half_
       int rc = launch_side<NT>(g, xe, y, E, stream);
       if (rc) return rc;
     }
-    if (g->mtiles == 1) return launch_scores<2, 1, TP16, true>(g, xm, y, E, S, ldS, stream);
-    if (g->mtiles == 2) return launch_scores<2, 2, TP16, true>(g, xm, y, E, S, ldS, stream);
+    if constexpr (6 % TP16 == 0)
+      if (g->mrows == 48) return launch_scores16_r48<true, TP16>(g, xm, y, E, S, ldS, stream);
+    if (g->mrows == 32) return launch_scores<2, 1, TP16, true>(g, xm, y, E, S, ldS, stream);
+    if (g->mrows == 64) return launch_scores<2, 2, TP16, true>(g, xm, y, E, S, ldS, stream);
   } else {
-    if (g->mtiles == 1) return launch_scores<2, 1, TP16, false>(g, xm, y, E, S, ldS, stream);
-    if (g->mtiles == 2) return launch_scores<2, 2, TP16, false>(g, xm, y, E, S, ldS, stream);
-    if (g->mtiles == 3) return launch_scores<3, 3, TP16, false>(g, xm, y, E, S, ldS, stream);
+    if constexpr (6 % TP16 == 0)
+      if (g->mrows == 48) return launch_scores16_r48<false, TP16>(g, xm, y, E, S, ldS, stream);
+    if (g->mrows == 32) return launch_scores<2, 1, TP16, false>(g, xm, y, E, S, ldS, stream);
+    if (g->mrows == 64) return launch_scores<2, 2, TP16, false>(g, xm, y, E, S, ldS, stream);
+    if (g->mrows == 96) return launch_scores<3, 3, TP16, false>(g, xm, y, E, S, ldS, stream);
   }
-  aladin_set_error("align_scores: unsupported tiling mtiles=%d rem=%d", g->mtiles, g->rem);
+  aladin_set_error("align_scores: unsupported tiling mrows=%d rem=%d", g->mrows, g->rem);
   return ALADIN_ERR_UNSUPPORTED;
 }
 
@@ -1188,9 +1352,6 @@ extern "C" int aladin_align_scores_ex(const void* xm, const void* xe, const void
   const half_t* a = (const half_t*)xm; const half_t* b = (const half_t*)xe; const half_t* c = (const half_t*)y;
   float* E = (float*)e_scratch;
   int rc;
-#ifdef ALADIN_DIAG
-  g_scores_flags = flags;
-#endif
   switch (g->tp16) {
     case 1: rc = dispatch_tp<1>(g, a, b, c, E, S, ldS, flags, st); break;
     case 2: rc = dispatch_tp<2>(g, a, b, c, E, S, ldS, flags, st); break;

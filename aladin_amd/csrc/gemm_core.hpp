@@ -359,7 +359,7 @@ __device__ __forceinline__ void gemm_mainloop16_tall(const half_t* __restrict__ 
                                                      int64_t ldk, int ktiles, char* smem,
                                                      f32x4 (&acc)[2 * Cfg::WM][2 * Cfg::WN], const KMap km = KMap()) {
   constexpr int RT = 2 * Cfg::WM, CT = 2 * Cfg::WN;
-  static_assert(RT == 8 && CT == 6, "written for a 128 x 96 wave tile");
+  static_assert((RT == 8 || RT == 6) && CT == 6, "written for a 128 x 96 (or 96 x 96: 48-row region class) wave tile");
   constexpr int CPW = Cfg::CHUNKS_PER_WAVE;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;

@@ -86,7 +86,7 @@ __device__ __forceinline__ void copy_row_split(const half_t* __restrict__ src, h
 // max-side operand (xm / xe) from a store: same row map as pack_images_kernel
 __global__ __launch_bounds__(256) void store_pack_x_kernel(const half_t* __restrict__ rows, const int64_t* __restrict__ offsets,
                                                            const int32_t* __restrict__ counts,
-                                                           const int32_t* __restrict__ ids, int Bi, int Rq, int Dp, int mtiles, int rem,
+                                                           const int32_t* __restrict__ ids, int Bi, int Rq, int Dp, int mrows, int rem,
                                                            int64_t xm_rows, int64_t total_rows, half_t* __restrict__ xm,
                                                            half_t* __restrict__ xe, int split) {
   const int lane = threadIdx.x & 63;
@@ -95,14 +95,14 @@ __global__ __launch_bounds__(256) void store_pack_x_kernel(const half_t* __restr
   int i, rho;
   half_t* dst;
   if (d < xm_rows) {
-    const int rows_per_img = 32 * mtiles;
+    const int rows_per_img = mrows;
     i = (int)(d / rows_per_img);
     rho = (int)(d % rows_per_img);
     if (rho >= Rq) rho = 0;
     dst = xm + d * Dp;
   } else {
     i = (int)((d - xm_rows) / rem);
-    rho = 32 * mtiles + (int)((d - xm_rows) % rem);
+    rho = mrows + (int)((d - xm_rows) % rem);
     dst = xe + (d - xm_rows) * Dp;
   }
   const half_t* src = nullptr;
@@ -175,7 +175,7 @@ extern "C" int aladin_align_pack_store_x(const void* rows, const int64_t* offset
   if (!rows || !offsets || !counts || !g || !xm || (g->rem && !xe)) { aladin_set_error("align_pack_store_x: null argument"); return ALADIN_ERR_ARG; }
   const int64_t total = g->xm_rows + g->xe_rows;
   hipLaunchKernelGGL(store_pack_x_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
-                     (const half_t*)rows, offsets, counts, ids, g->Bi, g->Rq, g->Dp, g->mtiles, g->rem > 0 ? g->rem : 1, g->xm_rows, total, (half_t*)xm,
+                     (const half_t*)rows, offsets, counts, ids, g->Bi, g->Rq, g->Dp, g->mrows, g->rem > 0 ? g->rem : 1, g->xm_rows, total, (half_t*)xm,
                      (half_t*)xe, g->split);
   return aladin_check_launch("store_pack_x_kernel");
 }

@@ -72,6 +72,12 @@ def _ld(t):
     return t.stride(0) if t.shape[0] > 1 else max(t.shape[1], 1)
 
 
+def _pair_kernel_covers(geom):
+    """Shapes the fp16 pair kernel of the backward covers (csrc/align_bwd.hip: bwd_pair_argmax16_kernel): a 64-row block per
+    pair = the image's 32 / 48 main rows + a window on its side rows, or its 64 main rows; at most 64 padded words."""
+    return (geom.mrows in (32, 48) or (geom.mrows == 64 and geom.rem == 0)) and geom.tp16 <= 4
+
+
 def _workspace(nbytes, device):
     return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
 
@@ -339,7 +345,7 @@ def _hinge_argmax_fused(S, margin, im, s, im_len_t, s_len_t, packed, loss_out=No
     holds the table until _align_backward_rows consumes it (its own buffer: the shared scratch would not survive the
     other heads)."""
     geom = packed[0]
-    if not ((geom.mtiles == 1 or (geom.mtiles == 2 and geom.rem == 0)) and geom.tp16 <= 4 and geom.Bi == geom.Bc and not geom.split):
+    if not (_pair_kernel_covers(geom) and geom.Bi == geom.Bc and not geom.split):
         return None
     lib = _lib.load()
     B = S.shape[0]
@@ -997,7 +1003,7 @@ def _heads_small_fwd(im, s, S, margin, max_violation, flags, temperature, eps, w
     out['dMl'] = torch.empty((B, B), **f32) if (want_grads and flags & HEAD_LISTNET and weights[2] != 0) else None
     out['dS'] = torch.empty((B, B), **f32) if (want_grads and flags & HEAD_ALIGN_HINGE) else None
     out['pairs'] = out['table_ws'] = out['sets'] = None
-    if (align is not None and out['dS'] is not None and max_violation and (align[4][0].mtiles == 1 or (align[4][0].mtiles == 2 and align[4][0].rem == 0)) and align[4][0].tp16 <= 4
+    if (align is not None and out['dS'] is not None and max_violation and _pair_kernel_covers(align[4][0])
             and not align[4][0].split):
         im_set, s_seq, im_len_t, s_len_t, packed = align
         geom = packed[0]

@@ -42,7 +42,13 @@ def parse():
     ap.add_argument('--repeats', type=int, default=5, help='how many times the --steps region is timed (median reported)')
     ap.add_argument('--preroll-s', type=float, default=1.0, help='clock-settling pre-roll before the warm-up, seconds')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-eval', action='store_true', help='skip the configs[2] (retrieval) secondary timing')
+    ap.add_argument('--no-eval', action='store_true', help='skip the secondary timings (configs[2] retrieval, shipped shape, loss heads at bs 32, '
+                                                            'configs[4] end to end, COCO-1k alignment grid)')
+    ap.add_argument('--no-cpu-b256', action='store_true', help='skip the live B = 256 CPU baseline (~25 s, ~40 GB of host memory); the committed '
+                                                               'one-off measurement is attached instead')
+    ap.add_argument('--stub-step', action='store_true',
+                    help='CPU self-test of the multi-rank protocol (tests/test_launch_cpu.py): gloo, a stub step, the same launcher, '
+                         'argument parsing, barriers, MAX over ranks and JSON line -- no GPU, no kernels, no performance claim')
     ap.add_argument('--eager', action='store_true', help='do not capture the step in a HIP graph')
     ap.add_argument('--graph', action='store_true', help='always replay the captured HIP graph (default: the faster of graph / eager in a short trial)')
     ap.add_argument('--force-sharded', action='store_true',
@@ -87,37 +93,68 @@ def kernel_roofline(im, s, il, sl, groups=5, iters=100):
     flops = B * B * 2 * 32 * (T - 3) * D
     achieved = flops / (ms * 1e-3) / 1e12
     traffic, src = pmc_traffic('align_scores16_tall_kernel')
-    return {'bound': 'mfma', 'traffic_source': src, 'kernel': 'align_scores16_tall_kernel<true,3,1> (256x384 tile, 8 waves of 128x96, v_mfma_f32_16x16x32_f16)',
-            'achieved': round(achieved, 2), 'peak': PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_TFLOPS, 4),
-            'traffic': traffic, 'kernel_us': round(ms * 1e3, 2), 'kernel_us_min_max': [round(min(ms_groups) * 1e3, 2), round(max(ms_groups) * 1e3, 2)],
-            'flops_per_launch': flops}
+    out = {'bound': 'mfma', 'traffic_source': src, 'kernel': 'align_scores16_tall_kernel<true,3,1> (256x384 tile, 8 waves of 128x96, v_mfma_f32_16x16x32_f16)',
+           'achieved': round(achieved, 2), 'peak': PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_TFLOPS, 4),
+           'traffic': traffic, 'kernel_us': round(ms * 1e3, 2), 'kernel_us_min_max': [round(min(ms_groups) * 1e3, 2), round(max(ms_groups) * 1e3, 2)],
+           'flops_per_launch': flops}
+    # the same fraction for what surrounds the kernel: the forward chain pack + side GEMM + score kernel against ALL
+    # of a pair's flops (33 regions), event-timed here; bench.py's main adds step_frac from the timed step itself
+    try:
+        sys.path.insert(0, os.path.join(ROOT, 'tools'))
+        import benchlib
+        chain_ms = benchlib.forward_chain(im, s, il, sl)
+        out['forward_chain_us'] = round(chain_ms * 1e3, 2)
+        out['forward_chain_frac'] = round(B * B * FLOPS_PER_PAIR / (chain_ms * 1e-3) / 1e12 / PEAK_TFLOPS, 4)
+    except Exception as exc:
+        out['forward_chain_error'] = str(exc)
+    return out
+
+
+def csrc_hash():
+    """sha256 over the kernel sources (aladin_amd/csrc/*.hip, *.hpp, sorted by name): what a committed PMC summary was collected
+    on.  tools/materialise_profiles.py stamps it into profiles/*_pmc.json."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, 'aladin_amd', 'csrc', '*.hip')) + glob.glob(os.path.join(ROOT, 'aladin_amd', 'csrc', '*.hpp'))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, 'rb').read())
+    return h.hexdigest()[:16]
 
 
 def pmc_traffic(kernel_substr):
     """HBM-side bytes per launch of the dominant kernel from the newest committed PMC summary
     (profiles/*_pmc.json, written by tools/materialise_profiles.py from separate rocprofv3 --pmc passes with
-    the gfx950 FETCH_SIZE x2 correction).  bench.py cannot run the profiler on itself, so it
-    reports the committed measurement and names its file; None if there is none."""
+    the gfx950 FETCH_SIZE x2 correction).  bench.py cannot run the profiler on itself, so it reports the committed
+    measurement and names its file -- but only while the kernel sources are the ones that were profiled: a summary stamped
+    with another csrc hash (or with none) is refused, traffic is null and traffic_source says why."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc.json')))
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc.json')), key=os.path.getmtime)
+    now = csrc_hash()
+    stale = None
     for f in reversed(files):
         try:
-            ks = json.load(open(f))['kernels']
+            d = json.load(open(f))
+            ks = d['kernels']
         except Exception:
             continue
-        for name, d in ks.items():
-            if kernel_substr in name and 'hbm_bytes_corrected' in d:
-                return int(d['hbm_bytes_corrected']), os.path.relpath(f, ROOT)
-    return None, None
+        for name, k in ks.items():
+            if kernel_substr in name and 'hbm_bytes_corrected' in k:
+                if d.get('csrc_hash') == now:
+                    return int(k['hbm_bytes_corrected']), os.path.relpath(f, ROOT)
+                if stale is None:
+                    stale = 'stale: %s was collected on kernel sources %s, these are %s (re-run tools/collect_pmc.sh)' % (
+                        os.path.relpath(f, ROOT), d.get('csrc_hash', 'unstamped'), now)
+    return None, stale
 
 
-def cpu_baseline():
+def cpu_baseline(live_b256=True):
     """BASELINE.json configs[0] verbatim: B=16, R=34, T=50, D=768 random tensors through the reference's
     AlignmentContrastiveLoss dataflow (oracle/faithful_torch.py restates alad/loss.py:79-159 op for op and is
     pinned to the reference's outputs by tests/test_oracle_golden.py), forward and forward+backward, on the
     host cores.  Thread counts {8, 32, all} are tried and the BEST is reported (B^2 tiny bmm's oversubscribe
-    a big host).  The faithful B=256 run (SURVEY 8(d) CPU timing plan) takes minutes and ~40 GB: it is a
-    one-off, tools/cpu_baseline_sweep.py, whose committed result is attached as `b256`."""
+    a big host).  `b256`: the same dataflow at the headline size, live (tools/benchlib.py: 1 warm-up + 2 timed steps,
+    ~25 s, ~40 GB) -- or, when the host cannot hold it / --no-cpu-b256, the committed one-off measurement, labelled so."""
     import torch
     sys.path.insert(0, os.path.join(ROOT, 'oracle'))
     import faithful_torch as FT
@@ -147,10 +184,18 @@ def cpu_baseline():
                      '(expand + bmm + masks, oracle/faithful_torch.py), fwd+bwd, >=10 reps after 2 warm-ups (2 reps where a step takes > 0.5 s), best of threads '
                      + str(sorted(sweep)) + ': %.1f ms/step at %d threads' % (sweep[best]['fwd_bwd'] * 1e3, best),
            'sweep_ms': {str(k): {t: round(v * 1e3, 2) for t, v in r.items()} for k, r in sweep.items()}}
-    b256 = os.path.join(ROOT, 'profiles', 'r02_cpu_baseline_b256.json')
-    if os.path.exists(b256):
+    # B = 256 (the >= 10x target is stated against this size): live, at the best thread count found above
+    committed = os.path.join(ROOT, 'profiles', 'r02_cpu_baseline_b256.json')
+    if live_b256:
         try:
-            out['b256'] = json.load(open(b256))
+            sys.path.insert(0, os.path.join(ROOT, 'tools'))
+            import benchlib
+            out['b256'] = benchlib.cpu_baseline_b256(min(32, nproc))      # 32 threads: the best of the round-2 sweep {8, 32, all} at this size
+        except Exception as exc:
+            out['b256_live_error'] = '%s: %s' % (type(exc).__name__, exc)
+    if 'b256' not in out and os.path.exists(committed):
+        try:
+            out['b256'] = dict(json.load(open(committed)), source='committed (profiles/r02_cpu_baseline_b256.json, a round-2 box)')
         except Exception:
             pass
     return out
@@ -233,6 +278,53 @@ def shipped_shape_step(dev):
             'flops_per_pair': 2 * 50 * 35 * D, 'tflops_algorithmic_fwd_equiv': round(2 * 50 * 35 * D * B * B / (ms * 1e-3) / 1e12, 1)}
 
 
+def stub_main(args, world, rank):
+    """--stub-step: the multi-rank PROTOCOL on CPU (gloo): what the driver's `torch.distributed.run ... bench.py --gpus N` relies
+    on besides the kernels -- rendezvous on 127.0.0.1, one rank per slot, barriers around the timed region, MAX over ranks,
+    exactly one JSON line from rank 0 carrying config.collectives.  The step is a stand-in (a rank-sized all-gather + all-reduce
+    of small CPU tensors), the numbers mean nothing and the line says so ("data": "stub")."""
+    import torch
+    import torch.distributed as dist
+    torch.set_num_threads(1)
+    dist.init_process_group('gloo')
+    x = torch.full((1024,), float(rank + 1))
+    parts = [torch.empty(1024) for _ in range(world)]
+
+    def step():
+        dist.all_gather(parts, x)                          # stands for the all-gather of the packed image operands
+        t = torch.stack(parts).sum(0)
+        dist.all_reduce(t)                                 # stands for the reduce-scatter of d(image sets)
+        return t
+
+    def agree_max(v):
+        tt = torch.tensor([v], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        return float(tt.item())
+    for _ in range(min(args.warmup, 5)):
+        step()
+    steps = min(args.steps, 20)
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = step()
+    dist.barrier()
+    ms = agree_max(time.perf_counter() - t0) / steps * 1e3
+    want = world * sum(range(1, world + 1))
+    ok = bool((out == want).all())
+    if rank == 0:
+        print(json.dumps({'metric': 'alignment image-text pairs/sec (BxB scores, triplet loss fwd+bwd) at B=256/GPU,R=34,T=50,D=768',
+                          'value': 0.0, 'unit': 'pairs/s', 'n_gpus': world, 'steps': steps, 'warmup': min(args.warmup, 5), 'ms_per_step': round(ms, 4),
+                          'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f16', 'data': 'stub',
+                          'config': {'workload': 'STUB STEP: protocol self-test on CPU, no kernels, no performance claim',
+                                     'collectives': {'backend': dist.get_backend(), 'ranks': dist.get_world_size(),
+                                                     'launcher': 'self (aladin_amd.launch)' if os.environ.get('ALADIN_SELF_LAUNCHED') else 'external'},
+                                     'stub_result_ok': ok}}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+    if not ok:
+        raise SystemExit(3)
+
+
 def main():
     args = parse()
     # before anything initialises the HIP runtime: the host driver only supports dmabuf IPC
@@ -254,6 +346,8 @@ def main():
     if args.gpus != world:
         raise SystemExit('bench.py --gpus %d runs as rank %d of a world of %d: --gpus must equal the number of ranks started'
                          % (args.gpus, rank, world))
+    if args.stub_step:
+        return stub_main(args, world, rank)
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X (no GPU visible); there is no CPU fallback')
     torch.cuda.set_device(local_rank)
@@ -441,14 +535,17 @@ def main():
             cfg['bwd_exchange_tuning_ms'] = {k: (round(v, 4) if v != float('inf') else None) for k, v in tuned.items()}
             cfg['phases_ms'] = phases          # rank 0's device timeline of one step (10-step mean), see PhaseRecorder
         if world == 1 and not args.no_eval:
-            try:
-                cfg['eval_config3'] = eval_config3(dev)
-            except Exception as exc:
-                cfg['eval_config3'] = {'error': str(exc)}
-            try:
-                cfg['shipped_shape'] = shipped_shape_step(dev)
-            except Exception as exc:
-                cfg['shipped_shape'] = {'error': str(exc)}
+            sys.path.insert(0, os.path.join(ROOT, 'tools'))
+            import benchlib
+            for key, fn in (('eval_config3', eval_config3), ('shipped_shape', shipped_shape_step), ('loss_heads_bs32', benchlib.loss_heads_bs32),
+                            ('e2e_config4', benchlib.e2e_config4), ('alignment_retrieval_coco1k', benchlib.alignment_retrieval_coco1k)):
+                try:
+                    cfg[key] = fn(dev)
+                except Exception as exc:
+                    cfg[key] = {'error': '%s: %s' % (type(exc).__name__, exc)}
+        # the three fractions of the 16-bit MFMA peak side by side: the score kernel alone (`frac`), the forward chain
+        # pack + side GEMM + score kernel (`forward_chain_frac`), the whole timed step forward + backward (`step_frac`)
+        roof['step_frac'] = round(value * FLOPS_PER_PAIR / world / 1e12 / PEAK_TFLOPS, 4)
         out = {
             'metric': 'alignment image-text pairs/sec (BxB scores, triplet loss fwd+bwd) at B=256/GPU,R=34,T=50,D=768',
             'value': round(value, 1), 'unit': 'pairs/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -456,7 +553,7 @@ def main():
             'dtype': 'f16', 'data': 'synthetic', 'config': cfg, 'roofline': roof,
         }
         if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline()
+            out['cpu_baseline'] = cpu_baseline(live_b256=not args.no_cpu_b256)
         print(json.dumps(out), flush=True)
     if sharded:
         dist.barrier()

@@ -52,8 +52,8 @@ ALADIN_API const char* aladin_last_error(void);
 typedef struct aladin_align_geom {
   int32_t Bi, Bc, R, T, D;      /* inputs: im (Bi,R,D), s (Bc,T,D)                              */
   int32_t Rq, Tq;               /* R-1 regions and T-3 words take part (alad/loss.py:87-88)     */
-  int32_t mtiles;               /* 32-row MFMA tiles per image in the main operand              */
-  int32_t rem;                  /* 1: the last region of every image goes through the side GEMM */
+  int32_t mrows;                /* rows per image in the main operand xm: 32, 48, 64 or 96 (rows past R' repeat region 0) */
+  int32_t rem;                  /* leftover regions per image (R' - mrows when positive) that go through the side GEMM: <= 8 */
   int32_t tp16;                 /* padded words per caption / 16                                */
   int32_t Dp;                   /* halfs per packed row: D rounded up to 64 (zero filled), x3 when split */
   int32_t img_unit, cap_unit;   /* images / captions per workgroup tile                         */
@@ -159,7 +159,7 @@ ALADIN_API int aladin_align_bwd_packed_strided(const float* im, int64_t im_strid
  * S: the square score matrix of this (geom, xm, xe, y) problem; loss: 1 float; dS: (B, B) contiguous, fully written;
  * hinge_workspace: aladin_hinge_workspace_bytes(B); bwd_workspace: aladin_align_bwd_workspace_bytes(...) -- it receives
  * the argmax table and must stay untouched until aladin_align_bwd_rows consumed it.  Needs the fp16 pair kernel's
- * shapes (geom->mtiles == 1, <= 64 padded words), else ALADIN_ERR_UNSUPPORTED.
+ * shapes (geom->mrows <= 64 with side rows only next to 32 or 48, <= 64 padded words), else ALADIN_ERR_UNSUPPORTED.
  * aladin_align_bwd_rows: the remaining kernel of the backward (autograd of alad/loss.py:80-125 given dS and the table),
  * gradients in the caller's layout as in aladin_align_bwd_packed_strided.  dS must be the matrix the fused call wrote: the
  * workspace also carries its transpose (the caption rows read their column of dS from it, coalesced). */

@@ -143,11 +143,24 @@ def test_checkpoint_directory_loads_strictly_and_feeds_the_encoder(tmp_path):
     # the key set of the reference encoder for this configuration (alad_model.py:43,55-56,104-108)
     top = {k.split('.')[0] for k in enc.state_dict()}
     assert top == {'oscar_model', 'img_proj', 'cap_proj', 'final_projection_net'}
-    with pytest.raises(RuntimeError):
+    # like the loader the reference goes through (pytorch_transformers' from_pretrained), keys outside the backbone are
+    # tolerated with a warning: a pre-training checkpoint has cls.* and no classifier.*, newer exports carry position_ids
+    other = dict(src.state_dict())
+    other.pop('classifier.bias')
+    other['cls.predictions.bias'] = torch.zeros(50)
+    other['bert.embeddings.position_ids'] = torch.arange(32)[None]
+    torch.save(other, tmp_path / 'pytorch_model.bin')
+    with pytest.warns(UserWarning) as rec:
+        m2 = ImageBertForSequenceClassification.from_pretrained(str(tmp_path))
+    msgs = ' '.join(str(w.message) for w in rec)
+    assert 'classifier.bias' in msgs and 'cls.predictions.bias' in msgs and 'position_ids' in msgs
+    assert torch.equal(m2.bert.pooler.dense.weight, src.bert.pooler.dense.weight)
+    with pytest.raises(RuntimeError, match='lacks backbone parameters'):        # a MISSING bert.* parameter is an error
         bad = dict(src.state_dict())
-        bad.pop('classifier.bias')
+        bad.pop('bert.encoder.layer.0.output.dense.weight')
         torch.save(bad, tmp_path / 'pytorch_model.bin')
         ImageBertForSequenceClassification.from_pretrained(str(tmp_path))
+    torch.save(src.state_dict(), tmp_path / 'pytorch_model.bin')
     # drive the 7-tuple once on CPU up to the HIP l2norm (which needs the GPU): shapes of the hand-off
     B, n_tok, n_reg = 2, 6, 4
     ids = torch.randint(1, 50, (B, n_tok))

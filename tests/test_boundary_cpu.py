@@ -41,12 +41,12 @@ def test_library_exports_nothing_but_the_declared_symbols():
 def test_geometry_headline_and_edges():
     from aladin_amd import _lib, ops
     g = ops.align_geometry(256, 256, 34, 50, 768)
-    assert (g.Rq, g.Tq, g.mtiles, g.rem, g.tp16, g.Dp) == (33, 47, 1, 1, 3, 768)
+    assert (g.Rq, g.Tq, g.mrows, g.rem, g.tp16, g.Dp) == (33, 47, 32, 1, 3, 768)
     assert g.xm_rows == 256 * 32 and g.xe_rows == 256 and g.y_rows == 256 * 48
     g = ops.align_geometry(1000, 5000, 71, 71, 768)         # evaluation shape: 70 regions x 68 words
-    assert (g.mtiles, g.rem, g.tp16) == (3, 0, 6)
+    assert (g.mrows, g.rem, g.tp16) == (96, 0, 6)
     g = ops.align_geometry(3, 7, 3, 5, 8)
-    assert (g.Rq, g.Tq, g.mtiles, g.rem, g.tp16, g.Dp) == (2, 2, 1, 0, 1, 64)
+    assert (g.Rq, g.Tq, g.mrows, g.rem, g.tp16, g.Dp) == (2, 2, 32, 0, 1, 64)
     gs = ops.align_geometry(256, 256, 34, 50, 768, precision='split')          # hi/lo split operands: three K segments per row
     g = ops.align_geometry(256, 256, 34, 50, 768)
     assert gs.split == 1 and g.split == 0 and gs.Dp == 3 * g.Dp and gs.xm_bytes == 3 * g.xm_bytes and gs.e_bytes == g.e_bytes

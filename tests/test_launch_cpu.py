@@ -47,6 +47,32 @@ def test_a_failing_rank_fails_the_launch():
 
 
 @pytest.mark.timeout(300)
+def test_a_failed_run_withholds_its_result_line_from_stdout():
+    """rank 0 prints its JSON line, then another rank dies: the driver reads the LAST stdout line and must not find it."""
+    rc, line, out, err = _run(['--gpus', '2', '--fail-after-result'], 2)
+    assert rc != 0 and line is None
+    assert '"n_gpus"' not in out
+    assert 'withheld from stdout' in err and '"n_gpus": 2' in err
+
+
+@pytest.mark.timeout(300)
+def test_a_lost_rendezvous_port_is_retried_once(tmp_path):
+    flag = str(tmp_path / 'first_attempt_done')
+    rc, line, out, err = _run(['--gpus', '2', '--bind-failure-once', flag], 2)
+    assert rc == 0, err
+    assert 'retrying once on a fresh port' in err and json.loads(line)['n_gpus'] == 2
+
+
+@pytest.mark.timeout(600)
+def test_eight_ranks():
+    """configs[3]'s world size under gloo: the launcher brings up 8 ranks on 127.0.0.1 and every one takes part."""
+    rc, line, out, err = _run(['--gpus', '8'], 8)
+    assert rc == 0, err
+    res = json.loads(line)
+    assert res['n_gpus'] == 8 and res['local_ranks_plus_1'] == list(range(1, 9))
+
+
+@pytest.mark.timeout(300)
 def test_success_without_a_result_line_is_an_error():
     rc, line, out, err = _run(['--gpus', '2', '--no-result'], 2)
     assert rc == 1 and line is None and 'without printing a result line' in err
@@ -56,6 +82,23 @@ def test_success_without_a_result_line_is_an_error():
 def test_timeout_ends_the_ranks():
     rc, line, out, err = _run(['--gpus', '2', '--hang'], 2, timeout=20)
     assert rc == 124 and line is None
+
+
+@pytest.mark.timeout(900)
+def test_bench_py_eight_ranks_stub_step():
+    """the REAL bench.py -- its argument parsing, self-launch, rendezvous, barriers, MAX over ranks and JSON
+    line -- at configs[3]'s world size, with a stub step on CPU (gloo).  No scaling number is claimed: this is the protocol."""
+    env = dict(os.environ, OMP_NUM_THREADS='1')
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '8', '--stub-step', '--steps', '5', '--warmup', '2'],
+                         env=env, capture_output=True, text=True, timeout=800)
+    assert out.returncode == 0, out.stderr[-2000:]
+    last = [l for l in out.stdout.splitlines() if l.strip()][-1]
+    res = json.loads(last)
+    assert res['n_gpus'] == 8 and res['data'] == 'stub' and res['steps'] == 5
+    assert res['config']['collectives'] == {'backend': 'gloo', 'ranks': 8, 'launcher': 'self (aladin_amd.launch)'}
+    assert res['config']['stub_result_ok'] is True
 
 
 def test_no_self_launch_inside_a_rank_or_for_one_gpu():

@@ -13,3 +13,4 @@ for P in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_VALU_MFMA_BUSY
   rocprofv3 --kernel-trace --pmc $P --output-format csv -d "$OUT/pmc_$N" -- python3 "$R/tools/bench_retrieval.py" --profile --only "$ONLY" > "$OUT/pmc_$N.log" 2>&1
   tail -1 "$OUT/pmc_$N.log"
 done
+cd "$R" && python3 -c "import bench; print(bench.csrc_hash())" > "$OUT/csrc_hash.txt"

@@ -27,7 +27,16 @@ for k, d in res.items():
         # rocprofv3 units: KiB.  gfx950: FETCH_SIZE reports half the bytes of wide coalesced reads
         # (MI355X_MICROARCH.md, HBM section) -> doubled; WRITE_SIZE is exact.
         d['hbm_bytes_corrected'] = (2.0 * d['FETCH_SIZE'] + d['WRITE_SIZE']) * 1024.0
-json.dump({'tag': tag, 'note': 'averages per dispatch; FETCH_SIZE doubled per the gfx950 correction', 'kernels': res},
+sys.path.insert(0, root)
+import bench                                                   # csrc_hash(): which kernel sources these counters belong to
+# gpurun ships the working tree as it is, so the sources profiled are the ones in the tree when the collection ran: the script
+# that collects (tools/collect_pmc.sh, collect_eval_pmc.sh) records `csrc_hash` next to the counters; fall back to the tree's
+stamp = None
+hfile = os.path.join(out, 'csrc_hash.txt')
+if os.path.exists(hfile):
+    stamp = open(hfile).read().strip()
+json.dump({'tag': tag, 'note': 'averages per dispatch; FETCH_SIZE doubled per the gfx950 correction', 'csrc_hash': stamp or bench.csrc_hash(),
+           'csrc_hash_source': 'recorded on the GPU box by the collection script' if stamp else 'working tree at materialisation time', 'kernels': res},
           open(os.path.join(prof, '%s_pmc.json' % tag), 'w'), indent=1, sort_keys=True)
 for name in ('bench_line_unprofiled.json', 'clock_probe.txt'):
     src = os.path.join(out, name)
