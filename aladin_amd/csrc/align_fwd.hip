@@ -723,7 +723,7 @@ __device__ __forceinline__ void scores16_epilogue_r48(f32x4 (&acc)[6][6], int mb
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int wm = wave / WGN, wn = wave % WGN;
   const int half = lane >> 5, l4 = lane & 15;
-  if constexpr (REMC == 1) rem = 1;
+  if constexpr (REMC >= 1) rem = REMC;
   constexpr int NC = CT / TP16;
   static_assert(CT % TP16 == 0, "a caption must be a whole number of 16-word column tiles of the strip");
   const int cap = (nb * WGN + wn) * NC;
@@ -739,8 +739,13 @@ __device__ __forceinline__ void scores16_epilogue_r48(f32x4 (&acc)[6][6], int mb
     auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(p0), __float_as_uint(p1), false, false);
     float m = vmax(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
     m = max_xor16(m);
-    if constexpr (HAS_E && REMC == 1) m = vmax(m, e[ct * 16]);
-    if constexpr (HAS_E && REMC != 1) {
+    if constexpr (HAS_E && REMC >= 1) {
+      // REMC side rows, known at compile time (1 and 2 -- VinVL's 50 regions = 48 + 2 -- have their own instantiations: a
+      // run-time trip count here costs the kernel several per cent)
+#pragma unroll
+      for (int k = 0; k < REMC; ++k) m = vmax(m, e[(int64_t)k * ldE + ct * 16]);
+    }
+    if constexpr (HAS_E && REMC == 0) {
       // branch-free: max is idempotent, so rows past the last side row re-read it (k clamped to rem - 1)
 #pragma unroll
       for (int k = 0; k < 8; ++k) m = vmax(m, e[(int64_t)(k < rem ? k : rem - 1) * ldE + ct * 16]);
@@ -768,6 +773,19 @@ __global__ __launch_bounds__(WGM * WGN * 64) void align_scores16_r48_kernel(cons
   for (int rt = 0; rt < 6; ++rt)
 #pragma unroll
     for (int ct = 0; ct < 6; ++ct) acc[rt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if constexpr (HAS_E && REMC >= 1 && REMC <= 2 && WGM == 2 && WGN == 4) {
+    // pull this tile's side-row values into this XCD's L2 now (they were written by the side GEMM on other XCDs; see
+    // align_scores16_kernel): per wave 2 images x REMC rows x 96 columns = 6 REMC lines of 32 floats; dropped into the piece
+    // of stage 1 this wave's own refill overwrites later
+    const int wave_u = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane_p = threadIdx.x & 63;
+    constexpr int LINES = 6 * REMC;
+    const int q = lane_p % LINES;
+    const int img_p = (mb * WGM + wave_u / WGN) * 2 + q / (3 * REMC);
+    const int k_p = (q / 3) % REMC;
+    const float* src = E + ((int64_t)img_p * REMC + k_p) * ldE + (int64_t)nb * Cfg::BN + (wave_u % WGN) * 96 + (q % 3) * 32;
+    __builtin_amdgcn_global_load_lds(GLOBAL_PTR(src), LDS_PTR(smem + Cfg::STAGE_BYTES + wave_u * 1024), 4, 0, 0);
+  }
   gemm_mainloop16_tall<Cfg, true>(xm + (int64_t)mb * Cfg::BM * ldk, y + (int64_t)nb * Cfg::BN * ldk, ldk, ktiles, smem, acc);
   scores16_epilogue_r48<HAS_E, TP16, REMC, WGM, WGN>(acc, mb, nb, E, ldE, rem, S, ldS, Bi, Bc);
 }
@@ -796,7 +814,9 @@ static int launch_scores16_r48(const aladin_align_geom* g, const half_t* xm, con
   // small grids (<= 64 tiles of 192 x 384, e.g. the shipped batch size 32): 96 x 192 tiles of two waves, four times the workgroups
   const bool small = (g->xm_rows / 192) * (g->y_rows / 384) <= 64;
   if constexpr (HAS_E) {
-    if (g->rem > 1) return small ? launch_scores16_r48_cfg<true, TP16, 0, 1, 2>(g, xm, y, E, S, ldS, stream)
+    if (g->rem == 2) return small ? launch_scores16_r48_cfg<true, TP16, 2, 1, 2>(g, xm, y, E, S, ldS, stream)
+                                  : launch_scores16_r48_cfg<true, TP16, 2, 2, 4>(g, xm, y, E, S, ldS, stream);
+    if (g->rem > 2) return small ? launch_scores16_r48_cfg<true, TP16, 0, 1, 2>(g, xm, y, E, S, ldS, stream)
                                  : launch_scores16_r48_cfg<true, TP16, 0, 2, 4>(g, xm, y, E, S, ldS, stream);
   }
   return small ? launch_scores16_r48_cfg<HAS_E, TP16, 1, 1, 2>(g, xm, y, E, S, ldS, stream)

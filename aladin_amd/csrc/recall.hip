@@ -133,6 +133,60 @@ __device__ __forceinline__ float sim_scale_of(float am) {
 // Norms are rounded UP (factor 1 + 2^-10 over an fp32 sum of squares whose own error is < 2^-14 relative).
 //   images: nrm = (P, R) = (|lo|, |hi|)      captions: nrm = (Q, T) = (|hi|, |lo|)
 // The grid also zeroes the fused retrieval's counters (zero0 / zero1 / zero2: int32 words; null for aladin_sim_matrix).
+// One wave packs one row: [hi | lo] with x * sc = hi + lo to dst (global) and, when lds != nullptr, to an LDS copy; returns the
+// two norms rounded UP (factor 1 + 2^-10 over an fp32 sum of squares whose own error is < 2^-14 relative).
+__device__ __forceinline__ float2 sim_pack_row(const float* __restrict__ x, int64_t rs, int64_t r, int rows, int D, int Dp, float sc, int lane,
+                                               bool vec4, half_t* __restrict__ d, half_t* __restrict__ lds) {
+  float sh = 0.f, sl = 0.f;
+  if (vec4) {
+    for (int c = lane * 4; c < Dp; c += 256) {
+      float4 v = {0.f, 0.f, 0.f, 0.f};
+      if (r < rows && c < D) v = *reinterpret_cast<const float4*>(x + r * rs + c);
+      const float w[4] = {v.x * sc, v.y * sc, v.z * sc, v.w * sc};
+      half4 hi, lo;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        hi[k] = (half_t)w[k];
+        lo[k] = (half_t)(w[k] - (float)hi[k]);
+        sh = fmaf((float)hi[k], (float)hi[k], sh);
+        sl = fmaf((float)lo[k], (float)lo[k], sl);
+      }
+      *reinterpret_cast<half4*>(d + c) = hi;
+      *reinterpret_cast<half4*>(d + Dp + c) = lo;
+      if (lds) { *reinterpret_cast<half4*>(lds + c) = hi; *reinterpret_cast<half4*>(lds + Dp + c) = lo; }
+    }
+  } else {
+    for (int c = lane; c < Dp; c += 64) {
+      float v = 0.f;
+      if (r < rows && c < D) v = x[r * rs + c] * sc;
+      const half_t hi = (half_t)v;
+      const half_t lo = (half_t)(v - (float)hi);
+      d[c] = hi;
+      d[Dp + c] = lo;
+      if (lds) { lds[c] = hi; lds[Dp + c] = lo; }
+      sh = fmaf((float)hi, (float)hi, sh);
+      sl = fmaf((float)lo, (float)lo, sl);
+    }
+  }
+  sh = wave_sum(sh);
+  sl = wave_sum(sl);
+  const float up = 1.0f + 0x1p-10f;
+  return float2{sqrtf(sh) * up, sqrtf(sl) * up};                    // (|hi|, |lo|)
+}
+
+// the two power-of-two scales from the per-block partial maxima (every block of the pack kernels does this itself: 8 KiB from L2)
+__device__ __forceinline__ void sim_block_scales(const float* __restrict__ partial, float (*red)[4], float& sc_img, float& sc_cap) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float mi = 0.f, mc = 0.f;
+  for (int e = threadIdx.x; e < SIM_ABS_BLOCKS; e += 256) { mi = fmaxf(mi, partial[e]); mc = fmaxf(mc, partial[SIM_ABS_BLOCKS + e]); }
+  mi = wave_max(mi);
+  mc = wave_max(mc);
+  if (lane == 0) { red[0][wave] = mi; red[1][wave] = mc; }
+  __syncthreads();
+  sc_img = sim_scale_of(fmaxf(fmaxf(red[0][0], red[0][1]), fmaxf(red[0][2], red[0][3])));
+  sc_cap = sim_scale_of(fmaxf(fmaxf(red[1][0], red[1][1]), fmaxf(red[1][2], red[1][3])));
+}
+
 constexpr int SIM_PACK_RPW = 4;
 __global__ __launch_bounds__(256) void sim_pack_kernel(const float* __restrict__ img, int64_t img_rs, int n_img, int Mp,
                                                        const float* __restrict__ cap, int64_t cap_rs, int n_cap, int Np, int D, int Dp,
@@ -142,16 +196,8 @@ __global__ __launch_bounds__(256) void sim_pack_kernel(const float* __restrict__
                                                        int32_t* __restrict__ zero1, int64_t nz1, int32_t* __restrict__ zero2, int64_t nz2) {
   __shared__ float red[2][4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  {
-    float mi = 0.f, mc = 0.f;
-    for (int e = threadIdx.x; e < SIM_ABS_BLOCKS; e += 256) { mi = fmaxf(mi, partial[e]); mc = fmaxf(mc, partial[SIM_ABS_BLOCKS + e]); }
-    mi = wave_max(mi);
-    mc = wave_max(mc);
-    if (lane == 0) { red[0][wave] = mi; red[1][wave] = mc; }
-    __syncthreads();
-  }
-  const float sc_img = sim_scale_of(fmaxf(fmaxf(red[0][0], red[0][1]), fmaxf(red[0][2], red[0][3])));
-  const float sc_cap = sim_scale_of(fmaxf(fmaxf(red[1][0], red[1][1]), fmaxf(red[1][2], red[1][3])));
+  float sc_img, sc_cap;
+  sim_block_scales(partial, red, sc_img, sc_cap);
   if (blockIdx.x == 0 && threadIdx.x == 0) { scale[0] = sc_img; scale[1] = sc_cap; }
   {
     const int64_t gtid = (int64_t)blockIdx.x * 256 + threadIdx.x, gsz = (int64_t)gridDim.x * 256;
@@ -167,47 +213,11 @@ __global__ __launch_bounds__(256) void sim_pack_kernel(const float* __restrict__
     if (r >= (int64_t)Mp + Np) return;
     const bool is_cap = r >= Mp;
     if (is_cap) r -= Mp;
-    const float* x = is_cap ? cap : img;
-    const int64_t rs = is_cap ? cap_rs : img_rs;
-    const int rows = is_cap ? n_cap : n_img;
-    const float sc = is_cap ? sc_cap : sc_img;
-    half_t* d = (is_cap ? b : a) + r * 2 * Dp;
-    float sh = 0.f, sl = 0.f;
-    if (is_cap ? v_cap : v_img) {
-      for (int c = lane * 4; c < Dp; c += 256) {
-        float4 v = {0.f, 0.f, 0.f, 0.f};
-        if (r < rows && c < D) v = *reinterpret_cast<const float4*>(x + r * rs + c);
-        const float w[4] = {v.x * sc, v.y * sc, v.z * sc, v.w * sc};
-        half4 hi, lo;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          hi[k] = (half_t)w[k];
-          lo[k] = (half_t)(w[k] - (float)hi[k]);
-          sh = fmaf((float)hi[k], (float)hi[k], sh);
-          sl = fmaf((float)lo[k], (float)lo[k], sl);
-        }
-        *reinterpret_cast<half4*>(d + c) = hi;
-        *reinterpret_cast<half4*>(d + Dp + c) = lo;
-      }
-    } else {
-      for (int c = lane; c < Dp; c += 64) {
-        float v = 0.f;
-        if (r < rows && c < D) v = x[r * rs + c] * sc;
-        const half_t hi = (half_t)v;
-        const half_t lo = (half_t)(v - (float)hi);
-        d[c] = hi;
-        d[Dp + c] = lo;
-        sh = fmaf((float)hi, (float)hi, sh);
-        sl = fmaf((float)lo, (float)lo, sl);
-      }
-    }
-    sh = wave_sum(sh);
-    sl = wave_sum(sl);
+    const float2 n = sim_pack_row(is_cap ? cap : img, is_cap ? cap_rs : img_rs, r, is_cap ? n_cap : n_img, D, Dp, is_cap ? sc_cap : sc_img, lane,
+                                  is_cap ? v_cap : v_img, (is_cap ? b : a) + r * 2 * Dp, nullptr);
     if (lane == 0) {
-      const float up = 1.0f + 0x1p-10f;
-      const float nh = sqrtf(sh) * up, nl = sqrtf(sl) * up;
-      if (is_cap) nb[r] = float2{nh, nl};
-      else na[r] = float2{nl, nh};
+      if (is_cap) nb[r] = float2{n.x, n.y};             // (Q, T) = (|hi|, |lo|)
+      else na[r] = float2{n.y, n.x};                    // (P, R) = (|lo|, |hi|)
     }
   }
 }
@@ -846,12 +856,150 @@ __global__ __launch_bounds__(256) void sim_gt_kernel(const half_t* __restrict__ 
   }
 }
 
-// scale search + split-fp16 packing shared by the GEMM modes (zero*: int32 words the pack grid clears on its way)
+// ------------------------------------------------------------------------------------------------
+// sim_pack_gt_kernel: packing and the ground-truth scores in ONE pass over the embeddings (fused retrieval only).
+// A block owns G images and their G * cpi captions: its waves pack those rows to global memory AND to LDS, then one wave per
+// (image, 16 captions) runs the exact chain from the LDS copies -- A = the image's row in all 16 rows of the MFMA tile,
+// B = its captions -- and the block stores gt[] and the arg-max entries of its pairs (it owns them: plain stores, nothing
+// to zero first).  Replaces sim_pack_kernel + sim_gt_kernel on this path: the ground-truth kernel re-read every packed row
+// (92 MB at configs[2] size) through 64-byte gathers at a wave and a half per SIMD, 35 us for work that fits under the
+// packing's own memory time.  Blocks past the last image zero-fill the padded operand rows.
+// ------------------------------------------------------------------------------------------------
+constexpr int SIM_PG_PAD = 8;                                          // halfs between LDS rows (keeps the 16 caption rows of a B fragment off one bank group)
+static int sim_pg_group(int cpi, int Dp, size_t* lds_bytes) {
+  const size_t row = (size_t)(2 * Dp + SIM_PG_PAD) * 2;
+  int G = 4;                                                           // G * (1 + cpi) rows, a multiple of the block's 4 waves
+  while (G > 1 && ((G * (1 + cpi)) % 4 != 0 || (size_t)G * (1 + cpi) * row > 65536)) G >>= 1;
+  *lds_bytes = (size_t)G * (1 + cpi) * row;
+  return G;
+}
+
+__device__ __forceinline__ void sim_chain_lds(const half_t* __restrict__ ap, const half_t* __restrict__ bp, int nblk, f32x4& acc) {
+  int k = 0;
+  for (; k + 4 <= nblk; k += 4) {
+    half8 af[4], bf[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      af[u] = *reinterpret_cast<const half8*>(ap + (k + u) * 32);
+      bf[u] = *reinterpret_cast<const half8*>(bp + (k + u) * 32);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[u], bf[u], acc, 0, 0, 0);
+  }
+  for (; k < nblk; ++k) {
+    const half8 af = *reinterpret_cast<const half8*>(ap + k * 32);
+    const half8 bf = *reinterpret_cast<const half8*>(bp + k * 32);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf, acc, 0, 0, 0);
+  }
+}
+
+__global__ __launch_bounds__(256) void sim_pack_gt_kernel(const float* __restrict__ img, int64_t img_rs, int n_img, int Mp,
+                                                          const float* __restrict__ cap, int64_t cap_rs, int n_cap, int Np, int D, int Dp,
+                                                          int cpi, int G, const float* __restrict__ partial, float* __restrict__ scale,
+                                                          half_t* __restrict__ a, half_t* __restrict__ b, float2* __restrict__ na,
+                                                          float2* __restrict__ nb, float* __restrict__ gt,
+                                                          unsigned long long* __restrict__ best_i2t, unsigned long long* __restrict__ best_t2i,
+                                                          int32_t* __restrict__ zero0, int64_t nz0, int32_t* __restrict__ zero1, int64_t nz1,
+                                                          int32_t* __restrict__ zero2, int64_t nz2) {
+  extern __shared__ __attribute__((aligned(16))) char pg_smem[];
+  __shared__ float red[2][4];
+  __shared__ unsigned long long l_best[4];                             // per image of the block
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float sc_img, sc_cap;
+  sim_block_scales(partial, red, sc_img, sc_cap);
+  if (blockIdx.x == 0 && threadIdx.x == 0) { scale[0] = sc_img; scale[1] = sc_cap; }
+  {
+    const int64_t gtid = (int64_t)blockIdx.x * 256 + threadIdx.x, gsz = (int64_t)gridDim.x * 256;
+    for (int64_t e = gtid; e < nz0; e += gsz) zero0[e] = 0;
+    for (int64_t e = gtid; e < nz1; e += gsz) zero1[e] = 0;
+    for (int64_t e = gtid; e < nz2; e += gsz) zero2[e] = 0;
+  }
+  const int n_groups = (n_img + G - 1) / G;
+  if ((int)blockIdx.x >= n_groups) {
+    // padded operand rows [n_img, Mp) and [n_cap, Np): zeros, dealt over the remaining blocks (wave per row)
+    const int64_t n_pad = (int64_t)(Mp - n_img) + (Np - n_cap);
+    for (int64_t q = ((int64_t)blockIdx.x - n_groups) * 4 + wave; q < n_pad; q += ((int64_t)gridDim.x - n_groups) * 4) {
+      const bool is_cap = q >= Mp - n_img;
+      const int64_t r = is_cap ? n_cap + (q - (Mp - n_img)) : n_img + q;
+      half_t* d = (is_cap ? b : a) + r * 2 * Dp;
+      for (int c = lane * 8; c < 2 * Dp; c += 512) *reinterpret_cast<half8*>(d + c) = half8{0, 0, 0, 0, 0, 0, 0, 0};
+      if (lane == 0) { if (is_cap) nb[r] = float2{0.f, 0.f}; else na[r] = float2{0.f, 0.f}; }
+    }
+    return;
+  }
+  const bool v_img = (D % 4 == 0) && (img_rs % 4 == 0) && (((uintptr_t)img & 15) == 0);      // Dp is a multiple of 64
+  const bool v_cap = (D % 4 == 0) && (cap_rs % 4 == 0) && (((uintptr_t)cap & 15) == 0);
+  const int ldl = 2 * Dp + SIM_PG_PAD;                                 // LDS row stride, halfs
+  half_t* lrows = reinterpret_cast<half_t*>(pg_smem);                  // row (g, 0) = image g of the block, (g, 1 + q) = its caption q
+  const int i0 = blockIdx.x * G;
+  const int n_here = (n_img - i0) < G ? (n_img - i0) : G;
+  if (threadIdx.x < 4) l_best[threadIdx.x] = 0ull;
+  for (int q = wave; q < n_here * (1 + cpi); q += 4) {
+    const int g = q / (1 + cpi), k = q % (1 + cpi);
+    if (k == 0) {
+      const int64_t r = i0 + g;
+      const float2 n = sim_pack_row(img, img_rs, r, n_img, D, Dp, sc_img, lane, v_img, a + r * 2 * Dp, lrows + (int64_t)q * ldl);
+      if (lane == 0) na[r] = float2{n.y, n.x};            // (P, R) = (|lo|, |hi|)
+    } else {
+      const int64_t r = (int64_t)(i0 + g) * cpi + (k - 1);
+      const float2 n = sim_pack_row(cap, cap_rs, r, n_cap, D, Dp, sc_cap, lane, v_cap, b + r * 2 * Dp, lrows + (int64_t)q * ldl);
+      if (lane == 0) nb[r] = float2{n.x, n.y};            // (Q, T) = (|hi|, |lo|)
+    }
+  }
+  __syncthreads();
+  // ---- ground truths: tile (g, t) = image g x its captions [16 t, 16 t + 16), one wave each; the chain stays in K order
+  const int tiles_per_img = (cpi + 15) / 16;
+  const int nblk = Dp / 32;
+  for (int tq = wave; tq < n_here * tiles_per_img; tq += 4) {
+    const int g = tq / tiles_per_img, t = tq % tiles_per_img;
+    int c = t * 16 + (lane & 15);
+    const bool live_c = c < cpi;
+    if (!live_c) c = cpi - 1;
+    const half_t* ap = lrows + (int64_t)(g * (1 + cpi)) * ldl + 8 * (lane >> 4);
+    const half_t* bp = lrows + (int64_t)(g * (1 + cpi) + 1 + c) * ldl + 8 * (lane >> 4);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    sim_chain_lds(ap, bp, nblk, acc);                      // hi.hi
+    sim_chain_lds(ap + Dp, bp, nblk, acc);                 // lo.hi
+    sim_chain_lds(ap, bp + Dp, nblk, acc);                 // hi.lo
+    // every row of the tile is the image: row 0 (lanes 0..15, register 0) carries caption c's score
+    if (lane < 16 && live_c) {
+      const int row = i0 + g, col = row * cpi + c;
+      gt[col] = acc[0];
+      best_t2i[col] = pack_best(acc[0], row);
+      atomicMax(&l_best[g], pack_best(acc[0], col));
+    }
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < n_here) best_i2t[i0 + threadIdx.x] = l_best[threadIdx.x];
+}
+
+// scale search + split-fp16 packing shared by the GEMM modes (zero*: int32 words the pack grid clears on its way).
+// gt != nullptr (fused retrieval): ground-truth scores and their arg-max entries come out of the same pass (sim_pack_gt_kernel)
+// unless a block's rows do not fit in LDS (huge caps_per_img x D) -- then *gt_done stays false and the caller runs sim_gt_kernel.
 static int sim_prepare(const float* img, int64_t img_rs, const float* cap, int64_t cap_rs, int n_img, int n_cap, int D,
                        void* workspace, SimWs* ws, int* Mp, int* Np, int* Dp, hipStream_t st, int32_t* zero0 = nullptr, int64_t nz0 = 0,
-                       int32_t* zero1 = nullptr, int64_t nz1 = 0, int32_t* zero2 = nullptr, int64_t nz2 = 0) {
+                       int32_t* zero1 = nullptr, int64_t nz1 = 0, int32_t* zero2 = nullptr, int64_t nz2 = 0, int cpi = 0,
+                       float* gt = nullptr, unsigned long long* best_i2t = nullptr, unsigned long long* best_t2i = nullptr,
+                       bool* gt_done = nullptr) {
   sim_ws_layout(n_img, n_cap, D, (char*)workspace, ws, Mp, Np, Dp);
   hipLaunchKernelGGL(sim_absmax_kernel, dim3(SIM_ABS_BLOCKS), dim3(256), 0, st, img, img_rs, n_img, cap, cap_rs, n_cap, D, ws->partial);
+  if (gt_done) *gt_done = false;
+  if (gt && cpi > 0 && n_cap == n_img * cpi) {
+    size_t lds = 0;
+    const int G = sim_pg_group(cpi, *Dp, &lds);
+    if (lds <= 65536) {
+      static unsigned long long lds_reserved = 0;
+      if (int rc = aladin_reserve_lds((const void*)sim_pack_gt_kernel, 65536, &lds_reserved, "sim_pack_gt")) return rc;
+      const int n_groups = cdiv(n_img, G);
+      const int64_t n_pad = (int64_t)(*Mp - n_img) + (*Np - n_cap);
+      const int pad_blocks = n_pad ? (int)((n_pad + 15) / 16) : 0;
+      hipLaunchKernelGGL(sim_pack_gt_kernel, dim3(n_groups + pad_blocks), dim3(256), lds, st, img, img_rs, n_img, *Mp, cap, cap_rs, n_cap, *Np, D,
+                         *Dp, cpi, G, ws->partial, ws->scale, ws->a, ws->b, ws->na, ws->nb, gt, best_i2t, best_t2i, zero0, nz0, zero1, nz1,
+                         zero2, nz2);
+      if (gt_done) *gt_done = true;
+      return aladin_check_launch("sim_pack_gt_kernel");
+    }
+  }
   const int rows_per_block = 4 * SIM_PACK_RPW;
   hipLaunchKernelGGL(sim_pack_kernel, dim3((*Mp + *Np + rows_per_block - 1) / rows_per_block), dim3(256), 0, st, img, img_rs, n_img, *Mp, cap,
                      cap_rs, n_cap, *Np, D, *Dp, ws->partial, ws->scale, ws->a, ws->b, ws->na, ws->nb, zero0, nz0, zero1, nz1, zero2, nz2);
@@ -1047,8 +1195,11 @@ static int retrieval_ranks_impl(const float* img, int64_t img_rs, const float* c
   size_t c_off, c_bytes;
   retr_layout(n_img, n_cap, D, (char*)workspace, &rw, &c_off, &c_bytes, nullptr);
   int Mp, Np, Dp;
-  int rc = sim_prepare(img, img_rs, cap, cap_rs, n_img, n_cap, D, workspace, &ws, &Mp, &Np, &Dp, st, (int32_t*)((char*)workspace + c_off),
-                       (int64_t)(c_bytes / 4), rank_i2t, n_img, rank_t2i, n_cap);
+  // the pack grid zeroes the statistics and the two rank (= counter) arrays; the arg-max arrays need no zeroing: every entry is
+  // first written (plain store) with its ground-truth pair by the kernel that computes the ground truths
+  bool gt_done = false;
+  int rc = sim_prepare(img, img_rs, cap, cap_rs, n_img, n_cap, D, workspace, &ws, &Mp, &Np, &Dp, st, rw.stats, 64, rank_i2t, n_img, rank_t2i,
+                       n_cap, caps_per_img, rw.gt, rw.best_i2t, rw.best_t2i, &gt_done);
   if (rc) return rc;
   static unsigned long long lds_reserved[2] = {0, 0};
   const void* kern = force_exact ? (const void*)sim_screen_kernel<true> : (const void*)sim_screen_kernel<false>;
@@ -1068,7 +1219,8 @@ static int retrieval_ranks_impl(const float* img, int64_t img_rs, const float* c
   ra.list = rw.list;
   ra.list_cnt = rw.list_cnt;
   ra.stats = rw.stats;
-  {
+  if (!gt_done) {
+    if (hipMemsetAsync(rw.best_i2t, 0, (size_t)n_img * 8, st) != hipSuccess) { aladin_set_error("retrieval_ranks: memset failed"); return ALADIN_ERR_HIP; }
     const int tiles = cdiv(n_img, 16) * caps_per_img;
     hipLaunchKernelGGL(sim_gt_kernel, dim3(cdiv(tiles, 4)), dim3(256), 0, st, ws.a, ws.b, n_img, n_cap, caps_per_img, ldk, kps, rw.gt,
                        rw.best_i2t, rw.best_t2i);

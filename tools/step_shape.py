@@ -1,6 +1,6 @@
 """the hardest-negative triplet step (fwd + bwd) at an arbitrary set shape, with the kernel breakdown under rocprofv3"""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from aladin_amd import synth
 from aladin_amd.loss import AlignmentContrastiveLoss
