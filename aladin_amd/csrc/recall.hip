@@ -302,6 +302,8 @@ __global__ __launch_bounds__(512) void sim_gemm_store_kernel(const half_t* __res
 struct SimEntry { int row, col; float s; int flags; };
 enum { SIM_F_ROWCNT = 1, SIM_F_COLCNT = 2, SIM_F_ROWARG = 4, SIM_F_COLARG = 8 };
 constexpr int SIM_LIST_CAP = 64;
+struct SimRaw { int rc; float s; };               // tile-local (row << 16 | column), prefix score
+constexpr int SIM_RAW_WAVE = 128;                 // scores of a wave's 128 x 96 block within reach of a ground truth (decided or not) before the tile gives up screening
 
 struct SimRankArgs {
   int cpi;
@@ -361,9 +363,9 @@ __device__ __forceinline__ int row16_imin(int t) {
 }
 
 // ALADIN_DIAG build (make diag): thread 0 of every tile leaves wall-clock stamps of its phases in the tile's list segment
-// (tools/retrieval_stamps.py reads them; a tile that lists pairs overwrites them -- the tool looks at the others)
+// (its last 96 bytes: tools/retrieval_stamps.py reads them; a tile that lists more than 58 pairs overwrites them)
 #ifdef ALADIN_DIAG
-#define SIM_STAMP(k) do { if (threadIdx.x == 0) reinterpret_cast<long long*>(ra.list + (int64_t)(mb * n_nblk + nb) * SIM_LIST_CAP)[k] = wall_clock64(); } while (0)
+#define SIM_STAMP(k) do { if (threadIdx.x == 0) reinterpret_cast<long long*>(ra.list + (int64_t)(mb * n_nblk + nb) * SIM_LIST_CAP + (SIM_LIST_CAP - 6))[k] = wall_clock64(); } while (0)
 #else
 #define SIM_STAMP(k) do { } while (0)
 #endif
@@ -557,6 +559,8 @@ __global__ __launch_bounds__(512) void sim_screen_kernel(const half_t* __restric
     SimEntry* l_list = reinterpret_cast<SimEntry*>(l_colcnt + Cfg::BN);        // 7 * (256 + 384) * 4 B = 17920 B: 16-B aligned
     int* l_listn = reinterpret_cast<int*>(l_list + SIM_LIST_CAP);
     float* l_wmax = reinterpret_cast<float*>(l_listn + 4);           // [8 waves][4]: per-wave maxima of P, R, Q, T over the tile
+    int* l_rawn = reinterpret_cast<int*>(l_wmax + 4 * Cfg::NWAVES);  // [8 waves] raw candidates of each wave
+    SimRaw* l_raw = reinterpret_cast<SimRaw*>(l_rawn + Cfg::NWAVES);  // [8 waves][SIM_RAW_WAVE]
     static_assert(Cfg::BM <= Cfg::THREADS && Cfg::BN <= Cfg::THREADS, "one row / column entry per thread");
     // the tile's largest band factors bound every pair's band from above: the cheap test of phase 1
     const int e = tid;
@@ -606,6 +610,7 @@ __global__ __launch_bounds__(512) void sim_screen_kernel(const half_t* __restric
       l_thrCol[e] = thr; l_Q[e] = qt.x; l_T[e] = qt.y; l_Gcol[e] = g; l_bmaxCol[e] = bm; l_colmax[e] = 0u; l_colcnt[e] = 0;
     }
     if (tid == 0) *l_listn = 0;
+    if (tid < Cfg::NWAVES) l_rawn[tid] = 0;
     __syncthreads();
     SIM_STAMP(2);
     // ---- phase 1: which rows / columns of this wave hold a score within reach of their ground truth at all
@@ -640,84 +645,92 @@ __global__ __launch_bounds__(512) void sim_screen_kernel(const half_t* __restric
     const unsigned rowAny = wave_or(rowmask), colAny = wave_or(colmask);      // wave-uniform
     __syncthreads();
     SIM_STAMP(3);
-    // ---- phase 2: the flagged rows / columns, one group of 4 rows x 16 columns (an accumulator register across the wave) at a
-    // time.  A group is looked at closely only if one of its 64 scores passes the cheap test of phase 1 against ITS row or
-    // column; pushes are aggregated per wave (one LDS atomic per group); once the list has overflowed the tile is going to
-    // continue its chains anyway and the rest of the analysis is skipped.
+    // ---- phase 2a: per accumulator register (rt, reg) = 4 rows x 96 columns of the wave, ONE cheap test over its 6 x 64 scores
+    // against their rows' and columns' thresholds of phase 1; the rare hit drops its scores into a RAW candidate list in LDS
+    // (tile-local row, column, prefix s), aggregated per wave -- nothing is decided here.  (Two earlier forms decided in
+    // place: unrolled 192 times they were 220 KB of instructions, as a compact loop a chain of LDS round trips per hit; either
+    // way a tile with a few dozen hits spent as long in its analysis as in its main loop -- phase stamps, tools/retrieval_stamps.py.)
     if (rowAny | colAny) {
-      float Q[CT], Tt[CT], Gc[CT], Lc[CT], thrC[CT];
-      int ccnt[CT];
+      float thrC[CT];
 #pragma unroll
-      for (int ct = 0; ct < CT; ++ct) {
-        const int lc = lcol0 + ct * 16;
-        Q[ct] = l_Q[lc]; Tt[ct] = l_T[lc]; Gc[ct] = l_Gcol[lc]; thrC[ct] = l_thrCol[lc];
-        const unsigned k = l_colmax[lc];
-        float L = -INFINITY;
-        if (k) { const float m = key_float(k); L = (m - l_bmaxCol[lc]) - 0x1p-13f * fabsf(m); }     // <= lo of that element <= the exact column maximum
-        Lc[ct] = fmaxf(Gc[ct], L);
-        ccnt[ct] = 0;
-      }
-      bool overflow = false;
-      // (a compile-time loop: the body is past the size up to which `#pragma unroll` is honoured, and an rt that is not a
-      // constant would put the accumulators in scratch)
+      for (int ct = 0; ct < CT; ++ct) thrC[ct] = l_thrCol[lcol0 + ct * 16];
+      // each wave fills its OWN segment of the raw list (SIM_RAW_WAVE slots, a running count in a scalar register): no LDS
+      // atomic, no round trip per hit; a wave that runs out of slots sends the tile to the exact path
+      int n_mine = 0;
+      SimRaw* my_raw = l_raw + wave * SIM_RAW_WAVE;
+#ifdef ALADIN_DIAG
+      int n_cheap = 0, n_full = 0;
+#endif
       static_for<RT>([&](auto rt_) {
         constexpr int rt = decltype(rt_)::value;
+        if (n_mine > SIM_RAW_WAVE) return;                   // wave-uniform
+        const float4 thr4 = *reinterpret_cast<const float4*>(l_thrRow + lrow0 + rt * 16);
+        const float thrRs[4] = {thr4.x, thr4.y, thr4.z, thr4.w};
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
-          if (overflow) continue;
-          overflow = *reinterpret_cast<volatile int*>(l_listn) > SIM_LIST_CAP;    // wave-uniform (one LDS address)
-          if (overflow) continue;
-          const bool rowbit = (rowAny >> (rt * 4 + reg)) & 1u;
-          if (!rowbit && !colAny) continue;
-          const int lr = lrow0 + rt * 16 + reg;
-          const float thrR = l_thrRow[lr];
-          float P = 0.f, R = 0.f, Gr = INFINITY, Lr = INFINITY;
-          bool loaded = false;
-          int rcnt = 0;
+          const float thrR = thrRs[reg];
+          bool pass = false;
+#pragma unroll
+          for (int ct = 0; ct < CT; ++ct) pass |= (acc[rt][ct][reg] >= thrR) | (acc[rt][ct][reg] >= thrC[ct]);
+#ifdef ALADIN_DIAG
+          ++n_cheap;
+#endif
+          if (!__any(pass)) continue;                        // nobody in these 384 scores is within reach of its row's or column's ground truth
+#ifdef ALADIN_DIAG
+          ++n_full;
+#endif
 #pragma unroll
           for (int ct = 0; ct < CT; ++ct) {
-            const bool colbit = (colAny >> ct) & 1u;
-            if (!rowbit && !colbit) continue;
             const float s = acc[rt][ct][reg];
-            if (!__any((s >= thrR) | (s >= thrC[ct]))) continue;      // nobody in this group is within reach of its row's or column's ground truth
-            if (!loaded) {
-              loaded = true;
-              P = l_P[lr]; R = l_R[lr]; Gr = l_Grow[lr];
-              const unsigned k = l_rowmax[lr];
-              Lr = -INFINITY;
-              if (k) { const float m = key_float(k); Lr = (m - l_bmaxRow[lr]) - 0x1p-13f * fabsf(m); }
-              Lr = fmaxf(Gr, Lr);
-            }
-            const float band = fmaf(fabsf(s), 0x1p-14f, fmaf(P, Q[ct], R * Tt[ct]));
-            const float hi = s + band, lo = s - band;
-            int f = 0;
-            const bool gr = lo > Gr;
-            rcnt += gr;
-            if (hi >= Gr) { if (!gr) f |= SIM_F_ROWCNT; if (hi >= Lr) f |= SIM_F_ROWARG; }
-            const bool gc = lo > Gc[ct];
-            ccnt[ct] += gc;
-            if (hi >= Gc[ct]) { if (!gc) f |= SIM_F_COLCNT; if (hi >= Lc[ct]) f |= SIM_F_COLARG; }
-            const unsigned long long pm = __ballot(f != 0);
-            if (pm) {
-              int base = 0;
-              if (lane == 0) base = atomicAdd(l_listn, __popcll(pm));
-              base = lane_bcast(base, 0);
-              const int idx = base + __popcll(pm & ((1ull << lane) - 1ull));
-              if (f && idx < SIM_LIST_CAP) l_list[idx] = SimEntry{row0 + rt * 16 + reg, col0 + ct * 16, s, f};
-            }
-          }
-          if (loaded) {
-            rcnt = row16_isum(rcnt);
-            if ((lane & 15) == 0 && rcnt) atomicAdd(&l_rowcnt[lr], rcnt);
+            const bool hit = (s >= thrR) | (s >= thrC[ct]);
+            const unsigned long long pm = __ballot(hit);
+            if (!pm) continue;                                 // usually one of the six column tiles holds the hit
+            const int idx = n_mine + __popcll(pm & ((1ull << lane) - 1ull));
+            if (hit && idx < SIM_RAW_WAVE) my_raw[idx] = SimRaw{((lrow0 + rt * 16 + reg) << 16) | (lcol0 + ct * 16), s};
+            n_mine += __popcll(pm);
           }
         }
       });
+      if (lane == 0) l_rawn[wave] = n_mine;
+#ifdef ALADIN_DIAG
+      if (lane == 0 && (blockIdx.x & 63) == 0) { atomicAdd(&ra.stats[2], n_cheap); atomicAdd(&ra.stats[3], n_full); atomicAdd(&ra.stats[4], 1); }     // a sample of the tiles
+#endif
+    }
+    __syncthreads();
+    // ---- phase 2b: the raw candidates, one per thread: the per-pair decisions with the pair's own band
+    {
+      bool raw_over = false;
 #pragma unroll
-      for (int ct = 0; ct < CT; ++ct) {
-        int c = ccnt[ct];
-        c += lane_xor16(c);
-        c += lane_xor32(c);
-        if (lane < 16 && c) atomicAdd(&l_colcnt[lcol0 + ct * 16], c);
+      for (int w = 0; w < Cfg::NWAVES; ++w) raw_over |= l_rawn[w] > SIM_RAW_WAVE;
+      if (!raw_over) {
+        const int seg = tid >> 6, n_seg = l_rawn[seg];
+        for (int slot = tid & 63; slot < n_seg; slot += 64) {
+          const SimRaw rw = l_raw[seg * SIM_RAW_WAVE + slot];
+          const int lr = rw.rc >> 16, lc = rw.rc & 0xffff;
+          const float s = rw.s;
+          const float P = l_P[lr], R = l_R[lr], Gr = l_Grow[lr], bmr = l_bmaxRow[lr];
+          const float Gc = l_Gcol[lc], Qc = l_Q[lc], Tc = l_T[lc], bmc = l_bmaxCol[lc];
+          const unsigned kr = l_rowmax[lr], kc = l_colmax[lc];
+          float Lr = -INFINITY, Lc = -INFINITY;
+          if (kr) { const float m = key_float(kr); Lr = (m - bmr) - 0x1p-13f * fabsf(m); }      // <= lo of that element <= the exact row maximum
+          if (kc) { const float m = key_float(kc); Lc = (m - bmc) - 0x1p-13f * fabsf(m); }
+          Lr = fmaxf(Gr, Lr);
+          Lc = fmaxf(Gc, Lc);
+          const float band = fmaf(fabsf(s), 0x1p-14f, fmaf(P, Qc, R * Tc));
+          const float hi = s + band, lo = s - band;
+          int f = 0;
+          const bool gr = lo > Gr, gc = lo > Gc;
+          if (gr) atomicAdd(&l_rowcnt[lr], 1);
+          if (gc) atomicAdd(&l_colcnt[lc], 1);
+          if (hi >= Gr) { if (!gr) f |= SIM_F_ROWCNT; if (hi >= Lr) f |= SIM_F_ROWARG; }
+          if (hi >= Gc) { if (!gc) f |= SIM_F_COLCNT; if (hi >= Lc) f |= SIM_F_COLARG; }
+          if (f) {
+            const int idx = atomicAdd(l_listn, 1);
+            if (idx < SIM_LIST_CAP) l_list[idx] = SimEntry{mb * Cfg::BM + lr, nb * Cfg::BN + lc, s, f};
+          }
+        }
+      } else if (tid == 0) {
+        *l_listn = SIM_LIST_CAP + 1;                           // too many scores within reach of a ground truth: continue the chains in place
       }
     }
     __syncthreads();

@@ -5,7 +5,7 @@ import numpy as np, torch
 from aladin_amd import ops, synth, _lib
 dev = torch.device('cuda:0')
 lib = _lib.load()
-for sigma, exact in ((3.0, False), (12.0, False), (12.0, True)):
+for sigma, exact in ((3.0, False), (6.0, False), (12.0, False), (12.0, True)):
     i, c = synth.retrieval_embeddings(5000, 768, seed=303, sigma=sigma)
     a, b = torch.from_numpy(i[0::5]).to(dev), torch.from_numpy(c).to(dev)
     n_img, n_cap, D = 5000, 25000, 768
@@ -20,11 +20,12 @@ for sigma, exact in ((3.0, False), (12.0, False), (12.0, True)):
     so = lib.aladin_retrieval_stats_offset(n_img, n_cap, D)
     n_tiles = 20 * 66
     lo = so + 256 + ((n_tiles * 4 + 255) // 256) * 256
-    seg = ws[lo:lo + n_tiles * 64 * 16].view(torch.int64).view(n_tiles, 128)[:, :12].cpu().numpy().astype(np.float64)
+    seg = ws[lo:lo + n_tiles * 64 * 16].view(torch.int64).view(n_tiles, 128)[:, 116:128].cpu().numpy().astype(np.float64)
     t0 = seg[:, 0].min()
     d = np.diff(seg[:, :8], axis=1) / 100.0          # 100 MHz -> us
     ep = np.round(np.median(np.diff(np.concatenate([seg[:, 6:7], seg[:, 8:12], seg[:, 7:8]], axis=1), axis=1) / 100.0, axis=0), 2).tolist()
     print('   exact epilogue: init+barrier, rows, cols, barrier, global atomics:', ep)
+    print('   diag counters [exact tiles, listed pairs, cheap group tests, full group evaluations, waves in phase 2]:', ws[so:so + 20].view(torch.int32).cpu().tolist())
     print('sigma', sigma, 'exact' if exact else 'screen', 'per-phase us (median over tiles):', np.round(np.median(d, axis=0), 2).tolist(),
           'tile total median', round(float(np.median((seg[:, 7] if (exact or sigma > 10) else seg[:, 4]) - seg[:, 0]) / 100.0), 2),
           'kernel span', round(float((seg.max() - t0) / 100.0), 1))
