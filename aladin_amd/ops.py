@@ -285,7 +285,7 @@ DENSE_GEMM_FORCE = False     # tests / tools: the GEMM row step whatever the cap
 
 def _caption_fill(s_len, T, y_tail=2):
     """Mean share of a caption's 16-word tiles that holds real words (None: lengths only on the device).  The gather row
-    step costs ~ real words, the GEMM one the padded tiles: measured crossover (B = 256, tools/debug/dense_fill_sweep.py)
+    step costs ~ real words, the GEMM one the padded tiles: measured crossover (B = 256, tools/dense_backward_probe.py fill)
     at a fill of 0.42 for R' = 33 and 0.50 for R' = 50 -- COCO captions (~12 of 35 tokens) are on the gather side."""
     if isinstance(s_len, torch.Tensor):
         return None

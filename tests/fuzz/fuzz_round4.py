@@ -1,0 +1,126 @@
+#!/usr/bin/env python3
+"""Randomised fuzz of what round 4 added (GPU):
+  retrieval  aladin_retrieval_ranks (prefix screening + raw-candidate lists + exact continuation) against the two-step split path
+             (stored scores + rank kernels), int for int, and the all-exact variant, over random sizes, captions per image,
+             feature widths and DATA REGIMES (clean / medium / ground truths in the bulk / near-duplicates / exact ties /
+             mixed row norms / half clean half bulk): the result must never depend on which mechanism ran
+  r48        the 48-row region class (R' 41..56) and its neighbours: scores vs the oracle, gradients of a random sparse dS vs the
+             oracle chained on the HIP scores, fused hinge + pair kernel vs the list path
+usage: tests/fuzz/fuzz_round4.py [seconds] [seed]"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+import numpy as np
+import torch
+
+import alad_oracle as O
+import faithful_torch as FT
+from aladin_amd import ops, synth
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+rng = np.random.RandomState(seed)
+dev = torch.device('cuda:0')
+t0 = time.time()
+counts = {'retrieval': 0, 'r48': 0}
+mech = {'screen_only': 0, 'lists': 0, 'exact_tiles': 0}
+
+
+def T(x):
+    return torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+
+
+def retrieval_case():
+    n_img = int(rng.choice([1, 3, 17, 100, 257, 600, 1500, 2600]))
+    cpi = int(rng.choice([1, 2, 3, 5, 5, 5, 8]))
+    D = int(rng.choice([8, 33, 64, 100, 256, 768]))
+    if n_img * cpi * n_img * D > 4e10:
+        n_img = 600
+    regime = str(rng.choice(['clean', 'medium', 'bulk', 'dups', 'ties', 'norms', 'mixed']))
+    g = np.random.RandomState(int(rng.randint(1, 1 << 30)))
+    img = g.standard_normal((n_img, D)).astype(np.float32)
+    noise = {'clean': 0.3, 'medium': 1.0 + 2.0 * g.rand(), 'bulk': 50.0, 'dups': 0.6, 'ties': 0.8, 'norms': 1.2, 'mixed': 0.3}[regime]
+    cap = np.repeat(img, cpi, axis=0) + noise * g.standard_normal((n_img * cpi, D)).astype(np.float32) * (1.0 if D >= 64 else 0.3)
+    k = n_img * cpi
+    if regime == 'mixed':
+        bad = np.repeat(g.rand(n_img) < 0.5, cpi)
+        cap[bad] = g.standard_normal((int(bad.sum()), D)).astype(np.float32)
+    if regime in ('dups', 'ties') and k > 2:
+        src = g.randint(0, k, size=max(1, k // 3))
+        dst = g.permutation(k)[:src.size]
+        eps = 0.0 if regime == 'ties' else (10.0 ** g.uniform(-7, -4, size=(src.size, 1))).astype(np.float32)
+        cap[dst] = cap[src] * (1 + eps * g.standard_normal((src.size, D)).astype(np.float32))
+    if regime != 'norms':
+        img /= np.maximum(np.linalg.norm(img, axis=1, keepdims=True), 1e-20)
+        cap /= np.maximum(np.linalg.norm(cap, axis=1, keepdims=True), 1e-20)
+    else:
+        cap *= (10.0 ** g.uniform(-3, 1, size=(k, 1))).astype(np.float32)
+        img *= (10.0 ** g.uniform(-3, 1, size=(n_img, 1))).astype(np.float32)
+        if n_img > 5:
+            img[::5] = 0.0
+    a, b = T(img), T(cap.astype(np.float32))
+    two = ops.recall_ranks(ops.sim_matrix(a, b), cpi)
+    *one, st = ops.retrieval_ranks(a, b, cpi, return_stats=True)
+    tag = 'retrieval n_img=%d cpi=%d D=%d regime=%s stats=%s' % (n_img, cpi, D, regime, st)
+    for x, y in zip(one, two):
+        assert torch.equal(x, y), tag
+    for x, y in zip(ops.retrieval_ranks(a, b, cpi, exact=True), two):
+        assert torch.equal(x, y), tag + ' (exact)'
+    mech['exact_tiles'] += st['exact_tiles'] > 0
+    mech['lists'] += st['listed_pairs'] > 0
+    mech['screen_only'] += st['exact_tiles'] == 0 and st['listed_pairs'] == 0
+
+
+def r48_case():
+    B = int(rng.choice([3, 8, 24, 40, 72, 96, 130]))
+    R = int(rng.choice([40, 41, 42, 45, 48, 49, 50, 51, 53, 56, 57, 58]))
+    Tn = int(rng.choice([5, 19, 20, 36, 38, 50, 51, 67, 99]))
+    D = int(rng.choice([24, 64, 128, 768]))
+    if B * B * R * Tn * D > 3e9:
+        B = 24
+    cs = int(rng.randint(1, 100000))
+    im, s, il, sl = synth.structured_alignment_batch(B, R, Tn, D, seed=cs, noise=float(rng.choice([1.0, 3.0])), ragged=bool(rng.randint(0, 2)))
+    il = [max(2, v) for v in il]
+    sl = [max(4, v) for v in sl]
+    il[0] = R                                         # the longest image fills the class
+    a, b = T(im).requires_grad_(True), T(s).requires_grad_(True)
+    S = ops.alignment_scores(a, b, il, sl)
+    ref = O.alignment_scores(im, s, il, sl)
+    tag = 'r48 B=%d R=%d T=%d D=%d seed=%d' % (B, R, Tn, D, cs)
+    mag = max(1e-6, float(np.abs(ref).max()))
+    assert float(np.abs(S.detach().cpu().numpy() - ref).max()) <= (2e-3 if D >= 64 else 2e-2) * mag + 1e-6, tag
+    w = np.random.RandomState(cs).standard_normal((B, B)).astype(np.float32) * (np.random.RandomState(cs + 1).rand(B, B) < 0.1)
+    (S * T(w)).sum().backward()
+    ra, rb = torch.from_numpy(im).double().requires_grad_(True), torch.from_numpy(s).double().requires_grad_(True)
+    (FT.alignment_scores_faithful(ra, rb, il, sl) * torch.from_numpy(w).double()).sum().backward()
+    for got, want in ((a.grad, ra.grad), (b.grad, rb.grad)):
+        want = want.numpy()
+        scale = max(1e-9, float(np.abs(want).max()))
+        bad = np.abs(got.cpu().numpy() - want) > 1e-3 * np.abs(want) + 5e-4 * scale
+        # a near-tie between two regions may go to the other one in fp32 vs float64: a handful of rows at most
+        assert bad.mean() < 2e-3, tag + ' gradient mismatch fraction %.4f' % bad.mean()
+    if Tn <= 67:
+        a2, b2 = T(im).requires_grad_(True), T(s).requires_grad_(True)
+        loss, S2 = ops.alignment_triplet_loss(a2, b2, il, sl, 0.2, True)
+        loss.backward()
+        with torch.no_grad():
+            ilt, slt = ops.lengths_tensor(il, dev), ops.lengths_tensor(sl, dev)
+            S3, packed = ops._align_forward(a2.detach(), b2.detach(), ilt, slt)
+            loss3, dS3, pairs = ops._hinge_raw(S3, 0.2, True, True, want_pairs=True)
+            d_im, d_s = ops._align_backward(a2.detach(), b2.detach(), ilt, slt, dS3, gscale=torch.ones((), device=dev), packed=packed, pairs=pairs)
+        assert torch.equal(S2, S3) and float(loss) == float(loss3), tag
+        assert torch.equal(a2.grad, d_im) and torch.equal(b2.grad, d_s), tag + ' fused vs list path'
+
+
+while time.time() - t0 < budget:
+    if rng.rand() < 0.5:
+        retrieval_case()
+        counts['retrieval'] += 1
+    else:
+        r48_case()
+        counts['r48'] += 1
+print('fuzz_round4 ok: %s cases, retrieval mechanisms seen %s, %d s, seed %d' % (counts, mech, int(time.time() - t0), seed))
