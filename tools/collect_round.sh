@@ -1,0 +1,22 @@
+#!/bin/bash
+# Everything profiles/<tag>_* is made from, in ONE gpurun call (run on the GPU box; materialise afterwards in the build container with
+# tools/materialise_round.sh <tag>):
+#   bench.py line (unprofiled), rocprofv3 kernel stats + PMC passes of bench.py, retrieval: per-data-set timings, kernel stats, PMC
+#   (clean input), phase stamps (diagnostic library, if built), the shipped-shape step with its kernel breakdown
+# usage: tools/collect_round.sh <tag>
+set -u
+TAG=${1:-r04}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+O=$R/gpurun_out/$TAG
+mkdir -p "$O"
+cd "$R"
+python3 bench.py > "$O/bench_line_unprofiled.json" 2> "$O/bench.err"
+python3 tools/bench_retrieval.py > "$O/bench_retrieval.txt" 2>&1
+if [ -f aladin_amd/lib/libaladin_hip_diag.so ]; then
+  ALADIN_LIB=$R/aladin_amd/lib/libaladin_hip_diag.so python3 tools/retrieval_stamps.py > "$O/retrieval_phase_stamps.txt" 2>&1
+fi
+bash tools/collect_shipped_shape.sh > /dev/null 2>&1; cp gpurun_out/shipped_shape.txt "$O/shipped_shape.txt"
+bash tools/collect_pmc.sh "$TAG" > "$O/collect_pmc.log" 2>&1
+bash tools/collect_eval_pmc.sh "${TAG}_eval" 0.05 > "$O/collect_eval_pmc.log" 2>&1
+bash tools/collect_retrieval_stats.sh "$TAG" > "$O/collect_retrieval_stats.log" 2>&1
+tail -2 "$O/bench_retrieval.txt"; head -c 400 "$O/bench_line_unprofiled.json"; echo
