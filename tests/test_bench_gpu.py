@@ -51,3 +51,45 @@ def test_bench_sharded_step_on_one_rank():
     for phase in ('pack+issue_gathers', 'local_block', 'S_allgather', 'hinge', 'bwd_start'):
         assert phase in c['phases_ms'], phase
     assert c['loss'] == d0['config']['loss']                           # the global-batch loss of one rank IS the single-device loss
+
+
+def _bench_raw(*args, timeout=900):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '20', '--warmup', '5', '--repeats', '1', '--preroll-s', '0.3'] + list(args),
+                       capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    return json.loads([l for l in p.stdout.splitlines() if l.strip()][-1])
+
+
+def test_bench_secondary_fields_are_in_the_line():
+    """what DESIGN.md claims next to the headline is timed by the driver's own run -- configs[2] retrieval with its
+    data-dependent cost, the shipped data shape, the loss heads at the shipped batch size, configs[4] end to end, the COCO-1k
+    alignment grid -- and the roofline carries the kernel, forward-chain and step fractions side by side."""
+    d = _bench_raw('--no-cpu-baseline')
+    c, r = d['config'], d['roofline']
+    for k in ('eval_config3', 'shipped_shape', 'loss_heads_bs32', 'e2e_config4', 'alignment_retrieval_coco1k'):
+        assert k in c and 'error' not in c[k], (k, c.get(k))
+    e = c['eval_config3']
+    assert 0.1 < e['ms'] < 0.6 and e['exact_tiles'] == 0 and e['all_exact_ms'] > e['ms'] and len(e['by_data']) == 2
+    assert all(0 <= b['exact_tiles'] <= e['tiles'] for b in e['by_data'])
+    assert 0.1 < c['shipped_shape']['ms_per_step'] < 0.6
+    h = c['loss_heads_bs32']
+    assert 0 < h['graph_replay_only_ms'] < h['graphed_step_ms'] < 1.0 and h['eager_ms'] > 0
+    x = c['e2e_config4']
+    assert x['fp32_step_ms'] > x['loss_heads_ms'] > 0 and 0 < x['loss_heads_share_of_fp32_step'] < 0.1 and x['bf16_autocast_batched_passes_step_ms'] > 0
+    a = c['alignment_retrieval_coco1k']
+    assert 0 < a['fp16_ms'] < a['split_ms'] < 100
+    assert 0.2 < r['step_frac'] < r['forward_chain_frac'] < r['frac'] < 0.8
+    assert r['traffic'] is None or r['traffic'] > 1e8                   # null when the committed PMC summary belongs to other kernel sources
+    assert (r['traffic'] is None) == str(r['traffic_source']).startswith('stale')
+
+
+def test_bench_cpu_baseline_is_live():
+    """cpu_baseline: BASELINE configs[0] (B = 16) swept over thread counts, and the B = 256 step of the same dataflow timed in THIS run."""
+    d = _bench_raw('--no-eval', timeout=1500)
+    cb = d['cpu_baseline']
+    assert cb['kind'] == 'port' and cb['unit'] == 'pairs/s' and cb['value'] > 0 and cb['cores'] >= 1 and 'sample' in cb
+    b = cb['b256']
+    assert b.get('source') == 'live' or str(b.get('source', '')).startswith('committed'), b
+    if b.get('source') == 'live':
+        assert b['steps_timed'] >= 1 and 1e3 < b['pairs_per_s_fwd_bwd'] < 1e6
