@@ -1494,6 +1494,44 @@ def test_sharded_loss_under_rccl_world1():
             dist.destroy_process_group()
 
 
+def test_many_sharded_forwards_before_one_backward_under_rccl_world1():
+    """micro-batch losses summed, ONE backward.  Every sparse-exchange plan keeps its own pinned counts buffer until
+    its backward resolved it: with more than 8 plans outstanding (round 3's rotation depth) the gradients of every micro-batch
+    must still equal the single-device ones, and the buffers are handed back afterwards."""
+    import os
+    import torch.distributed as dist
+    from aladin_amd import distributed as AD, synth
+    from aladin_amd.loss import AlignmentContrastiveLoss
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29613')
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev())
+        created = True
+    try:
+        n_micro = 11
+        batches = [synth.structured_alignment_batch(24, 34, 50, 256, seed=300 + k, noise=3.0, ragged=True) for k in range(n_micro)]
+        leaves = [(T(im).requires_grad_(True), T(s).requires_grad_(True)) for im, s, _, _ in batches]
+        total = None
+        for (a, b), (_, _, il, sl) in zip(leaves, batches):
+            loss, _ = AD.sharded_alignment_loss_fast(a, b, il, sl, 0.2, True, exchange='sparse')
+            total = loss if total is None else total + loss
+        outstanding = AD._PINNED.allocated - sum(len(v) for v in AD._PINNED.free.values())
+        assert outstanding >= n_micro                       # one buffer per unresolved plan
+        total.backward()
+        crit = AlignmentContrastiveLoss(0.2, 'dot', True, 'MrSw')
+        for (a, b), (im, s, il, sl) in zip(leaves, batches):
+            a2, b2 = T(im).requires_grad_(True), T(s).requires_grad_(True)
+            crit(a2, b2, il, sl).backward()
+            np.testing.assert_allclose(a.grad.cpu().numpy(), a2.grad.cpu().numpy(), rtol=1e-5, atol=1e-8)
+            np.testing.assert_allclose(b.grad.cpu().numpy(), b2.grad.cpu().numpy(), rtol=1e-5, atol=1e-8)
+        assert AD._PINNED.allocated == sum(len(v) for v in AD._PINNED.free.values())      # all handed back
+    finally:
+        if created:
+            dist.destroy_process_group()
+
+
 SWEEP = [
     # Bi, Bc, R,  T,  D    -> tiling class exercised
     (3, 5, 2, 4, 8),        # one region, one word
