@@ -282,7 +282,9 @@ __global__ __launch_bounds__(512) void sim_gemm_store_kernel(const half_t* __res
 //     |v - s| <= band = |lo_a||hi_b| + |hi_a||lo_b| + 2^-14 |s|
 // (Cauchy-Schwarz per segment on the actual fp16 operands, norms rounded up by the packer; the last term
 // covers the fp32 rounding of the 48 more accumulator steps, each within a few ulp of the running value,
-// ~16 x what round-to-nearest gives).  Rigorous per pair: no statistics, no tuning to the data.  Then
+// ~16 x what round-to-nearest gives; where |s| is tiny the roundings are bounded by a few ulp of the largest
+// lo.hi product instead, ~2^-22 of the Cauchy-Schwarz terms, inside the 2^-9 by which the packer's rounded-up
+// norms overstate them).  Rigorous per pair: no statistics, no tuning to the data.  Then
 //     s - band >  G  : counted          s + band < G : not counted          otherwise: AMBIGUOUS
 // and for the arg-maxima, with L = max(G, tile-local lower bound of the row / column maximum) <= the exact
 // maximum, only pairs with s + band >= L can be the exact arg-max (the true one always is: v >= L).
