@@ -1639,14 +1639,16 @@ def test_alignment_backward_shape_sweep(shape, mv):
         np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=1e-3, atol=2e-5 * scale)
 
 
-def test_sharded_fast_path_rank_logic_emulated_world3():
+@pytest.mark.parametrize('R,Tn', [(34, 50), (51, 38)])
+def test_sharded_fast_path_rank_logic_emulated_world3(R, Tn):
     """The per-rank pieces of aladin_amd.distributed's fast path, driven for rank 0 and rank 1 on
     ONE GPU (three emulated ranks) with hand-made 'gathered' tensors (concatenation == all-gather, sum == reduce-scatter):
     global loss, score matrix and both gradients must equal the single-device result on the
-    concatenated batch."""
+    concatenated batch.  (51, 38): the shipped data shape -- the 48-row region class with two side rows per image, whose
+    packed operands must concatenate across ranks like the headline class's."""
     from aladin_amd import distributed as DD, ops, synth
     from aladin_amd.loss import AlignmentContrastiveLoss
-    W, B, R, Tn, D = 3, 64, 34, 50, 768
+    W, B, D = 3, 64, 768
     im, s, il, sl = synth.alignment_batch(W * B, R, Tn, D, seed=4242, ragged=True)
     d = dev()
     g_loc, g_glob, ok = DD._local_and_global_geometry(B, W, R, Tn, D)
