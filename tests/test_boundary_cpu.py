@@ -277,3 +277,29 @@ def test_eval_grid_memo_is_keyed_on_live_objects_not_addresses(monkeypatch):
     E._eval_scores(a.numpy(), b.numpy(), il, cl, 'dot', None)
     assert len(calls) == 9
     E.clear_eval_cache()
+
+
+def test_bucket_classes_follow_the_library_geometry():
+    """ops.X_CLASS_BOUNDS / Y_CLASS_BOUNDS are the planner's cost model of the packed geometry: every bound must be the top
+    of a class the library really builds (main rows + side rows == the bound, nothing padded past it), and a ragged COCO-like
+    grid (up to 50 boxes + the global slot) must put its long images in the 48-row classes, not the 64-row one."""
+    from aladin_amd import ops
+    for b in ops.X_CLASS_BOUNDS:
+        g = ops.align_geometry(512, 512, b + 1, 50, 768)         # R = b + 1 set positions -> b scored positions
+        assert g.Rq == b and g.mrows + g.rem == b, (b, g.mrows, g.rem)
+        if b < ops.X_CLASS_BOUNDS[-1]:
+            g = ops.align_geometry(512, 512, b + 2, 50, 768)     # one more position leaves the class
+            assert g.mrows + g.rem > b
+    for b in ops.Y_CLASS_BOUNDS:
+        g = ops.align_geometry(512, 512, 34, b + 3, 768)         # T = b + 3 set positions -> b scored words
+        assert g.Tq == b and g.tp16 * 16 == b
+    rng = np.random.RandomState(5)
+    il = [int(v) for v in np.minimum(rng.randint(18, 70, size=1000), 51)]        # VinVL-like: most images clipped at 50 boxes
+    cl = [int(v) for v in rng.randint(7, 30, size=5000)]
+    x_need, y_need = ops._needed_positions(il, 0, 71, True), ops._needed_positions(cl, 2, 71, False)
+    assert max(x_need) == 51
+    plan = ops.bucket_plan(x_need, y_need)
+    assert plan is not None
+    tops = sorted(max(x_need[k] for k in g) for g in plan[0])
+    assert tops[-1] == 51 and len(tops) >= 2
+    assert sorted(k for g in plan[0] for k in g) == list(range(1000)) and sorted(k for g in plan[1] for k in g) == list(range(5000))

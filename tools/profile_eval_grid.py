@@ -1,5 +1,9 @@
 #!/usr/bin/env python3
-"""Where the time of the COCO-1k alignment grid goes: wall time per call, host profile (cProfile), GPU time (events)."""
+"""Where the time of the COCO-1k alignment grid goes: wall time per call, host profile (cProfile), GPU time (events).
+  --img-range LO HI    image lengths (default 12 34, the bench fixture; 18 51 = images of up to 50 boxes + the global slot)
+  --x-bounds a,b,...   override ops.X_CLASS_BOUNDS (A/B of the planner's image classes)
+  --no-host-profile"""
+import argparse
 import cProfile
 import os
 import pstats
@@ -13,9 +17,17 @@ from aladin_amd import evaluation as E, ops, synth
 
 
 def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--img-range', type=int, nargs=2, default=(12, 34))
+    ap.add_argument('--x-bounds', type=str, default=None)
+    ap.add_argument('--no-host-profile', action='store_true')
+    a = ap.parse_args()
+    if a.x_bounds:
+        ops.X_CLASS_BOUNDS = tuple(int(v) for v in a.x_bounds.split(','))
     dev = torch.device('cuda:0')
     n = 1000
-    images, captions, il, cl = synth.eval_sets(n, 768, seed=9)
+    images, captions, il, cl = synth.eval_sets(n, 768, seed=9, img_len_range=tuple(a.img_range))
+    print('image lengths %d..%d, X_CLASS_BOUNDS %s' % (min(il), max(il), ops.X_CLASS_BOUNDS), flush=True)
     ia = torch.from_numpy(images[0::5]).to(dev)
     ca = torch.from_numpy(captions).to(dev)
     ilen = il[0::5]
@@ -41,7 +53,7 @@ def main():
             t_wall = (time.perf_counter() - t0) / 5 * 1e3
             print('precision %-5s bucketed %-5s  wall %.2f ms/call  host issue %.2f ms/call  gpu (events) %.2f ms/call'
                   % (prec, bucket, t_wall, t_issue, e0.elapsed_time(e1) / 5), flush=True)
-            if bucket and prec == 'fp16':
+            if bucket and prec == 'fp16' and not a.no_host_profile:
                 pr = cProfile.Profile()
                 pr.enable()
                 for _ in range(5):
