@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # ALADIN_LIB points at an alternative build of the same ABI (kernel A/B runs, tools/ab_bench.py)
 LIB_PATH = os.environ.get('ALADIN_LIB') or os.path.join(_HERE, 'lib', 'libaladin_hip.so')
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 PRECISION_FP16, PRECISION_SPLIT = 0, 1      # ALADIN_PRECISION_* of include/aladin_hip.h
 BWD_PARTNERS_FP16, BWD_DENSE, BWD_DENSE_GATHER = 1, 2, 4          # ALADIN_BWD_PARTNERS_FP16, ALADIN_BWD_DENSE
 
@@ -39,7 +39,7 @@ SYMBOLS = [
 
 class AlignGeom(C.Structure):
     """struct aladin_align_geom."""
-    _fields_ = [(n, C.c_int32) for n in ('Bi', 'Bc', 'R', 'T', 'D', 'Rq', 'Tq', 'mrows', 'rem', 'tp16', 'Dp',
+    _fields_ = [(n, C.c_int32) for n in ('Bi', 'Bc', 'R', 'T', 'D', 'Rq', 'Tq', 'mrows', 'rem', 'tp16', 'trows', 'Dp',
                                          'img_unit', 'cap_unit', 'Bi_pad', 'Bc_pad', 'x_tail', 'y_tail', 'split')] + \
                [(n, C.c_int64) for n in ('xm_rows', 'xe_rows', 'y_rows', 'xm_bytes', 'xe_bytes', 'y_bytes',
                                          'e_bytes')]

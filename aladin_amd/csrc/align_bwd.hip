@@ -813,7 +813,7 @@ static int align_bwd_impl(const float* im, int64_t im_sb, int64_t im_sr, const i
       sfin.dST = (float*)ws.pairs;                        // the list region is free in this mode: it carries dS^T
       hipLaunchKernelGGL(bwd_pair_argmax16_kernel<2>, dim3(npb + cdiv(Bc * Bc, 256)), dim3(256),
                          (size_t)PAIR_STAGES * PairCfg::STAGE_BYTES, st, (const half_t*)xm, (const half_t*)xe, (const half_t*)y,
-                         g->Dp, g->mrows, g->rem, 16 * g->tp16, (int)g->xe_rows, (int)g->y_rows, im, im_sb, im_sr, im_len, s, s_sb, s_st,
+                         g->Dp, g->mrows, g->rem, g->trows, (int)g->xe_rows, (int)g->y_rows, im, im_sb, im_sr, im_len, s, s_sb, s_st,
                          s_len, Bc, Rq, Tq, D, nullptr, nullptr, ws.table, tstride, x_tail, y_tail, hfs, sfin);
       return aladin_check_launch("bwd_pair_argmax16_kernel<small heads>");
     }
@@ -825,7 +825,7 @@ static int align_bwd_impl(const float* im, int64_t im_sb, int64_t im_sr, const i
     const int nfin = Bc < 1024 ? Bc : 1024;
     const PairHinge hf = {ha->S, ha->ldS, ha->margin, val, arg, ha->loss, ha->dS, Bc, npb, (float*)ws.pairs};
     hipLaunchKernelGGL(bwd_pair_argmax16_kernel<1>, dim3(npb + nfin), dim3(256), (size_t)PAIR_STAGES * PairCfg::STAGE_BYTES, st,
-                       (const half_t*)xm, (const half_t*)xe, (const half_t*)y, g->Dp, g->mrows, g->rem, 16 * g->tp16, (int)g->xe_rows,
+                       (const half_t*)xm, (const half_t*)xe, (const half_t*)y, g->Dp, g->mrows, g->rem, g->trows, (int)g->xe_rows,
                        (int)g->y_rows, im, im_sb, im_sr, im_len, s, s_sb, s_st, s_len, Bc, Rq, Tq, D, nullptr, nullptr,
                        ws.table, tstride, x_tail, y_tail, hf, SmallFin{});
     return aladin_check_launch("bwd_pair_argmax16_kernel<hinge>");
@@ -872,7 +872,7 @@ static int align_bwd_impl(const float* im, int64_t im_sb, int64_t im_sr, const i
   if (phase == BWD_ROWS) {
   } else if (packed) {
     hipLaunchKernelGGL(bwd_pair_argmax16_kernel<0>, dim3(pgrid), dim3(256), (size_t)PAIR_STAGES * PairCfg::STAGE_BYTES, st,
-                       (const half_t*)xm, (const half_t*)xe, (const half_t*)y, g->Dp, g->mrows, g->rem, 16 * g->tp16, (int)g->xe_rows,
+                       (const half_t*)xm, (const half_t*)xe, (const half_t*)y, g->Dp, g->mrows, g->rem, g->trows, (int)g->xe_rows,
                        (int)g->y_rows, im, im_sb, im_sr, im_len, s, s_sb, s_st, s_len, Bc, Rq, Tq, D, ws.counter, ws.pairs,
                        ws.table, tstride, x_tail, y_tail, PairHinge{}, SmallFin{});
     rc = aladin_check_launch("bwd_pair_argmax16_kernel");
@@ -900,7 +900,7 @@ static int align_bwd_impl(const float* im, int64_t im_sb, int64_t im_sr, const i
       aladin_set_error("align_bwd: ALADIN_BWD_PARTNERS_FP16 needs the forward's fp16 packed operands and their geometry");
       return ALADIN_ERR_ARG;
     }
-    pk = PackedRows{(const half_t*)xm, (const half_t*)xe, (const half_t*)y, g->Dp, g->mrows, g->rem, 16 * g->tp16};
+    pk = PackedRows{(const half_t*)xm, (const half_t*)xe, (const half_t*)y, g->Dp, g->mrows, g->rem, g->trows};
   }
 #define LAUNCH_ROWS_FP(N, F, P)                                                                                         \
   hipLaunchKernelGGL((bwd_rows_kernel<N, F, P>), dim3(rgrid), dim3(256), 0, st, im, im_sb, im_sr, im_len, s, s_sb, s_st, s_len, \

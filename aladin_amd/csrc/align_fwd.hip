@@ -58,6 +58,13 @@ static int scores_class48() {
   return v != 0;
 }
 
+// the 40-word caption class (T' 33..40 at the 48-row region class: VinVL's 35-token captions); ALADIN_ALIGN_CLASS40=0 in the
+// diagnostic build pads to 48 words as before (A/B runs)
+static int scores_class40() {
+  static const int v = diag_env("ALADIN_ALIGN_CLASS40", 1);
+  return v != 0;
+}
+
 static int scores_side_max() {
   static int v = -1;
   if (v < 0) {
@@ -106,11 +113,18 @@ extern "C" int aladin_align_geometry_mode(int Bi, int Bc, int R, int T, int D, i
   g->Dp = round_up(D, 64) * (g->split ? 3 : 1);
   g->img_unit = (g->mrows == 32) ? 8 : 4;                     // images per workgroup tile: 256 rows (192 in the 48-row class, 384 at 96)
   g->cap_unit = (scores_strip_mult(g->tp16, g->mrows) == 2) ? 24 / g->tp16 : 2 * ((g->tp16 & 1) ? 2 : 1);
+  // rows per caption in y: whole 16-word tiles, except the 40-word class -- T' 33..40 (VinVL's 35-token captions: 35 words of
+  // 48 would be 27 % padding) packs a caption into 2.5 tiles; a wave's 80-column strip holds two of them and the epilogue
+  // splits the middle tile between them by lane.  48-row region class, fp16 operands (the arg-max table kernel of the dense
+  // backward, which runs on split operands, keeps whole tiles).  16 captions per unit: 640 rows, whole 320-column score
+  // tiles and whole 128-column side GEMM tiles.
+  g->trows = 16 * g->tp16;
+  if (!g->split && g->mrows == 48 && g->Tq > 32 && g->Tq <= 40 && scores_class40()) { g->trows = 40; g->cap_unit = 16; }
   g->Bi_pad = round_up(Bi, g->img_unit);
   g->Bc_pad = round_up(Bc, g->cap_unit);
   g->xm_rows = (int64_t)g->Bi_pad * g->mrows;
   g->xe_rows = g->rem ? round_up(g->Bi_pad * g->rem, 64) : 0;      // image i: rows [i*rem, i*rem + rem)
-  g->y_rows = (int64_t)g->Bc_pad * 16 * g->tp16;
+  g->y_rows = (int64_t)g->Bc_pad * g->trows;
   g->xm_bytes = g->xm_rows * g->Dp * 2;
   g->xe_bytes = g->xe_rows * g->Dp * 2;
   g->y_bytes = g->y_rows * g->Dp * 2;
@@ -324,7 +338,7 @@ extern "C" int aladin_align_pack_captions(const float* s, int64_t stride_b, int6
   if (!s || !s_len || !g || !y) { aladin_set_error("align_pack_captions: null argument"); return ALADIN_ERR_ARG; }
   const unsigned grid = (unsigned)((g->y_rows + 3) / 4);
   hipLaunchKernelGGL(pack_captions_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, s, stride_b, stride_t, s_len,
-                     g->Bc, g->Tq, g->y_tail, g->D, g->Dp, 16 * g->tp16, g->y_rows, (half_t*)y,
+                     g->Bc, g->Tq, g->y_tail, g->D, g->Dp, g->trows, g->y_rows, (half_t*)y,
                      is_vec4_ok(s, stride_b, stride_t, g->D), g->split);
   return aladin_check_launch("pack_captions_kernel");
 }
@@ -336,7 +350,7 @@ extern "C" int aladin_align_pack_both(const float* im, int64_t im_stride_b, int6
   const int64_t img_rows = g->xm_rows + g->xe_rows, total = img_rows + g->y_rows;
   hipLaunchKernelGGL(pack_both_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, (hipStream_t)stream, im, im_stride_b,
                      im_stride_r, im_len, s, s_stride_b, s_stride_t, s_len, g->Bi, g->Bc, g->Rq, g->Tq, g->x_tail, g->y_tail, g->D, g->Dp, g->mrows,
-                     g->rem > 0 ? g->rem : 1, g->xm_rows, img_rows, total, 16 * g->tp16, (half_t*)xm, (half_t*)xe, (half_t*)y,
+                     g->rem > 0 ? g->rem : 1, g->xm_rows, img_rows, total, g->trows, (half_t*)xm, (half_t*)xe, (half_t*)y,
                      is_vec4_ok(im, im_stride_b, im_stride_r, g->D), is_vec4_ok(s, s_stride_b, s_stride_t, g->D), g->split);
   return aladin_check_launch("pack_both_kernel");
 }
@@ -345,7 +359,7 @@ extern "C" int aladin_align_pack_both(const float* im, int64_t im_stride_b, int6
 // side GEMM: E[i][col] = <last region of image i, word col>   (fp32, xe_rows x y_rows)
 // ------------------------------------------------------------------------------------------------
 #define SIDE_STAGES 3
-template <int NT, int SWM>
+template <int NT, int SWM, int NS = SIDE_STAGES>
 __global__ __launch_bounds__(256) void align_side_gemm_kernel(const half_t* __restrict__ xe, const half_t* __restrict__ y,
                                                               float* __restrict__ E, int64_t ldE, int64_t ldk,
                                                               int ktiles, int n_nblk) {
@@ -359,7 +373,7 @@ __global__ __launch_bounds__(256) void align_side_gemm_kernel(const half_t* __re
     for (int n = 0; n < NT; ++n)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
-  gemm_mainloop<Cfg, SIDE_STAGES>(xe + (int64_t)mb * Cfg::BM * ldk, y + (int64_t)nb * Cfg::BN * ldk, ldk, ktiles, smem, acc);
+  gemm_mainloop<Cfg, NS>(xe + (int64_t)mb * Cfg::BM * ldk, y + (int64_t)nb * Cfg::BN * ldk, ldk, ktiles, smem, acc);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int wm = wave / 2, wn = wave % 2;
   const int64_t row0 = (int64_t)mb * Cfg::BM + wm * SWM * 32 + 4 * (lane >> 5);
@@ -715,20 +729,21 @@ __device__ __forceinline__ float max12(const f32x4& a, const f32x4& b, const f32
   return vmax(t, c[3]);
 }
 
-template <bool HAS_E, int TP16, int REMC, int WGM, int WGN>
-__device__ __forceinline__ void scores16_epilogue_r48(f32x4 (&acc)[6][6], int mb, int nb, const float* __restrict__ E, int64_t ldE,
+// CT = 5: the 40-word caption class -- the wave's 80 columns are two captions of 40, the middle tile belongs to the first
+// caption in lanes with column < 8 and to the second in the others (TP16 is 3 and not looked at).
+template <bool HAS_E, int TP16, int REMC, int WGM, int WGN, int CT>
+__device__ __forceinline__ void scores16_epilogue_r48(f32x4 (&acc)[6][CT], int mb, int nb, const float* __restrict__ E, int64_t ldE,
                                                       int rem, float* __restrict__ S, int64_t ldS, int Bi, int Bc) {
-  using Cfg = GemmCfg<WGM, WGN, 3, 3>;
-  constexpr int CT = 6;
+  using Cfg = GemmCfg<WGM, WGN, 3, 3, CT>;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int wm = wave / WGN, wn = wave % WGN;
   const int half = lane >> 5, l4 = lane & 15;
   if constexpr (REMC >= 1) rem = REMC;
-  constexpr int NC = CT / TP16;
-  static_assert(CT % TP16 == 0, "a caption must be a whole number of 16-word column tiles of the strip");
+  constexpr int NC = CT == 5 ? 2 : CT / TP16;
+  static_assert(CT == 5 || CT % TP16 == 0, "a caption must be a whole number of 16-word column tiles of the strip");
   const int cap = (nb * WGN + wn) * NC;
   const int img = (mb * WGM + wm) * 2 + half;                      // lanes 0-31 finish the wave's first image, 32-63 the second
-  const float* e = HAS_E ? E + (int64_t)img * rem * ldE + (int64_t)nb * Cfg::BN + wn * 96 + l4 : nullptr;
+  const float* e = HAS_E ? E + (int64_t)img * rem * ldE + (int64_t)nb * Cfg::BN + wn * Cfg::WCOLS + l4 : nullptr;
   float v[NC];
 #pragma unroll
   for (int c = 0; c < NC; ++c) v[c] = 0.f;
@@ -750,7 +765,13 @@ __device__ __forceinline__ void scores16_epilogue_r48(f32x4 (&acc)[6][6], int mb
 #pragma unroll
       for (int k = 0; k < 8; ++k) m = vmax(m, e[(int64_t)(k < rem ? k : rem - 1) * ldE + ct * 16]);
     }
-    v[ct / TP16] += m;
+    if constexpr (CT == 5) {
+      if (ct < 2) v[0] += m;
+      else if (ct > 2) v[1] += m;
+      else { v[0] += l4 < 8 ? m : 0.f; v[1] += l4 < 8 ? 0.f : m; }
+    } else {
+      v[ct / TP16] += m;
+    }
   }
 #pragma unroll
   for (int c = 0; c < NC; ++c) {
@@ -759,47 +780,50 @@ __device__ __forceinline__ void scores16_epilogue_r48(f32x4 (&acc)[6][6], int mb
   }
 }
 
-template <bool HAS_E, int TP16, int REMC, int WGM, int WGN>
+template <bool HAS_E, int TP16, int REMC, int WGM, int WGN, int CT = 6>
 __global__ __launch_bounds__(WGM * WGN * 64) void align_scores16_r48_kernel(const half_t* __restrict__ xm, const half_t* __restrict__ y,
                                                                             const float* __restrict__ E, int64_t ldE,
                                                                             float* __restrict__ S, int64_t ldS, int Bi, int Bc,
                                                                             int64_t ldk, int ktiles, int n_nblk, int n_blocks, int rem) {
-  using Cfg = GemmCfg<WGM, WGN, 3, 3>;
+  using Cfg = GemmCfg<WGM, WGN, 3, 3, CT>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int mb, nb;
   tile_coords(blockIdx.x, n_blocks / n_nblk, n_nblk, 8, mb, nb);
-  f32x4 acc[6][6];
+  f32x4 acc[6][CT];
 #pragma unroll
   for (int rt = 0; rt < 6; ++rt)
 #pragma unroll
-    for (int ct = 0; ct < 6; ++ct) acc[rt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int ct = 0; ct < CT; ++ct) acc[rt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
   if constexpr (HAS_E && REMC >= 1 && REMC <= 2 && WGM == 2 && WGN == 4) {
     // pull this tile's side-row values into this XCD's L2 now (they were written by the side GEMM on other XCDs; see
-    // align_scores16_kernel): per wave 2 images x REMC rows x 96 columns = 6 REMC lines of 32 floats; dropped into the piece
-    // of stage 1 this wave's own refill overwrites later
+    // align_scores16_kernel): per wave 2 images x REMC rows x 96 columns = 6 REMC lines of 32 floats (80 columns: not line
+    // aligned, up to four lines -- touched at floats 0, 32, 64, 79); dropped into the piece of stage 1 this wave's own refill
+    // overwrites later
     const int wave_u = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane_p = threadIdx.x & 63;
-    constexpr int LINES = 6 * REMC;
+    constexpr int LPR = CT == 5 ? 4 : 3;
+    constexpr int LINES = 2 * LPR * REMC;
     const int q = lane_p % LINES;
-    const int img_p = (mb * WGM + wave_u / WGN) * 2 + q / (3 * REMC);
-    const int k_p = (q / 3) % REMC;
-    const float* src = E + ((int64_t)img_p * REMC + k_p) * ldE + (int64_t)nb * Cfg::BN + (wave_u % WGN) * 96 + (q % 3) * 32;
+    const int img_p = (mb * WGM + wave_u / WGN) * 2 + q / (LPR * REMC);
+    const int k_p = (q / LPR) % REMC;
+    const int off_p = (q % LPR) * 32 < Cfg::WCOLS ? (q % LPR) * 32 : Cfg::WCOLS - 1;
+    const float* src = E + ((int64_t)img_p * REMC + k_p) * ldE + (int64_t)nb * Cfg::BN + (wave_u % WGN) * Cfg::WCOLS + off_p;
     __builtin_amdgcn_global_load_lds(GLOBAL_PTR(src), LDS_PTR(smem + Cfg::STAGE_BYTES + wave_u * 1024), 4, 0, 0);
   }
   gemm_mainloop16_tall<Cfg, true>(xm + (int64_t)mb * Cfg::BM * ldk, y + (int64_t)nb * Cfg::BN * ldk, ldk, ktiles, smem, acc);
-  scores16_epilogue_r48<HAS_E, TP16, REMC, WGM, WGN>(acc, mb, nb, E, ldE, rem, S, ldS, Bi, Bc);
+  scores16_epilogue_r48<HAS_E, TP16, REMC, WGM, WGN, CT>(acc, mb, nb, E, ldE, rem, S, ldS, Bi, Bc);
 }
 
-template <bool HAS_E, int TP16, int REMC, int WGM, int WGN>
+template <bool HAS_E, int TP16, int REMC, int WGM, int WGN, int CT = 6>
 static int launch_scores16_r48_cfg(const aladin_align_geom* g, const half_t* xm, const half_t* y, const float* E, float* S,
                                    int64_t ldS, hipStream_t stream) {
-  using Cfg = GemmCfg<WGM, WGN, 3, 3>;
+  using Cfg = GemmCfg<WGM, WGN, 3, 3, CT>;
   const int n_mblk = (int)(g->xm_rows / Cfg::BM), n_nblk = (int)(g->y_rows / Cfg::BN);
   if ((int64_t)n_mblk * Cfg::BM != g->xm_rows || (int64_t)n_nblk * Cfg::BN != g->y_rows) {
     aladin_set_error("align_scores16_r48: packed rows do not tile");
     return ALADIN_ERR_ARG;
   }
-  auto kern = align_scores16_r48_kernel<HAS_E, TP16, REMC, WGM, WGN>;
+  auto kern = align_scores16_r48_kernel<HAS_E, TP16, REMC, WGM, WGN, CT>;
   static unsigned long long lds_reserved = 0;
   if (int rc = aladin_reserve_lds((const void*)kern, Cfg::LDS_BYTES, &lds_reserved, "align_scores16_r48")) return rc;
   const int n_blocks = n_mblk * n_nblk;
@@ -808,19 +832,137 @@ static int launch_scores16_r48_cfg(const aladin_align_geom* g, const half_t* xm,
   return aladin_check_launch("align_scores16_r48_kernel");
 }
 
-template <bool HAS_E, int TP16>
+// ------------------------------------------------------------------------------------------------
+// 48-row region class x 40-word caption class on large grids: 288 x 320 workgroup tile, 144 x 80 wave tile (THREE images x two
+// captions per wave, 45 accumulators).  The 192 x 320 tile above moves 0.0083 operand bytes through LDS per multiply-add and its
+// loop's LDS time equals its matrix-pipe time (1920 cycles each per K step); this one moves 0.0066 (the headline tile's figure:
+// 2400 LDS cycles under 2880 of matrix pipe).  Only the 80-column strip fits: two stages of 608 rows are 152 KB (96-column strips
+// would need 168).  The packed operands keep the class's 4-image unit (xm_rows is a multiple of 192, so the sharded path's
+// operands still concatenate): the last row tile may hang over the end and re-reads the operand's last 8-row piece for the rows
+// that do not exist (gemm_stage_k a_avail); their scores are not stored.
+// Epilogue: images 0 and 1 of the wave as in the 96-row tile (each finished by one half-wave), image 2 by both halves.
+// ------------------------------------------------------------------------------------------------
+using CfgR48x3 = GemmCfg<2, 4, 3, 3, 5, 9>;
+template <bool HAS_E, int REMC>
+__global__ __launch_bounds__(512) void align_scores16_r48x3_kernel(const half_t* __restrict__ xm, const half_t* __restrict__ y,
+                                                                   const float* __restrict__ E, int64_t ldE,
+                                                                   float* __restrict__ S, int64_t ldS, int Bi, int Bc,
+                                                                   int64_t ldk, int ktiles, int n_nblk, int n_blocks, int rem, int xm_rows) {
+  using Cfg = CfgR48x3;
+  constexpr int CT = 5, RT = 9;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int mb, nb;
+  tile_coords(blockIdx.x, n_blocks / n_nblk, n_nblk, 8, mb, nb);
+  f32x4 acc[RT][CT];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) acc[rt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int wave_u = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if constexpr (HAS_E && REMC >= 1 && REMC <= 2) {
+    // side-row values of this tile into this XCD's L2 (see align_scores16_r48_kernel): per wave 3 images x REMC rows x 80 columns
+    const int lane_p = threadIdx.x & 63;
+    constexpr int LINES = 12 * REMC;
+    const int q = lane_p % LINES;
+    int img_p = (mb * 2 + wave_u / 4) * 3 + q / (4 * REMC);
+    if (img_p * 48 >= xm_rows) img_p = xm_rows / 48 - 1;       // the overhanging tile
+    const int k_p = (q / 4) % REMC;
+    const int off_p = (q % 4) * 32 < 80 ? (q % 4) * 32 : 79;
+    const float* src = E + ((int64_t)img_p * REMC + k_p) * ldE + (int64_t)nb * Cfg::BN + (wave_u % 4) * 80 + off_p;
+    __builtin_amdgcn_global_load_lds(GLOBAL_PTR(src), LDS_PTR(smem + Cfg::STAGE_BYTES + wave_u * 1024), 4, 0, 0);
+  }
+  gemm_mainloop16_tall<Cfg, true>(xm + (int64_t)mb * Cfg::BM * ldk, y + (int64_t)nb * Cfg::BN * ldk, ldk, ktiles, smem, acc, KMapLinear(),
+                                  xm_rows - mb * Cfg::BM);
+  // ---- epilogue
+  const int lane = threadIdx.x & 63;
+  const int wm = wave_u / 4, wn = wave_u % 4;
+  const int half = lane >> 5, l4 = lane & 15;
+  if constexpr (REMC >= 1) rem = REMC;
+  const int cap = (nb * 4 + wn) * 2;
+  const int img0 = (mb * 2 + wm) * 3;
+  const int imgA = img0 + half, imgC = img0 + 2;
+  const int n_img = xm_rows / 48;                                  // images that exist in the operands (>= Bi)
+  const int64_t ecol = (int64_t)nb * Cfg::BN + wn * 80 + l4;
+  const float* eA = HAS_E ? E + (int64_t)(imgA < n_img ? imgA : n_img - 1) * rem * ldE + ecol : nullptr;
+  const float* eC = HAS_E ? E + (int64_t)(imgC < n_img ? imgC : n_img - 1) * rem * ldE + ecol : nullptr;
+  float vA[2] = {0.f, 0.f}, vC[2] = {0.f, 0.f};
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct) {
+    const float p0 = max12(acc[0][ct], acc[1][ct], acc[2][ct]);
+    const float p1 = max12(acc[3][ct], acc[4][ct], acc[5][ct]);
+    const float p2 = max12(acc[6][ct], acc[7][ct], acc[8][ct]);
+    auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(p0), __float_as_uint(p1), false, false);
+    float mA = max_xor16(vmax(__uint_as_float(sw[0]), __uint_as_float(sw[1])));
+    float mC = max_xor16(max_xor32(p2));
+    if constexpr (HAS_E && REMC >= 1) {
+#pragma unroll
+      for (int k = 0; k < REMC; ++k) { mA = vmax(mA, eA[(int64_t)k * ldE + ct * 16]); mC = vmax(mC, eC[(int64_t)k * ldE + ct * 16]); }
+    }
+    if constexpr (HAS_E && REMC == 0) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int64_t o = (int64_t)(k < rem ? k : rem - 1) * ldE + ct * 16;
+        mA = vmax(mA, eA[o]); mC = vmax(mC, eC[o]);
+      }
+    }
+    if (ct < 2) { vA[0] += mA; vC[0] += mC; }
+    else if (ct > 2) { vA[1] += mA; vC[1] += mC; }
+    else { vA[0] += l4 < 8 ? mA : 0.f; vA[1] += l4 < 8 ? 0.f : mA; vC[0] += l4 < 8 ? mC : 0.f; vC[1] += l4 < 8 ? 0.f : mC; }
+  }
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    const float tA = row16_sum(vA[c]), tC = row16_sum(vC[c]);
+    if ((lane & 31) == 0 && imgA < Bi && cap + c < Bc) S[(int64_t)imgA * ldS + cap + c] = tA;
+    if (lane == 0 && imgC < Bi && cap + c < Bc) S[(int64_t)imgC * ldS + cap + c] = tC;
+  }
+}
+
+template <bool HAS_E, int REMC>
+static int launch_scores16_r48x3(const aladin_align_geom* g, const half_t* xm, const half_t* y, const float* E, float* S, int64_t ldS,
+                                 hipStream_t stream) {
+  using Cfg = CfgR48x3;
+  const int n_mblk = (int)((g->xm_rows + Cfg::BM - 1) / Cfg::BM), n_nblk = (int)(g->y_rows / Cfg::BN);
+  if ((int64_t)n_nblk * Cfg::BN != g->y_rows || g->xm_rows % 48 != 0 || g->xm_rows < 8) { aladin_set_error("align_scores16_r48x3: packed rows do not tile"); return ALADIN_ERR_ARG; }
+  auto kern = align_scores16_r48x3_kernel<HAS_E, REMC>;
+  static unsigned long long lds_reserved = 0;
+  if (int rc = aladin_reserve_lds((const void*)kern, Cfg::LDS_BYTES, &lds_reserved, "align_scores16_r48x3")) return rc;
+  const int n_blocks = n_mblk * n_nblk;
+  hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(Cfg::THREADS), Cfg::LDS_BYTES, stream, xm, y, E, g->y_rows, S, ldS, g->Bi,
+                     g->Bc, (int64_t)g->Dp, g->Dp / 64, n_nblk, n_blocks, g->rem, (int)g->xm_rows);
+  return aladin_check_launch("align_scores16_r48x3_kernel");
+}
+
+template <bool HAS_E, int TP16, int CT = 6>
 static int launch_scores16_r48(const aladin_align_geom* g, const half_t* xm, const half_t* y, const float* E, float* S, int64_t ldS,
                                hipStream_t stream) {
   // small grids (<= 64 tiles of 192 x 384, e.g. the shipped batch size 32): 96 x 192 tiles of two waves, four times the workgroups
-  const bool small = (g->xm_rows / 192) * (g->y_rows / 384) <= 64;
-  if constexpr (HAS_E) {
-    if (g->rem == 2) return small ? launch_scores16_r48_cfg<true, TP16, 2, 1, 2>(g, xm, y, E, S, ldS, stream)
-                                  : launch_scores16_r48_cfg<true, TP16, 2, 2, 4>(g, xm, y, E, S, ldS, stream);
-    if (g->rem > 2) return small ? launch_scores16_r48_cfg<true, TP16, 0, 1, 2>(g, xm, y, E, S, ldS, stream)
-                                 : launch_scores16_r48_cfg<true, TP16, 0, 2, 4>(g, xm, y, E, S, ldS, stream);
+  const bool small = (g->xm_rows / 192) * (g->y_rows / (64 * CT)) <= 64;
+  if constexpr (CT == 5) {
+    // large grids of the 40-word class: the 288 x 320 tile where it wins.  One workgroup per CU either way, so a grid takes
+    // ceil(tiles / 256) rounds; a 288-row tile takes 1.37x the time of a 192-row one for 1.5x the work (measured at B = 256,
+    // D = 768: 29.0 vs 21.2 us), but B = 256 is 8.0 rounds of the small tile against 5.4 -> 6 of the big one (170 vs 174 us):
+    // the big tile is taken when its rounds come out at least 3 % ahead (ALADIN_ALIGN_R48X3=0/1 forces the choice).
+    static const int forced = diag_env("ALADIN_ALIGN_R48X3", -1);
+    const int64_t n_n = g->y_rows / 320, r192 = ((g->xm_rows / 192) * n_n + 255) / 256, r288 = (((g->xm_rows + 287) / 288) * n_n + 255) / 256;
+    const bool x3 = forced >= 0 ? forced != 0 : (!small && 1.37 * (double)r288 < 0.97 * (double)r192);
+    if (x3) {
+      if constexpr (HAS_E) {
+        if (g->rem == 1) return launch_scores16_r48x3<true, 1>(g, xm, y, E, S, ldS, stream);
+        if (g->rem == 2) return launch_scores16_r48x3<true, 2>(g, xm, y, E, S, ldS, stream);
+        return launch_scores16_r48x3<true, 0>(g, xm, y, E, S, ldS, stream);
+      } else {
+        return launch_scores16_r48x3<false, 1>(g, xm, y, E, S, ldS, stream);
+      }
+    }
   }
-  return small ? launch_scores16_r48_cfg<HAS_E, TP16, 1, 1, 2>(g, xm, y, E, S, ldS, stream)
-               : launch_scores16_r48_cfg<HAS_E, TP16, 1, 2, 4>(g, xm, y, E, S, ldS, stream);
+  if constexpr (HAS_E) {
+    if (g->rem == 2) return small ? launch_scores16_r48_cfg<true, TP16, 2, 1, 2, CT>(g, xm, y, E, S, ldS, stream)
+                                  : launch_scores16_r48_cfg<true, TP16, 2, 2, 4, CT>(g, xm, y, E, S, ldS, stream);
+    if (g->rem > 2) return small ? launch_scores16_r48_cfg<true, TP16, 0, 1, 2, CT>(g, xm, y, E, S, ldS, stream)
+                                 : launch_scores16_r48_cfg<true, TP16, 0, 2, 4, CT>(g, xm, y, E, S, ldS, stream);
+  }
+  return small ? launch_scores16_r48_cfg<HAS_E, TP16, 1, 1, 2, CT>(g, xm, y, E, S, ldS, stream)
+               : launch_scores16_r48_cfg<HAS_E, TP16, 1, 2, 4, CT>(g, xm, y, E, S, ldS, stream);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1304,12 +1446,13 @@ static int launch_scores(const aladin_align_geom* g, const half_t* xm, const hal
   return launch_scores_w<4, WM, Q, TP16, HAS_E, 1>(g, xm, y, E, S, ldS, stream);
 }
 
-template <int NT, int SWM>
+template <int NT, int SWM, int NS = SIDE_STAGES>
 static int launch_side_w(const aladin_align_geom* g, const half_t* xe, const half_t* y, float* E, hipStream_t stream) {
   using Cfg = GemmCfg<2, 2, SWM, NT>;
   const int n_mblk = (int)(g->xe_rows / Cfg::BM), n_nblk = (int)(g->y_rows / Cfg::BN);
-  auto kern = align_side_gemm_kernel<NT, SWM>;
-  constexpr int lds_bytes = SIDE_STAGES * Cfg::STAGE_BYTES;
+  if ((int64_t)n_mblk * Cfg::BM != g->xe_rows || (int64_t)n_nblk * Cfg::BN != g->y_rows) { aladin_set_error("align_side_gemm: packed rows do not tile"); return ALADIN_ERR_ARG; }
+  auto kern = align_side_gemm_kernel<NT, SWM, NS>;
+  constexpr int lds_bytes = NS * Cfg::STAGE_BYTES;
   static unsigned long long lds_reserved = 0;
   if (int rc = aladin_reserve_lds((const void*)kern, lds_bytes, &lds_reserved, "align_side_gemm")) return rc;
   hipLaunchKernelGGL(kern, dim3(n_mblk * n_nblk), dim3(Cfg::THREADS), lds_bytes, stream, xe, y, E, g->y_rows,
@@ -1323,15 +1466,32 @@ static int launch_side(const aladin_align_geom* g, const half_t* xe, const half_
   // 128-row tiles halve the LDS-DMA traffic of this fill-bound kernel; they pay once there are enough rows
   // for the grid to stay full: from two side rows per image on (measured at B=256: rem=1 0.187 vs 0.191 ms
   // forward, rem=2 0.209 vs 0.205, rem=6 0.287 vs 0.275).  ALADIN_SIDE_BIG=0/1 forces the choice.
-  const bool big = forced >= 0 ? forced != 0 : g->rem >= 2;
-  if (big && g->xe_rows % 128 == 0 && g->xe_rows >= 256) return launch_side_w<NT, 2>(g, xe, y, E, stream);
-  return launch_side_w<NT, 1>(g, xe, y, E, stream);
+  const bool big = (forced >= 0 ? forced != 0 : g->rem >= 2) && g->xe_rows % 128 == 0 && g->xe_rows >= 256;
+  // LDS ring: two stages (two workgroups per CU) once the grid fills the chip, three (one workgroup, deeper prefetch) for the
+  // latency-bound small grids.  tools/ab_side_ns.sh at B = 256, D = 768 (3 -> 2 stages): R' = 33 13.1 -> 13.0 us, R' = 35
+  // 31.9 -> 26.1, R' = 39 63.7 -> 49.9, 50 x 47 19.7 -> 18.2, T' = 17 11.5 -> 10.5, T' = 64 24.5 -> 22.3; B = 64: 10.6 -> 11.6.
+  static const int ns_forced = diag_env("ALADIN_SIDE_NS", 0);
+  const int64_t n_blocks = (g->xe_rows / (big ? 128 : 64)) * (g->y_rows / (64 * NT));
+  const bool two = ns_forced ? ns_forced == 2 : n_blocks >= 128;
+  if (big) return two ? launch_side_w<NT, 2, 2>(g, xe, y, E, stream) : launch_side_w<NT, 2, 3>(g, xe, y, E, stream);
+  return two ? launch_side_w<NT, 1, 2>(g, xe, y, E, stream) : launch_side_w<NT, 1, 3>(g, xe, y, E, stream);
 }
 
 template <int TP16>
 static int dispatch_tp(const aladin_align_geom* g, const half_t* xm, const half_t* xe, const half_t* y, float* E,
                        float* S, int64_t ldS, int flags, hipStream_t stream) {
   constexpr int NT = (TP16 & 1) ? TP16 : TP16 / 2;
+  if constexpr (TP16 == 3)
+    if (g->trows == 40) {                              // 40-word captions: 48-row region class only (aladin_align_geometry_mode)
+      if (g->mrows != 48) { aladin_set_error("align_scores: 40-word captions need the 48-row region class (mrows=%d)", g->mrows); return ALADIN_ERR_UNSUPPORTED; }
+      if (!g->rem) return launch_scores16_r48<false, 3, 5>(g, xm, y, E, S, ldS, stream);
+      if (!(flags & ALADIN_SCORES_REUSE_SIDE)) {
+        int rc;
+        rc = launch_side<2>(g, xe, y, E, stream);    // y_rows is a multiple of 640: 128-column tiles (tools/ab_side40.sh: 320-column tiles are slower)
+        if (rc) return rc;
+      }
+      return launch_scores16_r48<true, 3, 5>(g, xm, y, E, S, ldS, stream);
+    }
   if (g->rem) {
     if (!(flags & ALADIN_SCORES_REUSE_SIDE)) {
       int rc = launch_side<NT>(g, xe, y, E, stream);
@@ -1371,6 +1531,7 @@ extern "C" int aladin_align_scores_ex(const void* xm, const void* xe, const void
   hipStream_t st = (hipStream_t)stream;
   const half_t* a = (const half_t*)xm; const half_t* b = (const half_t*)xe; const half_t* c = (const half_t*)y;
   float* E = (float*)e_scratch;
+  if (g->trows != 16 * g->tp16 && !(g->trows == 40 && g->tp16 == 3)) { aladin_set_error("align_scores: bad geometry (trows=%d tp16=%d)", g->trows, g->tp16); return ALADIN_ERR_ARG; }
   int rc;
   switch (g->tp16) {
     case 1: rc = dispatch_tp<1>(g, a, b, c, E, S, ldS, flags, st); break;

@@ -15,19 +15,27 @@
 #pragma once
 #include "common.hpp"
 
-template <int WGM_, int WGN_, int WM_, int WN_>
+// CT16: 16-column accumulator tiles per wave (default 2 * WN).  An ODD count -- 5 tiles = 80 columns = two captions of 40 words,
+// the word class of VinVL's 35-token captions -- is only understood by gemm_mainloop16_tall; the 32 x 32 loops assert the default.
+// RT16: 16-row accumulator tiles per wave (default 2 * WM); 9 = 144 rows = three images of the 48-row region class.  A stage whose
+// 8-row pieces do not divide over the waves (EVEN_CHUNKS false) is only understood by gemm_stage_k / gemm_mainloop16_tall (the
+// last round of pieces is issued by the first waves only; the other loops count their pieces for s_waitcnt and assert it).
+template <int WGM_, int WGN_, int WM_, int WN_, int CT16_ = 2 * WN_, int RT16_ = 2 * WM_>
 struct GemmCfg {
-  static constexpr int WGM = WGM_, WGN = WGN_, WM = WM_, WN = WN_;
+  static constexpr int WGM = WGM_, WGN = WGN_, WM = WM_, WN = WN_, CT16 = CT16_, RT16 = RT16_;
+  static constexpr int WCOLS = 16 * CT16;               // columns per wave
+  static constexpr int WROWS = 16 * RT16;               // rows per wave
   static constexpr int NWAVES = WGM * WGN;
   static constexpr int THREADS = NWAVES * 64;
-  static constexpr int BM = WGM * WM * 32;
-  static constexpr int BN = WGN * WN * 32;
+  static constexpr int BM = WGM * WROWS;
+  static constexpr int BN = WGN * WCOLS;
   static constexpr int ROWS = BM + BN;
   static constexpr int STAGE_BYTES = ROWS * 128;
   static constexpr int CHUNKS = ROWS / 8;
-  static constexpr int CHUNKS_PER_WAVE = CHUNKS / NWAVES;
+  static constexpr bool EVEN_CHUNKS = CHUNKS % NWAVES == 0;
+  static constexpr int CHUNKS_PER_WAVE = (CHUNKS + NWAVES - 1) / NWAVES;
   static constexpr int LDS_BYTES = 2 * STAGE_BYTES;      // for the default 2-stage ring
-  static_assert(CHUNKS % NWAVES == 0, "stage chunks must divide over the waves");
+  static_assert(ROWS % 8 == 0, "stages are filled in 8-row pieces");
 };
 
 // One K-step (64 deep) of both panels -> LDS.  The A panel may come from two row segments
@@ -54,6 +62,7 @@ template <class Cfg, int C0 = 0, int C1 = Cfg::CHUNKS_PER_WAVE>
 __device__ __forceinline__ void gemm_stage(const half_t* __restrict__ a_rows, const half_t* __restrict__ a_rows2, int a_split,
                                            const half_t* __restrict__ b_rows, int64_t ldk, int kt, char* stage, int wave,
                                            uint32_t lane_off, uint32_t skip = 0) {
+  static_assert(Cfg::EVEN_CHUNKS && Cfg::RT16 == 2 * Cfg::WM, "the callers count their pieces: stage pieces must divide over the waves");
 #pragma unroll
   for (int c = C0; c < C1; ++c) {
     if ((skip >> c) & 1u) continue;
@@ -69,14 +78,18 @@ __device__ __forceinline__ void gemm_stage(const half_t* __restrict__ a_rows, co
 
 // The same staging with the K position given per panel (a_k / b_k, in halfs, wave-uniform): the evaluation similarity GEMM walks
 // operand rows laid out [hi | lo] in the chain order hi.hi, lo.hi, hi.lo (recall.hip), so the two panels sit at different K offsets.
+// a_avail > 0: only that many rows exist behind a_rows (a multiple of 8); pieces past them re-read the last piece -- the last row
+// tile of a grid whose row count is not a multiple of BM (their accumulator rows are never looked at).
 template <class Cfg, int C0 = 0, int C1 = Cfg::CHUNKS_PER_WAVE>
 __device__ __forceinline__ void gemm_stage_k(const half_t* __restrict__ a_rows, const half_t* __restrict__ b_rows, int64_t ldk,
-                                             int64_t a_k, int64_t b_k, char* stage, int wave, uint32_t lane_off) {
+                                             int64_t a_k, int64_t b_k, char* stage, int wave, uint32_t lane_off, int a_avail = 0) {
 #pragma unroll
   for (int c = C0; c < C1; ++c) {
     const int chunk = wave + c * Cfg::NWAVES;              // wave-uniform
+    if (!Cfg::EVEN_CHUNKS && chunk >= Cfg::CHUNKS) continue;
     const int row0 = chunk * 8;
-    const half_t* base = (row0 < Cfg::BM) ? a_rows + (int64_t)row0 * ldk + a_k : b_rows + (int64_t)(row0 - Cfg::BM) * ldk + b_k;
+    const int arow = (a_avail > 0 && row0 > a_avail - 8) ? a_avail - 8 : row0;
+    const half_t* base = (row0 < Cfg::BM) ? a_rows + (int64_t)arow * ldk + a_k : b_rows + (int64_t)(row0 - Cfg::BM) * ldk + b_k;
     const char* src = reinterpret_cast<const char*>(base) + lane_off;
     __builtin_amdgcn_global_load_lds(GLOBAL_PTR(src), LDS_PTR(stage + chunk * 1024), 16, 0, 0);
   }
@@ -136,6 +149,7 @@ __device__ __forceinline__ void gemm_mainloop(const half_t* __restrict__ a_rows,
                                               const half_t* __restrict__ a_rows2 = nullptr, int a_split = Cfg::BM,
                                               uint32_t skip = 0) {
   static_assert(NS >= 2 && Cfg::CHUNKS_PER_WAVE * (NS - 2) <= 32, "ring too deep for the vmcnt dispatcher");
+  static_assert(Cfg::CT16 == 2 * Cfg::WN, "32 x 32 accumulator tiles: whole 32-column units per wave");
   const int n_issued = Cfg::CHUNKS_PER_WAVE - __builtin_popcount(skip);       // LDS-DMA instructions per wave and K step
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
@@ -249,6 +263,7 @@ __device__ __forceinline__ void gemm_mainloop16(const half_t* __restrict__ a_row
                                                 f32x4 (&acc)[2 * Cfg::WM][2 * Cfg::WN]) {
   constexpr int RT = 2 * Cfg::WM, CT = 2 * Cfg::WN;
   static_assert(RT == 4, "written for a 64-row wave tile");
+  static_assert(Cfg::CT16 == 2 * Cfg::WN && Cfg::RT16 == 2 * Cfg::WM && Cfg::EVEN_CHUNKS, "whole 32-row / 32-column units per wave");
   constexpr int CPW = Cfg::CHUNKS_PER_WAVE;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
@@ -357,18 +372,19 @@ __device__ __forceinline__ void gemm_mainloop16(const half_t* __restrict__ a_row
 template <class Cfg, bool SPREAD = true, class KMap = KMapLinear>
 __device__ __forceinline__ void gemm_mainloop16_tall(const half_t* __restrict__ a_rows, const half_t* __restrict__ b_rows,
                                                      int64_t ldk, int ktiles, char* smem,
-                                                     f32x4 (&acc)[2 * Cfg::WM][2 * Cfg::WN], const KMap km = KMap()) {
-  constexpr int RT = 2 * Cfg::WM, CT = 2 * Cfg::WN;
-  static_assert((RT == 8 || RT == 6) && CT == 6, "written for a 128 x 96 (or 96 x 96: 48-row region class) wave tile");
+                                                     f32x4 (&acc)[Cfg::RT16][Cfg::CT16], const KMap km = KMap(), int a_avail = 0) {
+  constexpr int RT = Cfg::RT16, CT = Cfg::CT16;
+  static_assert((RT == 8 || RT == 6 || RT == 9) && (CT == 6 || CT == 5), "written for a 128 x 96 (or 96 x 96: 48-row region class) wave tile; 80 columns: 40-word captions; 144 rows: three 48-row images");
+  constexpr int C2 = CT - 4;                            // column tiles of the third cluster: 2, or 1 for the 80-column tile
   constexpr int CPW = Cfg::CHUNKS_PER_WAVE;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   const int wm = wave / Cfg::WGN, wn = wave % Cfg::WGN;
   const uint32_t lane_off = stage_lane_offset<Cfg>(ldk, wave, lane);
-  const int a_row0 = wm * Cfg::WM * 32 + (lane & 15);
-  const int b_row0 = Cfg::BM + wn * Cfg::WN * 32 + (lane & 15);
+  const int a_row0 = wm * Cfg::WROWS + (lane & 15);
+  const int b_row0 = Cfg::BM + wn * Cfg::WCOLS + (lane & 15);
 
-  gemm_stage_k<Cfg>(a_rows, b_rows, ldk, km.a(0), km.b(0), smem, wave, lane_off);
+  gemm_stage_k<Cfg>(a_rows, b_rows, ldk, km.a(0), km.b(0), smem, wave, lane_off, a_avail);
   for (int kt = 0; kt < ktiles; ++kt) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -376,7 +392,7 @@ __device__ __forceinline__ void gemm_mainloop16_tall(const half_t* __restrict__ 
     const bool refill = kt + 1 < ktiles;
     char* nxt = smem + ((kt + 1) & 1) * Cfg::STAGE_BYTES;
     const int64_t a_k = refill ? km.a(kt + 1) : 0, b_k = refill ? km.b(kt + 1) : 0;      // wave-uniform scalars
-    if (!SPREAD && refill) gemm_stage_k<Cfg>(a_rows, b_rows, ldk, a_k, b_k, nxt, wave, lane_off);
+    if (!SPREAD && refill) gemm_stage_k<Cfg>(a_rows, b_rows, ldk, a_k, b_k, nxt, wave, lane_off, a_avail);
 
     half8 a[RT], bA[2], bB[2];
     // the first MFMAs of the step need a[0], bA[0], bA[1], then a[1] ...: ask in that order (LDS returns in order)
@@ -391,7 +407,7 @@ __device__ __forceinline__ void gemm_mainloop16_tall(const half_t* __restrict__ 
 #pragma unroll
       for (int j = 0; j < 2; ++j) bB[j] = lds_frag16(cur, b_row0 + (2 + j) * 16, k32, lane);
       if (SPREAD && refill) {
-        if (k32 == 1) gemm_stage_k<Cfg, (6 * CPW) / 10, (8 * CPW) / 10>(a_rows, b_rows, ldk, a_k, b_k, nxt, wave, lane_off);
+        if (k32 == 1) gemm_stage_k<Cfg, (6 * CPW) / 10, (8 * CPW) / 10>(a_rows, b_rows, ldk, a_k, b_k, nxt, wave, lane_off, a_avail);
       }
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_setprio(1);
@@ -404,10 +420,10 @@ __device__ __forceinline__ void gemm_mainloop16_tall(const half_t* __restrict__ 
       __builtin_amdgcn_sched_barrier(0);
       // ---- cluster 1: column tiles 2, 3 (bB); fetch 4, 5 into bA
 #pragma unroll
-      for (int j = 0; j < 2; ++j) bA[j] = lds_frag16(cur, b_row0 + (4 + j) * 16, k32, lane);
+      for (int j = 0; j < C2; ++j) bA[j] = lds_frag16(cur, b_row0 + (4 + j) * 16, k32, lane);
       if (SPREAD && refill) {
-        if (k32 == 0) gemm_stage_k<Cfg, 0, (3 * CPW) / 10>(a_rows, b_rows, ldk, a_k, b_k, nxt, wave, lane_off);
-        else gemm_stage_k<Cfg, (8 * CPW) / 10, CPW>(a_rows, b_rows, ldk, a_k, b_k, nxt, wave, lane_off);
+        if (k32 == 0) gemm_stage_k<Cfg, 0, (3 * CPW) / 10>(a_rows, b_rows, ldk, a_k, b_k, nxt, wave, lane_off, a_avail);
+        else gemm_stage_k<Cfg, (8 * CPW) / 10, CPW>(a_rows, b_rows, ldk, a_k, b_k, nxt, wave, lane_off, a_avail);
       }
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_setprio(1);
@@ -424,14 +440,14 @@ __device__ __forceinline__ void gemm_mainloop16_tall(const half_t* __restrict__ 
         for (int j = 0; j < 2; ++j) bB[j] = lds_frag16(cur, b_row0 + j * 16, 1, lane);
       }
       if (SPREAD && refill) {
-        if (k32 == 0) gemm_stage_k<Cfg, (3 * CPW) / 10, (6 * CPW) / 10>(a_rows, b_rows, ldk, a_k, b_k, nxt, wave, lane_off);
+        if (k32 == 0) gemm_stage_k<Cfg, (3 * CPW) / 10, (6 * CPW) / 10>(a_rows, b_rows, ldk, a_k, b_k, nxt, wave, lane_off, a_avail);
       }
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < C2; ++j)
           acc[rt][4 + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[rt], bA[j], acc[rt][4 + j], 0, 0, 0);
         if (k32 == 0) a[rt] = lds_frag16(cur, a_row0 + rt * 16, 1, lane);      // a[rt] is dead: reuse its register
       }

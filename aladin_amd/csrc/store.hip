@@ -184,6 +184,6 @@ extern "C" int aladin_align_pack_store_y(const void* rows, const int64_t* offset
                                          const aladin_align_geom* g, void* y, void* stream) {
   if (!rows || !offsets || !counts || !g || !y) { aladin_set_error("align_pack_store_y: null argument"); return ALADIN_ERR_ARG; }
   hipLaunchKernelGGL(store_pack_y_kernel, dim3((unsigned)((g->y_rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
-                     (const half_t*)rows, offsets, counts, ids, g->Bc, g->Tq, g->Dp, 16 * g->tp16, g->y_rows, (half_t*)y, g->split);
+                     (const half_t*)rows, offsets, counts, ids, g->Bc, g->Tq, g->Dp, g->trows, g->y_rows, (half_t*)y, g->split);
   return aladin_check_launch("store_pack_y_kernel");
 }

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define ALADIN_ABI_VERSION 9
+#define ALADIN_ABI_VERSION 10
 
 /* The library is built with -fvisibility=hidden: the entry points declared here are its ONLY exports. */
 #if defined(__GNUC__)
@@ -54,7 +54,9 @@ typedef struct aladin_align_geom {
   int32_t Rq, Tq;               /* R-1 regions and T-3 words take part (alad/loss.py:87-88)     */
   int32_t mrows;                /* rows per image in the main operand xm: 32, 48, 64 or 96 (rows past R' repeat region 0) */
   int32_t rem;                  /* leftover regions per image (R' - mrows when positive) that go through the side GEMM: <= 8 */
-  int32_t tp16;                 /* padded words per caption / 16                                */
+  int32_t tp16;                 /* 16-word column tiles a caption needs: ceil(trows / 16)       */
+  int32_t trows;                /* rows per caption in y: 16 * tp16, or 40 (T' 33..40 at the 48-row region class, fp16
+                                   operands: two captions share five 16-word tiles)             */
   int32_t Dp;                   /* halfs per packed row: D rounded up to 64 (zero filled), x3 when split */
   int32_t img_unit, cap_unit;   /* images / captions per workgroup tile                         */
   int32_t Bi_pad, Bc_pad;       /* batch sizes rounded up to the units (zero rows)              */

@@ -47,6 +47,17 @@ def test_geometry_headline_and_edges():
     assert (g.mrows, g.rem, g.tp16) == (96, 0, 6)
     g = ops.align_geometry(3, 7, 3, 5, 8)
     assert (g.Rq, g.Tq, g.mrows, g.rem, g.tp16, g.Dp) == (2, 2, 32, 0, 1, 64)
+    # the shipped data shape (50 regions + 35 tokens): 48 rows + 2 side rows per image, 40 rows per caption (two captions share
+    # five 16-word tiles); split operands and the 32-row region class keep whole tiles
+    g = ops.align_geometry(256, 250, 51, 38, 768)
+    assert (g.Rq, g.Tq, g.mrows, g.rem, g.tp16, g.trows, g.cap_unit) == (50, 35, 48, 2, 3, 40, 16)
+    assert g.Bc_pad == 256 and g.y_rows == 256 * 40 and g.y_bytes == g.y_rows * 768 * 2 and g.e_bytes == g.xe_rows * g.y_rows * 4
+    for T_, rows in ((35, 32), (36, 40), (43, 40), (44, 48)):
+        assert ops.align_geometry(64, 64, 51, T_, 768).trows == rows
+    assert ops.align_geometry(256, 256, 51, 38, 768, precision='split').trows == 48
+    assert ops.align_geometry(256, 256, 34, 38, 768).trows == 48
+    for g in (ops.align_geometry(256, 256, 34, 50, 768), ops.align_geometry(9, 9, 71, 71, 64), ops.align_geometry(9, 9, 51, 60, 64)):
+        assert g.trows == 16 * g.tp16
     gs = ops.align_geometry(256, 256, 34, 50, 768, precision='split')          # hi/lo split operands: three K segments per row
     g = ops.align_geometry(256, 256, 34, 50, 768)
     assert gs.split == 1 and g.split == 0 and gs.Dp == 3 * g.Dp and gs.xm_bytes == 3 * g.xm_bytes and gs.e_bytes == g.e_bytes

@@ -1276,6 +1276,38 @@ def test_small_grid_score_variant_is_bit_identical():
                     assert torch.equal(S[ii, jj], part), (R, ragged, bi, bj, i0, j0)
 
 
+@pytest.mark.parametrize('Bi,Bc,R,Tn', [(254, 270, 51, 38), (250, 258, 49, 43), (256, 256, 50, 36), (262, 272, 54, 40)])
+def test_large_grid_40_word_tile_is_bit_identical(Bi, Bc, R, Tn):
+    """Large grids of the 48-row region class x 40-word caption class run the 288 x 320 workgroup tile (three images per wave; the
+    last row tile hangs over the operand's end when the image count is not a multiple of six: 254 -> 256 images = 42.67 tiles)
+    when its whole rounds of 256 workgroups come out ahead -- (254, 270), (250, 258), (262, 272) here; (256, 256) is exactly four
+    rounds of the 192 x 320 tile and stays there -- smaller ones the 192 x 320 / 96 x 160 tiles.  Same MFMA shape, K order and
+    epilogue arithmetic: the big matrix must equal its blocks bit for bit (no / one / two / five side rows per image), and the
+    oracle to the fp16 tolerance."""
+    from aladin_amd import ops, synth
+    im, s, il, sl = synth.alignment_batch(Bi, R, Tn, 256, seed=7000 + R, ragged=True, Bc=Bc)
+    il[0], sl[0] = R, Tn                                                 # every block keeps the geometry of the whole
+    il[-1], sl[-1] = R, Tn
+    g = ops.align_geometry(Bi, Bc, R, Tn, 256)
+    assert g.mrows == 48 and g.trows == 40 and (g.xm_rows // 192) * (g.y_rows // 320) >= 512
+    r192, r288 = -(-(g.xm_rows // 192) * (g.y_rows // 320) // 256), -(-(-(-g.xm_rows // 288)) * (g.y_rows // 320) // 256)
+    assert (1.37 * r288 < 0.97 * r192) == ((Bi, Bc) != (256, 256))          # which kernel the library picks (align_fwd.hip launch_scores16_r48)
+    a, b = T(im), T(s)
+    S = ops.alignment_scores(a, b, il, sl)
+    assert_scores_close(S.cpu().numpy(), O.alignment_scores(im, s, il, sl))
+    for bi, bj in ((64, 64), (128, Bc)):
+        for i0 in range(0, Bi, bi):
+            for j0 in range(0, Bc, bj):
+                ii, jj = slice(i0, min(Bi, i0 + bi)), slice(j0, min(Bc, j0 + bj))
+                il_b, sl_b = list(il[ii]), list(sl[jj])
+                il_b[0], sl_b[0] = R, Tn
+                aa, bb = a[ii].clone(), b[jj].clone()
+                part = ops.alignment_scores(aa, bb, il_b, sl_b)
+                keep_i = slice(1 if il_b[0] != il[i0] else 0, None)      # the sample whose length was raised scores differently
+                keep_j = slice(1 if sl_b[0] != sl[j0] else 0, None)
+                assert torch.equal(S[ii, jj][keep_i, keep_j], part[keep_i, keep_j]), (bi, bj, i0, j0)
+
+
 def test_l2norm_and_cosine_measure():
     """l2norm (alad/utils.py:134-139: no eps, zero row -> NaN) forward / backward, and measure='cosine'."""
     from aladin_amd.loss import ContrastiveLoss, l2norm
@@ -1548,7 +1580,11 @@ SWEEP = [
     (6, 3, 50, 50, 128),    # 48-row class + 1 side row (R' = 49), tp16 3
     (5, 7, 42, 20, 64),     # 48-row class with tile-filling copies (R' = 41), tp16 2
     (9, 5, 49, 9, 40),      # 48-row class exactly filled (R' = 48), tp16 1, odd D
-    (6, 6, 51, 38, 768),    # the shipped data shape: 50 regions + 35 tokens -> 48 rows + 2 side rows
+    (6, 6, 51, 38, 768),    # the shipped data shape: 50 regions + 35 tokens -> 48 rows + 2 side rows, 40-word caption class
+    (6, 5, 51, 36, 64),     # 40-word class, T' = 33 (its lower edge)
+    (5, 19, 45, 43, 128),   # 40-word class exactly filled (T' = 40), no side rows, captions past one 16-caption unit
+    (4, 33, 57, 44, 64),    # T' = 41: back to three whole tiles; 8 side rows
+    (40, 37, 51, 38, 72),   # 40-word class, several workgroup tiles in both directions, ragged
     (5, 4, 57, 90, 64),     # 48 rows + 8 side rows (R' = 56: the class limit), tp16 6
     (4, 4, 58, 38, 64),     # R' = 57: two 32-row tiles
     (7, 3, 51, 60, 64),     # R' = 50 with 64-word captions (tp16 4 does not tile a 96-column strip): two 32-row tiles
