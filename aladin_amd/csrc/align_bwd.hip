@@ -71,7 +71,7 @@ static size_t dense_ws_layout(const aladin_align_geom* gs, char* base, DenseWs* 
 }
 // the tile classes the arg-max kernel covers; fills the split geometry of the problem
 static bool dense_supported(int Bi, int Bc, int R, int T, int D, int x_tail, int y_tail, aladin_align_geom* gs) {
-  if (aladin_align_geometry_mode(Bi, Bc, R, T, D, x_tail, y_tail, ALADIN_PRECISION_SPLIT, gs) != ALADIN_OK) return false;
+  if (aladin_align_geometry_mode(Bi, Bc, R, T, D, x_tail, y_tail, ALADIN_PRECISION_SPLIT_TABLE, gs) != ALADIN_OK) return false;
   const int bm = gs->mrows == 48 ? 192 : 256;                  // the tile kernel's workgroup rows for the class
   return ((gs->mrows == 32 || gs->mrows == 48) ? gs->rem <= 8 : (gs->mrows == 64 && gs->rem == 0)) && 6 % gs->tp16 == 0 &&
          (gs->xm_rows / bm) * (gs->y_rows / 384) > 64 && gs->xm_rows % bm == 0 && gs->y_rows % 384 == 0;

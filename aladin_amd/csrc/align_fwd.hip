@@ -58,8 +58,8 @@ static int scores_class48() {
   return v != 0;
 }
 
-// the 40-word caption class (T' 33..40 at the 48-row region class: VinVL's 35-token captions); ALADIN_ALIGN_CLASS40=0 in the
-// diagnostic build pads to 48 words as before (A/B runs)
+// the 24- and 40-word caption classes (T' 17..24, 33..40: VinVL's 35-token captions); ALADIN_ALIGN_CLASS40=0 in the diagnostic
+// build pads to whole 16-word tiles as before (A/B runs)
 static int scores_class40() {
   static const int v = diag_env("ALADIN_ALIGN_CLASS40", 1);
   return v != 0;
@@ -86,14 +86,14 @@ extern "C" int aladin_align_geometry_ex(int Bi, int Bc, int R, int T, int D, int
 
 extern "C" int aladin_align_geometry_mode(int Bi, int Bc, int R, int T, int D, int x_tail, int y_tail, int precision,
                                           aladin_align_geom* g) {
-  if (precision != ALADIN_PRECISION_FP16 && precision != ALADIN_PRECISION_SPLIT) { aladin_set_error("align_geometry: unknown precision %d", precision); return ALADIN_ERR_ARG; }
+  if (precision != ALADIN_PRECISION_FP16 && precision != ALADIN_PRECISION_SPLIT && precision != ALADIN_PRECISION_SPLIT_TABLE) { aladin_set_error("align_geometry: unknown precision %d", precision); return ALADIN_ERR_ARG; }
   if (!g || Bi < 1 || Bc < 1 || D < 1) { aladin_set_error("align_geometry: bad sizes Bi=%d Bc=%d D=%d", Bi, Bc, D); return ALADIN_ERR_ARG; }
   if (x_tail < 0 || y_tail < 0 || x_tail > 8 || y_tail > 8) { aladin_set_error("align_geometry: bad tails %d %d", x_tail, y_tail); return ALADIN_ERR_ARG; }
   if (R < 2 + x_tail || T < 2 + y_tail) { aladin_set_error("align_geometry: sets too short (R=%d T=%d): position 0 and the last %d / %d positions are dropped", R, T, x_tail, y_tail); return ALADIN_ERR_ARG; }
   memset(g, 0, sizeof(*g));
   g->Bi = Bi; g->Bc = Bc; g->R = R; g->T = T; g->D = D;
   g->x_tail = x_tail; g->y_tail = y_tail;
-  g->split = precision == ALADIN_PRECISION_SPLIT;
+  g->split = precision != ALADIN_PRECISION_FP16;
   g->Rq = R - 1 - x_tail; g->Tq = T - 1 - y_tail;
   if (g->Rq > 96 || g->Tq > 96) { aladin_set_error("align_geometry: at most 97 regions / 99 tokens supported (got R=%d T=%d)", R, T); return ALADIN_ERR_UNSUPPORTED; }
   // R' = mrows + rem: `mrows` rows per image in the main operand (16-row MFMA tiles; rows past R' repeat region 0), `rem`
@@ -113,13 +113,17 @@ extern "C" int aladin_align_geometry_mode(int Bi, int Bc, int R, int T, int D, i
   g->Dp = round_up(D, 64) * (g->split ? 3 : 1);
   g->img_unit = (g->mrows == 32) ? 8 : 4;                     // images per workgroup tile: 256 rows (192 in the 48-row class, 384 at 96)
   g->cap_unit = (scores_strip_mult(g->tp16, g->mrows) == 2) ? 24 / g->tp16 : 2 * ((g->tp16 & 1) ? 2 : 1);
-  // rows per caption in y: whole 16-word tiles, except the 40-word class -- T' 33..40 (VinVL's 35-token captions: 35 words of
-  // 48 would be 27 % padding) packs a caption into 2.5 tiles; a wave's 80-column strip holds two of them and the epilogue
-  // splits the middle tile between them by lane.  48-row region class, fp16 operands (the arg-max table kernel of the dense
-  // backward, which runs on split operands, keeps whole tiles).  16 captions per unit: 640 rows, whole 320-column score
-  // tiles and whole 128-column side GEMM tiles.
+  // rows per caption in y: whole 16-word tiles, except the "half" classes -- T' 17..24 packs a caption into 1.5 tiles, T' 33..40
+  // (VinVL's 35-token captions: 35 words of 48 would be 27 % padding) into 2.5: two captions share 3 / 5 tiles and the epilogue
+  // splits the middle one between them by lane (caption_add).  Region classes of the 16x16x32 kernels (32, 48 or 64 main rows);
+  // every precision except ALADIN_PRECISION_SPLIT_TABLE (the arg-max table kernel of the dense backward keeps whole tiles).
+  // 16 captions per unit: 384 / 640 rows = whole score tiles (384; 320 and 160 columns) and whole side GEMM tiles (64 / 128).
   g->trows = 16 * g->tp16;
-  if (!g->split && g->mrows == 48 && g->Tq > 32 && g->Tq <= 40 && scores_class40()) { g->trows = 40; g->cap_unit = 16; }
+  if (precision != ALADIN_PRECISION_SPLIT_TABLE && g->mrows <= 64 && scores_strip_mult(g->tp16, g->mrows) == 2 && scores_class40() &&
+      (g->mrows != 48 || 6 % g->tp16 == 0)) {
+    if (g->Tq > 16 && g->Tq <= 24) { g->trows = 24; g->cap_unit = 16; }
+    else if (g->Tq > 32 && g->Tq <= 40) { g->trows = 40; g->cap_unit = 16; }
+  }
   g->Bi_pad = round_up(Bi, g->img_unit);
   g->Bc_pad = round_up(Bc, g->cap_unit);
   g->xm_rows = (int64_t)g->Bi_pad * g->mrows;
@@ -551,6 +555,21 @@ __device__ __forceinline__ float max8(const f32x4& a, const f32x4& b) {
   return vmax(t, b[3]);
 }
 
+// Word sums of the "half" caption classes (24 and 40 words: trows = 16 TP16 - 8): two captions share 2 TP16 - 1 column tiles,
+// the middle one split between them by lane column (0-7 / 8-15).  ct is a compile-time constant in the unrolled callers.
+template <int TP16, bool HALF, int NC>
+__device__ __forceinline__ void caption_add(float (&v)[NC], int ct, int l4, float m) {
+  if constexpr (!HALF) {
+    v[ct / TP16] += m;
+  } else {
+    constexpr int G = 2 * TP16 - 1;
+    const int p = ct / G, w = ct % G;
+    if (w < TP16 - 1) v[2 * p] += m;
+    else if (w > TP16 - 1) v[2 * p + 1] += m;
+    else { v[2 * p] += l4 < 8 ? m : 0.f; v[2 * p + 1] += l4 < 8 ? 0.f : m; }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // score kernel, v_mfma_f32_16x16x32_f16 body, for every class with one or two 32-row region tiles per image
 // (R' <= 64, plus the side row: Q = 1 -> a wave's 64 rows are two images, Q = 2 -> one) and captions of TP16 = 1, 2, 3, 4 or 6 sixteen-word tiles (headline: 3 = 48 words):
@@ -560,7 +579,7 @@ __device__ __forceinline__ float max8(const f32x4& a, const f32x4& b) {
 //                      images into the two half-waves, one 16-lane exchange finishes the 32 rows
 //   sum over words   : a caption is exactly TP16 column tiles -> in-lane adds, then a 16-lane reduction
 // ------------------------------------------------------------------------------------------------
-template <bool HAS_E, int TP16, int Q, int REMC, int WGM = 4, int WGN = 2>
+template <bool HAS_E, int TP16, int Q, int REMC, int WGM = 4, int WGN = 2, bool HALF = false>
 __device__ __forceinline__ void scores16_epilogue(f32x4 (&acc)[4][12], int mb, int nb, const float* __restrict__ E,
                                                   int64_t ldE, int rem, float* __restrict__ S, int64_t ldS, int Bi, int Bc) {
   using Cfg = GemmCfg<WGM, WGN, 2, 6>;
@@ -576,8 +595,8 @@ __device__ __forceinline__ void scores16_epilogue(f32x4 (&acc)[4][12], int mb, i
   // count here costs the whole kernel ~10 %); REMC == 0: `rem` side rows, run-time loop
   if constexpr (REMC == 1) rem = 1;
   const float* e = HAS_E ? E + (int64_t)img * rem * ldE + (int64_t)nb * Cfg::BN + wn * 192 + l4 : nullptr;
-  constexpr int NC = 12 / TP16;                                    // captions of the wave's 192-row strip
-  static_assert(12 % TP16 == 0, "a caption must be a whole number of 16-word column tiles of the strip");
+  constexpr int NC = HALF ? 24 / (2 * TP16 - 1) : 12 / TP16;       // captions of the wave's 192-row strip
+  static_assert(HALF ? (TP16 == 2) : (12 % TP16 == 0), "a caption must be a whole number of 16-word column tiles of the strip (or 24 words)");
   float v[NC];
 #pragma unroll
   for (int c = 0; c < NC; ++c) v[c] = 0.f;
@@ -602,7 +621,7 @@ __device__ __forceinline__ void scores16_epilogue(f32x4 (&acc)[4][12], int mb, i
 #pragma unroll
       for (int k = 0; k < 8; ++k) m = vmax(m, e[(int64_t)(k < rem ? k : rem - 1) * ldE + ct * 16]);
     }
-    v[ct / TP16] += m;
+    caption_add<TP16, HALF, NC>(v, ct, l4, m);
   }
   const int cap = (nb * WGN + wn) * NC;
 #pragma unroll
@@ -616,23 +635,22 @@ __device__ __forceinline__ void scores16_epilogue(f32x4 (&acc)[4][12], int mb, i
 // The same operations in the same order per score as scores16_epilogue -- in-lane max over an image's 2 row tiles x 4
 // registers, permlane32_swap pairing two images into the half-waves, one 16-lane exchange; in-lane adds over a caption's
 // column tiles, then the 16-lane sum -- so the scores are bit-identical.
-template <bool HAS_E, int TP16, int REMC, int Q = 1>
-__device__ __forceinline__ void scores16_epilogue_tall(f32x4 (&acc)[8][6], int mb, int nb, const float* __restrict__ E,
+template <bool HAS_E, int TP16, int REMC, int Q = 1, bool HALF = false, int CT = 6, int WGM = 2, int WGN = 4>
+__device__ __forceinline__ void scores16_epilogue_tall(f32x4 (&acc)[8][CT], int mb, int nb, const float* __restrict__ E,
                                                        int64_t ldE, int rem, float* __restrict__ S, int64_t ldS, int Bi, int Bc) {
-  using Cfg = GemmCfg<2, 4, 4, 3>;
-  constexpr int CT = 6;
+  using Cfg = GemmCfg<WGM, WGN, 4, 3, CT>;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int wm = wave / 4, wn = wave % 4;
+  const int wm = wave / WGN, wn = wave % WGN;
   const int half = lane >> 5, l4 = lane & 15;
   if constexpr (REMC == 1) rem = 1;
-  constexpr int NC = CT / TP16;
-  static_assert(CT % TP16 == 0, "a caption must be a whole number of 16-word column tiles of the strip");
-  const int cap = (nb * 4 + wn) * NC;
+  constexpr int NC = HALF ? 2 * CT / (2 * TP16 - 1) : CT / TP16;
+  static_assert(HALF ? (CT % (2 * TP16 - 1) == 0) : (CT % TP16 == 0), "a caption must be a whole number of 16-word column tiles of the strip, or two captions 2 TP16 - 1 tiles");
+  const int cap = (nb * WGN + wn) * NC;
 #pragma unroll
   for (int p = 0; p < 2; ++p) {
     // Q == 1: the pair's 64 rows are two images (lanes 0-31 finish the first, 32-63 the second); Q == 2: one image
-    const int img = (Q == 1) ? (mb * 2 + wm) * 4 + 2 * p + half : (mb * 2 + wm) * 2 + p;
-    const float* e = HAS_E ? E + (int64_t)img * rem * ldE + (int64_t)nb * Cfg::BN + wn * 96 + l4 : nullptr;
+    const int img = (Q == 1) ? (mb * WGM + wm) * 4 + 2 * p + half : (mb * WGM + wm) * 2 + p;
+    const float* e = HAS_E ? E + (int64_t)img * rem * ldE + (int64_t)nb * Cfg::BN + wn * Cfg::WCOLS + l4 : nullptr;
     float v[NC];
 #pragma unroll
     for (int c = 0; c < NC; ++c) v[c] = 0.f;
@@ -655,7 +673,7 @@ __device__ __forceinline__ void scores16_epilogue_tall(f32x4 (&acc)[8][6], int m
 #pragma unroll
         for (int k = 0; k < 8; ++k) m = vmax(m, e[(int64_t)(k < rem ? k : rem - 1) * ldE + ct * 16]);
       }
-      v[ct / TP16] += m;
+      caption_add<TP16, HALF, NC>(v, ct, l4, m);
     }
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
@@ -665,43 +683,49 @@ __device__ __forceinline__ void scores16_epilogue_tall(f32x4 (&acc)[8][6], int m
   }
 }
 
-template <bool HAS_E, int TP16, int REMC, int Q = 1>
-__global__ __launch_bounds__(512) void align_scores16_tall_kernel(const half_t* __restrict__ xm, const half_t* __restrict__ y,
+// HALF / CT: the 24- and 40-word caption classes (CT = 5: an 80-column strip = two captions of 40).  WGM x WGN = 1 x 2: the
+// two-wave 128 x 160 tile the small grids of the 40-word class use (the other classes' small grids run align_scores16_kernel).
+template <bool HAS_E, int TP16, int REMC, int Q = 1, bool HALF = false, int CT = 6, int WGM = 2, int WGN = 4>
+__global__ __launch_bounds__(WGM * WGN * 64) void align_scores16_tall_kernel(const half_t* __restrict__ xm, const half_t* __restrict__ y,
                                                                   const float* __restrict__ E, int64_t ldE,
                                                                   float* __restrict__ S, int64_t ldS, int Bi, int Bc,
                                                                   int64_t ldk, int ktiles, int n_nblk, int n_blocks, int rem) {
-  using Cfg = GemmCfg<2, 4, 4, 3>;
+  using Cfg = GemmCfg<WGM, WGN, 4, 3, CT>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int mb, nb;
   tile_coords(blockIdx.x, n_blocks / n_nblk, n_nblk, 8, mb, nb);
-  f32x4 acc[8][6];
+  f32x4 acc[8][CT];
 #pragma unroll
   for (int rt = 0; rt < 8; ++rt)
 #pragma unroll
-    for (int ct = 0; ct < 6; ++ct) acc[rt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
-  if constexpr (HAS_E && REMC == 1 && Q == 1) {
+    for (int ct = 0; ct < CT; ++ct) acc[rt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if constexpr (HAS_E && REMC == 1 && Q == 1 && WGM == 2 && WGN == 4) {
     // pull this tile's side-row values into this XCD's L2 now (see align_scores16_kernel): per wave 4 images x 96 columns
-    // = 12 lines of 32 floats; dropped into the piece of stage 1 this wave's own refill overwrites later
+    // = 12 lines of 32 floats (80 columns: not line aligned, touched at floats 0, 32, 64, 79); dropped into the piece of stage 1
+    // this wave's own refill overwrites later
     const int wave_u = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane_p = threadIdx.x & 63;
-    const int img_p = (mb * 2 + wave_u / 4) * 4 + ((lane_p % 12) / 3);
-    const float* src = E + (int64_t)img_p * ldE + (int64_t)nb * Cfg::BN + (wave_u % 4) * 96 + (lane_p % 3) * 32;
+    constexpr int LPR = CT == 5 ? 4 : 3;
+    const int q = lane_p % (4 * LPR);
+    const int img_p = (mb * 2 + wave_u / 4) * 4 + q / LPR;
+    const int off_p = (q % LPR) * 32 < Cfg::WCOLS ? (q % LPR) * 32 : Cfg::WCOLS - 1;
+    const float* src = E + (int64_t)img_p * ldE + (int64_t)nb * Cfg::BN + (wave_u % 4) * Cfg::WCOLS + off_p;
     __builtin_amdgcn_global_load_lds(GLOBAL_PTR(src), LDS_PTR(smem + Cfg::STAGE_BYTES + wave_u * 1024), 4, 0, 0);
   }
   gemm_mainloop16_tall<Cfg, true>(xm + (int64_t)mb * Cfg::BM * ldk, y + (int64_t)nb * Cfg::BN * ldk, ldk, ktiles, smem, acc);
-  scores16_epilogue_tall<HAS_E, TP16, REMC, Q>(acc, mb, nb, E, ldE, rem, S, ldS, Bi, Bc);
+  scores16_epilogue_tall<HAS_E, TP16, REMC, Q, HALF, CT, WGM, WGN>(acc, mb, nb, E, ldE, rem, S, ldS, Bi, Bc);
 }
 
-template <bool HAS_E, int TP16, int REMC, int Q = 1>
+template <bool HAS_E, int TP16, int REMC, int Q = 1, bool HALF = false, int CT = 6, int WGM = 2, int WGN = 4>
 static int launch_scores16_tall(const aladin_align_geom* g, const half_t* xm, const half_t* y, const float* E, float* S,
                                 int64_t ldS, hipStream_t stream) {
-  using Cfg = GemmCfg<2, 4, 4, 3>;
+  using Cfg = GemmCfg<WGM, WGN, 4, 3, CT>;
   const int n_mblk = (int)(g->xm_rows / Cfg::BM), n_nblk = (int)(g->y_rows / Cfg::BN);
   if ((int64_t)n_mblk * Cfg::BM != g->xm_rows || (int64_t)n_nblk * Cfg::BN != g->y_rows) {
     aladin_set_error("align_scores16: packed rows do not tile");
     return ALADIN_ERR_ARG;
   }
-  auto kern = align_scores16_tall_kernel<HAS_E, TP16, REMC, Q>;
+  auto kern = align_scores16_tall_kernel<HAS_E, TP16, REMC, Q, HALF, CT, WGM, WGN>;
   static unsigned long long lds_reserved = 0;
   if (int rc = aladin_reserve_lds((const void*)kern, Cfg::LDS_BYTES, &lds_reserved, "align_scores16_tall")) return rc;
   const int n_blocks = n_mblk * n_nblk;
@@ -729,9 +753,8 @@ __device__ __forceinline__ float max12(const f32x4& a, const f32x4& b, const f32
   return vmax(t, c[3]);
 }
 
-// CT = 5: the 40-word caption class -- the wave's 80 columns are two captions of 40, the middle tile belongs to the first
-// caption in lanes with column < 8 and to the second in the others (TP16 is 3 and not looked at).
-template <bool HAS_E, int TP16, int REMC, int WGM, int WGN, int CT>
+// HALF: the 24- / 40-word caption classes (caption_add); CT = 5: the wave's 80 columns are two captions of 40 words.
+template <bool HAS_E, int TP16, int REMC, int WGM, int WGN, int CT, bool HALF>
 __device__ __forceinline__ void scores16_epilogue_r48(f32x4 (&acc)[6][CT], int mb, int nb, const float* __restrict__ E, int64_t ldE,
                                                       int rem, float* __restrict__ S, int64_t ldS, int Bi, int Bc) {
   using Cfg = GemmCfg<WGM, WGN, 3, 3, CT>;
@@ -739,8 +762,8 @@ __device__ __forceinline__ void scores16_epilogue_r48(f32x4 (&acc)[6][CT], int m
   const int wm = wave / WGN, wn = wave % WGN;
   const int half = lane >> 5, l4 = lane & 15;
   if constexpr (REMC >= 1) rem = REMC;
-  constexpr int NC = CT == 5 ? 2 : CT / TP16;
-  static_assert(CT == 5 || CT % TP16 == 0, "a caption must be a whole number of 16-word column tiles of the strip");
+  constexpr int NC = HALF ? 2 * CT / (2 * TP16 - 1) : CT / TP16;
+  static_assert(HALF ? (CT % (2 * TP16 - 1) == 0) : (CT % TP16 == 0), "a caption must be a whole number of 16-word column tiles of the strip, or two captions 2 TP16 - 1 tiles");
   const int cap = (nb * WGN + wn) * NC;
   const int img = (mb * WGM + wm) * 2 + half;                      // lanes 0-31 finish the wave's first image, 32-63 the second
   const float* e = HAS_E ? E + (int64_t)img * rem * ldE + (int64_t)nb * Cfg::BN + wn * Cfg::WCOLS + l4 : nullptr;
@@ -765,13 +788,7 @@ __device__ __forceinline__ void scores16_epilogue_r48(f32x4 (&acc)[6][CT], int m
 #pragma unroll
       for (int k = 0; k < 8; ++k) m = vmax(m, e[(int64_t)(k < rem ? k : rem - 1) * ldE + ct * 16]);
     }
-    if constexpr (CT == 5) {
-      if (ct < 2) v[0] += m;
-      else if (ct > 2) v[1] += m;
-      else { v[0] += l4 < 8 ? m : 0.f; v[1] += l4 < 8 ? 0.f : m; }
-    } else {
-      v[ct / TP16] += m;
-    }
+    caption_add<TP16, HALF, NC>(v, ct, l4, m);
   }
 #pragma unroll
   for (int c = 0; c < NC; ++c) {
@@ -780,7 +797,7 @@ __device__ __forceinline__ void scores16_epilogue_r48(f32x4 (&acc)[6][CT], int m
   }
 }
 
-template <bool HAS_E, int TP16, int REMC, int WGM, int WGN, int CT = 6>
+template <bool HAS_E, int TP16, int REMC, int WGM, int WGN, int CT = 6, bool HALF = false>
 __global__ __launch_bounds__(WGM * WGN * 64) void align_scores16_r48_kernel(const half_t* __restrict__ xm, const half_t* __restrict__ y,
                                                                             const float* __restrict__ E, int64_t ldE,
                                                                             float* __restrict__ S, int64_t ldS, int Bi, int Bc,
@@ -811,10 +828,10 @@ __global__ __launch_bounds__(WGM * WGN * 64) void align_scores16_r48_kernel(cons
     __builtin_amdgcn_global_load_lds(GLOBAL_PTR(src), LDS_PTR(smem + Cfg::STAGE_BYTES + wave_u * 1024), 4, 0, 0);
   }
   gemm_mainloop16_tall<Cfg, true>(xm + (int64_t)mb * Cfg::BM * ldk, y + (int64_t)nb * Cfg::BN * ldk, ldk, ktiles, smem, acc);
-  scores16_epilogue_r48<HAS_E, TP16, REMC, WGM, WGN, CT>(acc, mb, nb, E, ldE, rem, S, ldS, Bi, Bc);
+  scores16_epilogue_r48<HAS_E, TP16, REMC, WGM, WGN, CT, HALF>(acc, mb, nb, E, ldE, rem, S, ldS, Bi, Bc);
 }
 
-template <bool HAS_E, int TP16, int REMC, int WGM, int WGN, int CT = 6>
+template <bool HAS_E, int TP16, int REMC, int WGM, int WGN, int CT = 6, bool HALF = false>
 static int launch_scores16_r48_cfg(const aladin_align_geom* g, const half_t* xm, const half_t* y, const float* E, float* S,
                                    int64_t ldS, hipStream_t stream) {
   using Cfg = GemmCfg<WGM, WGN, 3, 3, CT>;
@@ -823,7 +840,7 @@ static int launch_scores16_r48_cfg(const aladin_align_geom* g, const half_t* xm,
     aladin_set_error("align_scores16_r48: packed rows do not tile");
     return ALADIN_ERR_ARG;
   }
-  auto kern = align_scores16_r48_kernel<HAS_E, TP16, REMC, WGM, WGN, CT>;
+  auto kern = align_scores16_r48_kernel<HAS_E, TP16, REMC, WGM, WGN, CT, HALF>;
   static unsigned long long lds_reserved = 0;
   if (int rc = aladin_reserve_lds((const void*)kern, Cfg::LDS_BYTES, &lds_reserved, "align_scores16_r48")) return rc;
   const int n_blocks = n_mblk * n_nblk;
@@ -932,7 +949,7 @@ static int launch_scores16_r48x3(const aladin_align_geom* g, const half_t* xm, c
   return aladin_check_launch("align_scores16_r48x3_kernel");
 }
 
-template <bool HAS_E, int TP16, int CT = 6>
+template <bool HAS_E, int TP16, int CT = 6, bool HALF = (CT == 5)>
 static int launch_scores16_r48(const aladin_align_geom* g, const half_t* xm, const half_t* y, const float* E, float* S, int64_t ldS,
                                hipStream_t stream) {
   // small grids (<= 64 tiles of 192 x 384, e.g. the shipped batch size 32): 96 x 192 tiles of two waves, four times the workgroups
@@ -956,13 +973,13 @@ static int launch_scores16_r48(const aladin_align_geom* g, const half_t* xm, con
     }
   }
   if constexpr (HAS_E) {
-    if (g->rem == 2) return small ? launch_scores16_r48_cfg<true, TP16, 2, 1, 2, CT>(g, xm, y, E, S, ldS, stream)
-                                  : launch_scores16_r48_cfg<true, TP16, 2, 2, 4, CT>(g, xm, y, E, S, ldS, stream);
-    if (g->rem > 2) return small ? launch_scores16_r48_cfg<true, TP16, 0, 1, 2, CT>(g, xm, y, E, S, ldS, stream)
-                                 : launch_scores16_r48_cfg<true, TP16, 0, 2, 4, CT>(g, xm, y, E, S, ldS, stream);
+    if (g->rem == 2) return small ? launch_scores16_r48_cfg<true, TP16, 2, 1, 2, CT, HALF>(g, xm, y, E, S, ldS, stream)
+                                  : launch_scores16_r48_cfg<true, TP16, 2, 2, 4, CT, HALF>(g, xm, y, E, S, ldS, stream);
+    if (g->rem > 2) return small ? launch_scores16_r48_cfg<true, TP16, 0, 1, 2, CT, HALF>(g, xm, y, E, S, ldS, stream)
+                                 : launch_scores16_r48_cfg<true, TP16, 0, 2, 4, CT, HALF>(g, xm, y, E, S, ldS, stream);
   }
-  return small ? launch_scores16_r48_cfg<HAS_E, TP16, 1, 1, 2, CT>(g, xm, y, E, S, ldS, stream)
-               : launch_scores16_r48_cfg<HAS_E, TP16, 1, 2, 4, CT>(g, xm, y, E, S, ldS, stream);
+  return small ? launch_scores16_r48_cfg<HAS_E, TP16, 1, 1, 2, CT, HALF>(g, xm, y, E, S, ldS, stream)
+               : launch_scores16_r48_cfg<HAS_E, TP16, 1, 2, 4, CT, HALF>(g, xm, y, E, S, ldS, stream);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1242,7 +1259,7 @@ int aladin_internal_align_argmax(const aladin_align_geom* g, const void* xm, con
                                  const int32_t* im_len, const int32_t* s_len, uint8_t* table, int tstride, uint8_t* flags,
                                  hipStream_t stream) {
   using Cfg = GemmCfg<2, 4, 4, 3>;
-  const bool ok_class = g && g->split && 6 % g->tp16 == 0 &&
+  const bool ok_class = g && g->split && 6 % g->tp16 == 0 && g->trows == 16 * g->tp16 &&
                         ((g->mrows == 32 && g->rem <= 8) || (g->mrows == 48 && g->rem <= 8) || (g->mrows == 64 && g->rem == 0));
   if (!ok_class) { aladin_set_error("align_argmax: unsupported tile class (mrows=%d rem=%d tp16=%d split=%d)", g ? g->mrows : -1, g ? g->rem : -1, g ? g->tp16 : -1, g ? g->split : -1); return ALADIN_ERR_UNSUPPORTED; }
   const int BMc = g->mrows == 48 ? 192 : Cfg::BM;
@@ -1309,7 +1326,7 @@ int aladin_internal_align_argmax(const aladin_align_geom* g, const void* xm, con
 // workgroups) a workgroup's 12 K steps are a chain of exposed memory latencies (24 us at B = 32, the same as B = 256's
 // whole wave of tiles), and a second K step in flight on four times as many CUs halves it.  Same MFMA shape, same K
 // order, same epilogue: a score is bit-identical whichever variant computed it.
-template <bool HAS_E, int TP16 = 3, bool PROBE = false, int Q = 1, int REMC = 1, int WGM = 4, int WGN = 2, int NS = 2>
+template <bool HAS_E, int TP16 = 3, bool PROBE = false, int Q = 1, int REMC = 1, int WGM = 4, int WGN = 2, int NS = 2, bool HALF = false>
 __global__ __launch_bounds__(WGM * WGN * 64) void align_scores16_kernel(const half_t* __restrict__ xm, const half_t* __restrict__ y,
                                                              const float* __restrict__ E, int64_t ldE,
                                                              float* __restrict__ S, int64_t ldS, int Bi, int Bc,
@@ -1342,7 +1359,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void align_scores16_kernel(const ha
   gemm_mainloop16<Cfg, true, NS>(xm + (int64_t)mb * Cfg::BM * ldk, y + (int64_t)nb * Cfg::BN * ldk, ldk, ktiles, smem, acc);
   if constexpr (PROBE) { pt1 = __builtin_amdgcn_s_memtime(); pr1 = __builtin_amdgcn_s_memrealtime(); }
 
-  scores16_epilogue<HAS_E, TP16, Q, REMC, WGM, WGN>(acc, mb, nb, E, ldE, rem, S, ldS, Bi, Bc);
+  scores16_epilogue<HAS_E, TP16, Q, REMC, WGM, WGN, HALF>(acc, mb, nb, E, ldE, rem, S, ldS, Bi, Bc);
 #ifdef ALADIN_DIAG
   if constexpr (PROBE) {
     __syncthreads();
@@ -1359,7 +1376,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void align_scores16_kernel(const ha
 #endif
 }
 
-template <bool HAS_E, int TP16, bool PROBE, int Q, int REMC, int WGM, int WGN, int NS>
+template <bool HAS_E, int TP16, bool PROBE, int Q, int REMC, int WGM, int WGN, int NS, bool HALF = false>
 static int launch_scores16_cfg(const aladin_align_geom* g, const half_t* xm, const half_t* y, const float* E, float* S,
                                int64_t ldS, hipStream_t stream) {
   using Cfg = GemmCfg<WGM, WGN, 2, 6>;
@@ -1368,7 +1385,7 @@ static int launch_scores16_cfg(const aladin_align_geom* g, const half_t* xm, con
     aladin_set_error("align_scores16: packed rows do not tile");
     return ALADIN_ERR_ARG;
   }
-  auto kern = align_scores16_kernel<HAS_E, TP16, PROBE, Q, REMC, WGM, WGN, NS>;
+  auto kern = align_scores16_kernel<HAS_E, TP16, PROBE, Q, REMC, WGM, WGN, NS, HALF>;
   static unsigned long long lds_reserved = 0;
   if (int rc = aladin_reserve_lds((const void*)kern, NS * Cfg::STAGE_BYTES, &lds_reserved, "align_scores16")) return rc;
   const int n_blocks = n_mblk * n_nblk;
@@ -1377,25 +1394,33 @@ static int launch_scores16_cfg(const aladin_align_geom* g, const half_t* xm, con
   return aladin_check_launch("align_scores16_kernel");
 }
 
-template <bool HAS_E, int TP16 = 3, bool PROBE = false, int Q = 1, int REMC = 1>
+// HALF: the 24- (TP16 = 2) and 40-word (TP16 = 3) caption classes.  24 words: the same kernels, four captions per 96-column strip.
+// 40 words: two captions per 80-column strip -- the tall kernel with five column tiles, as a 1 x 2-wave 128 x 160 tile for small grids.
+template <bool HAS_E, int TP16 = 3, bool PROBE = false, int Q = 1, int REMC = 1, bool HALF = false>
 static int launch_scores16(const aladin_align_geom* g, const half_t* xm, const half_t* y, const float* E, float* S,
                            int64_t ldS, hipStream_t stream) {
+  if constexpr (HALF && TP16 == 3) {
+    static_assert(!PROBE, "no clock probe instantiation of the 40-word class");
+    if ((g->xm_rows / 256) * (g->y_rows / 320) <= 64) return launch_scores16_tall<HAS_E, 3, REMC, Q, true, 5, 1, 2>(g, xm, y, E, S, ldS, stream);
+    return launch_scores16_tall<HAS_E, 3, REMC, Q, true, 5, 2, 4>(g, xm, y, E, S, ldS, stream);
+  } else {
   // small grids (<= 64 tiles of 256 x 384, i.e. B <= 64 at the headline shape): the 128 x 192 / three-stage variant
   if constexpr (!PROBE) {
 #ifdef ALADIN_DIAG
     // ALADIN_SCORE_VARIANT=1 / 2: force the two-wave 128 x 192 tile with a 2- / 3-stage ring at any size (experiments)
     static const int variant = diag_env("ALADIN_SCORE_VARIANT", 0);
-    if (variant == 1) return launch_scores16_cfg<HAS_E, TP16, false, Q, REMC, 2, 1, 2>(g, xm, y, E, S, ldS, stream);
-    if (variant == 2) return launch_scores16_cfg<HAS_E, TP16, false, Q, REMC, 2, 1, 3>(g, xm, y, E, S, ldS, stream);
-    if (variant == 4) return launch_scores16_cfg<HAS_E, TP16, false, Q, REMC, 4, 2, 2>(g, xm, y, E, S, ldS, stream);   // 64 x 192 wave tiles
+    if (variant == 1) return launch_scores16_cfg<HAS_E, TP16, false, Q, REMC, 2, 1, 2, HALF>(g, xm, y, E, S, ldS, stream);
+    if (variant == 2) return launch_scores16_cfg<HAS_E, TP16, false, Q, REMC, 2, 1, 3, HALF>(g, xm, y, E, S, ldS, stream);
+    if (variant == 4) return launch_scores16_cfg<HAS_E, TP16, false, Q, REMC, 4, 2, 2, HALF>(g, xm, y, E, S, ldS, stream);   // 64 x 192 wave tiles
 #endif
     if ((g->xm_rows / 256) * (g->y_rows / 384) <= 64)
-      return launch_scores16_cfg<HAS_E, TP16, false, Q, REMC, 2, 1, 3>(g, xm, y, E, S, ldS, stream);
+      return launch_scores16_cfg<HAS_E, TP16, false, Q, REMC, 2, 1, 3, HALF>(g, xm, y, E, S, ldS, stream);
     // captions that tile a 96-column strip (one or two 32-row region tiles per image): the 128 x 96 wave tile (14 instead of 16
     // fragment reads per 32-deep step; -2.4 % on the kernel, bit-identical scores)
-    if constexpr (6 % TP16 == 0) return launch_scores16_tall<HAS_E, TP16, REMC, Q>(g, xm, y, E, S, ldS, stream);
+    if constexpr (6 % TP16 == 0) return launch_scores16_tall<HAS_E, TP16, REMC, Q, HALF>(g, xm, y, E, S, ldS, stream);
   }
-  return launch_scores16_cfg<HAS_E, TP16, PROBE, Q, REMC, 4, 2, 2>(g, xm, y, E, S, ldS, stream);
+  return launch_scores16_cfg<HAS_E, TP16, PROBE, Q, REMC, 4, 2, 2, HALF>(g, xm, y, E, S, ldS, stream);
+  }
 }
 
 template <int WGM, int WM, int Q, int TP16, bool HAS_E, int SM, int SCHED = 1>
@@ -1418,9 +1443,15 @@ static int launch_scores_w(const aladin_align_geom* g, const half_t* xm, const h
   return aladin_check_launch("align_scores_kernel");
 }
 
-template <int WM, int Q, int TP16, bool HAS_E>
+template <int WM, int Q, int TP16, bool HAS_E, bool HALF = false>
 static int launch_scores(const aladin_align_geom* g, const half_t* xm, const half_t* y, const float* E, float* S,
                          int64_t ldS, hipStream_t stream) {
+  if constexpr (HALF) {                                // geometry only picks the half classes for the 16x16x32 kernels
+    static_assert(Q <= 2 && (TP16 == 2 || TP16 == 3), "24- / 40-word captions: one or two 32-row region tiles per image");
+    if constexpr (HAS_E && Q == 1)
+      if (g->rem > 1) return launch_scores16<HAS_E, TP16, false, Q, 0, true>(g, xm, y, E, S, ldS, stream);
+    return launch_scores16<HAS_E, TP16, false, Q, 1, true>(g, xm, y, E, S, ldS, stream);
+  }
   if constexpr (Q <= 2 && TP16 <= 6)
     if (scores_strip_mult(TP16, g->mrows) == 2) {
       // ALADIN_ALIGN_SPREAD: 16 (default) = v_mfma_f32_16x16x32_f16 body; 26 = the same + clock probe
@@ -1481,16 +1512,27 @@ template <int TP16>
 static int dispatch_tp(const aladin_align_geom* g, const half_t* xm, const half_t* xe, const half_t* y, float* E,
                        float* S, int64_t ldS, int flags, hipStream_t stream) {
   constexpr int NT = (TP16 & 1) ? TP16 : TP16 / 2;
-  if constexpr (TP16 == 3)
-    if (g->trows == 40) {                              // 40-word captions: 48-row region class only (aladin_align_geometry_mode)
-      if (g->mrows != 48) { aladin_set_error("align_scores: 40-word captions need the 48-row region class (mrows=%d)", g->mrows); return ALADIN_ERR_UNSUPPORTED; }
-      if (!g->rem) return launch_scores16_r48<false, 3, 5>(g, xm, y, E, S, ldS, stream);
-      if (!(flags & ALADIN_SCORES_REUSE_SIDE)) {
-        int rc;
-        rc = launch_side<2>(g, xe, y, E, stream);    // y_rows is a multiple of 640: 128-column tiles (tools/ab_side40.sh: 320-column tiles are slower)
+  if constexpr (TP16 == 2 || TP16 == 3)
+    if (g->trows == 16 * TP16 - 8) {                   // 24- / 40-word captions (aladin_align_geometry_mode): mrows 32, 48 or 64
+      constexpr int NTH = TP16 == 3 ? 2 : 1;             // y_rows is a multiple of 640 (128-column side tiles) / 384 (64)
+      if (g->rem && !(flags & ALADIN_SCORES_REUSE_SIDE)) {
+        int rc = launch_side<NTH>(g, xe, y, E, stream);  // tools/ab_side40.sh: 320-column side tiles are slower
         if (rc) return rc;
       }
-      return launch_scores16_r48<true, 3, 5>(g, xm, y, E, S, ldS, stream);
+      if (g->mrows == 48) {
+        if (g->rem) return launch_scores16_r48<true, TP16, TP16 == 3 ? 5 : 6, true>(g, xm, y, E, S, ldS, stream);
+        return launch_scores16_r48<false, TP16, TP16 == 3 ? 5 : 6, true>(g, xm, y, E, S, ldS, stream);
+      }
+      if (g->mrows == 32) {
+        if (g->rem) return launch_scores<2, 1, TP16, true, true>(g, xm, y, E, S, ldS, stream);
+        return launch_scores<2, 1, TP16, false, true>(g, xm, y, E, S, ldS, stream);
+      }
+      if (g->mrows == 64) {
+        if (g->rem) return launch_scores<2, 2, TP16, true, true>(g, xm, y, E, S, ldS, stream);
+        return launch_scores<2, 2, TP16, false, true>(g, xm, y, E, S, ldS, stream);
+      }
+      aladin_set_error("align_scores: %d-word captions with mrows=%d", g->trows, g->mrows);
+      return ALADIN_ERR_UNSUPPORTED;
     }
   if (g->rem) {
     if (!(flags & ALADIN_SCORES_REUSE_SIDE)) {
@@ -1531,7 +1573,7 @@ extern "C" int aladin_align_scores_ex(const void* xm, const void* xe, const void
   hipStream_t st = (hipStream_t)stream;
   const half_t* a = (const half_t*)xm; const half_t* b = (const half_t*)xe; const half_t* c = (const half_t*)y;
   float* E = (float*)e_scratch;
-  if (g->trows != 16 * g->tp16 && !(g->trows == 40 && g->tp16 == 3)) { aladin_set_error("align_scores: bad geometry (trows=%d tp16=%d)", g->trows, g->tp16); return ALADIN_ERR_ARG; }
+  if (g->trows != 16 * g->tp16 && !(g->trows == 16 * g->tp16 - 8 && (g->tp16 == 2 || g->tp16 == 3))) { aladin_set_error("align_scores: bad geometry (trows=%d tp16=%d)", g->trows, g->tp16); return ALADIN_ERR_ARG; }
   int rc;
   switch (g->tp16) {
     case 1: rc = dispatch_tp<1>(g, a, b, c, E, S, ldS, flags, st); break;

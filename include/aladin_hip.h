@@ -55,8 +55,8 @@ typedef struct aladin_align_geom {
   int32_t mrows;                /* rows per image in the main operand xm: 32, 48, 64 or 96 (rows past R' repeat region 0) */
   int32_t rem;                  /* leftover regions per image (R' - mrows when positive) that go through the side GEMM: <= 8 */
   int32_t tp16;                 /* 16-word column tiles a caption needs: ceil(trows / 16)       */
-  int32_t trows;                /* rows per caption in y: 16 * tp16, or 40 (T' 33..40 at the 48-row region class, fp16
-                                   operands: two captions share five 16-word tiles)             */
+  int32_t trows;                /* rows per caption in y: 16 * tp16, or 16 * tp16 - 8 = 24 / 40 (T' 17..24 / 33..40 with 32,
+                                   48 or 64 main rows: two captions share three / five 16-word tiles) */
   int32_t Dp;                   /* halfs per packed row: D rounded up to 64 (zero filled), x3 when split */
   int32_t img_unit, cap_unit;   /* images / captions per workgroup tile                         */
   int32_t Bi_pad, Bc_pad;       /* batch sizes rounded up to the units (zero rows)              */
@@ -89,6 +89,8 @@ ALADIN_API int aladin_align_geometry_ex(int Bi, int Bc, int R, int T, int D, int
  *                           Forward only: aladin_align_bwd_packed rejects split operands. */
 #define ALADIN_PRECISION_FP16 0
 #define ALADIN_PRECISION_SPLIT 1
+#define ALADIN_PRECISION_SPLIT_TABLE 2   /* split operands in whole 16-word caption tiles (no 24- / 40-word classes): the layout
+                                            the dense backward's arg-max table kernel reads; geometry_mode only */
 ALADIN_API int aladin_align_geometry_mode(int Bi, int Bc, int R, int T, int D, int x_tail, int y_tail, int precision,
                                aladin_align_geom* out);
 

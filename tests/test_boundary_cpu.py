@@ -52,10 +52,15 @@ def test_geometry_headline_and_edges():
     g = ops.align_geometry(256, 250, 51, 38, 768)
     assert (g.Rq, g.Tq, g.mrows, g.rem, g.tp16, g.trows, g.cap_unit) == (50, 35, 48, 2, 3, 40, 16)
     assert g.Bc_pad == 256 and g.y_rows == 256 * 40 and g.y_bytes == g.y_rows * 768 * 2 and g.e_bytes == g.xe_rows * g.y_rows * 4
-    for T_, rows in ((35, 32), (36, 40), (43, 40), (44, 48)):
-        assert ops.align_geometry(64, 64, 51, T_, 768).trows == rows
-    assert ops.align_geometry(256, 256, 51, 38, 768, precision='split').trows == 48
-    assert ops.align_geometry(256, 256, 34, 38, 768).trows == 48
+    for T_, rows in ((19, 16), (20, 24), (27, 24), (28, 32), (35, 32), (36, 40), (43, 40), (44, 48), (51, 48), (52, 64)):
+        for R_ in (34, 40, 51, 60, 66):                              # 32 (+ side rows), 48 + 2, 64 and 64 + 1 main rows
+            if R_ == 51 and T_ == 52:
+                continue                                             # 64-word captions do not tile the 48-row class's strip
+            g = ops.align_geometry(64, 64, R_, T_, 768)
+            assert g.trows == rows and g.tp16 == -(-rows // 16) and g.y_rows == g.Bc_pad * rows, (R_, T_, g.trows)
+            assert g.cap_unit == 16 if rows in (24, 40) else g.trows == 16 * g.tp16
+    assert ops.align_geometry(256, 256, 51, 38, 768, precision='split').trows == 40       # split operands: the same layout, K x 3
+    assert ops.align_geometry(9, 9, 71, 38, 64).trows == 48                              # three region tiles per image: whole tiles
     for g in (ops.align_geometry(256, 256, 34, 50, 768), ops.align_geometry(9, 9, 71, 71, 64), ops.align_geometry(9, 9, 51, 60, 64)):
         assert g.trows == 16 * g.tp16
     gs = ops.align_geometry(256, 256, 34, 50, 768, precision='split')          # hi/lo split operands: three K segments per row
@@ -303,7 +308,7 @@ def test_bucket_classes_follow_the_library_geometry():
             assert g.mrows + g.rem > b
     for b in ops.Y_CLASS_BOUNDS:
         g = ops.align_geometry(512, 512, 34, b + 3, 768)         # T = b + 3 set positions -> b scored words
-        assert g.Tq == b and g.tp16 * 16 == b
+        assert g.Tq == b and g.trows == b
     rng = np.random.RandomState(5)
     il = [int(v) for v in np.minimum(rng.randint(18, 70, size=1000), 51)]        # VinVL-like: most images clipped at 50 boxes
     cl = [int(v) for v in rng.randint(7, 30, size=5000)]

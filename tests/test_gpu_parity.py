@@ -1276,6 +1276,30 @@ def test_small_grid_score_variant_is_bit_identical():
                     assert torch.equal(S[ii, jj], part), (R, ragged, bi, bj, i0, j0)
 
 
+@pytest.mark.parametrize('Bi,Bc,R,Tn', [(200, 208, 34, 26), (200, 200, 36, 40), (130, 140, 60, 27), (140, 130, 66, 39), (200, 200, 50, 24)])
+def test_large_grid_half_caption_classes_are_bit_identical(Bi, Bc, R, Tn):
+    """The 24- / 40-word caption classes on grids of more than 64 workgroup tiles (eight-wave kernels: the 128 x 96 wave tile with
+    four captions of 24 per strip, the 128 x 80 one with two of 40; one or two region tiles per image, with side rows) against
+    their own small-grid blocks (two-wave kernels) bit for bit, and against the oracle."""
+    from aladin_amd import ops, synth
+    im, s, il, sl = synth.alignment_batch(Bi, R, Tn, 192, seed=7100 + R, ragged=True, Bc=Bc)
+    il[0], sl[0] = R, Tn
+    g = ops.align_geometry(Bi, Bc, R, Tn, 192)
+    assert g.trows in (24, 40) and g.trows == 16 * g.tp16 - 8 and (g.xm_rows // 256) * (g.y_rows // (16 * g.trows)) > 64
+    a, b = T(im), T(s)
+    S = ops.alignment_scores(a, b, il, sl)
+    assert_scores_close(S.cpu().numpy(), O.alignment_scores(im, s, il, sl))
+    for i0 in range(0, Bi, 64):
+        for j0 in range(0, Bc, 64):
+            ii, jj = slice(i0, min(Bi, i0 + 64)), slice(j0, min(Bc, j0 + 64))
+            il_b, sl_b = list(il[ii]), list(sl[jj])
+            il_b[0], sl_b[0] = R, Tn                                     # every block keeps the geometry of the whole
+            part = ops.alignment_scores(a[ii].clone(), b[jj].clone(), il_b, sl_b)
+            keep_i = slice(1 if il_b[0] != il[i0] else 0, None)          # the sample whose length was raised scores differently
+            keep_j = slice(1 if sl_b[0] != sl[j0] else 0, None)
+            assert torch.equal(S[ii, jj][keep_i, keep_j], part[keep_i, keep_j]), (i0, j0)
+
+
 @pytest.mark.parametrize('Bi,Bc,R,Tn', [(254, 270, 51, 38), (250, 258, 49, 43), (256, 256, 50, 36), (262, 272, 54, 40)])
 def test_large_grid_40_word_tile_is_bit_identical(Bi, Bc, R, Tn):
     """Large grids of the 48-row region class x 40-word caption class run the 288 x 320 workgroup tile (three images per wave; the
@@ -1584,6 +1608,12 @@ SWEEP = [
     (6, 5, 51, 36, 64),     # 40-word class, T' = 33 (its lower edge)
     (5, 19, 45, 43, 128),   # 40-word class exactly filled (T' = 40), no side rows, captions past one 16-caption unit
     (4, 33, 57, 44, 64),    # T' = 41: back to three whole tiles; 8 side rows
+    (7, 7, 33, 20, 64),     # 24-word class (T' = 17: its lower edge), 32-row region class, small grid
+    (9, 21, 36, 27, 96),    # 24-word class exactly filled (T' = 24), 3 side rows, captions past one 16-caption unit
+    (6, 18, 34, 43, 128),   # 40-word class on the 32-row region class + side row (two-wave 128 x 160 tile)
+    (5, 9, 60, 25, 64),     # 24-word class, two region tiles per image (R' = 59)
+    (5, 6, 66, 36, 64),     # 40-word class, two region tiles + side row (R' = 65)
+    (7, 40, 44, 22, 72),    # 24-word class on the 48-row region class
     (40, 37, 51, 38, 72),   # 40-word class, several workgroup tiles in both directions, ragged
     (5, 4, 57, 90, 64),     # 48 rows + 8 side rows (R' = 56: the class limit), tp16 6
     (4, 4, 58, 38, 64),     # R' = 57: two 32-row tiles
