@@ -113,15 +113,16 @@ extern "C" int aladin_align_geometry_mode(int Bi, int Bc, int R, int T, int D, i
   g->Dp = round_up(D, 64) * (g->split ? 3 : 1);
   g->img_unit = (g->mrows == 32) ? 8 : 4;                     // images per workgroup tile: 256 rows (192 in the 48-row class, 384 at 96)
   g->cap_unit = (scores_strip_mult(g->tp16, g->mrows) == 2) ? 24 / g->tp16 : 2 * ((g->tp16 & 1) ? 2 : 1);
-  // rows per caption in y: whole 16-word tiles, except the "half" classes -- T' 17..24 packs a caption into 1.5 tiles, T' 33..40
-  // (VinVL's 35-token captions: 35 words of 48 would be 27 % padding) into 2.5: two captions share 3 / 5 tiles and the epilogue
-  // splits the middle one between them by lane (caption_add).  Region classes of the 16x16x32 kernels (32, 48 or 64 main rows);
-  // every precision except ALADIN_PRECISION_SPLIT_TABLE (the arg-max table kernel of the dense backward keeps whole tiles).
-  // 16 captions per unit: 384 / 640 rows = whole score tiles (384; 320 and 160 columns) and whole side GEMM tiles (64 / 128).
+  // rows per caption in y: whole 16-word tiles, except the "half" classes -- T' <= 8 packs a caption into half a tile, T' 17..24
+  // into 1.5, T' 33..40 (VinVL's 35-token captions: 35 words of 48 would be 27 % padding) into 2.5: two captions share 1 / 3 / 5
+  // tiles and the epilogue splits the middle one between them by lane (caption_add).  Region classes of the 16x16x32 kernels (32,
+  // 48 or 64 main rows); every precision except ALADIN_PRECISION_SPLIT_TABLE (the arg-max table kernel of the dense backward keeps
+  // whole tiles).  Captions per unit: 384 / 640 rows = whole score tiles (384; 320 and 160 columns) and side GEMM tiles (64 / 128).
   g->trows = 16 * g->tp16;
   if (precision != ALADIN_PRECISION_SPLIT_TABLE && g->mrows <= 64 && scores_strip_mult(g->tp16, g->mrows) == 2 && scores_class40() &&
       (g->mrows != 48 || 6 % g->tp16 == 0)) {
-    if (g->Tq > 16 && g->Tq <= 24) { g->trows = 24; g->cap_unit = 16; }
+    if (g->Tq <= 8) { g->trows = 8; g->cap_unit = 48; }
+    else if (g->Tq > 16 && g->Tq <= 24) { g->trows = 24; g->cap_unit = 16; }
     else if (g->Tq > 32 && g->Tq <= 40) { g->trows = 40; g->cap_unit = 16; }
   }
   g->Bi_pad = round_up(Bi, g->img_unit);
@@ -555,7 +556,7 @@ __device__ __forceinline__ float max8(const f32x4& a, const f32x4& b) {
   return vmax(t, b[3]);
 }
 
-// Word sums of the "half" caption classes (24 and 40 words: trows = 16 TP16 - 8): two captions share 2 TP16 - 1 column tiles,
+// Word sums of the "half" caption classes (8, 24 and 40 words: trows = 16 TP16 - 8): two captions share 2 TP16 - 1 column tiles,
 // the middle one split between them by lane column (0-7 / 8-15).  ct is a compile-time constant in the unrolled callers.
 template <int TP16, bool HALF, int NC>
 __device__ __forceinline__ void caption_add(float (&v)[NC], int ct, int l4, float m) {
@@ -596,7 +597,7 @@ __device__ __forceinline__ void scores16_epilogue(f32x4 (&acc)[4][12], int mb, i
   if constexpr (REMC == 1) rem = 1;
   const float* e = HAS_E ? E + (int64_t)img * rem * ldE + (int64_t)nb * Cfg::BN + wn * 192 + l4 : nullptr;
   constexpr int NC = HALF ? 24 / (2 * TP16 - 1) : 12 / TP16;       // captions of the wave's 192-row strip
-  static_assert(HALF ? (TP16 == 2) : (12 % TP16 == 0), "a caption must be a whole number of 16-word column tiles of the strip (or 24 words)");
+  static_assert(HALF ? (TP16 <= 2) : (12 % TP16 == 0), "a caption must be a whole number of 16-word column tiles of the strip (or 8 / 24 words)");
   float v[NC];
 #pragma unroll
   for (int c = 0; c < NC; ++c) v[c] = 0.f;
@@ -1447,7 +1448,7 @@ template <int WM, int Q, int TP16, bool HAS_E, bool HALF = false>
 static int launch_scores(const aladin_align_geom* g, const half_t* xm, const half_t* y, const float* E, float* S,
                          int64_t ldS, hipStream_t stream) {
   if constexpr (HALF) {                                // geometry only picks the half classes for the 16x16x32 kernels
-    static_assert(Q <= 2 && (TP16 == 2 || TP16 == 3), "24- / 40-word captions: one or two 32-row region tiles per image");
+    static_assert(Q <= 2 && TP16 <= 3, "8- / 24- / 40-word captions: one or two 32-row region tiles per image");
     if constexpr (HAS_E && Q == 1)
       if (g->rem > 1) return launch_scores16<HAS_E, TP16, false, Q, 0, true>(g, xm, y, E, S, ldS, stream);
     return launch_scores16<HAS_E, TP16, false, Q, 1, true>(g, xm, y, E, S, ldS, stream);
@@ -1512,8 +1513,8 @@ template <int TP16>
 static int dispatch_tp(const aladin_align_geom* g, const half_t* xm, const half_t* xe, const half_t* y, float* E,
                        float* S, int64_t ldS, int flags, hipStream_t stream) {
   constexpr int NT = (TP16 & 1) ? TP16 : TP16 / 2;
-  if constexpr (TP16 == 2 || TP16 == 3)
-    if (g->trows == 16 * TP16 - 8) {                   // 24- / 40-word captions (aladin_align_geometry_mode): mrows 32, 48 or 64
+  if constexpr (TP16 <= 3)
+    if (g->trows == 16 * TP16 - 8) {                   // 8- / 24- / 40-word captions (aladin_align_geometry_mode): mrows 32, 48 or 64
       constexpr int NTH = TP16 == 3 ? 2 : 1;             // y_rows is a multiple of 640 (128-column side tiles) / 384 (64)
       if (g->rem && !(flags & ALADIN_SCORES_REUSE_SIDE)) {
         int rc = launch_side<NTH>(g, xe, y, E, stream);  // tools/ab_side40.sh: 320-column side tiles are slower
@@ -1573,7 +1574,7 @@ extern "C" int aladin_align_scores_ex(const void* xm, const void* xe, const void
   hipStream_t st = (hipStream_t)stream;
   const half_t* a = (const half_t*)xm; const half_t* b = (const half_t*)xe; const half_t* c = (const half_t*)y;
   float* E = (float*)e_scratch;
-  if (g->trows != 16 * g->tp16 && !(g->trows == 16 * g->tp16 - 8 && (g->tp16 == 2 || g->tp16 == 3))) { aladin_set_error("align_scores: bad geometry (trows=%d tp16=%d)", g->trows, g->tp16); return ALADIN_ERR_ARG; }
+  if (g->trows != 16 * g->tp16 && !(g->trows == 16 * g->tp16 - 8 && g->tp16 <= 3)) { aladin_set_error("align_scores: bad geometry (trows=%d tp16=%d)", g->trows, g->tp16); return ALADIN_ERR_ARG; }
   int rc;
   switch (g->tp16) {
     case 1: rc = dispatch_tp<1>(g, a, b, c, E, S, ldS, flags, st); break;

@@ -514,7 +514,7 @@ def _host_lengths(lens):
 
 # ------------------------------------------------------------------------------------------------
 # Length-bucketed evaluation grids.  The packed geometry pads the max side to its region classes (32 rows, 32 + up to 8
-# side rows, 48, 48 + up to 8 side rows, 64, 96: align_fwd.hip geometry) and the sum side to 16, 24, 32, 40, 48, 64 or 96
+# side rows, 48, 48 + up to 8 side rows, 64, 96: align_fwd.hip geometry) and the sum side to 8, 16, 24, 32, 40, 48, 64 or 96
 # words: one launch over the whole grid pays
 # for the LONGEST image and caption at every pair.  Real sets are ragged (COCO: 10-50 boxes, captions of ~12 tokens),
 # so the samples of each side are grouped by the tile class their own length needs, every (image class x caption
@@ -523,7 +523,7 @@ def _host_lengths(lens):
 # those of the single launch up to the summation order of a different kernel variant (~1e-7 in split precision).
 # ------------------------------------------------------------------------------------------------
 X_CLASS_BOUNDS = (32, 40, 48, 56, 64, 96)  # scored max-side positions (incl. the one masked position kept for the zero fill)
-Y_CLASS_BOUNDS = (16, 24, 32, 40, 48, 64, 96)   # scored sum-side positions (24 / 40: two captions share three / five 16-word tiles)
+Y_CLASS_BOUNDS = (8, 16, 24, 32, 40, 48, 64, 96)   # scored sum-side positions (8 / 24 / 40: two captions share one / three / five 16-word tiles)
 BUCKET_MIN_PAIRS = 1 << 18                 # below this a grid is one launch
 BUCKET_MIN_SAMPLES = 64                    # smaller classes join the next longer one
 BUCKET_MIN_GAIN = 0.10                     # padded work saved before bucketing is worth its extra launches

@@ -55,8 +55,8 @@ typedef struct aladin_align_geom {
   int32_t mrows;                /* rows per image in the main operand xm: 32, 48, 64 or 96 (rows past R' repeat region 0) */
   int32_t rem;                  /* leftover regions per image (R' - mrows when positive) that go through the side GEMM: <= 8 */
   int32_t tp16;                 /* 16-word column tiles a caption needs: ceil(trows / 16)       */
-  int32_t trows;                /* rows per caption in y: 16 * tp16, or 16 * tp16 - 8 = 24 / 40 (T' 17..24 / 33..40 with 32,
-                                   48 or 64 main rows: two captions share three / five 16-word tiles) */
+  int32_t trows;                /* rows per caption in y: 16 * tp16, or 16 * tp16 - 8 = 8 / 24 / 40 (T' <= 8 / 17..24 / 33..40
+                                   with 32, 48 or 64 main rows: two captions share one / three / five 16-word tiles) */
   int32_t Dp;                   /* halfs per packed row: D rounded up to 64 (zero filled), x3 when split */
   int32_t img_unit, cap_unit;   /* images / captions per workgroup tile                         */
   int32_t Bi_pad, Bc_pad;       /* batch sizes rounded up to the units (zero rows)              */

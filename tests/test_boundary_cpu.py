@@ -46,19 +46,19 @@ def test_geometry_headline_and_edges():
     g = ops.align_geometry(1000, 5000, 71, 71, 768)         # evaluation shape: 70 regions x 68 words
     assert (g.mrows, g.rem, g.tp16) == (96, 0, 6)
     g = ops.align_geometry(3, 7, 3, 5, 8)
-    assert (g.Rq, g.Tq, g.mrows, g.rem, g.tp16, g.Dp) == (2, 2, 32, 0, 1, 64)
+    assert (g.Rq, g.Tq, g.mrows, g.rem, g.tp16, g.trows, g.Dp) == (2, 2, 32, 0, 1, 8, 64)
     # the shipped data shape (50 regions + 35 tokens): 48 rows + 2 side rows per image, 40 rows per caption (two captions share
     # five 16-word tiles); split operands and the 32-row region class keep whole tiles
     g = ops.align_geometry(256, 250, 51, 38, 768)
     assert (g.Rq, g.Tq, g.mrows, g.rem, g.tp16, g.trows, g.cap_unit) == (50, 35, 48, 2, 3, 40, 16)
     assert g.Bc_pad == 256 and g.y_rows == 256 * 40 and g.y_bytes == g.y_rows * 768 * 2 and g.e_bytes == g.xe_rows * g.y_rows * 4
-    for T_, rows in ((19, 16), (20, 24), (27, 24), (28, 32), (35, 32), (36, 40), (43, 40), (44, 48), (51, 48), (52, 64)):
+    for T_, rows in ((4, 8), (11, 8), (12, 16), (19, 16), (20, 24), (27, 24), (28, 32), (35, 32), (36, 40), (43, 40), (44, 48), (51, 48), (52, 64)):
         for R_ in (34, 40, 51, 60, 66):                              # 32 (+ side rows), 48 + 2, 64 and 64 + 1 main rows
             if R_ == 51 and T_ == 52:
                 continue                                             # 64-word captions do not tile the 48-row class's strip
             g = ops.align_geometry(64, 64, R_, T_, 768)
             assert g.trows == rows and g.tp16 == -(-rows // 16) and g.y_rows == g.Bc_pad * rows, (R_, T_, g.trows)
-            assert g.cap_unit == 16 if rows in (24, 40) else g.trows == 16 * g.tp16
+            assert g.cap_unit == {8: 48, 24: 16, 40: 16}[rows] if rows in (8, 24, 40) else g.trows == 16 * g.tp16
     assert ops.align_geometry(256, 256, 51, 38, 768, precision='split').trows == 40       # split operands: the same layout, K x 3
     assert ops.align_geometry(9, 9, 71, 38, 64).trows == 48                              # three region tiles per image: whole tiles
     for g in (ops.align_geometry(256, 256, 34, 50, 768), ops.align_geometry(9, 9, 71, 71, 64), ops.align_geometry(9, 9, 51, 60, 64)):

@@ -1276,16 +1276,16 @@ def test_small_grid_score_variant_is_bit_identical():
                     assert torch.equal(S[ii, jj], part), (R, ragged, bi, bj, i0, j0)
 
 
-@pytest.mark.parametrize('Bi,Bc,R,Tn', [(200, 208, 34, 26), (200, 200, 36, 40), (130, 140, 60, 27), (140, 130, 66, 39), (200, 200, 50, 24)])
+@pytest.mark.parametrize('Bi,Bc,R,Tn', [(200, 208, 34, 26), (200, 200, 36, 40), (130, 140, 60, 27), (140, 130, 66, 39), (200, 200, 50, 24), (200, 600, 34, 10), (200, 500, 51, 11)])
 def test_large_grid_half_caption_classes_are_bit_identical(Bi, Bc, R, Tn):
-    """The 24- / 40-word caption classes on grids of more than 64 workgroup tiles (eight-wave kernels: the 128 x 96 wave tile with
-    four captions of 24 per strip, the 128 x 80 one with two of 40; one or two region tiles per image, with side rows) against
+    """The 8- / 24- / 40-word caption classes on grids of more than 64 workgroup tiles (eight-wave kernels: the 128 x 96 wave tile with
+    twelve captions of 8 or four of 24 per strip, the 128 x 80 one with two of 40; one or two region tiles per image, with side rows) against
     their own small-grid blocks (two-wave kernels) bit for bit, and against the oracle."""
     from aladin_amd import ops, synth
     im, s, il, sl = synth.alignment_batch(Bi, R, Tn, 192, seed=7100 + R, ragged=True, Bc=Bc)
     il[0], sl[0] = R, Tn
     g = ops.align_geometry(Bi, Bc, R, Tn, 192)
-    assert g.trows in (24, 40) and g.trows == 16 * g.tp16 - 8 and (g.xm_rows // 256) * (g.y_rows // (16 * g.trows)) > 64
+    assert g.trows in (8, 24, 40) and g.trows == 16 * g.tp16 - 8 and (g.xm_rows // 256) * (g.y_rows // (640 if g.trows == 40 else 384)) > 64
     a, b = T(im), T(s)
     S = ops.alignment_scores(a, b, il, sl)
     assert_scores_close(S.cpu().numpy(), O.alignment_scores(im, s, il, sl))
@@ -1609,6 +1609,9 @@ SWEEP = [
     (5, 19, 45, 43, 128),   # 40-word class exactly filled (T' = 40), no side rows, captions past one 16-caption unit
     (4, 33, 57, 44, 64),    # T' = 41: back to three whole tiles; 8 side rows
     (7, 7, 33, 20, 64),     # 24-word class (T' = 17: its lower edge), 32-row region class, small grid
+    (6, 50, 34, 11, 64),    # 8-word class exactly filled (T' = 8), past one 48-caption unit, side row
+    (5, 7, 51, 9, 40),      # 8-word class on the 48-row region class (T' = 6)
+    (4, 9, 60, 12, 64),     # T' = 9: one whole tile; two region tiles per image
     (9, 21, 36, 27, 96),    # 24-word class exactly filled (T' = 24), 3 side rows, captions past one 16-caption unit
     (6, 18, 34, 43, 128),   # 40-word class on the 32-row region class + side row (two-wave 128 x 160 tile)
     (5, 9, 60, 25, 64),     # 24-word class, two region tiles per image (R' = 59)
