@@ -27,7 +27,7 @@ while time.time() - t0 < budget:
     square = rng.rand() < 0.6
     Bc = Bi if square else int(rng.randint(1, 40))
     R = int(rng.choice([2, 3, 8, 17, 33, 34, 35, 36, 38, 39, 40, 41, 42, 45, 49, 50, 51, 54, 57, 58, 65, 66, 71, 97]))      # 42..57: the 48-row class (round 4)
-    Tn = int(rng.choice([4, 5, 12, 19, 20, 35, 36, 37, 39, 41, 44, 50, 51, 67, 68, 71, 99]))
+    Tn = int(rng.choice([4, 5, 9, 11, 12, 19, 20, 25, 27, 28, 35, 36, 37, 39, 41, 43, 44, 50, 51, 67, 68, 71, 99]))      # 11 / 27 / 43: the 8- / 24- / 40-word classes filled
     D = int(rng.choice([8, 24, 64, 100, 128, 768]))
     if Bi * Bc * R * Tn * D > 6e8:
         continue
