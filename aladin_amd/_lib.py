@@ -10,16 +10,15 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # ALADIN_LIB points at an alternative build of the same ABI (kernel A/B runs, tools/ab_bench.py)
 LIB_PATH = os.environ.get('ALADIN_LIB') or os.path.join(_HERE, 'lib', 'libaladin_hip.so')
 
-ABI_VERSION = 11
+ABI_VERSION = 10
 PRECISION_FP16, PRECISION_SPLIT = 0, 1      # ALADIN_PRECISION_* of include/aladin_hip.h
-PACK_MAIN, PACK_SIDE_Y = 1, 2               # ALADIN_PACK_* (aladin_align_pack_part)
 BWD_PARTNERS_FP16, BWD_DENSE, BWD_DENSE_GATHER = 1, 2, 4          # ALADIN_BWD_PARTNERS_FP16, ALADIN_BWD_DENSE
 
 # every symbol include/aladin_hip.h declares (tests check that the library exports all of them)
 SYMBOLS = [
     'aladin_version', 'aladin_last_error', 'aladin_align_geometry', 'aladin_align_geometry_ex', 'aladin_align_geometry_mode',
     'aladin_align_pack_images',
-    'aladin_align_pack_captions', 'aladin_align_pack_both', 'aladin_align_pack_part', 'aladin_align_side', 'aladin_align_scores', 'aladin_align_scores_ex',
+    'aladin_align_pack_captions', 'aladin_align_pack_both', 'aladin_align_scores', 'aladin_align_scores_ex',
     'aladin_align_bwd_workspace_bytes',
     'aladin_align_bwd', 'aladin_align_bwd_packed', 'aladin_align_bwd_packed_strided', 'aladin_hinge_workspace_bytes', 'aladin_hinge_fwd_bwd',
     'aladin_hinge_fused', 'aladin_hinge_argmax_fused', 'aladin_align_bwd_rows', 'aladin_heads_small_fwd_argmax',
@@ -61,8 +60,6 @@ def _declare(lib):
         'aladin_align_pack_images': (C.c_int, [p, i64, i64, p, G, p, p, p]),
         'aladin_align_pack_captions': (C.c_int, [p, i64, i64, p, G, p, p]),
         'aladin_align_pack_both': (C.c_int, [p, i64, i64, p, p, i64, i64, p, G, p, p, p, p]),
-        'aladin_align_pack_part': (C.c_int, [p, i64, i64, p, p, i64, i64, p, G, p, p, p, i32, p]),
-        'aladin_align_side': (C.c_int, [p, p, G, p, p]),
         'aladin_align_scores': (C.c_int, [p, p, p, G, p, p, i64, p]),
         'aladin_align_scores_ex': (C.c_int, [p, p, p, G, p, p, i64, i32, p]),
         'aladin_align_bwd_workspace_bytes': (sz, [i32, i32, i32, i32, i32]),

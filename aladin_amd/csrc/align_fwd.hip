@@ -286,9 +286,9 @@ __global__ __launch_bounds__(256) void pack_both_kernel(const float* __restrict_
                                                         int Bc, int Rq, int Tq, int x_tail, int y_tail, int D, int Dp, int mrows, int rem, int64_t xm_rows,
                                                         int64_t img_rows, int64_t total_rows, int tpad,
                                                         half_t* __restrict__ xm, half_t* __restrict__ xe,
-                                                        half_t* __restrict__ y, int vec_i, int vec_s, int split, int64_t d0) {
+                                                        half_t* __restrict__ y, int vec_i, int vec_s, int split) {
   const int lane = threadIdx.x & 63;
-  const int64_t d = d0 + (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);      // rows [d0, total_rows) of the launch's part
+  const int64_t d = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (d >= total_rows) return;
   const float* src = nullptr;
   const int32_t* len_ptr = nullptr;
@@ -348,26 +348,16 @@ extern "C" int aladin_align_pack_captions(const float* s, int64_t stride_b, int6
   return aladin_check_launch("pack_captions_kernel");
 }
 
-// part: 0 = every row (aladin_align_pack_both); ALADIN_PACK_MAIN = the images' main rows (xm) only; ALADIN_PACK_SIDE_Y = the side rows
-// (xe) and the captions (y) -- what the side GEMM needs, so that it can run on a second stream beside the main rows' packing.
-extern "C" int aladin_align_pack_part(const float* im, int64_t im_stride_b, int64_t im_stride_r, const int32_t* im_len,
-                                      const float* s, int64_t s_stride_b, int64_t s_stride_t, const int32_t* s_len,
-                                      const aladin_align_geom* g, void* xm, void* xe, void* y, int part, void* stream) {
-  if (!im || !im_len || !s || !s_len || !g || !xm || !y || (g->rem && !xe)) { aladin_set_error("align_pack_both: null argument"); return ALADIN_ERR_ARG; }
-  if (part != 0 && part != ALADIN_PACK_MAIN && part != ALADIN_PACK_SIDE_Y) { aladin_set_error("align_pack_part: unknown part %d", part); return ALADIN_ERR_ARG; }
-  const int64_t img_rows = g->xm_rows + g->xe_rows, total = img_rows + g->y_rows;
-  const int64_t d0 = part == ALADIN_PACK_SIDE_Y ? g->xm_rows : 0, d1 = part == ALADIN_PACK_MAIN ? g->xm_rows : total;
-  hipLaunchKernelGGL(pack_both_kernel, dim3((unsigned)((d1 - d0 + 3) / 4)), dim3(256), 0, (hipStream_t)stream, im, im_stride_b,
-                     im_stride_r, im_len, s, s_stride_b, s_stride_t, s_len, g->Bi, g->Bc, g->Rq, g->Tq, g->x_tail, g->y_tail, g->D, g->Dp, g->mrows,
-                     g->rem > 0 ? g->rem : 1, g->xm_rows, img_rows, d1, g->trows, (half_t*)xm, (half_t*)xe, (half_t*)y,
-                     is_vec4_ok(im, im_stride_b, im_stride_r, g->D), is_vec4_ok(s, s_stride_b, s_stride_t, g->D), g->split, d0);
-  return aladin_check_launch("pack_both_kernel");
-}
-
 extern "C" int aladin_align_pack_both(const float* im, int64_t im_stride_b, int64_t im_stride_r, const int32_t* im_len,
                                       const float* s, int64_t s_stride_b, int64_t s_stride_t, const int32_t* s_len,
                                       const aladin_align_geom* g, void* xm, void* xe, void* y, void* stream) {
-  return aladin_align_pack_part(im, im_stride_b, im_stride_r, im_len, s, s_stride_b, s_stride_t, s_len, g, xm, xe, y, 0, stream);
+  if (!im || !im_len || !s || !s_len || !g || !xm || !y || (g->rem && !xe)) { aladin_set_error("align_pack_both: null argument"); return ALADIN_ERR_ARG; }
+  const int64_t img_rows = g->xm_rows + g->xe_rows, total = img_rows + g->y_rows;
+  hipLaunchKernelGGL(pack_both_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, (hipStream_t)stream, im, im_stride_b,
+                     im_stride_r, im_len, s, s_stride_b, s_stride_t, s_len, g->Bi, g->Bc, g->Rq, g->Tq, g->x_tail, g->y_tail, g->D, g->Dp, g->mrows,
+                     g->rem > 0 ? g->rem : 1, g->xm_rows, img_rows, total, g->trows, (half_t*)xm, (half_t*)xe, (half_t*)y,
+                     is_vec4_ok(im, im_stride_b, im_stride_r, g->D), is_vec4_ok(s, s_stride_b, s_stride_t, g->D), g->split);
+  return aladin_check_launch("pack_both_kernel");
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1601,24 +1591,4 @@ extern "C" int aladin_align_scores_ex(const void* xm, const void* xe, const void
   int grid = (int)((n + 255) / 256); if (grid > 2048) grid = 2048;
   hipLaunchKernelGGL(scores_unscale_kernel, dim3(grid), dim3(256), 0, st, S, ldS, g->Bi, g->Bc);
   return aladin_check_launch("scores_unscale_kernel");
-}
-
-// The side GEMM alone (E = xe . y^T): aladin_align_scores_ex(..., ALADIN_SCORES_REUSE_SIDE) then reads E instead of recomputing it.
-// Lets a caller run it on a second stream beside the packing of the main rows (aladin_align_pack_part).  No-op without side rows.
-extern "C" int aladin_align_side(const void* xe, const void* y, const aladin_align_geom* g, void* e_scratch, void* stream) {
-  if (!g || !y || (g->rem && (!xe || !e_scratch))) { aladin_set_error("align_side: null argument"); return ALADIN_ERR_ARG; }
-  if (!g->rem) return ALADIN_OK;
-  hipStream_t st = (hipStream_t)stream;
-  const half_t* b = (const half_t*)xe; const half_t* c = (const half_t*)y;
-  float* E = (float*)e_scratch;
-  if (g->trows == 16 * g->tp16 - 8) return g->tp16 == 3 ? launch_side<2>(g, b, c, E, st) : launch_side<1>(g, b, c, E, st);
-  switch (g->tp16) {
-    case 1: return launch_side<1>(g, b, c, E, st);
-    case 2: return launch_side<1>(g, b, c, E, st);
-    case 3: return launch_side<3>(g, b, c, E, st);
-    case 4: return launch_side<2>(g, b, c, E, st);
-    case 6: return launch_side<3>(g, b, c, E, st);
-  }
-  aladin_set_error("align_side: unsupported padded caption length %d", g->trows);
-  return ALADIN_ERR_UNSUPPORTED;
 }

@@ -194,23 +194,6 @@ def _check_backward_supported(im, s, x_tail, y_tail):
                          '(got %d on the max side, %d on the sum side)' % (R - 1 - x_tail, T - 1 - y_tail))
 
 
-# The forward as a fork / join over two streams: the side GEMM only needs the side rows and the captions, so those are packed first and
-# the side GEMM runs on a second stream WHILE the images' main rows are packed (an HBM-bound copy beside an L2-bound small GEMM);
-# the score kernel then starts from the join with E already in place.  Pays when an image has side rows and the grid is large enough for
-# the two kernels to be worth a fork (measured at B = 256, R = 34, T = 50: forward chain N -> N us; tools/forward_overlap_probe.py).
-# Inside a stream capture the fork / join becomes two branches of the graph.
-SIDE_OVERLAP = True
-SIDE_OVERLAP_MIN_PAIRS = 1 << 14
-_SIDE_STREAMS = {}
-
-
-def _side_stream(device):
-    st = _SIDE_STREAMS.get(device.index)
-    if st is None:
-        st = _SIDE_STREAMS[device.index] = torch.cuda.Stream(device=device)
-    return st
-
-
 def _align_forward(im, s, im_len_t, s_len_t, x_tail=0, y_tail=2, precision=None):
     """-> (S, packed) where packed = (geom, xm, xe, y) is kept for the backward pass.
     `im` is the max-side set, `s` the sum-side set (images / captions for 'MrSw')."""
@@ -224,27 +207,10 @@ def _align_forward(im, s, im_len_t, s_len_t, x_tail=0, y_tail=2, precision=None)
     xm = torch.empty(geom.xm_bytes // 2, dtype=torch.float16, device=im.device)
     xe = torch.empty(max(geom.xe_bytes // 2, 8), dtype=torch.float16, device=im.device)
     y = torch.empty(geom.y_bytes // 2, dtype=torch.float16, device=im.device)
-    lib = _lib.load()
-    if not (SIDE_OVERLAP and geom.rem > 0 and Bi * Bc >= SIDE_OVERLAP_MIN_PAIRS):
-        _lib.check(lib.aladin_align_pack_both(_ptr(im), im.stride(0), im.stride(1), _ptr(im_len_t),
-                                              _ptr(s), s.stride(0), s.stride(1), _ptr(s_len_t), C.byref(geom),
-                                              _ptr(xm), _ptr(xe), _ptr(y), _stream()), 'align_pack_both')
-        return scores_from_packed(xm, xe, y, geom), (geom, xm, xe, y)
-
-    def pack(part, stream):
-        _lib.check(lib.aladin_align_pack_part(_ptr(im), im.stride(0), im.stride(1), _ptr(im_len_t),
-                                              _ptr(s), s.stride(0), s.stride(1), _ptr(s_len_t), C.byref(geom),
-                                              _ptr(xm), _ptr(xe), _ptr(y), part, stream), 'align_pack_part')
-    e = _workspace(geom.e_bytes, im.device)
-    cur, side = torch.cuda.current_stream(im.device), _side_stream(im.device)
-    pack(_lib.PACK_SIDE_Y, C.c_void_p(cur.cuda_stream))
-    side.wait_stream(cur)                                    # fork: the side GEMM behind the side rows and captions ...
-    _lib.check(lib.aladin_align_side(_ptr(xe), _ptr(y), C.byref(geom), _ptr(e), C.c_void_p(side.cuda_stream)), 'align_side')
-    pack(_lib.PACK_MAIN, C.c_void_p(cur.cuda_stream))        # ... while the main rows are packed
-    cur.wait_stream(side)                                    # join
-    # xe, y and the scratch outlive the join in `cur`'s order (the score kernel reads them), so the caching allocator cannot hand
-    # them out while the side stream still uses them
-    return scores_from_packed(xm, xe, y, geom, e_scratch=e, reuse_side=True), (geom, xm, xe, y)
+    _lib.check(_lib.load().aladin_align_pack_both(_ptr(im), im.stride(0), im.stride(1), _ptr(im_len_t),
+                                                  _ptr(s), s.stride(0), s.stride(1), _ptr(s_len_t), C.byref(geom),
+                                                  _ptr(xm), _ptr(xe), _ptr(y), _stream()), 'align_pack_both')
+    return scores_from_packed(xm, xe, y, geom), (geom, xm, xe, y)
 
 
 def _grad_like(x):

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define ALADIN_ABI_VERSION 11
+#define ALADIN_ABI_VERSION 10
 
 /* The library is built with -fvisibility=hidden: the entry points declared here are its ONLY exports. */
 #if defined(__GNUC__)
@@ -108,25 +108,12 @@ ALADIN_API int aladin_align_pack_both(const float* im, int64_t im_stride_b, int6
                            const float* s, int64_t s_stride_b, int64_t s_stride_t, const int32_t* s_len,
                            const aladin_align_geom* geom, void* xm, void* xe, void* y, void* stream);
 
-/* The same launch restricted to a part of the rows: 0 = all of them (= aladin_align_pack_both), ALADIN_PACK_MAIN = the images' main
- * rows (xm), ALADIN_PACK_SIDE_Y = the images' side rows (xe) and the captions (y).  The side GEMM only needs the second part, so a
- * caller can run it (aladin_align_side) on another stream while the main rows are still being packed, and score with
- * ALADIN_SCORES_REUSE_SIDE once both are done (aladin_amd.ops._align_forward: -N us of the forward chain at B = 256). */
-#define ALADIN_PACK_MAIN 1
-#define ALADIN_PACK_SIDE_Y 2
-ALADIN_API int aladin_align_pack_part(const float* im, int64_t im_stride_b, int64_t im_stride_r, const int32_t* im_len,
-                           const float* s, int64_t s_stride_b, int64_t s_stride_t, const int32_t* s_len,
-                           const aladin_align_geom* geom, void* xm, void* xe, void* y, int part, void* stream);
-/* The side GEMM alone: e_scratch (geom->e_bytes) = xe . y^T, the leftover regions' dot products with every word (part of
- * alad/loss.py:97-99's bmm).  Returns at once when the geometry has no side rows. */
-ALADIN_API int aladin_align_side(const void* xe, const void* y, const aladin_align_geom* geom, void* e_scratch, void* stream);
-
 /* S (Bi x Bc, row stride ldS floats) from packed operands.  e_scratch: geom->e_bytes. */
 ALADIN_API int aladin_align_scores(const void* xm, const void* xe, const void* y, const aladin_align_geom* geom,
                         void* e_scratch, float* S, int64_t ldS, void* stream);
 /* Same with flags.  ALADIN_SCORES_REUSE_SIDE: e_scratch already holds the side-GEMM result of a
- * previous call on the same operands or of aladin_align_side, launch the score kernel alone (bench.py times the
- * dominant kernel in isolation with it; the forward runs the side GEMM beside the packing). */
+ * previous call on the same operands, launch the score kernel alone (used by bench.py to time the
+ * dominant kernel in isolation). */
 #define ALADIN_SCORES_REUSE_SIDE 1
 ALADIN_API int aladin_align_scores_ex(const void* xm, const void* xe, const void* y, const aladin_align_geom* geom,
                            void* e_scratch, float* S, int64_t ldS, int flags, void* stream);
