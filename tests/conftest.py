@@ -64,8 +64,9 @@ def golden_alignment_inputs(g):
 
 
 ALIGN_GOLDENS = ['align_tiny', 'align_b5_d64', 'align_b12_struct', 'align_b32_d64',
-                 'align_b16_d768', 'align_b8_d768_rag', 'align_rect', 'align_r33']
-SQUARE_ALIGN_GOLDENS = [n for n in ALIGN_GOLDENS if n != 'align_rect']
+                 'align_b16_d768', 'align_b8_d768_rag', 'align_rect', 'align_r33',
+                 'align_vinvl_b12', 'align_t27_b10', 'align_t11_rect']          # round 4: 48-row x 40-word, 24-word and 8-word tile classes
+SQUARE_ALIGN_GOLDENS = [n for n in ALIGN_GOLDENS if n not in ('align_rect', 'align_t11_rect')]
 
 
 @pytest.fixture(scope='session')

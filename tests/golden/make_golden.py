@@ -53,6 +53,10 @@ ALIGN_CASES = [
     ('align_b8_d768_rag', 'structured4', 8, 8, 34, 50, 768,  15, True,  0.2),
     ('align_rect',      'random',     3,  7, 34, 50,  64,  16, True,  0.2),
     ('align_r33',       'random',     6,  6, 33, 34, 128,  17, True,  0.2),    # R'=32 exactly
+    # round 4: the tile classes added for the shipped data shape and short captions
+    ('align_vinvl_b12', 'structured3', 12, 12, 51, 38, 768, 21, True,  0.2),   # 50 regions + 35 tokens: 48 rows + 2 side rows, 40-word class
+    ('align_t27_b10',   'random',    10, 10, 36, 27, 128,  22, True,  0.2),    # 32 rows + 3 side rows, 24-word caption class
+    ('align_t11_rect',  'random',     6, 20, 34, 11,  64,  23, True,  0.2),    # 8-word caption class, rectangular
 ]
 AGG_MODES = ['MrSw', 'MrAVGw', 'MwSr', 'symm', 'sum', 'mean']
 
@@ -65,7 +69,10 @@ def make_inputs(kind, B, Bc, R, T, D, seed, ragged):
 
 
 def gen_alignment():
+    only = [n for n in os.environ.get('GOLDEN_ONLY', '').split(',') if n]      # GOLDEN_ONLY=name,name: add cases without rewriting the others
     for name, kind, B, Bc, R, T, D, seed, ragged, margin in ALIGN_CASES:
+        if only and name not in only:
+            continue
         im, s, im_len, s_len = make_inputs(kind, B, Bc, R, T, D, seed, ragged)
         out = dict(kind=kind, B=B, Bc=Bc, R=R, T=T, D=D, seed=seed, ragged=ragged, margin=margin,
                    im_len=np.array(im_len), s_len=np.array(s_len),
