@@ -1517,7 +1517,7 @@ static int dispatch_tp(const aladin_align_geom* g, const half_t* xm, const half_
     if (g->trows == 16 * TP16 - 8) {                   // 8- / 24- / 40-word captions (aladin_align_geometry_mode): mrows 32, 48 or 64
       constexpr int NTH = TP16 == 3 ? 2 : 1;             // y_rows is a multiple of 640 (128-column side tiles) / 384 (64)
       if (g->rem && !(flags & ALADIN_SCORES_REUSE_SIDE)) {
-        int rc = launch_side<NTH>(g, xe, y, E, stream);  // tools/ab_side40.sh: 320-column side tiles are slower
+        int rc = launch_side<NTH>(g, xe, y, E, stream);  // 320-column side tiles measured slower (profiles/r04_ab_side_gemm_stages.txt)
         if (rc) return rc;
       }
       if (g->mrows == 48) {
