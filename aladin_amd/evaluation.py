@@ -209,7 +209,7 @@ def _fused_ranks(img, cap):
     return both[:n_img], both[n_img:2 * n_img], both[2 * n_img:2 * n_img + n_cap], both[2 * n_img + n_cap:]
 
 
-def recall(images, captions, model=None, mode='i2t', lenghts=None, return_ranks=False):
+def recall(images, captions, model, mode='i2t', lenghts=None, return_ranks=False):
     """reference alad/recall_auxiliary.py:8-69: rows 0::5 of `images` are the distinct images."""
     if mode not in ('i2t', 't2i'):
         raise ValueError('mode not correct')
@@ -219,7 +219,7 @@ def recall(images, captions, model=None, mode='i2t', lenghts=None, return_ranks=
     return (m, (ranks, top1)) if return_ranks else m
 
 
-def recall_test(img_embs, cap_embs, tot_lengths=None, model=None):
+def recall_test(img_embs, cap_embs, tot_lengths, model):
     """reference alad/recall_auxiliary.py:72-86; both directions from one fused GEMM + rank pass."""
     r_i2t, _, r_t2i, _ = _fused_ranks(torch.as_tensor(img_embs)[0::CAPS_PER_IMG], cap_embs)
     r1, r5, r10, _, _ = _metrics(r_i2t)
@@ -229,7 +229,7 @@ def recall_test(img_embs, cap_embs, tot_lengths=None, model=None):
 
 def compute_recall(img_embs, cap_embs, tot_lengths=None, model=None, verbose=True):
     """reference alad/recall_auxiliary.py:133-149."""
-    r1, r5, r10, r1i, r5i, r10i, _ = recall_test(img_embs, cap_embs)
+    r1, r5, r10, r1i, r5i, r10i, _ = recall_test(img_embs, cap_embs, tot_lengths, model)
     rsum = r1 + r5 + r10 + r1i + r5i + r10i
     if verbose:
         print("Recall Image to text: %.2f, %.2f, %.2f" % (r1, r5, r10))
@@ -246,7 +246,7 @@ def recall_1k_5fold_test(img_embs, cap_embs, tot_lengths=None, model=None, verbo
     for i in range(5):
         if verbose:
             print('Computing Test recall... chunk %s of 5' % (i + 1))
-        res.append(recall_test(img_folds[i], cap_folds[i])[:6])
+        res.append(recall_test(img_folds[i], cap_folds[i], tot_lengths, model)[:6])
     r1, r5, r10, r1i, r5i, r10i = (float(v) for v in np.mean(np.array(res, dtype=np.float64), axis=0))
     rsum = r1 + r5 + r10 + r1i + r5i + r10i
     if verbose:

@@ -605,6 +605,58 @@ def gen_recall_5fold():
     save('recall_5fold', **out)
 
 
+# ---------------------------------------------------------------- call signatures (SURVEY 8(b))
+SIGNATURE_TARGETS = [
+    # (key, module alias, dotted attribute) -- the drop-in surface SURVEY 8(b) lists
+    ('AlignmentContrastiveLoss.__init__', 'loss', 'AlignmentContrastiveLoss.__init__'),
+    ('AlignmentContrastiveLoss.forward', 'loss', 'AlignmentContrastiveLoss.forward'),
+    ('ContrastiveLoss.__init__', 'loss', 'ContrastiveLoss.__init__'),
+    ('ContrastiveLoss.forward', 'loss', 'ContrastiveLoss.forward'),
+    ('DistillationLoss.__init__', 'loss', 'DistillationLoss.__init__'),
+    ('DistillationLoss.forward', 'loss', 'DistillationLoss.forward'),
+    ('Contrastive.__init__', 'loss', 'Contrastive.__init__'),
+    ('Contrastive.compute_contrastive_loss', 'loss', 'Contrastive.compute_contrastive_loss'),
+    ('dot_sim', 'loss', 'dot_sim'), ('cosine_sim', 'loss', 'cosine_sim'), ('order_sim', 'loss', 'order_sim'),
+    ('ALADModel.forward', 'model', 'ALADModel.forward'),
+    ('ALADModel.forward_emb', 'model', 'ALADModel.forward_emb'),
+    ('ALADModel.forward_loss', 'model', 'ALADModel.forward_loss'),
+    ('recall', 'recall', 'recall'), ('recall_test', 'recall', 'recall_test'), ('compute_recall', 'recall', 'compute_recall'),
+    ('recall_1k_5fold_test', 'recall', 'recall_1k_5fold_test'),
+    ('i2t', 'eval', 'i2t'), ('t2i', 'eval', 't2i'), ('encode_data', 'eval', 'encode_data'),
+    ('l2norm', 'utils', 'l2norm'),
+]
+
+
+def signature_record(fn):
+    """[[name, kind, default-or-null], ...]: what inspect.signature says, as plain JSON data."""
+    import inspect
+    out = []
+    for p_ in inspect.signature(fn).parameters.values():
+        default = None if p_.default is inspect.Parameter.empty else repr(p_.default)
+        out.append([p_.name, p_.kind.name, default])
+    return out
+
+
+def gen_signatures():
+    """tests/golden/signatures.json: inspect.signature of every callable of the reference's drop-in surface (names,
+    parameter kinds, defaults as repr strings).  Data about the reference, not its text."""
+    import json
+    import alad.utils as ref_utils
+    am = import_alad_model()
+    mods = {'loss': ref_loss, 'model': am, 'recall': ref_recall, 'eval': ref_eval, 'utils': ref_utils}
+    rec = {}
+    for key, alias, dotted in SIGNATURE_TARGETS:
+        obj = mods[alias]
+        for part in dotted.split('.'):
+            obj = getattr(obj, part)
+        rec[key] = signature_record(obj)
+    path = os.path.join(HERE, 'signatures.json')
+    with open(path, 'w') as f:
+        json.dump(rec, f, indent=1, sort_keys=True)
+        f.write('\n')
+    print('signatures.json: %d callables' % len(rec))
+
+
 if __name__ == '__main__':
     only = sys.argv[1:]
     if only:                                   # e.g. `make_golden.py gen_eval_coco1k` regenerates one family
@@ -624,3 +676,4 @@ if __name__ == '__main__':
     gen_backbone()
     gen_recall()
     gen_recall_5fold()
+    gen_signatures()

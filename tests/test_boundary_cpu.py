@@ -319,3 +319,47 @@ def test_bucket_classes_follow_the_library_geometry():
     tops = sorted(max(x_need[k] for k in g) for g in plan[0])
     assert tops[-1] == 51 and len(tops) >= 2
     assert sorted(k for g in plan[0] for k in g) == list(range(1000)) and sorted(k for g in plan[1] for k in g) == list(range(5000))
+
+
+# where each callable of tests/golden/signatures.json (inspect.signature of the REFERENCE, tests/golden/make_golden.py
+# gen_signatures) lives in this package
+_SIGNATURE_HOMES = {
+    'AlignmentContrastiveLoss.__init__': ('loss', 'AlignmentContrastiveLoss.__init__'),
+    'AlignmentContrastiveLoss.forward': ('loss', 'AlignmentContrastiveLoss.forward'),
+    'ContrastiveLoss.__init__': ('loss', 'ContrastiveLoss.__init__'),
+    'ContrastiveLoss.forward': ('loss', 'ContrastiveLoss.forward'),
+    'DistillationLoss.__init__': ('loss', 'DistillationLoss.__init__'),
+    'DistillationLoss.forward': ('loss', 'DistillationLoss.forward'),
+    'Contrastive.__init__': ('loss', 'Contrastive.__init__'),
+    'Contrastive.compute_contrastive_loss': ('loss', 'Contrastive.compute_contrastive_loss'),
+    'dot_sim': ('loss', 'dot_sim'), 'cosine_sim': ('loss', 'cosine_sim'), 'order_sim': ('loss', 'order_sim'),
+    'l2norm': ('loss', 'l2norm'),
+    'ALADModel.forward': ('alad_model', 'ALADModel.forward'),
+    'ALADModel.forward_emb': ('alad_model', 'ALADModel.forward_emb'),
+    'ALADModel.forward_loss': ('alad_model', 'ALADModel.forward_loss'),
+    'recall': ('evaluation', 'recall'), 'recall_test': ('evaluation', 'recall_test'),
+    'compute_recall': ('evaluation', 'compute_recall'), 'recall_1k_5fold_test': ('evaluation', 'recall_1k_5fold_test'),
+    'i2t': ('evaluation', 'i2t'), 't2i': ('evaluation', 't2i'), 'encode_data': ('evaluation', 'encode_data'),
+}
+
+
+def test_drop_in_signatures_match_the_reference():
+    """SURVEY 8(b) / VERDICT r4 item 7: every callable of the drop-in surface takes the reference's parameters -- same
+    names, same order, same kinds, same defaults (compared as repr strings) -- so positional and keyword call sites of the
+    reference (alad_model.py:380,386,405; train.py:479,493-509; test.py:259-276) bind identically.  The drop-in may add
+    TRAILING parameters, each with a default (log=, verbose=, precision=...)."""
+    import importlib
+    import inspect
+    import json
+    ref = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'signatures.json')))
+    assert set(ref) == set(_SIGNATURE_HOMES), set(ref) ^ set(_SIGNATURE_HOMES)
+    for key, want in ref.items():
+        mod, dotted = _SIGNATURE_HOMES[key]
+        obj = importlib.import_module('aladin_amd.' + mod)
+        for part in dotted.split('.'):
+            obj = getattr(obj, part)
+        got = [[p.name, p.kind.name, None if p.default is inspect.Parameter.empty else repr(p.default)]
+               for p in inspect.signature(obj).parameters.values()]
+        assert got[:len(want)] == want, (key, got, want)
+        for extra in got[len(want):]:
+            assert extra[2] is not None or extra[1] in ('VAR_POSITIONAL', 'VAR_KEYWORD'), (key, 'extra parameter without a default', extra)

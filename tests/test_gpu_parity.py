@@ -562,7 +562,7 @@ def test_recall_vs_reference(name):
     np.testing.assert_allclose(sim, img[0::5].astype(np.float64) @ cap.astype(np.float64).T, rtol=0, atol=2e-6)
     np.testing.assert_allclose(E.compute_recall(img, cap, verbose=False), g['compute_recall'], rtol=0, atol=1e-9)
     for mode in ('i2t', 't2i'):
-        m, (ranks, top1) = E.recall(img, cap, mode=mode, return_ranks=True)
+        m, (ranks, top1) = E.recall(img, cap, None, mode=mode, return_ranks=True)
         np.testing.assert_allclose(m, g[mode + '_metrics'], rtol=0, atol=1e-9)
         np.testing.assert_array_equal(ranks, g[mode + '_ranks'])
         np.testing.assert_array_equal(top1, g[mode + '_top1'])
@@ -575,8 +575,8 @@ def test_recall_1k_5fold_and_recall_test_vs_reference():
     g = load_golden('recall_5fold')
     img, cap = synth.retrieval_embeddings(int(g['n_img']), int(g['D']), int(g['seed']), float(g['sigma']))
     np.testing.assert_allclose(E.recall_1k_5fold_test(img, cap, verbose=False), g['recall_1k_5fold_test'], rtol=0, atol=1e-9)
-    np.testing.assert_allclose(E.recall_test(img[:5000], cap[:5000]), g['recall_test_fold0'], rtol=0, atol=1e-9)
-    np.testing.assert_allclose(E.recall_test(T(img[:5000]), T(cap[:5000])), g['recall_test_fold0'], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(E.recall_test(img[:5000], cap[:5000], None, None), g['recall_test_fold0'], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(E.recall_test(T(img[:5000]), T(cap[:5000]), None, None), g['recall_test_fold0'], rtol=0, atol=1e-9)
 
 
 def _alignment_sim_fn():

@@ -3,8 +3,9 @@
 the cost of the screened kernel depends on where the ground-truth scores sit relative to the bulk of the scores
 (the RESULT never does: every run is checked against the two-step split path).  Prints one JSON line per data set:
 Recall@1 of both directions, fused ms (screened / all-exact), tiles continued in place, pairs continued through lists.
-usage: tools/bench_retrieval.py [--profile] [--only SUBSTRING]
-       --profile: a few calls only and no two-step check (for rocprofv3); --only: the data sets whose name contains SUBSTRING"""
+usage: tools/bench_retrieval.py [--profile] [--only SUBSTRING] [--sigmas 7,8,9]
+       --profile: a few calls only and no two-step check (for rocprofv3); --only: the data sets whose name contains SUBSTRING;
+       --sigmas: synth.retrieval_embeddings noise levels instead of the default 3, 6, 8 (R@1 75 / 41 %), 12"""
 import json
 import os
 import sys
@@ -38,9 +39,12 @@ def datasets(dev):
     for t in (0.05, 0.5, 0.8, 1.0):
         cap = torch.nn.functional.normalize(img.repeat_interleave(5, 0) + t * noise, dim=1)
         yield 'caption = image + %.2f * N(0, I)' % t, img.to(dev), cap.to(dev)
-    for sigma in (3.0, 6.0, 12.0):
+    sigmas = (3.0, 6.0, 8.0, 12.0)
+    if '--sigmas' in sys.argv:
+        sigmas = tuple(float(v) for v in sys.argv[sys.argv.index('--sigmas') + 1].split(','))
+    for sigma in sigmas:
         i, c = synth.retrieval_embeddings(n_img, D, seed=303, sigma=sigma)
-        yield 'synth.retrieval_embeddings(sigma=%g)%s' % (sigma, ' = tests/config 3 full size' if sigma == 12.0 else ''), \
+        yield 'synth.retrieval_embeddings(sigma=%g)%s' % (sigma, ' = bench.py eval_config3.ms' if sigma == 8.0 else ''), \
             torch.from_numpy(i[0::5]).to(dev), torch.from_numpy(c).to(dev)
 
 
