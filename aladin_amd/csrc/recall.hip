@@ -18,6 +18,7 @@
 // (a third of the work) and pays for the other two segments only where a decision needs them; see
 // sim_screen_kernel.
 #include "../../include/aladin_hip.h"
+#include <type_traits>
 #include <utility>
 
 #include "gemm_core.hpp"
@@ -303,9 +304,15 @@ __global__ __launch_bounds__(512) void sim_gemm_store_kernel(const half_t* __res
 // ------------------------------------------------------------------------------------------------
 struct SimEntry { int row, col; float s; int flags; };
 enum { SIM_F_ROWCNT = 1, SIM_F_COLCNT = 2, SIM_F_ROWARG = 4, SIM_F_COLARG = 8 };
-constexpr int SIM_LIST_CAP = 64;
+constexpr int SIM_LIST_CAP = 512;
 struct SimRaw { int rc; float s; };               // tile-local (row << 16 | column), prefix score
-constexpr int SIM_RAW_WAVE = 128;                 // scores of a wave's 128 x 96 block within reach of a ground truth (decided or not) before the tile gives up screening
+constexpr int SIM_RAW_WAVE = 192;                 // UNDECIDED scores and arg-max candidates of a wave's 128 x 96 block before the tile gives up screening
+                                                  // (scores that beat their ground truth by more than the band are counted in registers: round 5)
+// statistics words (int32, aladin_retrieval_stats_offset): [0] tiles continued in place, [1] pairs listed, [2..4] diagnostic build,
+// [5] listed pairs whose chains sim_rescore_kernel continued (the others were ruled out by the certified bounds), [6] tiles that ran
+// the analysis, [7] of those, tiles that overflowed their lists, [8] tiles that skipped the analysis (hopeless data, see sim_screen_kernel)
+enum { SIM_ST_EXACT = 0, SIM_ST_LISTED = 1, SIM_ST_RESCORED = 5, SIM_ST_ANALYSED = 6, SIM_ST_OVERFLOW = 7, SIM_ST_SKIPPED = 8 };
+constexpr int SIM_STATS_WORDS = 64;
 
 struct SimRankArgs {
   int cpi;
@@ -318,7 +325,9 @@ struct SimRankArgs {
   unsigned long long* best_t2i;       // n_cap
   SimEntry* list;                     // n_tiles x SIM_LIST_CAP
   int* list_cnt;                      // n_tiles
-  int* stats;                         // [0] tiles that went exact, [1] listed pairs
+  int* stats;                         // SIM_ST_*
+  unsigned* lob_i2t;                  // n_img: float_key of a certified lower bound of the row's exact maximum (0: none yet)
+  unsigned* lob_t2i;                  // n_cap
 };
 
 template <int... I, class F>
@@ -545,25 +554,43 @@ __global__ __launch_bounds__(512) void sim_screen_kernel(const half_t* __restric
     // barrier and nothing refills it any more, so no barrier is needed before writing them.
     char* ep = smem + ((kps & 1) ? Cfg::STAGE_BYTES : 0);
     float* l_thrRow = reinterpret_cast<float*>(ep);                  // [BM] s below this cannot reach the row's ground truth
-    float* l_P = l_thrRow + Cfg::BM;
+    float* l_hiRow = l_thrRow + Cfg::BM;                             // [BM] s above this beats it whatever the dropped segments add
+    float* l_argRow = l_hiRow + Cfg::BM;                             // [BM] s below this cannot be the row's arg-max (phase 1b)
+    float* l_Lrow = l_argRow + Cfg::BM;                              // [BM] certified lower bound of the row's exact maximum (phase 1b)
+    float* l_P = l_Lrow + Cfg::BM;
     float* l_R = l_P + Cfg::BM;
     float* l_Grow = l_R + Cfg::BM;
     float* l_bmaxRow = l_Grow + Cfg::BM;
     unsigned* l_rowmax = reinterpret_cast<unsigned*>(l_bmaxRow + Cfg::BM);     // key of the largest qualifying s of the row in this tile (0: none)
     int* l_rowcnt = reinterpret_cast<int*>(l_rowmax + Cfg::BM);
     float* l_thrCol = reinterpret_cast<float*>(l_rowcnt + Cfg::BM);  // [BN] ...
-    float* l_Q = l_thrCol + Cfg::BN;
+    float* l_hiCol = l_thrCol + Cfg::BN;
+    float* l_argCol = l_hiCol + Cfg::BN;
+    float* l_Lcol = l_argCol + Cfg::BN;
+    float* l_Q = l_Lcol + Cfg::BN;
     float* l_T = l_Q + Cfg::BN;
     float* l_Gcol = l_T + Cfg::BN;
     float* l_bmaxCol = l_Gcol + Cfg::BN;
     unsigned* l_colmax = reinterpret_cast<unsigned*>(l_bmaxCol + Cfg::BN);
     int* l_colcnt = reinterpret_cast<int*>(l_colmax + Cfg::BN);
-    SimEntry* l_list = reinterpret_cast<SimEntry*>(l_colcnt + Cfg::BN);        // 7 * (256 + 384) * 4 B = 17920 B: 16-B aligned
+    SimEntry* l_list = reinterpret_cast<SimEntry*>(l_colcnt + Cfg::BN);        // 10 * (256 + 384) * 4 B = 25600 B: 16-B aligned
     int* l_listn = reinterpret_cast<int*>(l_list + SIM_LIST_CAP);
     float* l_wmax = reinterpret_cast<float*>(l_listn + 4);           // [8 waves][4]: per-wave maxima of P, R, Q, T over the tile
     int* l_rawn = reinterpret_cast<int*>(l_wmax + 4 * Cfg::NWAVES);  // [8 waves] raw candidates of each wave
-    SimRaw* l_raw = reinterpret_cast<SimRaw*>(l_rawn + Cfg::NWAVES);  // [8 waves][SIM_RAW_WAVE]
+    int* l_hits = l_rawn + Cfg::NWAVES;                              // [2] rows / columns of the tile with a score in reach of their ground truth
+    SimRaw* l_raw = reinterpret_cast<SimRaw*>(l_hits + 2);            // [8 waves][SIM_RAW_WAVE]
     static_assert(Cfg::BM <= Cfg::THREADS && Cfg::BN <= Cfg::THREADS, "one row / column entry per thread");
+    static_assert(10 * (Cfg::BM + Cfg::BN) * 4 + SIM_LIST_CAP * 16 + 16 + 4 * Cfg::NWAVES * 4 + Cfg::NWAVES * 4 + 8 + Cfg::NWAVES * SIM_RAW_WAVE * 8 <= Cfg::STAGE_BYTES,
+                  "the analysis arrays share one operand stage");
+    // Hopeless data (ground truths deep in the bulk: every column of every tile nominates candidates and the lists overflow):
+    // the analysis would be paid for nothing.  Tiles count themselves as analysed / overflowed; once at least 32 have
+    // reported and 7 of 8 overflowed, a tile goes straight on to the exact path -- except every eighth, which keeps probing
+    // (data may differ between regions of the grid).  Both paths give the same integers; only the cost depends on the choice.
+    if (tid == 0) {
+      const int n_an = __hip_atomic_load(&ra.stats[SIM_ST_ANALYSED], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int n_ov = __hip_atomic_load(&ra.stats[SIM_ST_OVERFLOW], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      *l_listn = (n_an >= 32 && 8 * n_ov >= 7 * n_an && (blockIdx.x & 7) != 0) ? -1 : 0;
+    }
     // the tile's largest band factors bound every pair's band from above: the cheap test of phase 1
     const int e = tid;
     float2 pr = {0.f, 0.f}, qt = {0.f, 0.f};
@@ -586,33 +613,39 @@ __global__ __launch_bounds__(512) void sim_screen_kernel(const half_t* __restric
       if (lane == 0) { l_wmax[wave * 4 + 0] = wP; l_wmax[wave * 4 + 1] = wR; l_wmax[wave * 4 + 2] = wQ; l_wmax[wave * 4 + 3] = wT; }
     }
     __syncthreads();
+    const bool skip_analysis = *l_listn < 0;                         // workgroup-uniform
+    bool exact = true;
+    if (!skip_analysis) {
     float Pg = 0.f, Rg = 0.f, Qg = 0.f, Tg = 0.f;
 #pragma unroll
     for (int w = 0; w < Cfg::NWAVES; ++w) {
       Pg = fmaxf(Pg, l_wmax[w * 4 + 0]); Rg = fmaxf(Rg, l_wmax[w * 4 + 1]); Qg = fmaxf(Qg, l_wmax[w * 4 + 2]); Tg = fmaxf(Tg, l_wmax[w * 4 + 3]);
     }
+    // thr: s < thr  =>  s + bm + 2^-14 |s| < g;   hi: s > hi  =>  s - bm - 2^-14 |s| > g   (roundings included: the slack is
+    // 2^-13 against the band's 2^-14, plus 2^-20 of the band factor for the fp32 evaluation of g -+ bm itself)
     if (e < Cfg::BM) {
       const float g = g_row;
-      float thr = INFINITY;
+      float thr = INFINITY, hi = INFINITY;
       const float bm = fmaf(pr.x, Qg, pr.y * Tg);                    // >= fmaf(P, Q_j, R * T_j) for every j of the tile: the operations are monotone
       if (g < INFINITY) {
-        const float t = g - bm;
-        thr = t - 0x1p-13f * fabsf(t) - 0x1p-20f * bm;               // s < thr  =>  s + bm + 2^-14 |s| < g, roundings included
+        const float t = g - bm, u = g + bm;
+        thr = t - 0x1p-13f * fabsf(t) - 0x1p-20f * bm;
+        hi = u + 0x1p-13f * fabsf(u) + 0x1p-20f * bm;
       }
-      l_thrRow[e] = thr; l_P[e] = pr.x; l_R[e] = pr.y; l_Grow[e] = g; l_bmaxRow[e] = bm; l_rowmax[e] = 0u; l_rowcnt[e] = 0;
+      l_thrRow[e] = thr; l_hiRow[e] = hi; l_P[e] = pr.x; l_R[e] = pr.y; l_Grow[e] = g; l_bmaxRow[e] = bm; l_rowmax[e] = 0u; l_rowcnt[e] = 0;
     }
     if (e < Cfg::BN) {
       const float g = g_col;
-      float thr = INFINITY;
+      float thr = INFINITY, hi = INFINITY;
       const float bm = fmaf(Pg, qt.x, Rg * qt.y);
       if (g < INFINITY) {
-        const float t = g - bm;
+        const float t = g - bm, u = g + bm;
         thr = t - 0x1p-13f * fabsf(t) - 0x1p-20f * bm;
+        hi = u + 0x1p-13f * fabsf(u) + 0x1p-20f * bm;
       }
-      l_thrCol[e] = thr; l_Q[e] = qt.x; l_T[e] = qt.y; l_Gcol[e] = g; l_bmaxCol[e] = bm; l_colmax[e] = 0u; l_colcnt[e] = 0;
+      l_thrCol[e] = thr; l_hiCol[e] = hi; l_Q[e] = qt.x; l_T[e] = qt.y; l_Gcol[e] = g; l_bmaxCol[e] = bm; l_colmax[e] = 0u; l_colcnt[e] = 0;
     }
-    if (tid == 0) *l_listn = 0;
-    if (tid < Cfg::NWAVES) l_rawn[tid] = 0;
+    if (tid < Cfg::NWAVES + 2) l_rawn[tid] = 0;                      // and l_hits
     __syncthreads();
     SIM_STAMP(2);
     // ---- phase 1: which rows / columns of this wave hold a score within reach of their ground truth at all
@@ -646,62 +679,132 @@ __global__ __launch_bounds__(512) void sim_screen_kernel(const half_t* __restric
     }
     const unsigned rowAny = wave_or(rowmask), colAny = wave_or(colmask);      // wave-uniform
     __syncthreads();
+    // ---- phase 1b: per row / column, L = max(G, lower bound of the largest s of the tile) <= the exact maximum, and the prefix
+    // below which a score cannot be the arg-max (s + band < L).  A row without a score in reach keeps L = G: nothing qualifies.
+    if (e < Cfg::BM) {
+      const unsigned k = l_rowmax[e];
+      const float g = l_Grow[e], bm = l_bmaxRow[e];
+      float L = g;
+      if (k) { const float m = key_float(k); L = fmaxf(g, (m - bm) - 0x1p-13f * fabsf(m)); }      // <= lo of that element <= the exact row maximum
+      const float t = L - bm;
+      l_Lrow[e] = L;
+      l_argRow[e] = (g < INFINITY) ? t - 0x1p-13f * fabsf(t) - 0x1p-20f * bm : INFINITY;
+    }
+    if (e < Cfg::BN) {
+      const unsigned k = l_colmax[e];
+      const float g = l_Gcol[e], bm = l_bmaxCol[e];
+      float L = g;
+      if (k) { const float m = key_float(k); L = fmaxf(g, (m - bm) - 0x1p-13f * fabsf(m)); }
+      const float t = L - bm;
+      l_Lcol[e] = L;
+      l_argCol[e] = (g < INFINITY) ? t - 0x1p-13f * fabsf(t) - 0x1p-20f * bm : INFINITY;
+    }
+    {
+      // how many rows / columns of the tile hold a score in reach of their ground truth: each of them nominates at least the
+      // largest such score as an arg-max candidate, one list entry per row (column) -- more of either than the list holds and
+      // the tile cannot be listed: on to the exact path now, without paying for phase 2 (ground truths deep in the bulk)
+      const unsigned long long hr = __ballot(e < Cfg::BM && l_rowmax[e] != 0u), hc = __ballot(e < Cfg::BN && l_colmax[e] != 0u);
+      if (lane == 0) {
+        if (hr) atomicAdd(&l_hits[0], __popcll(hr));
+        if (hc) atomicAdd(&l_hits[1], __popcll(hc));
+      }
+    }
+    if (tid == 0) *l_listn = 0;
+    __syncthreads();
     SIM_STAMP(3);
-    // ---- phase 2a: per accumulator register (rt, reg) = 4 rows x 96 columns of the wave, ONE cheap test over its 6 x 64 scores
-    // against their rows' and columns' thresholds of phase 1; the rare hit drops its scores into a RAW candidate list in LDS
-    // (tile-local row, column, prefix s), aggregated per wave -- nothing is decided here.  (Two earlier forms decided in
-    // place: unrolled 192 times they were 220 KB of instructions, as a compact loop a chain of LDS round trips per hit; either
-    // way a tile with a few dozen hits spent as long in its analysis as in its main loop -- phase stamps, tools/retrieval_stamps.py.)
-    if (rowAny | colAny) {
-      float thrC[CT];
+    const bool hopeless = l_hits[0] + l_hits[1] > SIM_LIST_CAP;      // workgroup-uniform (a pair may serve a row AND a column: a heuristic, and both paths are exact)
+    // ---- phase 2a: per accumulator register (rt, reg) = 4 rows x 96 columns of the wave and per column tile, against the rows'
+    // and columns' thresholds -- only the SIDES phase 1 flagged (wave-uniform bits: with ground truths inside the bulk of one
+    // direction's scores and clear of the other's, the usual case, half of the compares are never issued):
+    //   * a score above its row's / column's `hi` beats that ground truth whatever the dropped segments add: COUNTED here, in a
+    //     register per lane (rows: reduced over the 16 lanes of a row; columns: summed over the wave's 128 rows at the end) --
+    //     round 4 sent these through the raw list too, and any data with ground truths inside the bulk of the scores (Recall@1
+    //     below ~90 %: hundreds of such pairs per tile) overflowed it and paid for the exact path in every tile;
+    //   * a score between `thr` and `hi` (undecided), or at / above `arg` (may be the arg-max), goes into the wave's segment of
+    //     the RAW list (tile-local row, column, prefix s) for phase 2b -- nothing else is decided here.
+    if ((rowAny | colAny) && !hopeless) {
+      float thrC[CT], hiC[CT], argC[CT];
+      int cntC[CT];
 #pragma unroll
-      for (int ct = 0; ct < CT; ++ct) thrC[ct] = l_thrCol[lcol0 + ct * 16];
+      for (int ct = 0; ct < CT; ++ct) {
+        thrC[ct] = l_thrCol[lcol0 + ct * 16]; hiC[ct] = l_hiCol[lcol0 + ct * 16]; argC[ct] = l_argCol[lcol0 + ct * 16];
+        cntC[ct] = 0;
+      }
       // each wave fills its OWN segment of the raw list (SIM_RAW_WAVE slots, a running count in a scalar register): no LDS
       // atomic, no round trip per hit; a wave that runs out of slots sends the tile to the exact path
       int n_mine = 0;
       SimRaw* my_raw = l_raw + wave * SIM_RAW_WAVE;
 #ifdef ALADIN_DIAG
-      int n_cheap = 0, n_full = 0;
+      int n_full = 0;
 #endif
+      // ONE straight-line pass over the lane's 192 scores.  Per pair, column side: `up` = beats the column's ground truth for sure
+      // (one compare, one add-with-carry into the lane's count of that column) and ONE more compare -- against `arg` if up,
+      // `thr` if not -- says whether the pair must be looked at again (undecided, or a possible arg-max): 4 vector
+      // instructions.  The row side runs only for the registers whose rows phase 1 flagged (a wave-uniform bit: with ground
+      // truths inside the bulk of one direction's scores and clear of the other's, the usual case, it is rare).  The code is
+      // executed ONCE per tile, so its SIZE is what it costs (three specialised copies of this pass, 100 KB of instructions,
+      // ran three times slower than one: the instruction cache holds 64 KB): the rare paths are kept short, not fast.
       static_for<RT>([&](auto rt_) {
         constexpr int rt = decltype(rt_)::value;
-        if (n_mine > SIM_RAW_WAVE) return;                   // wave-uniform
-        const float4 thr4 = *reinterpret_cast<const float4*>(l_thrRow + lrow0 + rt * 16);
-        const float thrRs[4] = {thr4.x, thr4.y, thr4.z, thr4.w};
+        if (n_mine > SIM_RAW_WAVE) return;                     // wave-uniform
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
-          const float thrR = thrRs[reg];
-          bool pass = false;
-#pragma unroll
-          for (int ct = 0; ct < CT; ++ct) pass |= (acc[rt][ct][reg] >= thrR) | (acc[rt][ct][reg] >= thrC[ct]);
-#ifdef ALADIN_DIAG
-          ++n_cheap;
-#endif
-          if (!__any(pass)) continue;                        // nobody in these 384 scores is within reach of its row's or column's ground truth
-#ifdef ALADIN_DIAG
-          ++n_full;
-#endif
+          unsigned long long pm[CT];
+          unsigned long long any = 0ull;
 #pragma unroll
           for (int ct = 0; ct < CT; ++ct) {
             const float s = acc[rt][ct][reg];
-            const bool hit = (s >= thrR) | (s >= thrC[ct]);
-            const unsigned long long pm = __ballot(hit);
-            if (!pm) continue;                                 // usually one of the six column tiles holds the hit
-            const int idx = n_mine + __popcll(pm & ((1ull << lane) - 1ull));
-            if (hit && idx < SIM_RAW_WAVE) my_raw[idx] = SimRaw{((lrow0 + rt * 16 + reg) << 16) | (lcol0 + ct * 16), s};
-            n_mine += __popcll(pm);
+            const bool upC = s > hiC[ct];
+            cntC[ct] += upC;
+            pm[ct] = __ballot(s >= (upC ? argC[ct] : thrC[ct]));      // in reach of the column's ground truth and (undecided or an arg-max candidate)
+            any |= pm[ct];
+          }
+          if ((rowAny >> (rt * 4 + reg)) & 1u) {               // wave-uniform
+            const float thrR = l_thrRow[lrow0 + rt * 16 + reg], hiR = l_hiRow[lrow0 + rt * 16 + reg], argR = l_argRow[lrow0 + rt * 16 + reg];
+            int cntR = 0;
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+              const float s = acc[rt][ct][reg];
+              const bool upR = s > hiR;
+              cntR += upR;
+              const unsigned long long m = __ballot(s >= (upR ? argR : thrR));
+              pm[ct] |= m;
+              any |= m;
+            }
+            cntR = row16_isum(cntR);
+            if ((lane & 15) == 0 && cntR) atomicAdd(&l_rowcnt[lrow0 + rt * 16 + reg], cntR);
+          }
+          if (any) {                                           // rare: a handful of such pairs per wave
+#ifdef ALADIN_DIAG
+            ++n_full;
+#endif
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+              if (!pm[ct]) continue;
+              const int idx = n_mine + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(pm[ct] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)pm[ct], 0u));
+              if (((pm[ct] >> lane) & 1ull) && idx < SIM_RAW_WAVE) my_raw[idx] = SimRaw{((lrow0 + rt * 16 + reg) << 16) | (lcol0 + ct * 16), acc[rt][ct][reg]};
+              n_mine += __popcll(pm[ct]);
+            }
           }
         }
       });
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) {
+        int c = cntC[ct];
+        c += lane_xor16(c);
+        c += lane_xor32(c);
+        if (lane < 16 && c) atomicAdd(&l_colcnt[lcol0 + ct * 16], c);
+      }
       if (lane == 0) l_rawn[wave] = n_mine;
 #ifdef ALADIN_DIAG
-      if (lane == 0 && (blockIdx.x & 63) == 0) { atomicAdd(&ra.stats[2], n_cheap); atomicAdd(&ra.stats[3], n_full); atomicAdd(&ra.stats[4], 1); }     // a sample of the tiles
+      if (lane == 0 && (blockIdx.x & 63) == 0) { atomicAdd(&ra.stats[2], 32); atomicAdd(&ra.stats[3], n_full); atomicAdd(&ra.stats[4], 1); }     // a sample of the tiles
 #endif
     }
     __syncthreads();
+    SIM_STAMP(8);                                                    // (slots 8.. are the exact epilogue's: a listed tile never gets there)
     // ---- phase 2b: the raw candidates, one per thread: the per-pair decisions with the pair's own band
     {
-      bool raw_over = false;
+      bool raw_over = hopeless;
 #pragma unroll
       for (int w = 0; w < Cfg::NWAVES; ++w) raw_over |= l_rawn[w] > SIM_RAW_WAVE;
       if (!raw_over) {
@@ -710,20 +813,15 @@ __global__ __launch_bounds__(512) void sim_screen_kernel(const half_t* __restric
           const SimRaw rw = l_raw[seg * SIM_RAW_WAVE + slot];
           const int lr = rw.rc >> 16, lc = rw.rc & 0xffff;
           const float s = rw.s;
-          const float P = l_P[lr], R = l_R[lr], Gr = l_Grow[lr], bmr = l_bmaxRow[lr];
-          const float Gc = l_Gcol[lc], Qc = l_Q[lc], Tc = l_T[lc], bmc = l_bmaxCol[lc];
-          const unsigned kr = l_rowmax[lr], kc = l_colmax[lc];
-          float Lr = -INFINITY, Lc = -INFINITY;
-          if (kr) { const float m = key_float(kr); Lr = (m - bmr) - 0x1p-13f * fabsf(m); }      // <= lo of that element <= the exact row maximum
-          if (kc) { const float m = key_float(kc); Lc = (m - bmc) - 0x1p-13f * fabsf(m); }
-          Lr = fmaxf(Gr, Lr);
-          Lc = fmaxf(Gc, Lc);
+          const float P = l_P[lr], R = l_R[lr], Gr = l_Grow[lr], Lr = l_Lrow[lr];
+          const float Gc = l_Gcol[lc], Qc = l_Q[lc], Tc = l_T[lc], Lc = l_Lcol[lc];
+          const bool upR = s > l_hiRow[lr], upC = s > l_hiCol[lc];           // counted in phase 2a already
           const float band = fmaf(fabsf(s), 0x1p-14f, fmaf(P, Qc, R * Tc));
           const float hi = s + band, lo = s - band;
           int f = 0;
-          const bool gr = lo > Gr, gc = lo > Gc;
-          if (gr) atomicAdd(&l_rowcnt[lr], 1);
-          if (gc) atomicAdd(&l_colcnt[lc], 1);
+          const bool gr = upR | (lo > Gr), gc = upC | (lo > Gc);
+          if (gr & !upR) atomicAdd(&l_rowcnt[lr], 1);
+          if (gc & !upC) atomicAdd(&l_colcnt[lc], 1);
           if (hi >= Gr) { if (!gr) f |= SIM_F_ROWCNT; if (hi >= Lr) f |= SIM_F_ROWARG; }
           if (hi >= Gc) { if (!gc) f |= SIM_F_COLCNT; if (hi >= Lc) f |= SIM_F_COLARG; }
           if (f) {
@@ -732,26 +830,37 @@ __global__ __launch_bounds__(512) void sim_screen_kernel(const half_t* __restric
           }
         }
       } else if (tid == 0) {
-        *l_listn = SIM_LIST_CAP + 1;                           // too many scores within reach of a ground truth: continue the chains in place
+        *l_listn = SIM_LIST_CAP + 1;                           // too many undecided scores / arg-max candidates: continue the chains in place
       }
     }
     __syncthreads();
     SIM_STAMP(4);
     const int n_list = *l_listn;
-    const bool exact = n_list > SIM_LIST_CAP;
+    exact = n_list > SIM_LIST_CAP;
     const int tile = mb * n_nblk + nb;
     if (threadIdx.x == 0) {
       ra.list_cnt[tile] = exact ? 0 : n_list;
-      if (exact) atomicAdd(&ra.stats[0], 1);
-      else if (n_list) atomicAdd(&ra.stats[1], n_list);
+      atomicAdd(&ra.stats[SIM_ST_ANALYSED], 1);
+      if (exact) { atomicAdd(&ra.stats[SIM_ST_EXACT], 1); atomicAdd(&ra.stats[SIM_ST_OVERFLOW], 1); }
+      else if (n_list) atomicAdd(&ra.stats[SIM_ST_LISTED], n_list);
     }
     if (!exact) {
-      for (int e = threadIdx.x; e < Cfg::BM; e += Cfg::THREADS)
-        if (l_rowcnt[e]) atomicAdd(&ra.cnt_i2t[mb * Cfg::BM + e], l_rowcnt[e]);       // only valid rows ever count
-      for (int e = threadIdx.x; e < Cfg::BN; e += Cfg::THREADS)
-        if (l_colcnt[e]) atomicAdd(&ra.cnt_t2i[nb * Cfg::BN + e], l_colcnt[e]);
-      for (int e = threadIdx.x; e < n_list; e += Cfg::THREADS) ra.list[(int64_t)tile * SIM_LIST_CAP + e] = l_list[e];
+      for (int q = threadIdx.x; q < Cfg::BM; q += Cfg::THREADS) {
+        if (l_rowcnt[q]) atomicAdd(&ra.cnt_i2t[mb * Cfg::BM + q], l_rowcnt[q]);       // only valid rows ever count
+        // the tile's certified lower bound of the row's exact maximum, for sim_rescore_kernel's filter
+        if (l_rowmax[q]) atomicMax(&ra.lob_i2t[mb * Cfg::BM + q], float_key(l_Lrow[q]));
+      }
+      for (int q = threadIdx.x; q < Cfg::BN; q += Cfg::THREADS) {
+        if (l_colcnt[q]) atomicAdd(&ra.cnt_t2i[nb * Cfg::BN + q], l_colcnt[q]);
+        if (l_colmax[q]) atomicMax(&ra.lob_t2i[nb * Cfg::BN + q], float_key(l_Lcol[q]));
+      }
+      for (int q = threadIdx.x; q < n_list; q += Cfg::THREADS) ra.list[(int64_t)tile * SIM_LIST_CAP + q] = l_list[q];
       return;
+    }
+    } else if (threadIdx.x == 0) {
+      ra.list_cnt[mb * n_nblk + nb] = 0;
+      atomicAdd(&ra.stats[SIM_ST_EXACT], 1);
+      atomicAdd(&ra.stats[SIM_ST_SKIPPED], 1);
     }
     __syncthreads();                                                 // the lists are dead: the stages may be refilled
   } else {
@@ -794,46 +903,75 @@ __device__ __forceinline__ void sim_chain_global(const half_t* __restrict__ ap, 
 // Continue the chains of the listed pairs: 16 pairs per wave on the DIAGONAL of one 16 x 16 MFMA tile (row m of A = pair
 // m's image, column m of B = pair m's caption, C[m][m] = its prefix s; the off-diagonal products are waste, the loads are
 // what this costs: 4 x 2 Dp bytes per pair), then patch the counters / packed maxima with the exact value.
+// Round 5: an entry listed ONLY as an arg-max candidate is first held against the certified bounds every tile left in
+// lob_*: L* = the largest lower bound any tile proved for the row's (column's) exact maximum.  s + band < L* <= the maximum
+// means the pair is strictly below it: no chain needed.  With ground truths inside the bulk every tile nominates the largest
+// score of each column it holds (it cannot know the other tiles'), ~100 entries per tile, and all but ~one per column fall here.
+// One workgroup per tile; its four waves take the tile's 16-entry groups in turn.
 __global__ __launch_bounds__(256) void sim_rescore_kernel(const half_t* __restrict__ a, const half_t* __restrict__ b, int64_t ldk,
                                                           int kps, int n_tiles, SimRankArgs ra) {
-  constexpr int GROUPS = SIM_LIST_CAP / 16;
-  const int lane = threadIdx.x & 63;
-  const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int tile = w / GROUPS, grp = w % GROUPS;
+  __shared__ SimEntry l_e[SIM_LIST_CAP];
+  __shared__ int l_n;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int tile = blockIdx.x;
   if (tile >= n_tiles) return;
   const int n = ra.list_cnt[tile];
-  if (grp * 16 >= n) return;
-  const int m = lane & 15;
-  const bool live = grp * 16 + m < n;
-  SimEntry e = SimEntry{0, 0, 0.f, 0};
-  if (live) e = ra.list[(int64_t)tile * SIM_LIST_CAP + grp * 16 + m];
-  const half_t* ap = a + (int64_t)e.row * ldk + 8 * (lane >> 4);
-  const half_t* bp = b + (int64_t)e.col * ldk + 8 * (lane >> 4);
-  const bool diag = (lane >> 4) == (m >> 2);                          // C[row][col]: col = lane & 15, row = 4 * (lane >> 4) + reg
-  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int reg = 0; reg < 4; ++reg)
-    if (diag && reg == (m & 3)) acc[reg] = e.s;
-  const int Dp = kps * 64;
-  sim_chain_global(ap + Dp, bp, 2 * kps, acc);                        // lo.hi
-  sim_chain_global(ap, bp + Dp, 2 * kps, acc);                        // hi.lo
-  if (!(live && diag)) return;
-  float v = acc[0];
-#pragma unroll
-  for (int reg = 1; reg < 4; ++reg)
-    if (reg == (m & 3)) v = acc[reg];
-  if (e.flags & (SIM_F_ROWCNT | SIM_F_ROWARG)) {
-    if (e.flags & SIM_F_ROWCNT) {
-      float g = -INFINITY;
-      for (int q = 0; q < ra.cpi; ++q) g = fmaxf(g, ra.gt[e.row * ra.cpi + q]);
-      if (v > g) atomicAdd(&ra.cnt_i2t[e.row], 1);
+  if (n == 0) return;                                                   // workgroup-uniform
+  if (threadIdx.x == 0) l_n = 0;
+  __syncthreads();
+  // filter and compact: the chains cost 6 KB of operand rows per pair, so the 16-pair groups below should hold live pairs only
+  for (int q = threadIdx.x; q < n; q += 256) {
+    SimEntry e = ra.list[(int64_t)tile * SIM_LIST_CAP + q];
+    if (e.flags & (SIM_F_ROWARG | SIM_F_COLARG)) {
+      const float2 pr = ra.na[e.row], qt = ra.nb[e.col];
+      const float hi = e.s + fmaf(fabsf(e.s), 0x1p-14f, fmaf(pr.x, qt.x, pr.y * qt.y));
+      if (e.flags & SIM_F_ROWARG) {
+        const unsigned k = ra.lob_i2t[e.row];
+        if (k && hi < key_float(k)) e.flags &= ~SIM_F_ROWARG;
+      }
+      if (e.flags & SIM_F_COLARG) {
+        const unsigned k = ra.lob_t2i[e.col];
+        if (k && hi < key_float(k)) e.flags &= ~SIM_F_COLARG;
+      }
     }
-    if (e.flags & SIM_F_ROWARG) atomicMax(&ra.best_i2t[e.row], pack_best(v, e.col));
+    if (e.flags) l_e[atomicAdd(&l_n, 1)] = e;
   }
-  if (e.flags & SIM_F_COLCNT) {
-    if (v > ra.gt[e.col]) atomicAdd(&ra.cnt_t2i[e.col], 1);
+  __syncthreads();
+  const int n_live = l_n;
+  if (threadIdx.x == 0 && n_live) atomicAdd(&ra.stats[SIM_ST_RESCORED], n_live);
+  const int m = lane & 15;
+  const int Dp = kps * 64;
+  for (int grp = wave; grp * 16 < n_live; grp += 4) {
+    const bool need = grp * 16 + m < n_live;
+    SimEntry e = SimEntry{0, 0, 0.f, 0};
+    if (need) e = l_e[grp * 16 + m];
+    const half_t* ap = a + (int64_t)e.row * ldk + 8 * (lane >> 4);
+    const half_t* bp = b + (int64_t)e.col * ldk + 8 * (lane >> 4);
+    const bool diag = (lane >> 4) == (m >> 2);                          // C[row][col]: col = lane & 15, row = 4 * (lane >> 4) + reg
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg)
+      if (diag && reg == (m & 3)) acc[reg] = e.s;
+    sim_chain_global(ap + Dp, bp, 2 * kps, acc);                        // lo.hi
+    sim_chain_global(ap, bp + Dp, 2 * kps, acc);                        // hi.lo
+    if (!(need && diag)) continue;
+    float v = acc[0];
+#pragma unroll
+    for (int reg = 1; reg < 4; ++reg)
+      if (reg == (m & 3)) v = acc[reg];
+    if (e.flags & (SIM_F_ROWCNT | SIM_F_ROWARG)) {
+      if (e.flags & SIM_F_ROWCNT) {
+        float g = -INFINITY;
+        for (int q = 0; q < ra.cpi; ++q) g = fmaxf(g, ra.gt[e.row * ra.cpi + q]);
+        if (v > g) atomicAdd(&ra.cnt_i2t[e.row], 1);
+      }
+      if (e.flags & SIM_F_ROWARG) atomicMax(&ra.best_i2t[e.row], pack_best(v, e.col));
+    }
+    if (e.flags & SIM_F_COLCNT) {
+      if (v > ra.gt[e.col]) atomicAdd(&ra.cnt_t2i[e.col], 1);
+    }
+    if (e.flags & SIM_F_COLARG) atomicMax(&ra.best_t2i[e.col], pack_best(v, e.row));
   }
-  if (e.flags & SIM_F_COLARG) atomicMax(&ra.best_t2i[e.col], pack_best(v, e.row));
 }
 
 // Ground-truth scores gt[c] = chain(c / cpi, c) in the accumulators' scale, with the bits every other kernel of this file
@@ -1149,6 +1287,8 @@ struct RetrWs {
   float* gt;
   unsigned long long *best_i2t, *best_t2i;
   int* stats;
+  unsigned *lob_i2t, *lob_t2i;       // right behind the statistics: one zeroing range (stats_zero_words)
+  int64_t stats_zero_words;
   int* list_cnt;
   SimEntry* list;
 };
@@ -1162,11 +1302,15 @@ static size_t retr_layout(int n_img, int n_cap, int D, char* base, RetrWs* w, si
   unsigned long long* bi = (unsigned long long*)take((size_t)n_img * 8);
   unsigned long long* bt = (unsigned long long*)take((size_t)n_cap * 8);
   if (stats_off) *stats_off = off;
-  int* stats = (int*)take(256);
+  const size_t z0 = off;
+  int* stats = (int*)take(SIM_STATS_WORDS * 4);
   const size_t c1 = off;
+  unsigned* li = (unsigned*)take((size_t)round_up(n_img, SimCfg::BM) * 4);
+  unsigned* lt = (unsigned*)take((size_t)round_up(n_cap, SimCfg::BN) * 4);
+  const int64_t zw = (int64_t)((off - z0) / 4);
   int* lc = (int*)take((size_t)n_tiles * 4);
   SimEntry* list = (SimEntry*)take((size_t)n_tiles * SIM_LIST_CAP * sizeof(SimEntry));
-  if (w) *w = RetrWs{gt, bi, bt, stats, lc, list};
+  if (w) *w = RetrWs{gt, bi, bt, stats, li, lt, zw, lc, list};
   if (counters_off) *counters_off = c0;
   if (counters_bytes) *counters_bytes = c1 - c0;
   return off;
@@ -1213,7 +1357,7 @@ static int retrieval_ranks_impl(const float* img, int64_t img_rs, const float* c
   // the pack grid zeroes the statistics and the two rank (= counter) arrays; the arg-max arrays need no zeroing: every entry is
   // first written (plain store) with its ground-truth pair by the kernel that computes the ground truths
   bool gt_done = false;
-  int rc = sim_prepare(img, img_rs, cap, cap_rs, n_img, n_cap, D, workspace, &ws, &Mp, &Np, &Dp, st, rw.stats, 64, rank_i2t, n_img, rank_t2i,
+  int rc = sim_prepare(img, img_rs, cap, cap_rs, n_img, n_cap, D, workspace, &ws, &Mp, &Np, &Dp, st, rw.stats, rw.stats_zero_words, rank_i2t, n_img, rank_t2i,
                        n_cap, caps_per_img, rw.gt, rw.best_i2t, rw.best_t2i, &gt_done);
   if (rc) return rc;
   static unsigned long long lds_reserved[2] = {0, 0};
@@ -1234,6 +1378,8 @@ static int retrieval_ranks_impl(const float* img, int64_t img_rs, const float* c
   ra.list = rw.list;
   ra.list_cnt = rw.list_cnt;
   ra.stats = rw.stats;
+  ra.lob_i2t = rw.lob_i2t;
+  ra.lob_t2i = rw.lob_t2i;
   if (!gt_done) {
     if (hipMemsetAsync(rw.best_i2t, 0, (size_t)n_img * 8, st) != hipSuccess) { aladin_set_error("retrieval_ranks: memset failed"); return ALADIN_ERR_HIP; }
     const int tiles = cdiv(n_img, 16) * caps_per_img;
@@ -1249,7 +1395,7 @@ static int retrieval_ranks_impl(const float* img, int64_t img_rs, const float* c
   rc = aladin_check_launch("sim_screen_kernel");
   if (rc) return rc;
   if (!force_exact) {
-    hipLaunchKernelGGL(sim_rescore_kernel, dim3(cdiv(n_tiles * (SIM_LIST_CAP / 16), 4)), dim3(256), 0, st, ws.a, ws.b, ldk, kps, n_tiles, ra);
+    hipLaunchKernelGGL(sim_rescore_kernel, dim3(n_tiles), dim3(256), 0, st, ws.a, ws.b, ldk, kps, n_tiles, ra);
     rc = aladin_check_launch("sim_rescore_kernel");
     if (rc) return rc;
   }

@@ -1312,7 +1312,8 @@ def retrieval_ranks(img, cap, caps_per_img=5, exact=False, return_stats=False):
     the two-step path; replaces reference alad/recall_auxiliary.py:30-56 in one pass.
     The kernel screens with the hi.hi third of the split product and continues to the exact score only the pairs a
     rigorous per-pair bound leaves undecided (include/aladin_hip.h); exact=True forces the three-product path on
-    every tile (same outputs).  return_stats=True appends {'exact_tiles', 'listed_pairs', 'tiles'} (one D2H copy)."""
+    every tile (same outputs).  return_stats=True appends {'exact_tiles', 'listed_pairs', 'rescored_pairs', 'skipped_tiles', 'tiles'}
+    (one D2H copy): tiles continued in place, pairs listed, listed pairs whose chains were continued, tiles that skipped the screen."""
     _require_gpu(img, cap)
     if img.dim() != 2 or cap.dim() != 2 or img.shape[1] != cap.shape[1]:
         raise ValueError('aladin_amd: (n_img,D) and (n_cap,D) embeddings expected')
@@ -1331,9 +1332,10 @@ def retrieval_ranks(img, cap, caps_per_img=5, exact=False, return_stats=False):
                   _ptr(r_i2t), _ptr(t_i2t), _ptr(r_t2i), _ptr(t_t2i), _ptr(ws), _stream()), 'retrieval_ranks')
     if return_stats:
         off = lib.aladin_retrieval_stats_offset(n_img, n_cap, D)
-        st = ws[off:off + 8].view(torch.int32).cpu().tolist()
+        st = ws[off:off + 36].view(torch.int32).cpu().tolist()
         tiles = -(-n_img // 256) * -(-n_cap // 384)
-        return r_i2t, t_i2t, r_t2i, t_t2i, {'exact_tiles': st[0], 'listed_pairs': st[1], 'tiles': tiles}
+        return r_i2t, t_i2t, r_t2i, t_t2i, {'exact_tiles': st[0], 'listed_pairs': st[1], 'rescored_pairs': st[5], 'skipped_tiles': st[8],
+                                            'tiles': tiles}
     return r_i2t, t_i2t, r_t2i, t_t2i
 
 

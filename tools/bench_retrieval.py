@@ -67,7 +67,8 @@ def main():
         ms_x = ev_ms(lambda: ops.retrieval_ranks(a, b, exact=True), iters=it)
         print(json.dumps({'data': name, 'R@1_i2t': round(r1_i, 1), 'R@1_t2i': round(r1_t, 1), 'fused_ms': round(ms, 4),
                           'fused_all_exact_ms': round(ms_x, 4), 'exact_tiles': st['exact_tiles'], 'tiles': st['tiles'],
-                          'listed_pairs': st['listed_pairs'], 'equal_to_two_step': not profile}), flush=True)
+                          'listed_pairs': st['listed_pairs'], 'rescored_pairs': st['rescored_pairs'], 'skipped_tiles': st['skipped_tiles'],
+                          'equal_to_two_step': not profile}), flush=True)
 
 
 if __name__ == '__main__':
