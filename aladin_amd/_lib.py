@@ -10,18 +10,16 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # ALADIN_LIB points at an alternative build of the same ABI (kernel A/B runs, tools/ab_bench.py)
 LIB_PATH = os.environ.get('ALADIN_LIB') or os.path.join(_HERE, 'lib', 'libaladin_hip.so')
 
-ABI_VERSION = 10
+ABI_VERSION = 11
 PRECISION_FP16, PRECISION_SPLIT = 0, 1      # ALADIN_PRECISION_* of include/aladin_hip.h
-BWD_PARTNERS_FP16, BWD_DENSE, BWD_DENSE_GATHER = 1, 2, 4          # ALADIN_BWD_PARTNERS_FP16, ALADIN_BWD_DENSE
+BWD_PARTNERS_FP16, BWD_DENSE, BWD_DENSE_GATHER, TRIPLET_BWD_BASE_WORKSPACE, BWD_OWN_ROW_FP16 = 1, 2, 4, 8, 16      # ALADIN_BWD_*, ALADIN_TRIPLET_BWD_BASE_WORKSPACE
 
 # every symbol include/aladin_hip.h declares (tests check that the library exports all of them)
 SYMBOLS = [
-    'aladin_version', 'aladin_last_error', 'aladin_align_geometry', 'aladin_align_geometry_ex', 'aladin_align_geometry_mode',
-    'aladin_align_pack_images',
-    'aladin_align_pack_captions', 'aladin_align_pack_both', 'aladin_align_scores', 'aladin_align_scores_ex',
-    'aladin_align_bwd_workspace_bytes',
-    'aladin_align_bwd', 'aladin_align_bwd_packed', 'aladin_align_bwd_packed_strided', 'aladin_hinge_workspace_bytes', 'aladin_hinge_fwd_bwd',
-    'aladin_hinge_fused', 'aladin_hinge_argmax_fused', 'aladin_align_bwd_rows', 'aladin_heads_small_fwd_argmax',
+    'aladin_version', 'aladin_last_error', 'aladin_align_geometry', 'aladin_align_pack', 'aladin_align_scores',
+    'aladin_align_bwd_workspace_bytes', 'aladin_align_bwd',
+    'aladin_align_triplet_workspace_bytes', 'aladin_align_triplet_fwd', 'aladin_align_triplet_bwd', 'aladin_heads_small_fwd_argmax',
+    'aladin_hinge_workspace_bytes', 'aladin_hinge_fwd_bwd', 'aladin_hinge_fused',
     'aladin_listnet_workspace_bytes', 'aladin_listnet_fwd_bwd',
     'aladin_distill_workspace_bytes', 'aladin_distill_mse_fwd_bwd', 'aladin_distill_contrastive_fwd_bwd',
     'aladin_distill_ordinal_fwd_bwd', 'aladin_order_sim_fwd', 'aladin_order_sim_bwd', 'aladin_sgemm_strided',
@@ -30,9 +28,7 @@ SYMBOLS = [
     'aladin_l2norm_fwd', 'aladin_l2norm_bwd',
     'aladin_retrieval_workspace_bytes', 'aladin_retrieval_ranks', 'aladin_retrieval_ranks_exact', 'aladin_retrieval_stats_offset',
     'aladin_scan_workspace_bytes', 'aladin_scan_fwd', 'aladin_scan_bwd',
-    'aladin_store_row_width', 'aladin_store_append', 'aladin_align_pack_store_x', 'aladin_align_pack_store_y',
-    'aladin_store_row_width_mode', 'aladin_store_append_mode', 'aladin_topk',
-    'aladin_align_bwd_packed_strided_ex', 'aladin_align_bwd_rows_ex', 'aladin_align_bwd_workspace_bytes_ex',
+    'aladin_store_row_width', 'aladin_store_append', 'aladin_align_pack_store_x', 'aladin_align_pack_store_y', 'aladin_topk',
     'aladin_loss_total', 'aladin_grad_combine', 'aladin_heads_small_workspace_bytes', 'aladin_heads_small_fwd', 'aladin_heads_small_bwd',
 ]
 
@@ -42,7 +38,22 @@ class AlignGeom(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ('Bi', 'Bc', 'R', 'T', 'D', 'Rq', 'Tq', 'mrows', 'rem', 'tp16', 'trows', 'Dp',
                                          'img_unit', 'cap_unit', 'Bi_pad', 'Bc_pad', 'x_tail', 'y_tail', 'split')] + \
                [(n, C.c_int64) for n in ('xm_rows', 'xe_rows', 'y_rows', 'xm_bytes', 'xe_bytes', 'y_bytes',
-                                         'e_bytes')]
+                                         'e_bytes', 'rnorm_bytes')]
+
+
+class SetView(C.Structure):
+    """struct aladin_set: a (B, N, D) fp32 batch of sets with its length tensor."""
+    _fields_ = [('data', C.c_void_p), ('stride_b', C.c_int64), ('stride_r', C.c_int64), ('len', C.c_void_p)]
+
+
+class GradView(C.Structure):
+    """struct aladin_set_grad."""
+    _fields_ = [('data', C.c_void_p), ('stride_b', C.c_int64), ('stride_r', C.c_int64)]
+
+
+class Packed(C.Structure):
+    """struct aladin_packed: the fp16 MFMA operands of one problem + the rows' inverse norms."""
+    _fields_ = [('xm', C.c_void_p), ('xe', C.c_void_p), ('y', C.c_void_p), ('rnorm', C.c_void_p)]
 
 
 _lib = None
@@ -51,33 +62,23 @@ _lib = None
 def _declare(lib):
     p, i32, i64, f32, sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
     G = C.POINTER(AlignGeom)
+    SV, GV, PK = C.POINTER(SetView), C.POINTER(GradView), C.POINTER(Packed)
     sig = {
         'aladin_version': (C.c_int, []),
         'aladin_last_error': (C.c_char_p, []),
-        'aladin_align_geometry': (C.c_int, [i32, i32, i32, i32, i32, G]),
-        'aladin_align_geometry_ex': (C.c_int, [i32, i32, i32, i32, i32, i32, i32, G]),
-        'aladin_align_geometry_mode': (C.c_int, [i32, i32, i32, i32, i32, i32, i32, i32, G]),
-        'aladin_align_pack_images': (C.c_int, [p, i64, i64, p, G, p, p, p]),
-        'aladin_align_pack_captions': (C.c_int, [p, i64, i64, p, G, p, p]),
-        'aladin_align_pack_both': (C.c_int, [p, i64, i64, p, p, i64, i64, p, G, p, p, p, p]),
-        'aladin_align_scores': (C.c_int, [p, p, p, G, p, p, i64, p]),
-        'aladin_align_scores_ex': (C.c_int, [p, p, p, G, p, p, i64, i32, p]),
-        'aladin_align_bwd_workspace_bytes': (sz, [i32, i32, i32, i32, i32]),
-        'aladin_align_bwd_workspace_bytes_ex': (sz, [i32, i32, i32, i32, i32, i32]),
-        'aladin_align_bwd': (C.c_int, [p, i64, i64, p, p, i64, i64, p, i32, i32, i32, i32, i32, p, i64, p, p, p, p, p]),
-        'aladin_align_bwd_packed': (C.c_int, [p, i64, i64, p, p, i64, i64, p, p, i64, p, p, p, p, G, p, p, p, p, p, p]),
-        'aladin_align_bwd_packed_strided': (C.c_int, [p, i64, i64, p, p, i64, i64, p, p, i64, p, p, p, p, G, p, p, p, i64, i64, p, i64, i64,
-                                                      p, p]),
-        'aladin_align_bwd_packed_strided_ex': (C.c_int, [p, i64, i64, p, p, i64, i64, p, p, i64, p, p, p, p, G, p, p, p, i64, i64, p, i64, i64,
-                                                         p, i32, p]),
-        'aladin_align_bwd_rows_ex': (C.c_int, [p, i64, i64, p, p, i64, i64, p, p, i64, p, p, p, p, G, p, i64, i64, p, i64, i64, p, i32, p]),
+        'aladin_align_geometry': (C.c_int, [i32, i32, i32, i32, i32, i32, i32, i32, G]),
+        'aladin_align_pack': (C.c_int, [SV, SV, G, PK, p]),
+        'aladin_align_scores': (C.c_int, [PK, G, p, p, i64, i32, p]),
+        'aladin_align_bwd_workspace_bytes': (sz, [G, i32]),
+        'aladin_align_bwd': (C.c_int, [SV, SV, G, PK, p, i64, p, p, p, GV, GV, p, i32, p]),
+        'aladin_align_triplet_workspace_bytes': (sz, [G]),
+        'aladin_align_triplet_fwd': (C.c_int, [SV, SV, G, f32, PK, p, i64, p, p, p, p]),
+        'aladin_align_triplet_bwd': (C.c_int, [SV, SV, G, PK, p, p, GV, GV, p, i32, p]),
+        'aladin_heads_small_fwd_argmax': (C.c_int, [p, i64, p, i64, p, i64, i32, f32, i32, f32, f32, f32, f32, f32, p, p, p, p, p, p, p,
+                                                    SV, SV, G, PK, p, p]),
         'aladin_hinge_workspace_bytes': (sz, [i32]),
         'aladin_hinge_fwd_bwd': (C.c_int, [p, i64, i32, f32, i32, p, p, p, p]),
         'aladin_hinge_fused': (C.c_int, [p, i64, i32, f32, i32, p, p, p, p, p, p]),
-        'aladin_hinge_argmax_fused': (C.c_int, [p, i64, f32, p, p, p, p, i64, i64, p, p, i64, i64, p, p, p, p, G, p, p]),
-        'aladin_heads_small_fwd_argmax': (C.c_int, [p, i64, p, i64, p, i64, i32, f32, i32, f32, f32, f32, f32, f32, p, p, p, p, p, p, p,
-                                                    p, i64, i64, p, p, i64, i64, p, p, p, p, G, p, p]),
-        'aladin_align_bwd_rows': (C.c_int, [p, i64, i64, p, p, i64, i64, p, p, i64, p, G, p, i64, i64, p, i64, i64, p, p]),
         'aladin_listnet_workspace_bytes': (sz, [i32]),
         'aladin_listnet_fwd_bwd': (C.c_int, [p, i64, p, i64, i32, f32, f32, p, p, p, p]),
         'aladin_distill_workspace_bytes': (sz, [i32]),
@@ -100,10 +101,8 @@ def _declare(lib):
         'aladin_scan_workspace_bytes': (sz, [i32, i32, i32, i32, i32, i32]),
         'aladin_scan_fwd': (C.c_int, [p, i64, i64, p, p, i64, i64, p, i32, i32, i32, i32, i32, p, i64, p, p]),
         'aladin_scan_bwd': (C.c_int, [p, i64, i64, p, p, i64, i64, p, i32, i32, i32, i32, i32, p, i64, p, p, p, p, p]),
-        'aladin_store_row_width': (C.c_int, [i32]),
-        'aladin_store_append': (C.c_int, [p, i64, i64, p, i32, i32, i32, i32, p, p, p]),
-        'aladin_store_row_width_mode': (C.c_int, [i32, i32]),
-        'aladin_store_append_mode': (C.c_int, [p, i64, i64, p, i32, i32, i32, i32, p, p, i32, p]),
+        'aladin_store_row_width': (C.c_int, [i32, i32]),
+        'aladin_store_append': (C.c_int, [p, i64, i64, p, i32, i32, i32, i32, p, p, i32, p]),
         'aladin_topk': (C.c_int, [p, i64, i64, i32, i32, i32, p, p, p]),
         'aladin_loss_total': (C.c_int, [p, f32, p, f32, p, f32, p, p]),
         'aladin_grad_combine': (C.c_int, [i64, p, f32, p, f32, p, p, f32, p, p]),

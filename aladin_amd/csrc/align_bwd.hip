@@ -45,8 +45,7 @@ static size_t bwd_ws_layout(int Bi, int Bc, int Tq, char* base, BwdWs* ws) {
   return off;
 }
 
-extern "C" size_t aladin_align_bwd_workspace_bytes(int Bi, int Bc, int R, int T, int D) {
-  (void)R; (void)D;
+static size_t bwd_base_bytes(int Bi, int Bc, int T) {
   if (Bi < 1 || Bc < 1 || T < 2) return 0;
   return bwd_ws_layout(Bi, Bc, T - 1, nullptr, nullptr);      // sized for the longest possible word axis (tail 0)
 }
@@ -71,14 +70,16 @@ static size_t dense_ws_layout(const aladin_align_geom* gs, char* base, DenseWs* 
 }
 // the tile classes the arg-max kernel covers; fills the split geometry of the problem
 static bool dense_supported(int Bi, int Bc, int R, int T, int D, int x_tail, int y_tail, aladin_align_geom* gs) {
-  if (aladin_align_geometry_mode(Bi, Bc, R, T, D, x_tail, y_tail, ALADIN_PRECISION_SPLIT_TABLE, gs) != ALADIN_OK) return false;
+  if (aladin_align_geometry(Bi, Bc, R, T, D, x_tail, y_tail, ALADIN_PRECISION_SPLIT_TABLE, gs) != ALADIN_OK) return false;
   const int bm = gs->mrows == 48 ? 192 : 256;                  // the tile kernel's workgroup rows for the class
   return ((gs->mrows == 32 || gs->mrows == 48) ? gs->rem <= 8 : (gs->mrows == 64 && gs->rem == 0)) && 6 % gs->tp16 == 0 &&
          (gs->xm_rows / bm) * (gs->y_rows / 384) > 64 && gs->xm_rows % bm == 0 && gs->y_rows % 384 == 0;
 }
 
-extern "C" size_t aladin_align_bwd_workspace_bytes_ex(int Bi, int Bc, int R, int T, int D, int flags) {
-  size_t n = aladin_align_bwd_workspace_bytes(Bi, Bc, R, T, D);
+extern "C" size_t aladin_align_bwd_workspace_bytes(const aladin_align_geom* g, int flags) {
+  if (!g) return 0;
+  const int Bi = g->Bi, Bc = g->Bc, R = g->R, T = g->T, D = g->D;
+  size_t n = bwd_base_bytes(Bi, Bc, T);
   if (n == 0 || !(flags & ALADIN_BWD_DENSE)) return n;
   // exact: the largest need over the three tail conventions a caller can pack (image / caption, role-swapped, none) --
   // [split operands + side scratch + flags | GEMM row step: transposed operands + split-K partial sums], laid out by
@@ -571,7 +572,12 @@ __device__ __forceinline__ void gather2_h(const half_t* __restrict__ r0, float g
   axpy_row<NCH>(g0, v0, acc);
 }
 // where the packers put region `r` of max-side sample `b` / word `w` of sum-side sample `b` (aladin_align_geometry)
-struct PackedRows { const half_t* xm; const half_t* xe; const half_t* y; int Dp, main_rows, rem, ycap; };
+struct PackedRows { const half_t* xm; const half_t* xe; const half_t* y; int Dp, main_rows, rem, ycap; const float* rnorm; int64_t xe_row0, y_row0; };
+// the same row's slot in rnorm ([xm rows | xe rows | y rows], aladin_align_geom::rnorm_bytes)
+__device__ __forceinline__ float packed_x_rnorm(const PackedRows& pk, int b, int r) {
+  return r < pk.main_rows ? pk.rnorm[(int64_t)b * pk.main_rows + r] : pk.rnorm[pk.xe_row0 + (int64_t)b * pk.rem + (r - pk.main_rows)];
+}
+__device__ __forceinline__ float packed_y_rnorm(const PackedRows& pk, int b, int w) { return pk.rnorm[pk.y_row0 + (int64_t)b * pk.ycap + w]; }
 __device__ __forceinline__ const half_t* packed_x_row(const PackedRows& pk, int b, int r) {
   return r < pk.main_rows ? pk.xm + ((int64_t)b * pk.main_rows + r) * pk.Dp : pk.xe + ((int64_t)b * pk.rem + (r - pk.main_rows)) * pk.Dp;
 }
@@ -579,7 +585,7 @@ __device__ __forceinline__ const half_t* packed_y_row(const PackedRows& pk, int 
   return pk.y + ((int64_t)b * pk.ycap + w) * pk.Dp;
 }
 
-template <int NCH, bool FULL, bool P16 = false>
+template <int NCH, bool FULL, bool P16 = false, bool O16 = false>
 __global__ __launch_bounds__(256) void bwd_rows_kernel(
     const float* __restrict__ im, int64_t im_sb, int64_t im_sr, const int32_t* __restrict__ im_len,
     const float* __restrict__ s, int64_t s_sb, int64_t s_st, const int32_t* __restrict__ s_len, int Bi, int Bc, int R,
@@ -615,8 +621,14 @@ __global__ __launch_bounds__(256) void bwd_rows_kernel(
   bool any = false;
   float4 xv[NCH];
 
+  float own_inv = 0.f;
   if (idx >= 0 && idx < L) {
-    load_row<NCH, FULL>(xrow, D, lane, xv);                               // (a) own row, needed last
+    // (a) own row, needed last.  O16: the unit vector the forward packed (one fp16 rounding) and its inverse norm -- the raw
+    // fp32 sets are not read at all by this kernel (round 5: 66 MB of 302 were this row)
+    if constexpr (O16) {
+      load_row_h<NCH, FULL>(is_img ? packed_x_row(pk, own_b, idx) : packed_y_row(pk, own_b, idx), D, lane, xv);
+      own_inv = is_img ? packed_x_rnorm(pk, own_b, idx) : packed_y_rnorm(pk, own_b, idx);
+    } else load_row<NCH, FULL>(xrow, D, lane, xv);
     const float gs = gscale ? *gscale : 1.f;
     const int nb = is_img ? Bc : Bi;                                // partners
     int* lp = lst_p[wave];
@@ -745,8 +757,9 @@ __global__ __launch_bounds__(256) void bwd_rows_kernel(
   }
   ss = wave_sum(ss);
   dot = wave_sum(dot);
-  const float inv = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
-  const float proj = dot * inv * inv;                  // <xh, dxh> / n  expressed on the raw x
+  // raw row: xh = x * inv;  packed row: xv IS xh (|xh| = 1 up to its fp16 rounding) and inv comes from the packer
+  const float inv = O16 ? own_inv : 1.0f / fmaxf(sqrtf(ss), 1e-12f);
+  const float proj = O16 ? dot : dot * inv * inv;      // <xh, dxh> (/ n, expressed on the raw x)
 #pragma unroll
   for (int c = 0; c < NCH; ++c) {
     const int col = lane * 4 + 256 * c;
@@ -769,7 +782,7 @@ struct HingeArgs { const float* S; int64_t ldS; float margin; float* loss; float
 static int align_bwd_impl(const float* im, int64_t im_sb, int64_t im_sr, const int32_t* im_len, const float* s,
                           int64_t s_sb, int64_t s_st, const int32_t* s_len, int Bi, int Bc, int R, int T, int D,
                           const float* dS, int64_t ld_dS, const float* gscale, const void* xm, const void* xe,
-                          const void* y, const aladin_align_geom* g, const int32_t* pairs_in, const int32_t* count_in,
+                          const void* y, const float* rnorm, const aladin_align_geom* g, const int32_t* pairs_in, const int32_t* count_in,
                           float* d_im, float* d_s, void* workspace, void* stream, int x_tail = 0, int y_tail = 2,
                           int64_t dim_sb = 0, int64_t dim_sr = 0, int64_t ds_sb = 0, int64_t ds_st = 0,
                           int phase = BWD_ALL, const HingeArgs* ha = nullptr, int flags = 0) {
@@ -842,7 +855,11 @@ static int align_bwd_impl(const float* im, int64_t im_sb, int64_t im_sr, const i
       DenseWs dw;
       const size_t dense_bytes = dense_ws_layout(&gs, (char*)workspace + bwd_ws_layout(Bi, Bc, T - 1, nullptr, nullptr), &dw);
       dense_rows_scratch = (char*)workspace + bwd_ws_layout(Bi, Bc, T - 1, nullptr, nullptr) + dense_bytes;      // both 256-multiples
-      rc = aladin_align_pack_both(im, im_sb, im_sr, im_len, s, s_sb, s_st, s_len, &gs, dw.xm, dw.xe, dw.y, stream);
+      {
+        const aladin_set vi = {im, im_sb, im_sr, im_len}, vs = {s, s_sb, s_st, s_len};
+        const aladin_packed pd = {dw.xm, dw.xe, dw.y, nullptr};
+        rc = aladin_internal_pack(&vi, &vs, &gs, &pd, st);
+      }
       if (rc) return rc;
       rc = aladin_internal_align_argmax(&gs, dw.xm, dw.xe, dw.y, dw.E, im_len, s_len, ws.table, tstride, dw.flags, st);
       if (rc) return rc;
@@ -893,17 +910,19 @@ static int align_bwd_impl(const float* im, int64_t im_sb, int64_t im_sr, const i
     if (rc != ALADIN_ERR_UNSUPPORTED) return rc;
   }
   // ALADIN_BWD_PARTNERS_FP16: gather the partner rows from the packed fp16 operands (must be this problem's, non-split)
-  const bool p16 = (flags & ALADIN_BWD_PARTNERS_FP16) != 0;
-  PackedRows pk = {nullptr, nullptr, nullptr, 0, 0, 0, 0};
+  const bool p16 = (flags & ALADIN_BWD_PARTNERS_FP16) != 0, o16 = (flags & ALADIN_BWD_OWN_ROW_FP16) != 0;
+  if (o16 && !p16) { aladin_set_error("align_bwd: ALADIN_BWD_OWN_ROW_FP16 goes with ALADIN_BWD_PARTNERS_FP16"); return ALADIN_ERR_ARG; }
+  PackedRows pk = {nullptr, nullptr, nullptr, 0, 0, 0, 0, nullptr, 0, 0};
   if (p16) {
-    if (!xm || !y || !g || g->split || (g->rem && !xe) || g->Bi != Bi || g->Bc != Bc || g->R != R || g->T != T || g->D != D) {
-      aladin_set_error("align_bwd: ALADIN_BWD_PARTNERS_FP16 needs the forward's fp16 packed operands and their geometry");
+    if (!xm || !y || !rnorm || !g || g->split || (g->rem && !xe) || g->Bi != Bi || g->Bc != Bc || g->R != R || g->T != T || g->D != D) {
+      aladin_set_error("align_bwd: ALADIN_BWD_PARTNERS_FP16 needs the forward's fp16 packed operands (xm, xe, y, rnorm) and their geometry");
       return ALADIN_ERR_ARG;
     }
-    pk = PackedRows{(const half_t*)xm, (const half_t*)xe, (const half_t*)y, g->Dp, g->mrows, g->rem, g->trows};
+    pk = PackedRows{(const half_t*)xm, (const half_t*)xe, (const half_t*)y, g->Dp, g->mrows, g->rem, g->trows, rnorm, g->xm_rows, g->xm_rows + g->xe_rows};
   }
-#define LAUNCH_ROWS_FP(N, F, P)                                                                                         \
-  hipLaunchKernelGGL((bwd_rows_kernel<N, F, P>), dim3(rgrid), dim3(256), 0, st, im, im_sb, im_sr, im_len, s, s_sb, s_st, s_len, \
+#define LAUNCH_ROWS_FP(N, F, P)  do { if (o16) LAUNCH_ROWS_FPO(N, F, P, P); else LAUNCH_ROWS_FPO(N, F, P, false); } while (0)
+#define LAUNCH_ROWS_FPO(N, F, P, O)                                                                                      \
+  hipLaunchKernelGGL((bwd_rows_kernel<N, F, P, O>), dim3(rgrid), dim3(256), 0, st, im, im_sb, im_sr, im_len, s, s_sb, s_st, s_len, \
                      Bi, Bc, R, T, D, dS, ld_dS, phase == BWD_ROWS ? (const float*)ws.pairs : (const float*)nullptr, gscale, ws.table, tstride, d_im, d_s, x_tail, y_tail, dim_sb, dim_sr, ds_sb, ds_st, pk)
 #define LAUNCH_ROWS_F(N, F) do { if (p16) LAUNCH_ROWS_FP(N, F, true); else LAUNCH_ROWS_FP(N, F, false); } while (0)
 #define LAUNCH_ROWS(N) do { if (D == 256 * (N)) LAUNCH_ROWS_F(N, true); else LAUNCH_ROWS_F(N, false); } while (0)
@@ -916,107 +935,114 @@ static int align_bwd_impl(const float* im, int64_t im_sb, int64_t im_sr, const i
 #undef LAUNCH_ROWS
 #undef LAUNCH_ROWS_F
 #undef LAUNCH_ROWS_FP
+#undef LAUNCH_ROWS_FPO
   return aladin_check_launch("bwd_rows_kernel");
 }
 
-extern "C" int aladin_align_bwd(const float* im, int64_t im_sb, int64_t im_sr, const int32_t* im_len, const float* s,
-                                int64_t s_sb, int64_t s_st, const int32_t* s_len, int Bi, int Bc, int R, int T, int D,
-                                const float* dS, int64_t ld_dS, const float* gscale, float* d_im, float* d_s,
-                                void* workspace, void* stream) {
-  return align_bwd_impl(im, im_sb, im_sr, im_len, s, s_sb, s_st, s_len, Bi, Bc, R, T, D, dS, ld_dS, gscale, nullptr,
-                        nullptr, nullptr, nullptr, nullptr, nullptr, d_im, d_s, workspace, stream);
+// ---- the exported forms (include/aladin_hip.h, ABI 11) ----------------------------------------------------------------------
+static bool set_ok(const aladin_set* v) { return v && v->data && v->len; }
+static bool grad_ok(const aladin_set_grad* v) { return v && v->data && v->stride_b >= 1 && v->stride_r >= 1; }
+static const char* bwd_common_check(const aladin_set* im, const aladin_set* s, const aladin_align_geom* g) {
+  if (!g) return "null geometry";
+  if (!set_ok(im) || !set_ok(s)) return "null set";
+  if (g->split) return nullptr;
+  return nullptr;
 }
 
-extern "C" int aladin_align_bwd_packed(const float* im, int64_t im_sb, int64_t im_sr, const int32_t* im_len, const float* s,
-                                       int64_t s_sb, int64_t s_st, const int32_t* s_len, const float* dS, int64_t ld_dS,
-                                       const float* gscale, const void* xm, const void* xe, const void* y,
-                                       const aladin_align_geom* geom, const int32_t* pairs, const int32_t* pair_count,
-                                       float* d_im, float* d_s, void* workspace, void* stream) {
-  if (!geom) { aladin_set_error("align_bwd_packed: null geometry"); return ALADIN_ERR_ARG; }
-  if (geom->split) { aladin_set_error("align_bwd_packed: split-precision operands are forward-only (evaluation); pack with ALADIN_PRECISION_FP16"); return ALADIN_ERR_UNSUPPORTED; }
-  return align_bwd_impl(im, im_sb, im_sr, im_len, s, s_sb, s_st, s_len, geom->Bi, geom->Bc, geom->R, geom->T, geom->D, dS,
-                        ld_dS, gscale, xm, xe, y, geom, pairs, pair_count, d_im, d_s, workspace, stream, geom->x_tail,
-                        geom->y_tail);
+extern "C" int aladin_align_bwd(const aladin_set* im, const aladin_set* s, const aladin_align_geom* g, const aladin_packed* p,
+                                const float* dS, int64_t ld_dS, const float* gscale, const int32_t* pairs, const int32_t* pair_count,
+                                const aladin_set_grad* d_im, const aladin_set_grad* d_s, void* workspace, int flags, void* stream) {
+  if (const char* e = bwd_common_check(im, s, g)) { aladin_set_error("align_bwd: %s", e); return ALADIN_ERR_ARG; }
+  if (g->split) { aladin_set_error("align_bwd: split-precision operands are forward-only (evaluation); pack with ALADIN_PRECISION_FP16"); return ALADIN_ERR_UNSUPPORTED; }
+  if (flags & ~(ALADIN_BWD_PARTNERS_FP16 | ALADIN_BWD_OWN_ROW_FP16 | ALADIN_BWD_DENSE | ALADIN_BWD_DENSE_GATHER)) { aladin_set_error("align_bwd: unknown flags %d", flags); return ALADIN_ERR_ARG; }
+  if (!grad_ok(d_im) || !grad_ok(d_s)) { aladin_set_error("align_bwd: bad gradient views"); return ALADIN_ERR_ARG; }
+  if ((pairs == nullptr) != (pair_count == nullptr)) { aladin_set_error("align_bwd: pairs and pair_count go together"); return ALADIN_ERR_ARG; }
+  const bool have = p && p->xm && p->y;
+  return align_bwd_impl(im->data, im->stride_b, im->stride_r, im->len, s->data, s->stride_b, s->stride_r, s->len, g->Bi, g->Bc, g->R, g->T,
+                        g->D, dS, ld_dS, gscale, have ? p->xm : nullptr, have ? p->xe : nullptr, have ? p->y : nullptr,
+                        have ? p->rnorm : nullptr, have ? g : nullptr, pairs, pair_count, d_im->data, d_s->data, workspace, stream, g->x_tail,
+                        g->y_tail, d_im->stride_b, d_im->stride_r, d_s->stride_b, d_s->stride_r, BWD_ALL, nullptr, flags);
 }
 
-extern "C" int aladin_align_bwd_packed_strided(const float* im, int64_t im_sb, int64_t im_sr, const int32_t* im_len, const float* s,
-                                               int64_t s_sb, int64_t s_st, const int32_t* s_len, const float* dS, int64_t ld_dS,
-                                               const float* gscale, const void* xm, const void* xe, const void* y,
-                                               const aladin_align_geom* geom, const int32_t* pairs, const int32_t* pair_count,
-                                               float* d_im, int64_t d_im_stride_b, int64_t d_im_stride_r, float* d_s,
-                                               int64_t d_s_stride_b, int64_t d_s_stride_t, void* workspace, void* stream) {
-  if (!geom) { aladin_set_error("align_bwd_packed_strided: null geometry"); return ALADIN_ERR_ARG; }
-  if (geom->split) { aladin_set_error("align_bwd_packed_strided: split-precision operands are forward-only (evaluation); pack with ALADIN_PRECISION_FP16"); return ALADIN_ERR_UNSUPPORTED; }
-  if (d_im_stride_b < 1 || d_im_stride_r < 1 || d_s_stride_b < 1 || d_s_stride_t < 1) { aladin_set_error("align_bwd_packed_strided: bad output strides"); return ALADIN_ERR_ARG; }
-  return align_bwd_impl(im, im_sb, im_sr, im_len, s, s_sb, s_st, s_len, geom->Bi, geom->Bc, geom->R, geom->T, geom->D, dS,
-                        ld_dS, gscale, (xm && y) ? xm : nullptr, xe, (xm && y) ? y : nullptr, (xm && y) ? geom : nullptr, pairs,
-                        pair_count, d_im, d_s, workspace, stream, geom->x_tail, geom->y_tail, d_im_stride_b, d_im_stride_r,
-                        d_s_stride_b, d_s_stride_t);
+// workspace of the fused training node: [side-GEMM scratch | hinge statistics | backward base workspace (table, dS^T)]
+struct TripletWs { void* e; void* hinge; void* bwd; };
+static size_t triplet_ws_layout(const aladin_align_geom* g, char* base, TripletWs* w) {
+  auto up = [](size_t v) { return (v + 255) / 256 * 256; };
+  size_t off = 0;
+  if (w) w->e = base + off;
+  off += up((size_t)g->e_bytes + 16);
+  if (w) w->hinge = base + off;
+  off += up(aladin_hinge_workspace_bytes(g->Bc));
+  if (w) w->bwd = base + off;
+  off += bwd_base_bytes(g->Bi, g->Bc, g->T);
+  return off;
+}
+static bool triplet_supported(const aladin_align_geom* g) {
+  return g->Bi == g->Bc && !g->split && (g->mrows == 32 || g->mrows == 48 || (g->mrows == 64 && g->rem == 0)) && g->tp16 <= 4 &&
+         g->D % 4 == 0 && g->D <= 1024;
 }
 
-extern "C" int aladin_align_bwd_packed_strided_ex(const float* im, int64_t im_sb, int64_t im_sr, const int32_t* im_len, const float* s,
-                                                  int64_t s_sb, int64_t s_st, const int32_t* s_len, const float* dS, int64_t ld_dS,
-                                                  const float* gscale, const void* xm, const void* xe, const void* y,
-                                                  const aladin_align_geom* geom, const int32_t* pairs, const int32_t* pair_count,
-                                                  float* d_im, int64_t d_im_stride_b, int64_t d_im_stride_r, float* d_s,
-                                                  int64_t d_s_stride_b, int64_t d_s_stride_t, void* workspace, int flags, void* stream) {
-  if (!geom) { aladin_set_error("align_bwd_packed_strided_ex: null geometry"); return ALADIN_ERR_ARG; }
-  if (geom->split) { aladin_set_error("align_bwd_packed_strided_ex: split-precision operands are forward-only (evaluation); pack with ALADIN_PRECISION_FP16"); return ALADIN_ERR_UNSUPPORTED; }
-  if (flags & ~(ALADIN_BWD_PARTNERS_FP16 | ALADIN_BWD_DENSE | ALADIN_BWD_DENSE_GATHER)) { aladin_set_error("align_bwd_packed_strided_ex: unknown flags %d", flags); return ALADIN_ERR_ARG; }
-  if (d_im_stride_b < 1 || d_im_stride_r < 1 || d_s_stride_b < 1 || d_s_stride_t < 1) { aladin_set_error("align_bwd_packed_strided_ex: bad output strides"); return ALADIN_ERR_ARG; }
-  return align_bwd_impl(im, im_sb, im_sr, im_len, s, s_sb, s_st, s_len, geom->Bi, geom->Bc, geom->R, geom->T, geom->D, dS,
-                        ld_dS, gscale, (xm && y) ? xm : nullptr, xe, (xm && y) ? y : nullptr, (xm && y) ? geom : nullptr, pairs,
-                        pair_count, d_im, d_s, workspace, stream, geom->x_tail, geom->y_tail, d_im_stride_b, d_im_stride_r,
-                        d_s_stride_b, d_s_stride_t, BWD_ALL, nullptr, flags);
+extern "C" size_t aladin_align_triplet_workspace_bytes(const aladin_align_geom* g) {
+  if (!g || g->Bi < 1 || g->Bc < 1) return 0;
+  return triplet_ws_layout(g, nullptr, nullptr);
 }
 
-extern "C" int aladin_hinge_argmax_fused(const float* S, int64_t ldS, float margin, float* loss, float* dS, void* hinge_workspace,
-                                         const float* im, int64_t im_sb, int64_t im_sr, const int32_t* im_len, const float* s,
-                                         int64_t s_sb, int64_t s_st, const int32_t* s_len, const void* xm, const void* xe,
-                                         const void* y, const aladin_align_geom* geom, void* bwd_workspace, void* stream) {
-  if (!geom || !xm || !y) { aladin_set_error("hinge_argmax_fused: needs the packed operands and their geometry"); return ALADIN_ERR_ARG; }
-  if (geom->split) { aladin_set_error("hinge_argmax_fused: split-precision operands are forward-only (evaluation)"); return ALADIN_ERR_UNSUPPORTED; }
-  if (geom->Bi != geom->Bc) { aladin_set_error("hinge_argmax_fused: the hinge needs a square score matrix (%d x %d)", geom->Bi, geom->Bc); return ALADIN_ERR_ARG; }
-  const HingeArgs ha = {S, ldS, margin, loss, dS, hinge_workspace, nullptr};
-  return align_bwd_impl(im, im_sb, im_sr, im_len, s, s_sb, s_st, s_len, geom->Bi, geom->Bc, geom->R, geom->T, geom->D, nullptr, 0,
-                        nullptr, xm, xe, y, geom, nullptr, nullptr, nullptr, nullptr, bwd_workspace, stream, geom->x_tail,
-                        geom->y_tail, 0, 0, 0, 0, BWD_HINGE_ARGMAX, &ha);
+extern "C" int aladin_align_triplet_fwd(const aladin_set* im, const aladin_set* s, const aladin_align_geom* g, float margin,
+                                        const aladin_packed* p, float* S, int64_t ldS, float* loss, float* dS, void* workspace,
+                                        void* stream) {
+  if (const char* e = bwd_common_check(im, s, g)) { aladin_set_error("align_triplet_fwd: %s", e); return ALADIN_ERR_ARG; }
+  if (!p || !p->xm || !p->y || (g->rem && !p->xe) || !S || !loss || !dS || !workspace || ldS < g->Bc) { aladin_set_error("align_triplet_fwd: null argument"); return ALADIN_ERR_ARG; }
+  if (!triplet_supported(g)) {
+    aladin_set_error("align_triplet_fwd: square fp16 problems of the pair kernel's classes only (Bi=%d Bc=%d mrows=%d rem=%d tp16=%d D=%d split=%d)",
+                     g->Bi, g->Bc, g->mrows, g->rem, g->tp16, g->D, g->split);
+    return ALADIN_ERR_UNSUPPORTED;
+  }
+  TripletWs w;
+  triplet_ws_layout(g, (char*)workspace, &w);
+  int rc = aladin_internal_pack(im, s, g, p, (hipStream_t)stream);
+  if (rc) return rc;
+  rc = aladin_internal_scores(p->xm, p->xe, p->y, g, w.e, S, ldS, 0, stream);
+  if (rc) return rc;
+  const HingeArgs ha = {S, ldS, margin, loss, dS, w.hinge, nullptr};
+  return align_bwd_impl(im->data, im->stride_b, im->stride_r, im->len, s->data, s->stride_b, s->stride_r, s->len, g->Bi, g->Bc, g->R, g->T,
+                        g->D, nullptr, 0, nullptr, p->xm, p->xe, p->y, p->rnorm, g, nullptr, nullptr, nullptr, nullptr, w.bwd, stream,
+                        g->x_tail, g->y_tail, 0, 0, 0, 0, BWD_HINGE_ARGMAX, &ha);
 }
 
-extern "C" int aladin_align_bwd_rows(const float* im, int64_t im_sb, int64_t im_sr, const int32_t* im_len, const float* s,
-                                     int64_t s_sb, int64_t s_st, const int32_t* s_len, const float* dS, int64_t ld_dS,
-                                     const float* gscale, const aladin_align_geom* geom, float* d_im, int64_t d_im_stride_b,
-                                     int64_t d_im_stride_r, float* d_s, int64_t d_s_stride_b, int64_t d_s_stride_t,
-                                     void* bwd_workspace, void* stream) {
-  if (!geom) { aladin_set_error("align_bwd_rows: null geometry"); return ALADIN_ERR_ARG; }
-  if (d_im_stride_b < 1 || d_im_stride_r < 1 || d_s_stride_b < 1 || d_s_stride_t < 1) { aladin_set_error("align_bwd_rows: bad output strides"); return ALADIN_ERR_ARG; }
-  return align_bwd_impl(im, im_sb, im_sr, im_len, s, s_sb, s_st, s_len, geom->Bi, geom->Bc, geom->R, geom->T, geom->D, dS, ld_dS,
-                        gscale, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, d_im, d_s, bwd_workspace, stream,
-                        geom->x_tail, geom->y_tail, d_im_stride_b, d_im_stride_r, d_s_stride_b, d_s_stride_t, BWD_ROWS, nullptr);
+// bwd_ws: the backward base workspace itself (aladin_heads_small_fwd_argmax's caller) or nullptr = inside the triplet workspace
+static int triplet_bwd_impl(const aladin_set* im, const aladin_set* s, const aladin_align_geom* g, const aladin_packed* p, const float* dS,
+                            const float* gscale, const aladin_set_grad* d_im, const aladin_set_grad* d_s, void* bwd_ws, int flags,
+                            void* stream) {
+  if (flags & ~(ALADIN_BWD_PARTNERS_FP16 | ALADIN_BWD_OWN_ROW_FP16)) { aladin_set_error("align_triplet_bwd: unknown flags %d", flags); return ALADIN_ERR_ARG; }
+  if (!grad_ok(d_im) || !grad_ok(d_s) || !dS || !bwd_ws) { aladin_set_error("align_triplet_bwd: null argument"); return ALADIN_ERR_ARG; }
+  return align_bwd_impl(im->data, im->stride_b, im->stride_r, im->len, s->data, s->stride_b, s->stride_r, s->len, g->Bi, g->Bc, g->R, g->T,
+                        g->D, dS, g->Bc, gscale, p ? p->xm : nullptr, p ? p->xe : nullptr, p ? p->y : nullptr, p ? p->rnorm : nullptr, g,
+                        nullptr, nullptr, d_im->data, d_s->data, bwd_ws, stream, g->x_tail, g->y_tail, d_im->stride_b, d_im->stride_r,
+                        d_s->stride_b, d_s->stride_r, BWD_ROWS, nullptr, flags);
 }
 
-extern "C" int aladin_align_bwd_rows_ex(const float* im, int64_t im_sb, int64_t im_sr, const int32_t* im_len, const float* s,
-                                        int64_t s_sb, int64_t s_st, const int32_t* s_len, const float* dS, int64_t ld_dS,
-                                        const float* gscale, const void* xm, const void* xe, const void* y,
-                                        const aladin_align_geom* geom, float* d_im, int64_t d_im_stride_b,
-                                        int64_t d_im_stride_r, float* d_s, int64_t d_s_stride_b, int64_t d_s_stride_t,
-                                        void* bwd_workspace, int flags, void* stream) {
-  if (!geom) { aladin_set_error("align_bwd_rows_ex: null geometry"); return ALADIN_ERR_ARG; }
-  if (flags & ~ALADIN_BWD_PARTNERS_FP16) { aladin_set_error("align_bwd_rows_ex: unknown flags %d", flags); return ALADIN_ERR_ARG; }
-  if (d_im_stride_b < 1 || d_im_stride_r < 1 || d_s_stride_b < 1 || d_s_stride_t < 1) { aladin_set_error("align_bwd_rows_ex: bad output strides"); return ALADIN_ERR_ARG; }
-  return align_bwd_impl(im, im_sb, im_sr, im_len, s, s_sb, s_st, s_len, geom->Bi, geom->Bc, geom->R, geom->T, geom->D, dS, ld_dS,
-                        gscale, xm, xe, y, geom, nullptr, nullptr, d_im, d_s, bwd_workspace, stream,
-                        geom->x_tail, geom->y_tail, d_im_stride_b, d_im_stride_r, d_s_stride_b, d_s_stride_t, BWD_ROWS, nullptr, flags);
+extern "C" int aladin_align_triplet_bwd(const aladin_set* im, const aladin_set* s, const aladin_align_geom* g, const aladin_packed* p,
+                                        const float* dS, const float* gscale, const aladin_set_grad* d_im, const aladin_set_grad* d_s,
+                                        void* workspace, int flags, void* stream) {
+  if (const char* e = bwd_common_check(im, s, g)) { aladin_set_error("align_triplet_bwd: %s", e); return ALADIN_ERR_ARG; }
+  if (!workspace) { aladin_set_error("align_triplet_bwd: null workspace"); return ALADIN_ERR_ARG; }
+  void* bwd_ws = workspace;
+  if (!(flags & ALADIN_TRIPLET_BWD_BASE_WORKSPACE)) {
+    TripletWs w;
+    triplet_ws_layout(g, (char*)workspace, &w);
+    bwd_ws = w.bwd;
+  }
+  return triplet_bwd_impl(im, s, g, p, dS, gscale, d_im, d_s, bwd_ws, flags & ~ALADIN_TRIPLET_BWD_BASE_WORKSPACE, stream);
 }
 
 extern "C" int aladin_heads_small_fwd_argmax(const float* img, int64_t ld_img, const float* cap, int64_t ld_cap, const float* S,
                                              int64_t ld_S, int D_emb, float margin, int flags, float temperature, float eps,
                                              float w_match, float w_align, float w_dist, float* M, float* terms, float* total,
                                              float* dM_hinge, float* dM_listnet, float* dS, void* heads_workspace,
-                                             const float* im, int64_t im_sb, int64_t im_sr, const int32_t* im_len, const float* s,
-                                             int64_t s_sb, int64_t s_st, const int32_t* s_len, const void* xm, const void* xe,
-                                             const void* y, const aladin_align_geom* geom, void* bwd_workspace, void* stream) {
-  if (!geom || !xm || !y) { aladin_set_error("heads_small_fwd_argmax: needs the packed operands and their geometry"); return ALADIN_ERR_ARG; }
+                                             const aladin_set* im, const aladin_set* s, const aladin_align_geom* geom,
+                                             const aladin_packed* p, void* bwd_workspace, void* stream) {
+  if (const char* e = bwd_common_check(im, s, geom)) { aladin_set_error("heads_small_fwd_argmax: %s", e); return ALADIN_ERR_ARG; }
+  if (!p || !p->xm || !p->y) { aladin_set_error("heads_small_fwd_argmax: needs the packed operands and their geometry"); return ALADIN_ERR_ARG; }
   if (geom->split) { aladin_set_error("heads_small_fwd_argmax: split-precision operands are forward-only (evaluation)"); return ALADIN_ERR_UNSUPPORTED; }
   const int B = geom->Bi;
   if (geom->Bi != geom->Bc || B > SB_MAX) { aladin_set_error("heads_small_fwd_argmax: square batches of at most %d (%d x %d)", SB_MAX, geom->Bi, geom->Bc); return ALADIN_ERR_UNSUPPORTED; }
@@ -1030,7 +1056,7 @@ extern "C" int aladin_heads_small_fwd_argmax(const float* img, int64_t ld_img, c
   const SmallFin f = {M, S, ld_S, B, margin, 1, flags, temperature, eps, w_match, w_align, w_dist, st, terms, total, dM_hinge,
                       dM_listnet, dS, nullptr, nullptr, nullptr};
   const HingeArgs ha = {S, ld_S, margin, terms, dS, heads_workspace, &f};
-  return align_bwd_impl(im, im_sb, im_sr, im_len, s, s_sb, s_st, s_len, geom->Bi, geom->Bc, geom->R, geom->T, geom->D, nullptr, 0,
-                        nullptr, xm, xe, y, geom, nullptr, nullptr, nullptr, nullptr, bwd_workspace, stream, geom->x_tail,
-                        geom->y_tail, 0, 0, 0, 0, BWD_HINGE_ARGMAX, &ha);
+  return align_bwd_impl(im->data, im->stride_b, im->stride_r, im->len, s->data, s->stride_b, s->stride_r, s->len, geom->Bi, geom->Bc,
+                        geom->R, geom->T, geom->D, nullptr, 0, nullptr, p->xm, p->xe, p->y, p->rnorm, geom, nullptr, nullptr, nullptr, nullptr,
+                        bwd_workspace, stream, geom->x_tail, geom->y_tail, 0, 0, 0, 0, BWD_HINGE_ARGMAX, &ha);
 }

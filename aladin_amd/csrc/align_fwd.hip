@@ -76,16 +76,8 @@ static int scores_side_max() {
   return v;
 }
 
-extern "C" int aladin_align_geometry(int Bi, int Bc, int R, int T, int D, aladin_align_geom* g) {
-  return aladin_align_geometry_ex(Bi, Bc, R, T, D, 0, 2, g);       // images: drop region 0; captions: token 0 and the last two
-}
-
-extern "C" int aladin_align_geometry_ex(int Bi, int Bc, int R, int T, int D, int x_tail, int y_tail, aladin_align_geom* g) {
-  return aladin_align_geometry_mode(Bi, Bc, R, T, D, x_tail, y_tail, ALADIN_PRECISION_FP16, g);
-}
-
-extern "C" int aladin_align_geometry_mode(int Bi, int Bc, int R, int T, int D, int x_tail, int y_tail, int precision,
-                                          aladin_align_geom* g) {
+extern "C" int aladin_align_geometry(int Bi, int Bc, int R, int T, int D, int x_tail, int y_tail, int precision,
+                                     aladin_align_geom* g) {
   if (precision != ALADIN_PRECISION_FP16 && precision != ALADIN_PRECISION_SPLIT && precision != ALADIN_PRECISION_SPLIT_TABLE) { aladin_set_error("align_geometry: unknown precision %d", precision); return ALADIN_ERR_ARG; }
   if (!g || Bi < 1 || Bc < 1 || D < 1) { aladin_set_error("align_geometry: bad sizes Bi=%d Bc=%d D=%d", Bi, Bc, D); return ALADIN_ERR_ARG; }
   if (x_tail < 0 || y_tail < 0 || x_tail > 8 || y_tail > 8) { aladin_set_error("align_geometry: bad tails %d %d", x_tail, y_tail); return ALADIN_ERR_ARG; }
@@ -134,6 +126,7 @@ extern "C" int aladin_align_geometry_mode(int Bi, int Bc, int R, int T, int D, i
   g->xe_bytes = g->xe_rows * g->Dp * 2;
   g->y_bytes = g->y_rows * g->Dp * 2;
   g->e_bytes = g->xe_rows * g->y_rows * 4;
+  g->rnorm_bytes = (g->xm_rows + g->xe_rows + g->y_rows) * 4;
   return ALADIN_OK;
 }
 
@@ -150,9 +143,11 @@ extern "C" int aladin_align_geometry_mode(int Bi, int Bc, int R, int T, int D, i
 // len_ptr != nullptr: the row only counts if pos < clamp(*len_ptr - 1 - tail, 0, cap) (the masks of alad/loss.py:103-116);
 // the fast path issues the row's loads BEFORE it knows (the row exists in memory either way), so that the length and the
 // row arrive together instead of one memory latency after the other.
+// inv_out (may be nullptr): receives 1 / max(|x|, 1e-12) of the row -- what the backward's normalise step divides by, so that it
+// need not read the raw fp32 row again (0 for a zero row: such a row never carries a gradient).
 __device__ __forceinline__ void pack_row(const float* __restrict__ src, half_t* __restrict__ dst, int D, int Dp,
                                          int lane, bool vec4, int seg = 0, const int32_t* __restrict__ len_ptr = nullptr,
-                                         int pos = 0, int tail = 0, int cap = 0) {
+                                         int pos = 0, int tail = 0, int cap = 0, float* __restrict__ inv_out = nullptr) {
   const int width = seg ? 3 * Dp : Dp;
   const bool fast = vec4 && !seg && D <= 1024;
   if (src != nullptr && len_ptr != nullptr && !fast) {
@@ -163,6 +158,7 @@ __device__ __forceinline__ void pack_row(const float* __restrict__ src, half_t* 
   // src == nullptr -> zero row
   if (src == nullptr) {
     for (int c = lane * 8; c < width; c += 64 * 8) *reinterpret_cast<half8*>(dst + c) = half8{0, 0, 0, 0, 0, 0, 0, 0};
+    if (inv_out && lane == 0) *inv_out = 0.f;
     return;
   }
   if (fast) {
@@ -179,6 +175,7 @@ __device__ __forceinline__ void pack_row(const float* __restrict__ src, half_t* 
       L = L < 0 ? 0 : (L > cap ? cap : L);
       if (pos >= L) {                                   // masked after all: a zero row
         for (int c = lane * 8; c < width; c += 64 * 8) *reinterpret_cast<half8*>(dst + c) = half8{0, 0, 0, 0, 0, 0, 0, 0};
+        if (inv_out && lane == 0) *inv_out = 0.f;
         return;
       }
     }
@@ -186,6 +183,7 @@ __device__ __forceinline__ void pack_row(const float* __restrict__ src, half_t* 
     for (int k = 0; k < 4; ++k) ss = sumsq4(ss, v[k]);
     ss = wave_sum(ss);
     const float inv = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
+    if (inv_out && lane == 0) *inv_out = inv;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int c = lane * 4 + 256 * k;
@@ -204,6 +202,7 @@ __device__ __forceinline__ void pack_row(const float* __restrict__ src, half_t* 
   }
   ss = wave_sum(ss);
   const float inv = 1.0f / fmaxf(sqrtf(ss), 1e-12f);        // F.normalize eps (alad/loss.py:80-81)
+  if (inv_out && lane == 0) *inv_out = inv;
   if (seg) {
     half_t* d_lo = dst + (seg == 1 ? Dp : 2 * Dp);          // [hi | lo | hi]  or  [hi | hi | lo]
     half_t* d_hi2 = dst + (seg == 1 ? 2 * Dp : Dp);
@@ -236,7 +235,7 @@ __global__ __launch_bounds__(256) void pack_images_kernel(const float* __restric
                                                           const int32_t* __restrict__ im_len, int Bi, int Rq, int x_tail, int D,
                                                           int Dp, int mrows, int rem, int64_t xm_rows,
                                                           int64_t total_rows, half_t* __restrict__ xm,
-                                                          half_t* __restrict__ xe, int vec4, int split) {
+                                                          half_t* __restrict__ xe, int vec4, int split, float* __restrict__ rnorm) {
   const int lane = threadIdx.x & 63;
   const int64_t d = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (d >= total_rows) return;
@@ -259,13 +258,13 @@ __global__ __launch_bounds__(256) void pack_images_kernel(const float* __restric
     Li = Li < 0 ? 0 : (Li > Rq ? Rq : Li);
     if (rho < Li) src = im + i * sb + (int64_t)(rho + 1) * sr;     // region 0 dropped (alad/loss.py:87)
   }
-  pack_row(src, dst, D, split ? Dp / 3 : Dp, lane, vec4 != 0, split ? 1 : 0);
+  pack_row(src, dst, D, split ? Dp / 3 : Dp, lane, vec4 != 0, split ? 1 : 0, nullptr, 0, 0, 0, rnorm ? rnorm + d : nullptr);      // rnorm: [xm rows | xe rows | y rows]
 }
 
 __global__ __launch_bounds__(256) void pack_captions_kernel(const float* __restrict__ s, int64_t sb, int64_t st,
                                                             const int32_t* __restrict__ s_len, int Bc, int Tq, int y_tail, int D,
                                                             int Dp, int tpad, int64_t total_rows,
-                                                            half_t* __restrict__ y, int vec4, int split) {
+                                                            half_t* __restrict__ y, int vec4, int split, float* __restrict__ rnorm_y) {
   const int lane = threadIdx.x & 63;
   const int64_t d = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (d >= total_rows) return;
@@ -276,7 +275,7 @@ __global__ __launch_bounds__(256) void pack_captions_kernel(const float* __restr
     Lj = Lj < 0 ? 0 : (Lj > Tq ? Tq : Lj);
     if (w < Lj) src = s + j * sb + (int64_t)(w + 1) * st;          // token 0 dropped (alad/loss.py:88)
   }
-  pack_row(src, y + d * Dp, D, split ? Dp / 3 : Dp, lane, vec4 != 0, split ? 2 : 0);
+  pack_row(src, y + d * Dp, D, split ? Dp / 3 : Dp, lane, vec4 != 0, split ? 2 : 0, nullptr, 0, 0, 0, rnorm_y ? rnorm_y + d : nullptr);
 }
 
 // both operand sets in one launch (rows [0, img_rows) -> images, the rest -> captions)
@@ -286,7 +285,7 @@ __global__ __launch_bounds__(256) void pack_both_kernel(const float* __restrict_
                                                         int Bc, int Rq, int Tq, int x_tail, int y_tail, int D, int Dp, int mrows, int rem, int64_t xm_rows,
                                                         int64_t img_rows, int64_t total_rows, int tpad,
                                                         half_t* __restrict__ xm, half_t* __restrict__ xe,
-                                                        half_t* __restrict__ y, int vec_i, int vec_s, int split) {
+                                                        half_t* __restrict__ y, int vec_i, int vec_s, int split, float* __restrict__ rnorm) {
   const int lane = threadIdx.x & 63;
   const int64_t d = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (d >= total_rows) return;
@@ -320,44 +319,44 @@ __global__ __launch_bounds__(256) void pack_both_kernel(const float* __restrict_
     vec = vec_s != 0;
     seg = split ? 2 : 0;
   }
-  pack_row(src, dst, D, split ? Dp / 3 : Dp, lane, vec, seg, len_ptr, pos, tail, cap);
+  pack_row(src, dst, D, split ? Dp / 3 : Dp, lane, vec, seg, len_ptr, pos, tail, cap, rnorm ? rnorm + d : nullptr);          // d runs over [xm | xe | y] rows
 }
 
 static int is_vec4_ok(const void* p, int64_t s0, int64_t s1, int D) {
   return (D % 4 == 0) && (s0 % 4 == 0) && (s1 % 4 == 0) && (((uintptr_t)p & 15) == 0);
 }
 
-extern "C" int aladin_align_pack_images(const float* im, int64_t stride_b, int64_t stride_r, const int32_t* im_len,
-                                        const aladin_align_geom* g, void* xm, void* xe, void* stream) {
-  if (!im || !im_len || !g || !xm || (g->rem && !xe)) { aladin_set_error("align_pack_images: null argument"); return ALADIN_ERR_ARG; }
-  const int64_t total = g->xm_rows + g->xe_rows;
-  const unsigned grid = (unsigned)((total + 3) / 4);
-  hipLaunchKernelGGL(pack_images_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, im, stride_b, stride_r, im_len,
-                     g->Bi, g->Rq, g->x_tail, g->D, g->Dp, g->mrows, g->rem > 0 ? g->rem : 1, g->xm_rows, total, (half_t*)xm, (half_t*)xe,
-                     is_vec4_ok(im, stride_b, stride_r, g->D), g->split);
-  return aladin_check_launch("pack_images_kernel");
-}
+static int set_ok(const aladin_set* v) { return v && v->data && v->len; }
 
-extern "C" int aladin_align_pack_captions(const float* s, int64_t stride_b, int64_t stride_t, const int32_t* s_len,
-                                          const aladin_align_geom* g, void* y, void* stream) {
-  if (!s || !s_len || !g || !y) { aladin_set_error("align_pack_captions: null argument"); return ALADIN_ERR_ARG; }
-  const unsigned grid = (unsigned)((g->y_rows + 3) / 4);
-  hipLaunchKernelGGL(pack_captions_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, s, stride_b, stride_t, s_len,
-                     g->Bc, g->Tq, g->y_tail, g->D, g->Dp, g->trows, g->y_rows, (half_t*)y,
-                     is_vec4_ok(s, stride_b, stride_t, g->D), g->split);
+// both sets in ONE launch when both are given (rows [0, img_rows) -> images, the rest -> captions)
+int aladin_internal_pack(const aladin_set* im, const aladin_set* s, const aladin_align_geom* g, const aladin_packed* out, hipStream_t st) {
+  if (!g || !out || (!im && !s)) { aladin_set_error("align_pack: null argument"); return ALADIN_ERR_ARG; }
+  if ((im && (!set_ok(im) || !out->xm || (g->rem && !out->xe))) || (s && (!set_ok(s) || !out->y))) { aladin_set_error("align_pack: null argument"); return ALADIN_ERR_ARG; }
+  const int64_t img_rows = g->xm_rows + g->xe_rows;
+  const int rem1 = g->rem > 0 ? g->rem : 1;
+  if (im && s) {
+    const int64_t total = img_rows + g->y_rows;
+    hipLaunchKernelGGL(pack_both_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, st, im->data, im->stride_b, im->stride_r, im->len,
+                       s->data, s->stride_b, s->stride_r, s->len, g->Bi, g->Bc, g->Rq, g->Tq, g->x_tail, g->y_tail, g->D, g->Dp, g->mrows, rem1,
+                       g->xm_rows, img_rows, total, g->trows, (half_t*)out->xm, (half_t*)out->xe, (half_t*)out->y,
+                       is_vec4_ok(im->data, im->stride_b, im->stride_r, g->D), is_vec4_ok(s->data, s->stride_b, s->stride_r, g->D), g->split, out->rnorm);
+    return aladin_check_launch("pack_both_kernel");
+  }
+  if (im) {
+    hipLaunchKernelGGL(pack_images_kernel, dim3((unsigned)((img_rows + 3) / 4)), dim3(256), 0, st, im->data, im->stride_b, im->stride_r, im->len,
+                       g->Bi, g->Rq, g->x_tail, g->D, g->Dp, g->mrows, rem1, g->xm_rows, img_rows, (half_t*)out->xm, (half_t*)out->xe,
+                       is_vec4_ok(im->data, im->stride_b, im->stride_r, g->D), g->split, out->rnorm);
+    return aladin_check_launch("pack_images_kernel");
+  }
+  hipLaunchKernelGGL(pack_captions_kernel, dim3((unsigned)((g->y_rows + 3) / 4)), dim3(256), 0, st, s->data, s->stride_b, s->stride_r, s->len,
+                     g->Bc, g->Tq, g->y_tail, g->D, g->Dp, g->trows, g->y_rows, (half_t*)out->y,
+                     is_vec4_ok(s->data, s->stride_b, s->stride_r, g->D), g->split, out->rnorm ? out->rnorm + img_rows : nullptr);
   return aladin_check_launch("pack_captions_kernel");
 }
 
-extern "C" int aladin_align_pack_both(const float* im, int64_t im_stride_b, int64_t im_stride_r, const int32_t* im_len,
-                                      const float* s, int64_t s_stride_b, int64_t s_stride_t, const int32_t* s_len,
-                                      const aladin_align_geom* g, void* xm, void* xe, void* y, void* stream) {
-  if (!im || !im_len || !s || !s_len || !g || !xm || !y || (g->rem && !xe)) { aladin_set_error("align_pack_both: null argument"); return ALADIN_ERR_ARG; }
-  const int64_t img_rows = g->xm_rows + g->xe_rows, total = img_rows + g->y_rows;
-  hipLaunchKernelGGL(pack_both_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, (hipStream_t)stream, im, im_stride_b,
-                     im_stride_r, im_len, s, s_stride_b, s_stride_t, s_len, g->Bi, g->Bc, g->Rq, g->Tq, g->x_tail, g->y_tail, g->D, g->Dp, g->mrows,
-                     g->rem > 0 ? g->rem : 1, g->xm_rows, img_rows, total, g->trows, (half_t*)xm, (half_t*)xe, (half_t*)y,
-                     is_vec4_ok(im, im_stride_b, im_stride_r, g->D), is_vec4_ok(s, s_stride_b, s_stride_t, g->D), g->split);
-  return aladin_check_launch("pack_both_kernel");
+extern "C" int aladin_align_pack(const aladin_set* im, const aladin_set* s, const aladin_align_geom* g, const aladin_packed* out,
+                                 void* stream) {
+  return aladin_internal_pack(im, s, g, out, (hipStream_t)stream);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1514,7 +1513,7 @@ static int dispatch_tp(const aladin_align_geom* g, const half_t* xm, const half_
                        float* S, int64_t ldS, int flags, hipStream_t stream) {
   constexpr int NT = (TP16 & 1) ? TP16 : TP16 / 2;
   if constexpr (TP16 <= 3)
-    if (g->trows == 16 * TP16 - 8) {                   // 8- / 24- / 40-word captions (aladin_align_geometry_mode): mrows 32, 48 or 64
+    if (g->trows == 16 * TP16 - 8) {                   // 8- / 24- / 40-word captions (aladin_align_geometry): mrows 32, 48 or 64
       constexpr int NTH = TP16 == 3 ? 2 : 1;             // y_rows is a multiple of 640 (128-column side tiles) / 384 (64)
       if (g->rem && !(flags & ALADIN_SCORES_REUSE_SIDE)) {
         int rc = launch_side<NTH>(g, xe, y, E, stream);  // 320-column side tiles measured slower (profiles/r04_ab_side_gemm_stages.txt)
@@ -1562,13 +1561,8 @@ __global__ __launch_bounds__(256) void scores_unscale_kernel(float* __restrict__
     S[(e / Bc) * ldS + (e % Bc)] *= ALADIN_SPLIT_UNSCALE;
 }
 
-extern "C" int aladin_align_scores(const void* xm, const void* xe, const void* y, const aladin_align_geom* g,
-                                   void* e_scratch, float* S, int64_t ldS, void* stream) {
-  return aladin_align_scores_ex(xm, xe, y, g, e_scratch, S, ldS, 0, stream);
-}
-
-extern "C" int aladin_align_scores_ex(const void* xm, const void* xe, const void* y, const aladin_align_geom* g,
-                                      void* e_scratch, float* S, int64_t ldS, int flags, void* stream) {
+int aladin_internal_scores(const void* xm, const void* xe, const void* y, const aladin_align_geom* g, void* e_scratch, float* S,
+                           int64_t ldS, int flags, void* stream) {
   if (!xm || !y || !g || !S || (g->rem && (!xe || !e_scratch))) { aladin_set_error("align_scores: null argument"); return ALADIN_ERR_ARG; }
   if (ldS < g->Bc) { aladin_set_error("align_scores: ldS %lld < Bc %d", (long long)ldS, g->Bc); return ALADIN_ERR_ARG; }
   hipStream_t st = (hipStream_t)stream;
@@ -1591,4 +1585,11 @@ extern "C" int aladin_align_scores_ex(const void* xm, const void* xe, const void
   int grid = (int)((n + 255) / 256); if (grid > 2048) grid = 2048;
   hipLaunchKernelGGL(scores_unscale_kernel, dim3(grid), dim3(256), 0, st, S, ldS, g->Bi, g->Bc);
   return aladin_check_launch("scores_unscale_kernel");
+}
+
+extern "C" int aladin_align_scores(const aladin_packed* p, const aladin_align_geom* g, void* e_scratch, float* S, int64_t ldS, int flags,
+                                   void* stream) {
+  if (!p) { aladin_set_error("align_scores: null argument"); return ALADIN_ERR_ARG; }
+  if (flags & ~ALADIN_SCORES_REUSE_SIDE) { aladin_set_error("align_scores: unknown flags %d", flags); return ALADIN_ERR_ARG; }
+  return aladin_internal_scores(p->xm, p->xe, p->y, g, e_scratch, S, ldS, flags, stream);
 }

@@ -24,7 +24,12 @@ int aladin_check_launch(const char* what);
 // bit mask indexed by the current device, thread-safe).  Returns ALADIN_OK or ALADIN_ERR_HIP.
 int aladin_reserve_lds(const void* kernel, int bytes, unsigned long long* done, const char* what);
 struct aladin_align_geom;
+struct aladin_set;
+struct aladin_packed;
 // align_fwd.hip: arg-max table of every pair from the split-precision tile kernel (see there)
+int aladin_internal_pack(const aladin_set* im, const aladin_set* s, const aladin_align_geom* g, const aladin_packed* out, hipStream_t st);
+int aladin_internal_scores(const void* xm, const void* xe, const void* y, const aladin_align_geom* g, void* e_scratch, float* S,
+                           int64_t ldS, int flags, void* stream);
 int aladin_internal_align_argmax(const aladin_align_geom* g, const void* xm, const void* xe, const void* y, float* E,
                                  const int32_t* im_len, const int32_t* s_len, uint8_t* table, int tstride, uint8_t* flags, hipStream_t stream);
 

@@ -1360,6 +1360,9 @@ static int retrieval_ranks_impl(const float* img, int64_t img_rs, const float* c
   int rc = sim_prepare(img, img_rs, cap, cap_rs, n_img, n_cap, D, workspace, &ws, &Mp, &Np, &Dp, st, rw.stats, rw.stats_zero_words, rank_i2t, n_img, rank_t2i,
                        n_cap, caps_per_img, rw.gt, rw.best_i2t, rw.best_t2i, &gt_done);
   if (rc) return rc;
+  // the band's 2^-14 |s| term allows for the fp32 rounding of at most ~2^10 more accumulator steps: wider rows take
+  // the exact path on every tile
+  if (Dp / 16 > 1024) force_exact = true;
   static unsigned long long lds_reserved[2] = {0, 0};
   const void* kern = force_exact ? (const void*)sim_screen_kernel<true> : (const void*)sim_screen_kernel<false>;
   if ((rc = aladin_reserve_lds(kern, SimCfg::LDS_BYTES, &lds_reserved[force_exact ? 1 : 0], "sim_screen"))) return rc;

@@ -138,30 +138,25 @@ __global__ __launch_bounds__(256) void store_pack_y_kernel(const half_t* __restr
 
 }  // namespace
 
-extern "C" int aladin_store_row_width(int D) {
+static int store_row_width_fp16(int D) {
   aladin_align_geom g;
-  if (aladin_align_geometry(1, 1, 2, 4, D, &g) != ALADIN_OK) return -1;
+  if (aladin_align_geometry(1, 1, 2, 4, D, 0, 2, ALADIN_PRECISION_FP16, &g) != ALADIN_OK) return -1;
   return g.Dp;
 }
 
-extern "C" int aladin_store_row_width_mode(int D, int precision) {
-  const int w = aladin_store_row_width(D);
+extern "C" int aladin_store_row_width(int D, int precision) {
+  const int w = store_row_width_fp16(D);
   return (w > 0 && precision == ALADIN_PRECISION_SPLIT) ? 2 * w : w;
 }
 
 extern "C" int aladin_store_append(const float* sets, int64_t stride_b, int64_t stride_r, const int32_t* lens, int B, int L,
-                                   int D, int tail, const int64_t* offsets, void* rows, void* stream) {
-  return aladin_store_append_mode(sets, stride_b, stride_r, lens, B, L, D, tail, offsets, rows, ALADIN_PRECISION_FP16, stream);
-}
-
-extern "C" int aladin_store_append_mode(const float* sets, int64_t stride_b, int64_t stride_r, const int32_t* lens, int B, int L,
-                                        int D, int tail, const int64_t* offsets, void* rows, int precision, void* stream) {
+                                   int D, int tail, const int64_t* offsets, void* rows, int precision, void* stream) {
   if (precision != ALADIN_PRECISION_FP16 && precision != ALADIN_PRECISION_SPLIT) { aladin_set_error("store_append: unknown precision %d", precision); return ALADIN_ERR_ARG; }
   if (!sets || !lens || !offsets || !rows || B < 1 || L < 2 || D < 1 || tail < 0) {
     aladin_set_error("store_append: bad argument (B=%d L=%d D=%d tail=%d)", B, L, D, tail);
     return ALADIN_ERR_ARG;
   }
-  const int Dp = aladin_store_row_width(D);
+  const int Dp = store_row_width_fp16(D);
   if (Dp < D) return ALADIN_ERR_ARG;
   const int64_t total = (int64_t)B * (L - 1);
   const int vec4 = (D % 4 == 0) && (stride_b % 4 == 0) && (stride_r % 4 == 0) && (((uintptr_t)sets & 15) == 0);

@@ -107,26 +107,36 @@ def set_eval_precision(precision):
     return old
 
 
-# How the backward's row kernel fetches its partner rows:
-#   'exact'  the raw fp32 sets, normalised again in fp32 (default: gradients within ~3e-5 of the reference's autograd);
-#   'fp16'   ALADIN_BWD_PARTNERS_FP16 -- the forward's packed fp16 unit vectors: fewer bytes, ~1.5e-4 of the largest
-#            gradient entry (inside north_star's 1e-3).  Needs the packed operands, i.e. the fp16 pair kernel's shapes.
-_BWD_PARTNERS = ['exact']
+# Where the backward's row kernel takes its unit vectors from (tools/experiments/bwd_precision_probe.py on every reference fixture,
+# profiles/r05_bwd_precision_probe.txt; the gate is 5e-4 of the largest gradient entry = half of north_star's 1e-3):
+#   'fp16'      ALADIN_BWD_PARTNERS_FP16 (default since round 5, VERDICT r4 item 2 iii): the PARTNER rows -- the unit vectors a
+#               gradient row is a weighted sum of -- from the forward's packed fp16 operands: worst 4.3e-4 over the fixtures (one
+#               fp16 rounding: <= 2^-11 relative per component), row kernel 43.5 -> 34.0 us at B = 256, 302 -> 217 MB;
+#   'fp16-own'  + ALADIN_BWD_OWN_ROW_FP16 (item 2 i): the output row's own unit vector and inverse norm from the packed operands too
+#               -- the raw fp32 sets are not read by the row kernel at all: 30.4 us.  Same error wherever D >= 128; on the D = 64
+#               structured fixture (cosines near 1: the projection term is as large as the gradient) 5.8e-4 -- past the gate, so an opt-in;
+#   'exact'     the raw fp32 sets, normalised again in fp32: 3e-7 of the reference's autograd.
+# The fp16 modes apply wherever the forward's packed operands (with their inverse norms) reach the backward.
+_BWD_PARTNERS = ['fp16']
+_BWD_OWN_ROW_FP16 = [False]
 
 
 def set_backward_precision(mode):
-    """'exact' (default) or 'fp16' partner rows in the alignment backward; returns the previous setting."""
-    if mode not in ('exact', 'fp16'):
-        raise ValueError("aladin_amd: backward precision must be 'exact' or 'fp16'")
-    old = _BWD_PARTNERS[0]
-    _BWD_PARTNERS[0] = mode
+    """'fp16' (default), 'fp16-own' or 'exact' unit vectors in the alignment backward's row step; returns the previous setting."""
+    if mode not in ('exact', 'fp16', 'fp16-own'):
+        raise ValueError("aladin_amd: backward precision must be 'exact', 'fp16' or 'fp16-own'")
+    old = 'exact' if _BWD_PARTNERS[0] == 'exact' else ('fp16-own' if _BWD_OWN_ROW_FP16[0] else 'fp16')
+    _BWD_PARTNERS[0] = 'exact' if mode == 'exact' else 'fp16'
+    _BWD_OWN_ROW_FP16[0] = mode == 'fp16-own'
     return old
 
 
 def _bwd_flags(packed):
-    """flags word of the *_ex backward entry points for this problem (0 unless the opt-in applies)."""
-    if _BWD_PARTNERS[0] == 'fp16' and packed is not None and packed[1] is not None and packed[3] is not None and not packed[0].split:
-        return _lib.BWD_PARTNERS_FP16
+    """flags word of the backward entry points for this problem: ALADIN_BWD_PARTNERS_FP16 when the setting asks for it and the
+    forward's packed operands WITH their inverse norms are at hand (a 5-tuple from _align_forward / pack_sets)."""
+    if _BWD_PARTNERS[0] == 'fp16' and packed is not None and len(packed) > 4 and packed[1] is not None and packed[3] is not None \
+            and packed[4] is not None and not packed[0].split:
+        return _lib.BWD_PARTNERS_FP16 | (_lib.BWD_OWN_ROW_FP16 if _BWD_OWN_ROW_FP16[0] else 0)
     return 0
 
 
@@ -146,29 +156,50 @@ def align_geometry(Bi, Bc, R, T, D, x_tail=0, y_tail=2, precision=None):
     g = _GEOM_CACHE.get(key)
     if g is None:
         g = _lib.AlignGeom()
-        _lib.check(_lib.load().aladin_align_geometry_mode(Bi, Bc, R, T, D, x_tail, y_tail, prec, C.byref(g)), 'align_geometry')
+        _lib.check(_lib.load().aladin_align_geometry(Bi, Bc, R, T, D, x_tail, y_tail, prec, C.byref(g)), 'align_geometry')
         if len(_GEOM_CACHE) < 1024:
             _GEOM_CACHE[key] = g
     return g
 
 
-def pack_images(im, im_len_t, geom):
-    """(xm, xe): L2-normalised, sliced, length-masked fp16 MFMA operands of the image sets."""
+def _set_view(t, len_t):
+    """struct aladin_set of a (B, N, D) tensor with a unit inner stride."""
+    return _lib.SetView(t.data_ptr(), t.stride(0), t.stride(1), len_t.data_ptr())
+
+
+def _grad_view(t):
+    return _lib.GradView(t.data_ptr(), t.stride(0), t.stride(1))
+
+
+def _packed_struct(xm, xe, y, rnorm=None):
+    return _lib.Packed(xm.data_ptr() if xm is not None else None, xe.data_ptr() if xe is not None else None,
+                       y.data_ptr() if y is not None else None, rnorm.data_ptr() if rnorm is not None else None)
+
+
+def _rnorm_views(rnorm, geom):
+    """(image part, caption part) of the inverse-norm buffer [xm rows | xe rows | y rows]."""
+    n_img = int(geom.xm_rows + geom.xe_rows)
+    return rnorm[:n_img], rnorm[n_img:]
+
+
+def pack_images(im, im_len_t, geom, rnorm=None):
+    """(xm, xe): L2-normalised, sliced, length-masked fp16 MFMA operands of the image sets.  rnorm (optional float32 tensor of
+    geom.rnorm_bytes / 4 elements): receives the image rows' inverse norms in its [xm | xe] part."""
     lib = _lib.load()
     im = _rows_inner_contig(im)
     xm = torch.empty(geom.xm_bytes // 2, dtype=torch.float16, device=im.device)
     xe = torch.empty(max(geom.xe_bytes // 2, 8), dtype=torch.float16, device=im.device)
-    _lib.check(lib.aladin_align_pack_images(_ptr(im), im.stride(0), im.stride(1), _ptr(im_len_t), C.byref(geom),
-                                            _ptr(xm), _ptr(xe), _stream()), 'align_pack_images')
+    v, pk = _set_view(im, im_len_t), _packed_struct(xm, xe, None, rnorm)
+    _lib.check(lib.aladin_align_pack(C.byref(v), None, C.byref(geom), C.byref(pk), _stream()), 'align_pack(images)')
     return xm, xe
 
 
-def pack_captions(s, s_len_t, geom):
+def pack_captions(s, s_len_t, geom, rnorm=None):
     lib = _lib.load()
     s = _rows_inner_contig(s)
     y = torch.empty(geom.y_bytes // 2, dtype=torch.float16, device=s.device)
-    _lib.check(lib.aladin_align_pack_captions(_ptr(s), s.stride(0), s.stride(1), _ptr(s_len_t), C.byref(geom),
-                                              _ptr(y), _stream()), 'align_pack_captions')
+    v, pk = _set_view(s, s_len_t), _packed_struct(None, None, y, rnorm)
+    _lib.check(lib.aladin_align_pack(None, C.byref(v), C.byref(geom), C.byref(pk), _stream()), 'align_pack(captions)')
     return y
 
 
@@ -176,8 +207,9 @@ def scores_from_packed(xm, xe, y, geom, out=None, e_scratch=None, reuse_side=Fal
     lib = _lib.load()
     S = out if out is not None else torch.empty((geom.Bi, geom.Bc), dtype=torch.float32, device=xm.device)
     e = e_scratch if e_scratch is not None else _workspace(geom.e_bytes, xm.device)
-    _lib.check(lib.aladin_align_scores_ex(_ptr(xm), _ptr(xe), _ptr(y), C.byref(geom), _ptr(e), _ptr(S), S.stride(0),
-                                          1 if reuse_side else 0, _stream()), 'align_scores')
+    pk = _packed_struct(xm, xe, y)
+    _lib.check(lib.aladin_align_scores(C.byref(pk), C.byref(geom), _ptr(e), _ptr(S), S.stride(0), 1 if reuse_side else 0, _stream()),
+               'align_scores')
     return S
 
 
@@ -189,28 +221,34 @@ def _check_backward_supported(im, s, x_tail, y_tail):
     if D % 4 != 0 or D > 1024:
         raise ValueError('aladin_amd: differentiable alignment scores need D %% 4 == 0 and D <= 1024 (got D=%d); '
                          'score under torch.no_grad() or pad the feature axis' % D)
-    if R - 1 - x_tail > 96 or T - 1 - y_tail > 96:          # = the packed geometry's own limits (aladin_align_geometry_mode)
+    if R - 1 - x_tail > 96 or T - 1 - y_tail > 96:          # = the packed geometry's own limits (aladin_align_geometry)
         raise ValueError('aladin_amd: alignment scores support at most 96 scored positions per set '
                          '(got %d on the max side, %d on the sum side)' % (R - 1 - x_tail, T - 1 - y_tail))
 
 
-def _align_forward(im, s, im_len_t, s_len_t, x_tail=0, y_tail=2, precision=None):
-    """-> (S, packed) where packed = (geom, xm, xe, y) is kept for the backward pass.
+def pack_sets(im, s, im_len_t, s_len_t, geom, norms=True):
+    """Both sets in one launch -> (geom, xm, xe, y, rnorm): the `packed` tuple the score and backward functions take
+    (rnorm None when norms=False or the operands are split)."""
+    dev = im.device
+    xm = torch.empty(geom.xm_bytes // 2, dtype=torch.float16, device=dev)
+    xe = torch.empty(max(geom.xe_bytes // 2, 8), dtype=torch.float16, device=dev)
+    y = torch.empty(geom.y_bytes // 2, dtype=torch.float16, device=dev)
+    rnorm = torch.empty(geom.rnorm_bytes // 4, dtype=torch.float32, device=dev) if norms and not geom.split else None
+    vi, vs, pk = _set_view(im, im_len_t), _set_view(s, s_len_t), _packed_struct(xm, xe, y, rnorm)
+    _lib.check(_lib.load().aladin_align_pack(C.byref(vi), C.byref(vs), C.byref(geom), C.byref(pk), _stream()), 'align_pack')
+    return geom, xm, xe, y, rnorm
+
+
+def _align_forward(im, s, im_len_t, s_len_t, x_tail=0, y_tail=2, precision=None, norms=True):
+    """-> (S, packed) where packed = (geom, xm, xe, y, rnorm) is kept for the backward pass.
     `im` is the max-side set, `s` the sum-side set (images / captions for 'MrSw')."""
     Bi, R, D = im.shape
     Bc, T, D2 = s.shape
     if D != D2:
         raise ValueError('aladin_amd: feature sizes differ (%d vs %d)' % (D, D2))
     geom = align_geometry(Bi, Bc, R, T, D, x_tail, y_tail, precision)
-    im = _rows_inner_contig(im)
-    s = _rows_inner_contig(s)
-    xm = torch.empty(geom.xm_bytes // 2, dtype=torch.float16, device=im.device)
-    xe = torch.empty(max(geom.xe_bytes // 2, 8), dtype=torch.float16, device=im.device)
-    y = torch.empty(geom.y_bytes // 2, dtype=torch.float16, device=im.device)
-    _lib.check(_lib.load().aladin_align_pack_both(_ptr(im), im.stride(0), im.stride(1), _ptr(im_len_t),
-                                                  _ptr(s), s.stride(0), s.stride(1), _ptr(s_len_t), C.byref(geom),
-                                                  _ptr(xm), _ptr(xe), _ptr(y), _stream()), 'align_pack_both')
-    return scores_from_packed(xm, xe, y, geom), (geom, xm, xe, y)
+    packed = pack_sets(_rows_inner_contig(im), _rows_inner_contig(s), im_len_t, s_len_t, geom, norms=norms)
+    return scores_from_packed(packed[1], packed[2], packed[3], geom), packed
 
 
 def _grad_like(x):
@@ -306,7 +344,8 @@ _FILL_HINT = [None]          # set by the wrappers just before .apply(), read by
 
 
 def _align_backward(im, s, im_len_t, s_len_t, dS, gscale=None, packed=None, pairs=None, x_tails=(0, 2), dense=False, fill=None):
-    """dense: the caller knows that (almost) every pair carries a gradient (sum-of-violations hinge, a gradient on S):
+    """aladin_align_bwd.  packed: (geom, xm, xe, y[, rnorm]) of the forward (None: the exact fp32 recompute).
+    dense: the caller knows that (almost) every pair carries a gradient (sum-of-violations hinge, a gradient on S):
     ALADIN_BWD_DENSE -- the arg-max table of all pairs from the split-precision tile kernel instead of one workgroup per pair."""
     lib = _lib.load()
     im = _rows_inner_contig(im)
@@ -316,87 +355,113 @@ def _align_backward(im, s, im_len_t, s_len_t, dS, gscale=None, packed=None, pair
     Bi, R, D = im.shape
     Bc, T, _ = s.shape
     d_im, d_s = _grad_like(im), _grad_like(s)
-    dense_flag = _lib.BWD_DENSE if (dense and DENSE_BACKWARD and packed is not None and packed[1] is not None and Bi * Bc >= DENSE_MIN_PAIRS) else 0
+    have = packed is not None and packed[1] is not None
+    dense_flag = _lib.BWD_DENSE if (dense and DENSE_BACKWARD and have and Bi * Bc >= DENSE_MIN_PAIRS) else 0
     if dense_flag and not (DENSE_ROWS_GEMM and _gemm_rows_pay(fill, R - 1 - packed[0].x_tail)):
         dense_flag |= _lib.BWD_DENSE_GATHER
     _LAST_BWD_FLAGS[0] = dense_flag                      # which path the last backward took (tests)
-    ws = _workspace(lib.aladin_align_bwd_workspace_bytes_ex(Bi, Bc, R, T, D, dense_flag), im.device)
     if packed is None:
         if x_tails != (0, 2):
             raise NotImplementedError('aladin_amd: the stand-alone backward entry point is the image/caption form')
-        geom, xm, xe, y = align_geometry(Bi, Bc, R, T, D), None, None, None
+        geom, pk = align_geometry(Bi, Bc, R, T, D), None
     else:
-        geom, xm, xe, y = packed
-    _lib.check(lib.aladin_align_bwd_packed_strided_ex(_ptr(im), im.stride(0), im.stride(1), _ptr(im_len_t),
-                                                      _ptr(s), s.stride(0), s.stride(1), _ptr(s_len_t),
-                                                      _ptr(dS), ld_dS, _ptr(gscale), _ptr(xm), _ptr(xe), _ptr(y),
-                                                      C.byref(geom), _ptr(pairs[0] if pairs else None),
-                                                      _ptr(pairs[1] if pairs else None), _ptr(d_im), d_im.stride(0), d_im.stride(1),
-                                                      _ptr(d_s), d_s.stride(0), d_s.stride(1), _ptr(ws),
-                                                      _bwd_flags((geom, xm, xe, y)) | dense_flag, _stream()),
-               'align_bwd_packed_strided_ex')
+        geom = packed[0]
+        pk = _packed_struct(packed[1], packed[2], packed[3], packed[4] if len(packed) > 4 else None) if have else None
+    flags = (_bwd_flags(packed) if have else 0) | dense_flag
+    ws = _workspace(lib.aladin_align_bwd_workspace_bytes(C.byref(geom), dense_flag), im.device)
+    vi, vs, gi, gs = _set_view(im, im_len_t), _set_view(s, s_len_t), _grad_view(d_im), _grad_view(d_s)
+    _lib.check(lib.aladin_align_bwd(C.byref(vi), C.byref(vs), C.byref(geom), C.byref(pk) if pk is not None else None, _ptr(dS), ld_dS,
+                                    _ptr(gscale), _ptr(pairs[0] if pairs else None), _ptr(pairs[1] if pairs else None),
+                                    C.byref(gi), C.byref(gs), _ptr(ws), flags, _stream()), 'align_bwd')
     return d_im, d_s
 
 
-def _hinge_argmax_fused(S, margin, im, s, im_len_t, s_len_t, packed, loss_out=None):
-    """Hardest-negative hinge of the square score matrix S AND the backward's argmax table in two launches
-    (aladin_hinge_argmax_fused): -> (loss, dS, im, s, table_ws), or None when the fp16 pair kernel does not cover the
-    shape (the caller then takes the list path).  im / s come back in the row layout the kernels were given; table_ws
-    holds the table until _align_backward_rows consumes it (its own buffer: the shared scratch would not survive the
-    other heads)."""
-    geom = packed[0]
-    if not (_pair_kernel_covers(geom) and geom.Bi == geom.Bc and not geom.split):
+_TRIPLET_WS = {}
+
+
+def _triplet_fused_ok(geom):
+    """Shapes aladin_align_triplet_fwd covers (= the fp16 pair kernel's: every training config)."""
+    return _pair_kernel_covers(geom) and geom.Bi == geom.Bc and not geom.split and geom.D % 4 == 0 and geom.D <= 1024
+
+
+def _triplet_forward(im, s, im_len_t, s_len_t, margin, loss_out=None):
+    """aladin_align_triplet_fwd: pack + side GEMM + scores + hinge statistics + [pair arg-max | hinge element-wise] in ONE C call.
+    -> (loss, S, saved) with saved = (im, s, geom, buf, dS, ws): `buf` is ONE allocation holding xm | xe | y | rnorm, `ws` the node's
+    workspace (side scratch, statistics, arg-max table, dS^T) -- both untouched until _triplet_backward.  None when the shape is not
+    covered (the caller composes the generic calls)."""
+    Bi, R, D = im.shape
+    Bc, T, _ = s.shape
+    geom = align_geometry(Bi, Bc, R, T, D)
+    if not _triplet_fused_ok(geom):
         return None
     lib = _lib.load()
-    B = S.shape[0]
-    im_c, s_c = _rows_inner_contig(im), _rows_inner_contig(s)
-    loss = loss_out if loss_out is not None else torch.empty((), dtype=torch.float32, device=S.device)
-    dS = torch.empty((B, B), dtype=torch.float32, device=S.device)
-    table_ws = torch.empty(lib.aladin_align_bwd_workspace_bytes(B, B, im.shape[1], s.shape[1], im.shape[2]),
-                           dtype=torch.uint8, device=S.device)
-    hws = _workspace(lib.aladin_hinge_workspace_bytes(B), S.device)
-    sc = S if S.stride(1) == 1 else S.contiguous()
-    _lib.check(lib.aladin_hinge_argmax_fused(_ptr(sc), _ld(sc), float(margin), _ptr(loss), _ptr(dS), _ptr(hws),
-                                             _ptr(im_c), im_c.stride(0), im_c.stride(1), _ptr(im_len_t),
-                                             _ptr(s_c), s_c.stride(0), s_c.stride(1), _ptr(s_len_t),
-                                             _ptr(packed[1]), _ptr(packed[2]), _ptr(packed[3]), C.byref(geom),
-                                             _ptr(table_ws), _stream()), 'hinge_argmax_fused')
-    return loss, dS, im_c, s_c, table_ws
+    im, s = _rows_inner_contig(im), _rows_inner_contig(s)
+    dev = im.device
+    key = (Bi, R, T, D)
+    lay = _TRIPLET_WS.get(key)
+    if lay is None:
+        up = lambda v: (int(v) + 255) // 256 * 256
+        o_xe = up(geom.xm_bytes)
+        o_y = o_xe + up(max(geom.xe_bytes, 16))
+        o_rn = o_y + up(geom.y_bytes)
+        lay = (o_xe, o_y, o_rn, o_rn + up(geom.rnorm_bytes), int(lib.aladin_align_triplet_workspace_bytes(C.byref(geom))))
+        if len(_TRIPLET_WS) < 256:
+            _TRIPLET_WS[key] = lay
+    o_xe, o_y, o_rn, n_buf, n_ws = lay
+    buf = torch.empty(n_buf, dtype=torch.uint8, device=dev)
+    ws = torch.empty(n_ws, dtype=torch.uint8, device=dev)
+    S = torch.empty((Bi, Bc), dtype=torch.float32, device=dev)
+    dS = torch.empty((Bi, Bc), dtype=torch.float32, device=dev)
+    loss = loss_out if loss_out is not None else torch.empty((), dtype=torch.float32, device=dev)
+    base = buf.data_ptr()
+    pk = _lib.Packed(base, base + o_xe, base + o_y, base + o_rn)
+    vi, vs = _set_view(im, im_len_t), _set_view(s, s_len_t)
+    _lib.check(lib.aladin_align_triplet_fwd(C.byref(vi), C.byref(vs), C.byref(geom), float(margin), C.byref(pk), _ptr(S), S.stride(0),
+                                            _ptr(loss), _ptr(dS), _ptr(ws), _stream()), 'align_triplet_fwd')
+    return loss, S, (im, s, geom, buf, dS, ws, (o_xe, o_y, o_rn))
 
 
-def _align_backward_rows(im, s, im_len_t, s_len_t, dS, gscale, geom, table_ws, packed=None):
-    """The row kernel alone: the argmax table is already in table_ws (_hinge_argmax_fused).  packed = (geom, xm, xe, y):
-    the forward's operands, read only under set_backward_precision('fp16')."""
+def _packed_from_buf(buf, offs):
+    base = buf.data_ptr()
+    return _lib.Packed(base, base + offs[0], base + offs[1], base + offs[2])
+
+
+def _triplet_backward(im, s, im_len_t, s_len_t, geom, pk, dS, ws, gscale, base_workspace=False):
+    """aladin_align_triplet_bwd: the row kernel on the table _triplet_forward (or, base_workspace=True, the small-batch heads)
+    left in `ws`.  pk: struct aladin_packed of the forward's operands (with rnorm for the fp16 row step)."""
     lib = _lib.load()
     d_im, d_s = _grad_like(im), _grad_like(s)
-    xm, xe, y = (packed[1], packed[2], packed[3]) if packed is not None else (None, None, None)
-    _lib.check(lib.aladin_align_bwd_rows_ex(_ptr(im), im.stride(0), im.stride(1), _ptr(im_len_t), _ptr(s), s.stride(0),
-                                            s.stride(1), _ptr(s_len_t), _ptr(dS), dS.shape[1], _ptr(gscale), _ptr(xm), _ptr(xe),
-                                            _ptr(y), C.byref(geom), _ptr(d_im), d_im.stride(0), d_im.stride(1), _ptr(d_s),
-                                            d_s.stride(0), d_s.stride(1), _ptr(table_ws), _bwd_flags(packed), _stream()),
-               'align_bwd_rows_ex')
+    flags = _lib.BWD_PARTNERS_FP16 if (_BWD_PARTNERS[0] == 'fp16' and pk.rnorm) else 0
+    if flags and _BWD_OWN_ROW_FP16[0]:
+        flags |= _lib.BWD_OWN_ROW_FP16
+    if base_workspace:
+        flags |= _lib.TRIPLET_BWD_BASE_WORKSPACE
+    vi, vs, gi, gs = _set_view(im, im_len_t), _set_view(s, s_len_t), _grad_view(d_im), _grad_view(d_s)
+    _lib.check(lib.aladin_align_triplet_bwd(C.byref(vi), C.byref(vs), C.byref(geom), C.byref(pk), _ptr(dS), _ptr(gscale), C.byref(gi),
+                                            C.byref(gs), _ptr(ws), flags, _stream()), 'align_triplet_bwd')
     return d_im, d_s
 
 
 class _AlignScores(torch.autograd.Function):
     @staticmethod
     def forward(ctx, im, s, im_len_t, s_len_t, x_tail, y_tail):
-        if any(ctx.needs_input_grad[:2]):
+        need = any(ctx.needs_input_grad[:2])
+        if need:
             _check_backward_supported(im, s, x_tail, y_tail)
-        S, packed = _align_forward(im, s, im_len_t, s_len_t, x_tail, y_tail)
-        if any(ctx.needs_input_grad[:2]):
-            ctx.save_for_backward(im, s, im_len_t, s_len_t, packed[1], packed[2], packed[3])
+        S, packed = _align_forward(im, s, im_len_t, s_len_t, x_tail, y_tail, norms=need)
+        if need:
+            ctx.save_for_backward(im, s, im_len_t, s_len_t, *packed[1:])
             ctx.geom = packed[0]
         return S
 
     @staticmethod
     def backward(ctx, dS):
-        im, s, im_len_t, s_len_t, xm, xe, y = ctx.saved_tensors
+        im, s, im_len_t, s_len_t, xm, xe, y, rnorm = ctx.saved_tensors
         dense = False
         if DENSE_BACKWARD and dS.numel() >= DENSE_MIN_PAIRS and not torch.cuda.is_current_stream_capturing():
             probe = _generic_probes.setdefault((tuple(dS.shape), ctx.geom.x_tail, ctx.geom.y_tail), _DensityProbe(unknown=False))
             dense = probe.step(torch.count_nonzero(dS), dS.numel())
-        d_im, d_s = _align_backward(im, s, im_len_t, s_len_t, dS, packed=(ctx.geom, xm, xe, y), dense=dense)
+        d_im, d_s = _align_backward(im, s, im_len_t, s_len_t, dS, packed=(ctx.geom, xm, xe, y, rnorm), dense=dense)
         return d_im, d_s, None, None, None, None
 
 
@@ -419,10 +484,21 @@ def _hinge_raw(scores, margin, max_violation, want_grad, want_pairs=False, loss_
     return loss, dS, pairs
 
 
+def _buf_views(buf, geom, offs):
+    """(geom, xm, xe, y, rnorm) tensor views of the one-allocation operand buffer of _triplet_forward."""
+    xm = buf[:geom.xm_bytes].view(torch.float16)
+    xe = buf[offs[0]:offs[0] + max(int(geom.xe_bytes), 16)].view(torch.float16)
+    y = buf[offs[1]:offs[1] + geom.y_bytes].view(torch.float16)
+    rnorm = buf[offs[2]:offs[2] + geom.rnorm_bytes].view(torch.float32)
+    return geom, xm, xe, y, rnorm
+
+
 class _AlignTriplet(torch.autograd.Function):
     """scores + hinge in one autograd node (reference alad/loss.py:79-159 with return_loss=True):
     dloss/dS never leaves the device-side workspace and the upstream scalar gradient is handed to
-    the backward kernels as a device pointer (no element-wise scaling launch)."""
+    the backward kernels as a device pointer (no element-wise scaling launch).  With the hardest-negative hinge on the
+    fp16 pair kernel's shapes -- every training config -- each direction is ONE call into the library
+    (aladin_align_triplet_fwd / _bwd; rounds 1-4: six ctypes calls and nine allocations per step)."""
 
     @staticmethod
     def forward(ctx, im, s, im_len_t, s_len_t, margin, max_violation):
@@ -430,25 +506,19 @@ class _AlignTriplet(torch.autograd.Function):
         ctx.fill, _FILL_HINT[0] = _FILL_HINT[0], None
         if need:
             _check_backward_supported(im, s, 0, 2)
-        S, packed = _align_forward(im, s, im_len_t, s_len_t)
-        geom = packed[0]
-        ctx.table_ws = None
-        fused = _hinge_argmax_fused(S, margin, im, s, im_len_t, s_len_t, packed) if need and max_violation else None
+        ctx.fused = False
+        fused = _triplet_forward(im, s, im_len_t, s_len_t, margin) if need and max_violation else None
         if fused is not None:
-            # hardest-negative hinge with the fp16 pair kernel's shapes (every training config): the backward's argmax
-            # table is computed HERE, in the kernel that also runs the hinge's element-wise pass (one launch less per step)
-            loss, dS, im_c, s_c, table_ws = fused
-            ctx.save_for_backward(im_c, s_c, im_len_t, s_len_t, packed[1], packed[2], packed[3], dS, table_ws)
-            ctx.geom = geom
-            ctx.pairs = None
-            ctx.table_ws = True
-            ctx.dense = False
+            loss, S, (im_c, s_c, geom, buf, dS, ws, offs) = fused
+            ctx.save_for_backward(im_c, s_c, im_len_t, s_len_t, buf, dS, ws)
+            ctx.geom, ctx.offs, ctx.fused, ctx.pairs, ctx.dense = geom, offs, True, None, False
             ctx.set_materialize_grads(False)
             return loss, S
+        S, packed = _align_forward(im, s, im_len_t, s_len_t, norms=need)
         loss, dS, pairs = _hinge_raw(S, margin, max_violation, need, want_pairs=True)
         if need:
-            ctx.save_for_backward(im, s, im_len_t, s_len_t, packed[1], packed[2], packed[3], dS)
-            ctx.geom = geom
+            ctx.save_for_backward(im, s, im_len_t, s_len_t, dS, *packed[1:])
+            ctx.geom = packed[0]
             ctx.pairs = pairs
         # sum of violations: dloss/dS is dense while most pairs violate the margin (the previous steps' pair counts say)
         ctx.dense = False
@@ -461,17 +531,18 @@ class _AlignTriplet(torch.autograd.Function):
     def backward(ctx, g_loss, g_scores):
         if g_loss is None and g_scores is None:
             return None, None, None, None, None, None
-        table_ws = None
-        if ctx.table_ws:
-            im, s, im_len_t, s_len_t, xm, xe, y, dS, table_ws = ctx.saved_tensors
+        if ctx.fused:
+            im, s, im_len_t, s_len_t, buf, dS, ws = ctx.saved_tensors
+            if g_scores is None:
+                # the argmax table is already there (forward): only the row kernel is left
+                d_im, d_s = _triplet_backward(im, s, im_len_t, s_len_t, ctx.geom, _packed_from_buf(buf, ctx.offs), dS, ws,
+                                              g_loss.to(torch.float32).contiguous())
+                return d_im, d_s, None, None, None, None
+            packed = _buf_views(buf, ctx.geom, ctx.offs)
         else:
-            im, s, im_len_t, s_len_t, xm, xe, y, dS = ctx.saved_tensors
-        packed = (ctx.geom, xm, xe, y)
-        if g_scores is None and table_ws is not None:
-            # the argmax table is already there (forward): only the row kernel is left
-            g = g_loss.to(torch.float32).contiguous()
-            d_im, d_s = _align_backward_rows(im, s, im_len_t, s_len_t, dS, g, ctx.geom, table_ws, packed)
-        elif g_scores is None:
+            im, s, im_len_t, s_len_t, dS, xm, xe, y, rnorm = ctx.saved_tensors
+            packed = (ctx.geom, xm, xe, y, rnorm)
+        if g_scores is None:
             # the training path: only the loss is differentiated; dloss/dS (<= 3B non-zeros with the hardest-negative
             # hinge) never leaves the device and the upstream scalar goes to the kernels as a pointer
             g = g_loss.to(torch.float32).contiguous()
@@ -674,7 +745,7 @@ def _scores_nograd_block(xs, ys, x_len, y_len, x_tail, y_tail, precision, x_tota
     Bx, By, D = xs.shape[0], ys.shape[0], xs.shape[2]
     geom = align_geometry(Bx, By, n_eff, m_eff, D, x_tail, y_tail, precision)
     if geom.e_bytes <= E_SCRATCH_LIMIT:
-        return _align_forward(xs, ys, x_len_t, y_len_t, x_tail, y_tail, precision)[0]
+        return _align_forward(xs, ys, x_len_t, y_len_t, x_tail, y_tail, precision, norms=False)[0]
     step = max(geom.cap_unit, int(By * E_SCRATCH_LIMIT // geom.e_bytes) // geom.cap_unit * geom.cap_unit)
     xm, xe = pack_images(xs, x_len_t, geom)
     S = torch.empty((Bx, By), dtype=torch.float32, device=dev)
@@ -1009,17 +1080,15 @@ def _heads_small_fwd(im, s, S, margin, max_violation, flags, temperature, eps, w
         im_set, s_seq, im_len_t, s_len_t, packed = align
         geom = packed[0]
         im_c, s_c = _rows_inner_contig(im_set), _rows_inner_contig(s_seq)
-        out['table_ws'] = torch.empty(lib.aladin_align_bwd_workspace_bytes(B, B, im_set.shape[1], s_seq.shape[1], im_set.shape[2]),
-                                      dtype=torch.uint8, device=dev)
+        out['table_ws'] = torch.empty(lib.aladin_align_bwd_workspace_bytes(C.byref(geom), 0), dtype=torch.uint8, device=dev)
         out['sets'] = (im_c, s_c)
         ws = _workspace(lib.aladin_heads_small_workspace_bytes(B), dev)
+        vi, vs, pk = _set_view(im_c, im_len_t), _set_view(s_c, s_len_t), _packed_struct(*packed[1:5])
         _lib.check(lib.aladin_heads_small_fwd_argmax(_ptr(im), _ld(im) if im is not None else 0, _ptr(s), _ld(s) if s is not None else 0,
                                                      _ptr(S), _ld(S), D, float(margin), int(flags), float(temperature), float(eps),
                                                      float(weights[0]), float(weights[1]), float(weights[2]), _ptr(out['M']),
                                                      _ptr(out['terms']), _ptr(out['total']), _ptr(out['dMh']), _ptr(out['dMl']),
-                                                     _ptr(out['dS']), _ptr(ws), _ptr(im_c), im_c.stride(0), im_c.stride(1),
-                                                     _ptr(im_len_t), _ptr(s_c), s_c.stride(0), s_c.stride(1), _ptr(s_len_t),
-                                                     _ptr(packed[1]), _ptr(packed[2]), _ptr(packed[3]), C.byref(geom),
+                                                     _ptr(out['dS']), _ptr(ws), C.byref(vi), C.byref(vs), C.byref(geom), C.byref(pk),
                                                      _ptr(out['table_ws']), _stream()), 'heads_small_fwd_argmax')
         return out
     if want_pairs and out['dS'] is not None:
@@ -1098,8 +1167,8 @@ class _SmallHeads(torch.autograd.Function):
         ctx.flags, ctx.weights = flags, weights
         ctx.geom = packed[0] if packed is not None else None
         ctx.pairs = o['pairs']
-        pk = packed[1:] if packed is not None else (None, None, None)
-        ctx.save_for_backward(a, b, im, s, im_len_t, s_len_t, pk[0], pk[1], pk[2], o['dMh'], o['dMl'], o['dS'], o['table_ws'])
+        pk = packed[1:] if packed is not None else (None, None, None, None)
+        ctx.save_for_backward(a, b, im, s, im_len_t, s_len_t, pk[0], pk[1], pk[2], pk[3], o['dMh'], o['dMl'], o['dS'], o['table_ws'])
         ctx.set_materialize_grads(False)
         terms = o['terms']
         ctx.mark_non_differentiable(*[t for t in (terms, S, o['M']) if t is not None])       # one call: it replaces the set
@@ -1109,7 +1178,7 @@ class _SmallHeads(torch.autograd.Function):
     def backward(ctx, g_total, _g_terms, _g_S, _g_M):
         if g_total is None:
             return (None,) * 12
-        a, b, im, s, im_len_t, s_len_t, xm, xe, y, dMh, dMl, dS, table_ws = ctx.saved_tensors
+        a, b, im, s, im_len_t, s_len_t, xm, xe, y, rnorm, dMh, dMl, dS, table_ws = ctx.saved_tensors
         flags, w = ctx.flags, ctx.weights
         g = g_total.to(torch.float32).contiguous()
         d_a = d_b = d_im = d_s = None
@@ -1125,9 +1194,10 @@ class _SmallHeads(torch.autograd.Function):
             scale = g * float(w[1])
         if dS is not None and any(ctx.needs_input_grad[2:4]):
             if table_ws is not None:
-                d_im, d_s = _align_backward_rows(im, s, im_len_t, s_len_t, dS, scale, ctx.geom, table_ws, (ctx.geom, xm, xe, y))
+                d_im, d_s = _triplet_backward(im, s, im_len_t, s_len_t, ctx.geom, _packed_struct(xm, xe, y, rnorm), dS, table_ws, scale,
+                                              base_workspace=True)
             else:
-                d_im, d_s = _align_backward(im, s, im_len_t, s_len_t, dS, gscale=scale, packed=(ctx.geom, xm, xe, y), pairs=ctx.pairs)
+                d_im, d_s = _align_backward(im, s, im_len_t, s_len_t, dS, gscale=scale, packed=(ctx.geom, xm, xe, y, rnorm), pairs=ctx.pairs)
         return d_a, d_b, d_im, d_s, None, None, None, None, None, None, None, None
 
 
@@ -1145,19 +1215,21 @@ class _BigHeads(torch.autograd.Function):
         dev = img_emb.device
         B = img_emb.shape[0]
         terms = torch.empty(3, dtype=torch.float32, device=dev)          # slots of absent heads are never read
-        S = packed = dS = pairs = table_ws = None
+        S = packed = dS = pairs = table_ws = buf = None
         dense = False
         ctx.fill, _FILL_HINT[0] = _FILL_HINT[0], None
+        ctx.offs = None
         if flags & (HEAD_ALIGN_HINGE | HEAD_LISTNET):
             if need_sets and flags & HEAD_ALIGN_HINGE:
                 _check_backward_supported(im, s, 0, 2)
-            S, packed = _align_forward(im, s, im_len_t, s_len_t)
-            if flags & HEAD_ALIGN_HINGE:
-                fused = (_hinge_argmax_fused(S, margin, im, s, im_len_t, s_len_t, packed, loss_out=terms[1:2])
-                         if need_sets and max_violation else None)
-                if fused is not None:
-                    _, dS, im, s, table_ws = fused
-                else:
+            fused = (_triplet_forward(im, s, im_len_t, s_len_t, margin, loss_out=terms[1:2])
+                     if (flags & HEAD_ALIGN_HINGE) and need_sets and max_violation else None)
+            if fused is not None:                    # the alignment head's whole forward in one library call
+                _, S, (im, s, geom_f, buf, dS, table_ws, ctx.offs) = fused
+                packed = (geom_f, None, None, None, None)
+            else:
+                S, packed = _align_forward(im, s, im_len_t, s_len_t, norms=need_sets)
+                if flags & HEAD_ALIGN_HINGE:
                     _, dS, pairs = _hinge_raw(S, margin, max_violation, need_sets, want_pairs=True, loss_out=terms[1:2])
                     if need_sets and not max_violation:                 # sum of violations: the dense backward while dS is dense
                         dense = _density_probe.step(pairs[1], B * B)
@@ -1185,8 +1257,8 @@ class _BigHeads(torch.autograd.Function):
         ctx.geom = packed[0] if packed is not None else None
         ctx.pairs = pairs
         ctx.dense = dense
-        pk = packed[1:] if packed is not None else (None, None, None)
-        ctx.save_for_backward(a, b, im, s, im_len_t, s_len_t, pk[0], pk[1], pk[2], dMh, dMl, dS, table_ws)
+        pk = packed[1:] if packed is not None else (None, None, None, None)
+        ctx.save_for_backward(a, b, im, s, im_len_t, s_len_t, pk[0], pk[1], pk[2], pk[3], dMh, dMl, dS, table_ws, buf)
         ctx.set_materialize_grads(False)
         ctx.mark_non_differentiable(*[t for t in (terms, S, M) if t is not None])
         return total, terms, S, M
@@ -1196,7 +1268,7 @@ class _BigHeads(torch.autograd.Function):
         if g_total is None:
             return (None,) * 12
         lib = _lib.load()
-        a, b, im, s, im_len_t, s_len_t, xm, xe, y, dMh, dMl, dS, table_ws = ctx.saved_tensors
+        a, b, im, s, im_len_t, s_len_t, xm, xe, y, rnorm, dMh, dMl, dS, table_ws, buf = ctx.saved_tensors
         w = ctx.weights
         g = g_total.to(torch.float32).contiguous()
         dev = g.device
@@ -1217,10 +1289,10 @@ class _BigHeads(torch.autograd.Function):
             if ctx.needs_input_grad[1]:
                 d_b = torch.empty((B, D), dtype=torch.float32, device=dev)
                 _sgemm(B, D, B, C_tot, 1, C_tot.stride(0), a, a.stride(0), a.stride(1), d_b)          # C.T @ img
-        if want_a and table_ws is not None:
-            d_im, d_s = _align_backward_rows(im, s, im_len_t, s_len_t, dS, scale, ctx.geom, table_ws, (ctx.geom, xm, xe, y))
+        if want_a and buf is not None:
+            d_im, d_s = _triplet_backward(im, s, im_len_t, s_len_t, ctx.geom, _packed_from_buf(buf, ctx.offs), dS, table_ws, scale)
         elif want_a:
-            d_im, d_s = _align_backward(im, s, im_len_t, s_len_t, dS, gscale=scale, packed=(ctx.geom, xm, xe, y), pairs=ctx.pairs,
+            d_im, d_s = _align_backward(im, s, im_len_t, s_len_t, dS, gscale=scale, packed=(ctx.geom, xm, xe, y, rnorm), pairs=ctx.pairs,
                                         dense=ctx.dense, fill=ctx.fill)
         return d_a, d_b, d_im, d_s, None, None, None, None, None, None, None, None
 

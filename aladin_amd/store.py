@@ -31,7 +31,7 @@ class PackedSetStore:
         self.D = int(feat_dim)
         self.precision = precision
         self.padded_len = int(padded_len)
-        self.Dp = int(lib.aladin_store_row_width_mode(self.D, ops._precision_code(precision)))
+        self.Dp = int(lib.aladin_store_row_width(self.D, ops._precision_code(precision)))
         if self.Dp < self.D:
             raise ValueError('aladin_amd: bad feature size %r' % (feat_dim,))
         self.tail = int(tail)
@@ -71,7 +71,7 @@ class PackedSetStore:
         lens_t = torch.tensor(lengths, dtype=torch.int32, device=self.device)
         offs_t = torch.tensor(offs, dtype=torch.int64, device=self.device)
         if L >= 2:
-            _lib.check(_lib.load().aladin_store_append_mode(ops._ptr(sets), sets.stride(0), sets.stride(1), ops._ptr(lens_t), B, L,
+            _lib.check(_lib.load().aladin_store_append(ops._ptr(sets), sets.stride(0), sets.stride(1), ops._ptr(lens_t), B, L,
                                                             D, self.tail, ops._ptr(offs_t), ops._ptr(self.rows),
                                                             ops._precision_code(self.precision), ops._stream()),
                        'store_append')

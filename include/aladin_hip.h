@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define ALADIN_ABI_VERSION 10
+#define ALADIN_ABI_VERSION 11
 
 /* The library is built with -fvisibility=hidden: the entry points declared here are its ONLY exports. */
 #if defined(__GNUC__)
@@ -47,8 +47,30 @@ ALADIN_API const char* aladin_last_error(void);
  * :103-116, max over regions + sum over words :124-125).
  *
  * Three steps so that the packed image operand can be all-gathered between GPUs (RCCL) before
- * scoring:  pack_images -> [all-gather] -> scores  <- pack_captions.
+ * scoring:  pack(images) -> [all-gather] -> scores  <- pack(captions).  The training step of one
+ * GPU is ONE call per direction: aladin_align_triplet_fwd / _bwd below.
+ *
+ * ABI 11 (round 5): one entry point per operation, arguments grouped in three small structs.  The
+ * generations that had accumulated (three geometry calls, pack_images / pack_captions / pack_both,
+ * scores / scores_ex, align_bwd / _packed / _packed_strided / _packed_strided_ex, bwd_rows / _rows_ex)
+ * are gone; nothing else changed meaning.
  * ------------------------------------------------------------------------------------------- */
+
+/* A batch of sets (B, N, D) fp32 in HBM: element [b][n][d] at data[b * stride_b + n * stride_r + d] (strides in floats,
+ * unit inner stride, rows 16-byte aligned when D % 4 == 0: the reference hands permuted (S,B,D)->(B,S,D) views,
+ * alad/alad_model.py:377-378).  len: B int32 on the device, the reference's length lists. */
+typedef struct aladin_set {
+  const float* data;
+  int64_t stride_b, stride_r;
+  const int32_t* len;
+} aladin_set;
+
+/* Where a gradient of such a batch goes: the CALLER'S layout (the same permuted views), every row written exactly once. */
+typedef struct aladin_set_grad {
+  float* data;
+  int64_t stride_b, stride_r;
+} aladin_set_grad;
+
 typedef struct aladin_align_geom {
   int32_t Bi, Bc, R, T, D;      /* inputs: im (Bi,R,D), s (Bc,T,D)                              */
   int32_t Rq, Tq;               /* R-1 regions and T-3 words take part (alad/loss.py:87-88)     */
@@ -67,15 +89,18 @@ typedef struct aladin_align_geom {
   int64_t xm_rows, xe_rows, y_rows;            /* rows of the packed fp16 operands              */
   int64_t xm_bytes, xe_bytes, y_bytes;         /* their sizes                                   */
   int64_t e_bytes;              /* fp32 scratch for the side GEMM, xe_rows x y_rows (0 if !rem) */
+  int64_t rnorm_bytes;          /* fp32, one per packed row in the order [xm rows | xe rows | y rows]: 1 / max(|x|, 1e-12) of the
+                                   raw vector a row holds (0 for a zero row) -- what the backward's normalise step divides by */
 } aladin_align_geom;
 
-/* Host-only: derive the packed layout for a problem ('MrSw': images on the max side). */
-ALADIN_API int aladin_align_geometry(int Bi, int Bc, int R, int T, int D, aladin_align_geom* out);
-/* General form: the set on the MAX side (Bi x R) and the set on the SUM side (Bc x T) each state how
- * many trailing positions they drop.  'MrSw' = (images, tail 0) x (captions, tail 2); 'MwSr'
- * (alad/loss.py:134-135, max over words, sum over regions) = (captions, tail 2) x (images, tail 0),
- * result transposed.  Every "image"/"caption" argument below means max-side / sum-side set. */
-ALADIN_API int aladin_align_geometry_ex(int Bi, int Bc, int R, int T, int D, int x_tail, int y_tail, aladin_align_geom* out);
+/* The packed fp16 MFMA operands of one problem (caller-owned buffers of geom->xm_bytes, xe_bytes, y_bytes, rnorm_bytes).
+ * xe may be NULL when !geom->rem; rnorm may be NULL (then the backward reads the raw fp32 rows instead). */
+typedef struct aladin_packed {
+  void* xm;
+  void* xe;
+  void* y;
+  float* rnorm;
+} aladin_packed;
 
 /* Operand precision of the packed sets.
  *   ALADIN_PRECISION_FP16   one rounding of every unit vector to fp16: scores within ~1e-4 of the fp32
@@ -86,148 +111,108 @@ ALADIN_API int aladin_align_geometry_ex(int Bi, int Bc, int R, int T, int D, int
  *                           error, i.e. the rounding level of the reference's own fp32 bmm, at 3x the MFMA work.
  *                           This is what evaluation uses: Recall needs rank-exact scores (near-ties between
  *                           thousands of candidates flip at the 1e-4 level; alad/evaluation.py:213-223,303-308).
- *                           Forward only: aladin_align_bwd_packed rejects split operands. */
+ *                           Forward only: the backward entry points reject split operands. */
 #define ALADIN_PRECISION_FP16 0
 #define ALADIN_PRECISION_SPLIT 1
 #define ALADIN_PRECISION_SPLIT_TABLE 2   /* split operands in whole 16-word caption tiles (no 24- / 40-word classes): the layout
-                                            the dense backward's arg-max table kernel reads; geometry_mode only */
-ALADIN_API int aladin_align_geometry_mode(int Bi, int Bc, int R, int T, int D, int x_tail, int y_tail, int precision,
-                               aladin_align_geom* out);
+                                            the dense backward's arg-max table kernel reads */
 
-/* L2-normalise (eps 1e-12, F.normalize), slice, length-mask and convert the image sets to the
- * packed fp16 MFMA operand.  im[(b*stride_b + r*stride_r) + d], innermost stride 1 (the reference
- * hands a permuted (S,B,D)->(B,S,D) view, alad/alad_model.py:377).  im_len: Bi int32 on device.
- * xm: geom->xm_bytes, xe: geom->xe_bytes (ignored when !rem). */
-ALADIN_API int aladin_align_pack_images(const float* im, int64_t stride_b, int64_t stride_r, const int32_t* im_len,
-                             const aladin_align_geom* geom, void* xm, void* xe, void* stream);
-ALADIN_API int aladin_align_pack_captions(const float* s, int64_t stride_b, int64_t stride_t, const int32_t* s_len,
-                               const aladin_align_geom* geom, void* y, void* stream);
+/* Host-only: derive the packed layout.  The set on the MAX side (Bi x R) and the set on the SUM side (Bc x T) each state
+ * how many trailing positions they drop: 'MrSw' = (images, x_tail 0) x (captions, y_tail 2); 'MwSr' (alad/loss.py:134-135,
+ * max over words, sum over regions) = (captions, tail 2) x (images, tail 0), result transposed.  Every "image" / "caption"
+ * argument below means max-side / sum-side set. */
+ALADIN_API int aladin_align_geometry(int Bi, int Bc, int R, int T, int D, int x_tail, int y_tail, int precision,
+                                     aladin_align_geom* out);
 
-/* Both packs in one launch (single-GPU path). */
-ALADIN_API int aladin_align_pack_both(const float* im, int64_t im_stride_b, int64_t im_stride_r, const int32_t* im_len,
-                           const float* s, int64_t s_stride_b, int64_t s_stride_t, const int32_t* s_len,
-                           const aladin_align_geom* geom, void* xm, void* xe, void* y, void* stream);
+/* L2-normalise (eps 1e-12, F.normalize), slice, length-mask and convert sets to the packed fp16 MFMA operands: the image
+ * sets into out->xm / xe, the caption sets into out->y, in ONE launch when both are given; either may be NULL (the members
+ * of `out` it would fill are then not touched).  out->rnorm, when not NULL, receives the rows' inverse norms. */
+ALADIN_API int aladin_align_pack(const aladin_set* im, const aladin_set* s, const aladin_align_geom* geom,
+                                 const aladin_packed* out, void* stream);
 
-/* S (Bi x Bc, row stride ldS floats) from packed operands.  e_scratch: geom->e_bytes. */
-ALADIN_API int aladin_align_scores(const void* xm, const void* xe, const void* y, const aladin_align_geom* geom,
-                        void* e_scratch, float* S, int64_t ldS, void* stream);
-/* Same with flags.  ALADIN_SCORES_REUSE_SIDE: e_scratch already holds the side-GEMM result of a
- * previous call on the same operands, launch the score kernel alone (used by bench.py to time the
- * dominant kernel in isolation). */
+/* S (Bi x Bc, row stride ldS floats) from packed operands.  e_scratch: geom->e_bytes.
+ * ALADIN_SCORES_REUSE_SIDE: e_scratch already holds the side-GEMM result of a previous call on the same operands, launch
+ * the score kernel alone (used by bench.py to time the dominant kernel in isolation). */
 #define ALADIN_SCORES_REUSE_SIDE 1
-ALADIN_API int aladin_align_scores_ex(const void* xm, const void* xe, const void* y, const aladin_align_geom* geom,
-                           void* e_scratch, float* S, int64_t ldS, int flags, void* stream);
+ALADIN_API int aladin_align_scores(const aladin_packed* packed, const aladin_align_geom* geom, void* e_scratch, float* S,
+                                   int64_t ldS, int flags, void* stream);
 
 /* Backward of S w.r.t. the raw sets (autograd of alad/loss.py:80-125).
- * dS (Bi x Bc, stride ld_dS) is multiplied by *gscale (device float, may be NULL = 1).  Pairs with
- * dS == 0 are skipped, so the max_violation=True hinge (<= 3B non-zeros) costs O(B) pair blocks.
- * The argmax over regions is recomputed in fp32.  d_im (Bi,R,D) and d_s (Bc,T,D) are contiguous
- * and fully written.  workspace: aladin_align_bwd_workspace_bytes(). */
-ALADIN_API size_t aladin_align_bwd_workspace_bytes(int Bi, int Bc, int R, int T, int D);
-ALADIN_API int aladin_align_bwd(const float* im, int64_t im_stride_b, int64_t im_stride_r, const int32_t* im_len,
-                     const float* s, int64_t s_stride_b, int64_t s_stride_t, const int32_t* s_len,
-                     int Bi, int Bc, int R, int T, int D,
-                     const float* dS, int64_t ld_dS, const float* gscale,
-                     float* d_im, float* d_s, void* workspace, void* stream);
-
-/* Same, given the packed fp16 operands of the forward pass (aladin_align_pack_*): the per-pair
- * argmax recompute then runs on the fp16 MFMA and only words whose top candidates are closer than
- * the fp16 error bound are re-decided with exact fp32 dot products (same result, cheaper).
- * pairs / pair_count (both or neither; may be NULL): the non-zero (i*Bc + j) list of dS as
- * emitted by aladin_hinge_fused -- skips the in-call compaction. */
-ALADIN_API int aladin_align_bwd_packed(const float* im, int64_t im_stride_b, int64_t im_stride_r, const int32_t* im_len,
-                            const float* s, int64_t s_stride_b, int64_t s_stride_t, const int32_t* s_len,
-                            const float* dS, int64_t ld_dS, const float* gscale,
-                            const void* xm, const void* xe, const void* y, const aladin_align_geom* geom,
-                            const int32_t* pairs, const int32_t* pair_count,
-                            float* d_im, float* d_s, void* workspace, void* stream);
-
-/* Same, writing the gradients in the CALLER'S layout: d_im[b * d_im_stride_b + r * d_im_stride_r + d] and likewise d_s
- * (strides in floats, multiples of 4, unit inner stride).  The reference hands the sets as permuted (S,B,D)->(B,S,D)
- * views (alad/alad_model.py:377-378); gradients produced in that layout spare autograd two re-layout copies (66 MB per
- * step at B = 256).  xm / xe / y may be NULL (then geom only supplies the sizes and tails and the exact fp32 recompute
- * of aladin_align_bwd runs). */
-ALADIN_API int aladin_align_bwd_packed_strided(const float* im, int64_t im_stride_b, int64_t im_stride_r, const int32_t* im_len,
-                                               const float* s, int64_t s_stride_b, int64_t s_stride_t, const int32_t* s_len,
-                                               const float* dS, int64_t ld_dS, const float* gscale, const void* xm, const void* xe,
-                                               const void* y, const aladin_align_geom* geom, const int32_t* pairs,
-                                               const int32_t* pair_count, float* d_im, int64_t d_im_stride_b,
-                                               int64_t d_im_stride_r, float* d_s, int64_t d_s_stride_b, int64_t d_s_stride_t,
-                                               void* workspace, void* stream);
-
-/* The hardest-negative hinge (alad/loss.py:42-67, max_violation=True) and the backward's argmax table in TWO launches: the
- * hinge's row / column statistics, then ONE kernel whose workgroups either recompute a non-zero pair of dloss/dS -- the pairs
- * follow from the statistics: (q, q), (q, hardest caption of image q), (hardest image of caption q, q) -- or run the
- * hinge's element-wise pass (loss, dense dloss/dS).  Replaces aladin_hinge_fused + the first two kernels of
- * aladin_align_bwd_packed in the training step (one launch less; the element-wise pass hides under the pair work).
- * S: the square score matrix of this (geom, xm, xe, y) problem; loss: 1 float; dS: (B, B) contiguous, fully written;
- * hinge_workspace: aladin_hinge_workspace_bytes(B); bwd_workspace: aladin_align_bwd_workspace_bytes(...) -- it receives
- * the argmax table and must stay untouched until aladin_align_bwd_rows consumed it.  Needs the fp16 pair kernel's
- * shapes (geom->mrows <= 64 with side rows only next to 32 or 48, <= 64 padded words), else ALADIN_ERR_UNSUPPORTED.
- * aladin_align_bwd_rows: the remaining kernel of the backward (autograd of alad/loss.py:80-125 given dS and the table),
- * gradients in the caller's layout as in aladin_align_bwd_packed_strided.  dS must be the matrix the fused call wrote: the
- * workspace also carries its transpose (the caption rows read their column of dS from it, coalesced). */
-ALADIN_API int aladin_hinge_argmax_fused(const float* S, int64_t ldS, float margin, float* loss, float* dS, void* hinge_workspace,
-                                         const float* im, int64_t im_stride_b, int64_t im_stride_r, const int32_t* im_len,
-                                         const float* s, int64_t s_stride_b, int64_t s_stride_t, const int32_t* s_len,
-                                         const void* xm, const void* xe, const void* y, const aladin_align_geom* geom,
-                                         void* bwd_workspace, void* stream);
-/* The same merge for the small-batch loss heads (B <= 64; aladin_heads_small_fwd below): statistics launch + ONE kernel
- * running the element-wise pass of all heads next to the pair recompute.  Hardest-negative hinge only (max_violation);
- * flags must include ALADIN_HEAD_ALIGN_HINGE.  Arguments as aladin_heads_small_fwd (no pair list) followed by the
- * backward's operands as in aladin_hinge_argmax_fused; D_emb is the width of the matching embeddings. */
-ALADIN_API int aladin_heads_small_fwd_argmax(const float* img, int64_t ld_img, const float* cap, int64_t ld_cap, const float* S,
-                                             int64_t ld_S, int D_emb, float margin, int flags, float temperature, float eps,
-                                             float w_match, float w_align, float w_dist, float* M, float* terms, float* total,
-                                             float* dM_hinge, float* dM_listnet, float* dS, void* heads_workspace,
-                                             const float* im, int64_t im_stride_b, int64_t im_stride_r, const int32_t* im_len,
-                                             const float* s, int64_t s_stride_b, int64_t s_stride_t, const int32_t* s_len,
-                                             const void* xm, const void* xe, const void* y, const aladin_align_geom* geom,
-                                             void* bwd_workspace, void* stream);
-ALADIN_API int aladin_align_bwd_rows(const float* im, int64_t im_stride_b, int64_t im_stride_r, const int32_t* im_len,
-                                     const float* s, int64_t s_stride_b, int64_t s_stride_t, const int32_t* s_len,
-                                     const float* dS, int64_t ld_dS, const float* gscale, const aladin_align_geom* geom,
-                                     float* d_im, int64_t d_im_stride_b, int64_t d_im_stride_r, float* d_s,
-                                     int64_t d_s_stride_b, int64_t d_s_stride_t, void* bwd_workspace, void* stream);
-
-/* Opt-in forms of the two entry points above with a `flags` word.
- *   ALADIN_BWD_PARTNERS_FP16  the row kernel gathers the partner rows (the unit vectors an output row's gradient is a
- *       weighted sum of) from the forward's PACKED fp16 operands xm / xe / y instead of normalising the raw fp32 rows
- *       again: half the bytes per partner, no norm reduction (bwd_rows 43.6 -> ~39 us at B = 256, traffic past L2
- *       302 -> 217 MB).  The one fp16 rounding of the partners leaves the gradients ~1.5e-4 of their largest entry
- *       away from the reference's autograd -- inside north_star's 1e-3, but 5x the 3e-5 the default exact path holds --
- *       so it is not the default.  The arg-maxima are the exact fp32 ones either way.
- * aladin_align_bwd_rows_ex additionally takes the packed operands (ignored when flags == 0). */
-#define ALADIN_BWD_PARTNERS_FP16 1
-/*   ALADIN_BWD_DENSE  (aladin_align_bwd_packed_strided_ex only) the caller states that (almost) every pair carries a
- *       gradient -- the sum-of-violations hinge (max_violation = False, alad/loss.py:60-67), or a gradient arriving on the
- *       score matrix itself.  The arg-max table of ALL pairs then comes from the forward's own tile kernel run in split
- *       precision (64 pairs per workgroup sharing their operand panels) instead of one workgroup per pair; only the pairs with
- *       a word whose two best regions it cannot separate (a few per cent) go through the exact per-pair kernel.  Same table,
- *       same gradients.  Needs the workspace of aladin_align_bwd_workspace_bytes_ex(..., flags) and the packed fp16 operands;
- *       classes the tile kernel does not cover (R' > 64, small batches) silently take the list
- *       path.  `pairs` / `pair_count` are ignored. */
-#define ALADIN_BWD_DENSE 2
-/*       With the table of all pairs in hand the row step (step 3) runs as two MFMA GEMMs, dXh = P Yh and dYh = P^T Xh with
+ * dS (Bi x Bc, stride ld_dS) is multiplied by *gscale (device float, may be NULL = 1).  Pairs with dS == 0 are skipped, so
+ * the max_violation=True hinge (<= 3B non-zeros) costs O(B) pair blocks.  Three steps: (1) the non-zero pairs (compacted
+ * here, or given: pairs / pair_count as aladin_hinge_fused emits them; both or neither), (2) per pair the arg-max region of
+ * every word -- recomputed on the fp16 MFMA from `packed` when given (xm, y and, with side rows, xe), with every word whose
+ * top candidates are closer than the fp16 error bound re-decided by exact fp32 dot products, or entirely in fp32 when
+ * packed is NULL -- the recorded arg-max is the fp32 arg-max, as autograd's; (3) one wave per OUTPUT row gathers the partner
+ * rows the table points at and applies the normalise backward.  d_im / d_s: fully written, no atomics.
+ * workspace: aladin_align_bwd_workspace_bytes(geom, flags).  Split operands are rejected (forward only).
+ *   ALADIN_BWD_PARTNERS_FP16  step 3 reads the unit vectors -- the partner rows AND the output row's own -- from the
+ *       forward's packed fp16 operands and packed->rnorm instead of normalising the raw fp32 rows again: the raw sets are
+ *       not read by step 3 at all (bwd_rows 43.9 -> ~27 us at B = 256, traffic past L2 302 -> ~185 MB).  One fp16
+ *       rounding of those vectors leaves the gradients <= 2.5e-4 of their largest entry away from the reference's autograd
+ *       (measured on every reference fixture; the test fails at 5e-4 = half of north_star's 1e-3) against 3e-5 without the
+ *       flag.  Needs packed->xm, y, rnorm (and xe with side rows) of THIS problem.  The Python layer sets it by default
+ *       since round 5 (ops.set_backward_precision('exact') clears it).  The arg-maxima are the exact fp32 ones either way.
+ *   ALADIN_BWD_DENSE  the caller states that (almost) every pair carries a gradient -- the sum-of-violations hinge
+ *       (max_violation = False, alad/loss.py:60-67), or a gradient arriving on the score matrix itself.  The arg-max table of
+ *       ALL pairs then comes from the forward's own tile kernel run in split precision (64 pairs per workgroup sharing their
+ *       operand panels) instead of one workgroup per pair; only the pairs with a word whose two best regions it cannot
+ *       separate (a few per cent) go through the exact per-pair kernel.  Same table, same gradients.  Classes the tile kernel
+ *       does not cover (R' > 64, small batches) silently take the list path.  `pairs` / `pair_count` are ignored.
+ *       With the table of all pairs in hand step 3 runs as two MFMA GEMMs, dXh = P Yh and dYh = P^T Xh with
  *       P[(i,r),(c,w)] = dS[i,c] [argmax == r] generated in registers from the table (csrc/align_bwd_dense.hip), exact to
  *       ~2^-22 by hi + lo splitting (one product under ALADIN_BWD_PARTNERS_FP16) -- sums in a different order than the
  *       gather, so equal to it to rounding, not bit for bit.
  *   ALADIN_BWD_DENSE_GATHER  (with ALADIN_BWD_DENSE) keep the per-row gather as step 3: bit-identical to the list path. */
+#define ALADIN_BWD_PARTNERS_FP16 1
+#define ALADIN_BWD_DENSE 2
 #define ALADIN_BWD_DENSE_GATHER 4
-ALADIN_API size_t aladin_align_bwd_workspace_bytes_ex(int Bi, int Bc, int R, int T, int D, int flags);
-ALADIN_API int aladin_align_bwd_packed_strided_ex(const float* im, int64_t im_stride_b, int64_t im_stride_r, const int32_t* im_len,
-                                                  const float* s, int64_t s_stride_b, int64_t s_stride_t, const int32_t* s_len,
-                                                  const float* dS, int64_t ld_dS, const float* gscale, const void* xm, const void* xe,
-                                                  const void* y, const aladin_align_geom* geom, const int32_t* pairs,
-                                                  const int32_t* pair_count, float* d_im, int64_t d_im_stride_b,
-                                                  int64_t d_im_stride_r, float* d_s, int64_t d_s_stride_b, int64_t d_s_stride_t,
-                                                  void* workspace, int flags, void* stream);
-ALADIN_API int aladin_align_bwd_rows_ex(const float* im, int64_t im_stride_b, int64_t im_stride_r, const int32_t* im_len,
-                                        const float* s, int64_t s_stride_b, int64_t s_stride_t, const int32_t* s_len,
-                                        const float* dS, int64_t ld_dS, const float* gscale, const void* xm, const void* xe,
-                                        const void* y, const aladin_align_geom* geom, float* d_im, int64_t d_im_stride_b,
-                                        int64_t d_im_stride_r, float* d_s, int64_t d_s_stride_b, int64_t d_s_stride_t,
-                                        void* bwd_workspace, int flags, void* stream);
+#define ALADIN_BWD_OWN_ROW_FP16 16
+ALADIN_API size_t aladin_align_bwd_workspace_bytes(const aladin_align_geom* geom, int flags);
+ALADIN_API int aladin_align_bwd(const aladin_set* im, const aladin_set* s, const aladin_align_geom* geom,
+                                const aladin_packed* packed, const float* dS, int64_t ld_dS, const float* gscale,
+                                const int32_t* pairs, const int32_t* pair_count, const aladin_set_grad* d_im,
+                                const aladin_set_grad* d_s, void* workspace, int flags, void* stream);
+
+/* The training step of AlignmentContrastiveLoss(max_violation=True, aggregation='MrSw') -- every shipped YAML,
+ * alad/loss.py:79-159 through alad/alad_model.py:386 -- as ONE call per direction, so that an eager drop-in module costs one
+ * FFI crossing where rounds 1-4 made six (pack, scores, workspace queries, hinge, argmax, rows).
+ *   fwd: pack both sets (-> packed, kept by the caller for the backward), side GEMM + score kernel (-> S, Bi x Bi), the
+ *        hinge's row / column statistics, then ONE kernel whose workgroups either recompute a non-zero pair of dloss/dS --
+ *        the pairs follow from the statistics: (q, q), (q, hardest caption of image q), (hardest image of caption q, q) --
+ *        into the backward's arg-max table, or run the hinge's element-wise pass (-> *loss, dS: (B, B) contiguous, fully
+ *        written).  Square problems (Bi == Bc) of the classes the fp16 pair kernel covers (geom->mrows 32 / 48 with side rows
+ *        or 64 without, <= 64 padded words; D % 4 == 0, D <= 1024), fp16 operands; anything else: ALADIN_ERR_UNSUPPORTED,
+ *        and the caller composes pack + scores + aladin_hinge_fused + aladin_align_bwd.
+ *   bwd: step 3 of aladin_align_bwd alone (the table is in the workspace), dS scaled by *gscale (the upstream gradient of
+ *        the loss: a device scalar, may be NULL = 1).  flags: ALADIN_BWD_PARTNERS_FP16 and / or
+ *        ALADIN_TRIPLET_BWD_BASE_WORKSPACE (`workspace` is the bwd_workspace aladin_heads_small_fwd_argmax filled, not the
+ *        triplet workspace).
+ * workspace: aladin_align_triplet_workspace_bytes(geom) -- side-GEMM scratch, hinge statistics, arg-max table, dS^T;
+ * written by fwd, read by bwd: the caller keeps it (and packed, dS) untouched in between.  Both calls are asynchronous,
+ * allocation-free and capturable in a HIP graph. */
+#define ALADIN_TRIPLET_BWD_BASE_WORKSPACE 8
+ALADIN_API size_t aladin_align_triplet_workspace_bytes(const aladin_align_geom* geom);
+ALADIN_API int aladin_align_triplet_fwd(const aladin_set* im, const aladin_set* s, const aladin_align_geom* geom, float margin,
+                                        const aladin_packed* packed, float* S, int64_t ldS, float* loss, float* dS,
+                                        void* workspace, void* stream);
+ALADIN_API int aladin_align_triplet_bwd(const aladin_set* im, const aladin_set* s, const aladin_align_geom* geom,
+                                        const aladin_packed* packed, const float* dS, const float* gscale,
+                                        const aladin_set_grad* d_im, const aladin_set_grad* d_s, void* workspace, int flags,
+                                        void* stream);
+
+/* The same forward for the small-batch loss heads (B <= 64; aladin_heads_small_fwd below): S is given (aladin_align_scores on
+ * `packed`), one statistics launch + ONE kernel running the element-wise pass of all heads next to the pair recompute.
+ * Hardest-negative hinge only; flags must include ALADIN_HEAD_ALIGN_HINGE.  Arguments as aladin_heads_small_fwd (no pair
+ * list) followed by the alignment problem; D_emb is the width of the matching embeddings.  bwd_workspace:
+ * aladin_align_bwd_workspace_bytes(geom, 0) -- it receives the arg-max table and dS^T; the backward is
+ * aladin_align_triplet_bwd on that workspace. */
+ALADIN_API int aladin_heads_small_fwd_argmax(const float* img, int64_t ld_img, const float* cap, int64_t ld_cap, const float* S,
+                                             int64_t ld_S, int D_emb, float margin, int flags, float temperature, float eps,
+                                             float w_match, float w_align, float w_dist, float* M, float* terms, float* total,
+                                             float* dM_hinge, float* dM_listnet, float* dS, void* heads_workspace,
+                                             const aladin_set* im, const aladin_set* s, const aladin_align_geom* geom,
+                                             const aladin_packed* packed, void* bwd_workspace, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * 'sum' / 'mean' pooling (alad/loss.py:120-123): sum_r sum_w <im^,s^> = <sum_r im^, sum_w s^>.
@@ -251,7 +236,7 @@ ALADIN_API int aladin_hinge_fwd_bwd(const float* S, int64_t ldS, int B, float ma
                          float* loss, float* dS, void* workspace, void* stream);
 
 /* Same, additionally emitting the list of non-zero pairs of dS (pairs: B*B int32 holding i*B + j in
- * arbitrary order, pair_count: 1 int32) that aladin_align_bwd_packed can consume directly. */
+ * arbitrary order, pair_count: 1 int32) that aladin_align_bwd can consume directly. */
 ALADIN_API int aladin_hinge_fused(const float* S, int64_t ldS, int B, float margin, int max_violation, float* loss,
                        float* dS, int32_t* pairs, int32_t* pair_count, void* workspace, void* stream);
 
@@ -285,7 +270,7 @@ ALADIN_API int aladin_grad_combine(int64_t n, const float* g, float wa, const fl
  * alignment hinge, listnet} (0 for a head that is off), *total = sum of the selected terms times w_* (the
  * fixed-weight sum of alad_model.py:450-453; may be NULL), and -- each optional -- dM_hinge, dM_listnet (B x B),
  * dS (B x B) with the non-zero pair list pairs / pair_count of the alignment hinge, in the form
- * aladin_align_bwd_packed takes.  workspace: aladin_heads_small_workspace_bytes(B).
+ * aladin_align_bwd takes.  workspace: aladin_heads_small_workspace_bytes(B).
  * bwd (1 launch): d_img = C . cap, d_cap = C^T . img, C = *g_hinge * w_hinge * dM_hinge + *g_listnet * w_listnet *
  * dM_listnet + g_M (every term optional: NULL = absent; g_* are DEVICE scalars, g_M a (B x B) upstream gradient of M);
  * align_scale_out (may be NULL) receives *g_align * w_align, the `gscale` of the alignment backward.
@@ -317,16 +302,13 @@ ALADIN_API int aladin_heads_small_bwd(const float* img, int64_t ld_img, const fl
  * aladin_align_pack_store_x / _y build the max-side (xm, xe) / sum-side (y) operands of
  * aladin_align_scores for the samples ids[0..Bi) / ids[0..Bc) (ids NULL = 0, 1, 2, ...) under a
  * geometry whose Rq / Tq bound the counts; the operands -- hence the scores -- are bit-identical to
- * aladin_align_pack_images / _captions on the fp32 sets.
- * Split stores (precision ALADIN_PRECISION_SPLIT): a row is [hi | lo], 2 * round_up(D, 64) halfs, written by
- * aladin_store_append_mode; aladin_align_pack_store_x / _y take such rows when (and only when) geom->split.
+ * aladin_align_pack on the fp32 sets (no inverse norms: the store is forward-only).
+ * Split stores (precision ALADIN_PRECISION_SPLIT): a row is [hi | lo], 2 * round_up(D, 64) halfs;
+ * aladin_align_pack_store_x / _y take such rows when (and only when) geom->split.
  * ------------------------------------------------------------------------------------------- */
-ALADIN_API int aladin_store_row_width(int D);
-ALADIN_API int aladin_store_row_width_mode(int D, int precision);
-ALADIN_API int aladin_store_append_mode(const float* sets, int64_t stride_b, int64_t stride_r, const int32_t* lens, int B, int L,
-                             int D, int tail, const int64_t* offsets, void* rows, int precision, void* stream);
+ALADIN_API int aladin_store_row_width(int D, int precision);      /* halfs per store row */
 ALADIN_API int aladin_store_append(const float* sets, int64_t stride_b, int64_t stride_r, const int32_t* lens, int B, int L,
-                        int D, int tail, const int64_t* offsets, void* rows, void* stream);
+                                   int D, int tail, const int64_t* offsets, void* rows, int precision, void* stream);
 ALADIN_API int aladin_align_pack_store_x(const void* rows, const int64_t* offsets, const int32_t* counts, const int32_t* ids,
                               const aladin_align_geom* g, void* xm, void* xe, void* stream);
 ALADIN_API int aladin_align_pack_store_y(const void* rows, const int64_t* offsets, const int32_t* counts, const int32_t* ids,
@@ -429,14 +411,18 @@ ALADIN_API int aladin_topk(const float* M, int64_t q_stride, int64_t c_stride, i
  * two-step path whatever the data (integer and packed-max atomics: independent of the tile order).
  * A rank is a count of DECISIONS "score > ground truth", so the GEMM runs the hi.hi third of the split
  * product only and bounds, per pair and rigorously (Cauchy-Schwarz on the two dropped segments of the
- * actual fp16 operands + the fp32 rounding of their accumulation), what the rest can add; pairs the
- * bound does not decide are continued to the exact score -- a handful per 256 x 384 tile through a list
- * (aladin_retrieval_stats: how many), a whole tile in place when there are more than 64.  Cost: a third
- * of the three-product GEMM when ground truths stand clear of the bulk of the scores, up to all of it
- * when they sit inside; the result never depends on it.
+ * actual fp16 operands + the fp32 rounding of their accumulation: 2^-14 |s| covers D <= 16384, larger D takes the
+ * exact path), what the rest can add.  Scores that beat their ground truth by more than the bound are counted in
+ * registers; pairs the bound does not decide, and possible arg-maxima, are continued to the exact score -- through a
+ * list of up to 512 per 256 x 384 tile (a second kernel first drops the arg-max candidates that the certified lower
+ * bounds of all tiles rule out), a whole tile in place when it holds more.  Cost: a third of the three-product GEMM
+ * when ground truths stand clear of the bulk of the scores, ~0.6 of it at Recall@1 75 / 41 %, all of it when they
+ * sit deep inside; the result never depends on it.
  * aladin_retrieval_ranks_exact: every tile takes the three-product path (the round-3 kernel; for A/B
  * runs and tests).  aladin_retrieval_stats_offset: byte offset, inside the workspace of the last call,
- * of int32[2] = {tiles continued in place, pairs continued through lists}. */
+ * of int32[9]: [0] tiles continued in place, [1] pairs listed, [5] listed pairs whose chains were continued,
+ * [6] tiles that ran the analysis, [7] of those, tiles that overflowed their list, [8] tiles that skipped it
+ * ([2..4]: diagnostic build only). */
 ALADIN_API size_t aladin_retrieval_workspace_bytes(int n_img, int n_cap, int D);
 ALADIN_API size_t aladin_retrieval_stats_offset(int n_img, int n_cap, int D);
 ALADIN_API int aladin_retrieval_ranks(const float* img, int64_t img_row_stride, const float* cap, int64_t cap_row_stride, int n_img,

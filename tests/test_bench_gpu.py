@@ -37,7 +37,7 @@ def _bench(*extra):
 
 def test_bench_single_gpu_line():
     d = _bench()
-    assert d['config']['launch'] in ('hipgraph', 'eager') and d['config']['bwd_partners'] == 'exact'
+    assert d['config']['launch'] in ('hipgraph', 'eager') and d['config']['bwd_partners'] == 'fp16'
     assert 0.1 < d['ms_per_step'] < 0.5
 
 
@@ -70,7 +70,10 @@ def test_bench_secondary_fields_are_in_the_line():
     for k in ('eval_config3', 'shipped_shape', 'loss_heads_bs32', 'e2e_config4', 'alignment_retrieval_coco1k'):
         assert k in c and 'error' not in c[k], (k, c.get(k))
     e = c['eval_config3']
-    assert 0.1 < e['ms'] < 0.6 and e['exact_tiles'] == 0 and e['all_exact_ms'] > e['ms'] and len(e['by_data']) == 2
+    # `ms` is timed on the SURVEY 8(d) input (Recall@1 of both directions in 40-80 %) and must run on the screen, not the exact path
+    assert 0.1 < e['ms'] < 0.5 and e['exact_tiles'] <= e['tiles'] // 10 and e['all_exact_ms'] > e['ms'] and len(e['by_data']) == 3
+    assert 40.0 <= e['R@1_i2t'] <= 80.0 and 40.0 <= e['R@1_t2i'] <= 80.0 and e['rescored_pairs'] <= e['listed_pairs']
+    assert e['by_data'][0]['ms'] <= e['ms'] and e['by_data'][2]['ms'] <= 1.08 * e['all_exact_ms']     # clean input cheaper; hard input never much above all-exact
     assert all(0 <= b['exact_tiles'] <= e['tiles'] for b in e['by_data'])
     assert 0.1 < c['shipped_shape']['ms_per_step'] < 0.6
     h = c['loss_heads_bs32']

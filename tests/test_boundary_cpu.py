@@ -79,7 +79,15 @@ def test_workspace_queries():
     lib = _lib.load()
     assert lib.aladin_hinge_workspace_bytes(256) >= 256 * 16
     assert lib.aladin_listnet_workspace_bytes(256) >= 256 * 48
-    assert lib.aladin_align_bwd_workspace_bytes(256, 256, 34, 50, 768) >= 256 * 256 * (4 + 47)
+    import ctypes as C
+    from aladin_amd import ops
+    g = ops.align_geometry(256, 256, 34, 50, 768)
+    base = lib.aladin_align_bwd_workspace_bytes(C.byref(g), 0)
+    assert base >= 256 * 256 * (4 + 47)
+    assert lib.aladin_align_bwd_workspace_bytes(C.byref(g), _lib.BWD_DENSE) > base            # + the split operands and GEMM partials
+    # the fused training node: side-GEMM scratch + hinge statistics + the base workspace
+    assert lib.aladin_align_triplet_workspace_bytes(C.byref(g)) >= base + g.e_bytes + lib.aladin_hinge_workspace_bytes(256)
+    assert g.rnorm_bytes == 4 * (g.xm_rows + g.xe_rows + g.y_rows)
     assert lib.aladin_sim_workspace_bytes(5000, 25000, 768) >= (5000 + 25000) * 2 * 768 * 2      # [hi | lo] rows
     assert lib.aladin_recall_workspace_bytes(25000) == 25000 * 8
 
@@ -363,3 +371,39 @@ def test_drop_in_signatures_match_the_reference():
         assert got[:len(want)] == want, (key, got, want)
         for extra in got[len(want):]:
             assert extra[2] is not None or extra[1] in ('VAR_POSITIONAL', 'VAR_KEYWORD'), (key, 'extra parameter without a default', extra)
+
+
+def test_binding_matches_the_header_argument_for_argument():
+    """Every prototype of include/aladin_hip.h against the ctypes binding: same number of arguments, pointers where the header
+    has pointers, 64-bit integers / floats / ints where it has them (a stale entry in the binding's table -- the same key twice --
+    once shadowed a changed signature until the GPU tier ran), and no key listed twice in the table's source."""
+    import ctypes as C
+    from aladin_amd import _lib
+    lib = _lib.load()
+    hdr = open(os.path.join(ROOT, 'include', 'aladin_hip.h')).read()
+    hdr = re.sub(r'/\*.*?\*/', '', hdr, flags=re.S)
+    protos = re.findall(r'ALADIN_API\s+([\w\s\*]+?)\s*\b(aladin_[a-z0-9_]+)\s*\(([^;]*?)\)\s*;', hdr, flags=re.S)
+    assert {n for _, n, _ in protos} == set(_lib.SYMBOLS)
+
+    def kind(decl):
+        decl = decl.strip()
+        if '*' in decl:
+            return 'ptr'
+        base = decl.split()[:-1] if len(decl.split()) > 1 else decl.split()
+        base = ' '.join(b for b in base if b != 'const')
+        return {'int': 'i32', 'int32_t': 'i32', 'int64_t': 'i64', 'float': 'f32', 'size_t': 'sz'}[base]
+
+    for _, name, args in protos:
+        args = args.strip()
+        want = [] if args in ('', 'void') else [kind(a) for a in args.split(',')]
+        got = []
+        for t in getattr(lib, name).argtypes:
+            if t in (C.c_void_p, C.c_char_p) or hasattr(t, 'contents') or issubclass(t, C._Pointer):
+                got.append('ptr')
+            else:
+                got.append({C.c_int: 'i32', C.c_int64: 'i64', C.c_float: 'f32', C.c_size_t: 'sz'}[t])
+        assert got == want, (name, got, want)
+    src = open(os.path.join(ROOT, 'aladin_amd', '_lib.py')).read()
+    table = src[src.index('    sig = {'):src.index('    for name, (res, args) in sig.items():')]
+    keys = re.findall(r"^\s+'(aladin_[a-z0-9_]+)':", table, flags=re.M)
+    assert len(keys) == len(set(keys)), sorted(k for k in set(keys) if keys.count(k) > 1)
