@@ -100,6 +100,10 @@ class ContrastiveLoss(Contrastive):
     """reference alad/loss.py:162-186."""
 
     def forward(self, im, s, return_similarity_mat=False):
+        if self.sim is dot_sim and getattr(im, 'is_cuda', False) and im.dim() == 2 and tuple(im.shape) == tuple(s.shape):
+            # measure 'dot' (every shipped config): scores + hinge behind ONE autograd node (ops.match_hinge)
+            loss, scores = ops.match_hinge(im, s, self.margin, self.max_violation)
+            return (loss, scores) if return_similarity_mat else loss
         scores = self.sim(im, s)
         loss = self.compute_contrastive_loss(scores)
         if return_similarity_mat:

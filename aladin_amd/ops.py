@@ -1322,6 +1322,65 @@ def small_batch_loss_heads(img_emb, cap_emb, im_set, s_seq, im_len, s_len, margi
 loss_heads = small_batch_loss_heads            # the single-node step at any batch size
 
 
+class _MatchHinge(torch.autograd.Function):
+    """(hinge loss on M, M) with M = im @ s.T (alad/loss.py:8-11 + :42-67) as ONE autograd node at any batch size: forward = the
+    exact-fp32 GEMM + the fused hinge, backward = aladin_grad_combine (g_loss * dLoss/dM + g_M in one launch) + two GEMMs.  Both
+    outputs are differentiable, as ContrastiveLoss(return_similarity_mat=True)'s are in the reference."""
+
+    @staticmethod
+    def forward(ctx, im, s, margin, max_violation):
+        a = im if im.stride(1) == 1 else im.contiguous()
+        b = s if s.stride(1) == 1 else s.contiguous()
+        B = a.shape[0]
+        M = torch.empty((B, B), dtype=torch.float32, device=a.device)
+        _sgemm(B, B, a.shape[1], a, a.stride(0), a.stride(1), b, b.stride(1), b.stride(0), M)
+        need = any(ctx.needs_input_grad[:2])
+        loss, dM, _ = _hinge_raw(M, margin, max_violation, need)
+        ctx.save_for_backward(a, b, dM)
+        ctx.set_materialize_grads(False)
+        return loss, M
+
+    @staticmethod
+    def backward(ctx, g_loss, g_M):
+        a, b, dM = ctx.saved_tensors
+        if (g_loss is None or dM is None) and g_M is None:
+            return None, None, None, None
+        lib = _lib.load()
+        B, D = a.shape
+        if g_loss is not None and dM is not None:
+            g = g_loss.to(torch.float32).contiguous()
+            gM = g_M.contiguous() if g_M is not None else None
+            C_tot = torch.empty_like(dM)
+            # C = g * (1 * dM) (+ g_M: the second matrix slot with weight 1 / g -- not expressible, so add it separately when present)
+            _lib.check(lib.aladin_grad_combine(C_tot.numel(), _ptr(g), 1.0, _ptr(dM), 0.0, _ptr(None), _ptr(C_tot), 0.0, _ptr(None),
+                                               _stream()), 'grad_combine')
+            if gM is not None:
+                C_tot = C_tot + gM
+        else:
+            C_tot = g_M.contiguous()
+        d_a = d_b = None
+        if ctx.needs_input_grad[0]:
+            d_a = torch.empty((B, D), dtype=torch.float32, device=a.device)
+            _sgemm(B, D, B, C_tot, C_tot.stride(0), 1, b, b.stride(0), b.stride(1), d_a)          # C @ cap
+        if ctx.needs_input_grad[1]:
+            d_b = torch.empty((B, D), dtype=torch.float32, device=a.device)
+            _sgemm(B, D, B, C_tot, 1, C_tot.stride(0), a, a.stride(0), a.stride(1), d_b)          # C.T @ img
+        return d_a, d_b, None, None
+
+
+def match_hinge(im, s, margin, max_violation):
+    """(loss, M) of ContrastiveLoss(measure='dot') in one autograd node -- the matching head as alad_model.py:380 calls it
+    every step.  B <= SMALL_BATCH_MAX: the small-batch kernels (two launches forward, one backward); above: GEMM + fused hinge."""
+    _require_gpu(im, s)
+    if im.dim() != 2 or s.dim() != 2 or im.shape != s.shape:
+        raise ValueError('aladin_amd: the contrastive loss needs a square score matrix: two (B, D) embedding matrices of equal shape '
+                         '(the reference fails in diag/expand_as, alad/loss.py:43-45); got %s and %s' % (tuple(im.shape), tuple(s.shape)))
+    if im.shape[0] <= SMALL_BATCH_MAX:
+        loss, _, M = _SmallMatchDistill.apply(im, s, None, margin, max_violation, True, 6.0, 1e-10)
+        return loss, M
+    return _MatchHinge.apply(im, s, margin, max_violation)
+
+
 def small_batch_match_distill(im, s, teacher, margin, max_violation, want_hinge=True, temperature=6.0, eps=1e-10):
     """-> (hinge_loss, listnet_loss, M) for B <= SMALL_BATCH_MAX unit-norm global embeddings im, s (B, D):
     M = im @ s.T (alad/loss.py:8-11), the VSE++ hinge on it (:42-67, if want_hinge) and the ListNet distillation from
