@@ -315,6 +315,45 @@ class SparseImageExchange:
         return d_im
 
 
+class FlatSegments:
+    """The one forward exchange of the fast path: every rank contributes ONE segment [xm | xe | image lengths] (256-byte aligned
+    parts) to a single all-gather.  Pure tensor bookkeeping (device-agnostic: the gloo tests run it on CPU tensors)."""
+
+    def __init__(self, xm_bytes, xe_bytes, B):
+        up = lambda v: (int(v) + 255) // 256 * 256
+        self.xm_b, self.xe_b, self.B = int(xm_bytes), max(int(xe_bytes), 16), int(B)
+        self.o_xe = up(self.xm_b)
+        self.o_il = self.o_xe + up(self.xe_b)
+        self.seg = self.o_il + up(4 * self.B)
+
+    def alloc(self, device):
+        """-> (flat, xm, xe, il): this rank's segment and typed views of its parts (fp16, fp16, int32)."""
+        flat = torch.empty(self.seg, dtype=torch.uint8, device=device)
+        return flat, flat[:self.xm_b].view(torch.float16), flat[self.o_xe:self.o_xe + self.xe_b].view(torch.float16), \
+            flat[self.o_il:self.o_il + 4 * self.B].view(torch.int32)
+
+    def gather(self, flat, group, async_op=True):
+        W, _ = _world(group)
+        flat_all = torch.empty(W * self.seg, dtype=torch.uint8, device=flat.device)
+        return flat_all, dist.all_gather_into_tensor(flat_all, flat, group=group, async_op=async_op)
+
+    def rank_views(self, flat_all, w):
+        """(xm, xe) of rank w, in place."""
+        base = w * self.seg
+        return flat_all[base:base + self.xm_b].view(torch.float16), flat_all[base + self.o_xe:base + self.o_xe + self.xe_b].view(torch.float16)
+
+    def lengths(self, flat_all):
+        W = flat_all.numel() // self.seg
+        return flat_all.view(W, self.seg)[:, self.o_il:self.o_il + 4 * self.B].contiguous().view(torch.int32).reshape(-1)
+
+    def contiguous_operands(self, flat_all):
+        """(xm_all, xe_all): the ranks' parts laid out as ONE operand each (device copies; the dense backward's pair kernel wants that)."""
+        W = flat_all.numel() // self.seg
+        segs = flat_all.view(W, self.seg)
+        return segs[:, :self.xm_b].contiguous().view(-1).view(torch.float16), \
+            segs[:, self.o_xe:self.o_xe + self.xe_b].contiguous().view(-1).view(torch.float16)
+
+
 class _ShardedTriplet(torch.autograd.Function):
     @staticmethod
     def forward(ctx, im, s, im_len_t, s_len_t, margin, max_violation, group, exchange='auto'):
@@ -331,34 +370,37 @@ class _ShardedTriplet(torch.autograd.Function):
                              'B=%d, tile unit %d); use sharded_alignment_loss(), the composable path, instead'
                              % (B, g_loc.img_unit))
         im_c = im.contiguous()
-        xm, xe = ops.pack_images(im_c, im_len_t, g_loc)
-        xm_all = torch.empty(W * xm.numel(), dtype=xm.dtype, device=im.device)
-        xe_all = torch.empty(W * xe.numel(), dtype=xe.dtype, device=im.device)
-        il_all = torch.empty(W * B, dtype=torch.int32, device=im.device)
-        gathers = [dist.all_gather_into_tensor(xm_all, xm, group=group, async_op=True),
-                   dist.all_gather_into_tensor(xe_all, xe, group=group, async_op=True),
-                   dist.all_gather_into_tensor(il_all, im_len_t.contiguous(), group=group, async_op=True)]
+        # ONE exchange for everything the forward needs from the other ranks (round 5; rounds 2-4 issued three gathers): each rank's
+        # segment is [xm | xe | image lengths], packed straight into it; the remote images are then scored rank by rank from their
+        # segments (a score depends only on its own image / caption rows, so any split gives the bits of one launch).
+        fs = FlatSegments(g_loc.xm_bytes, g_loc.xe_bytes, B)
+        flat, xm, xe, il_seg = fs.alloc(im.device)
+        il_seg.copy_(im_len_t)
+        ops.pack_images(im_c, im_len_t, g_loc, out=(xm, xe))
+        flat_all, gather = fs.gather(flat, group)
         need = any(ctx.needs_input_grad[:2])
         # <= 3 non-zeros of dS per row/column under max_violation: pair-driven exchange
         # (its fixed cost -- one host sync for the split sizes -- pays off once the dense form would move
         # >= 4 ranks' worth of fp32 sets; bench.py times both)
         sparse = (bool(max_violation) and W >= 4) if exchange == 'auto' else (exchange == 'sparse')
         im_all, work = None, None
-        if need and not sparse:                    # raw fp32 sets: only the exact backward reads them
+        if need and not sparse:                    # raw fp32 sets: only the exact backward reads them (the second and last gather)
             im_all = torch.empty((W * B, R, D), dtype=im.dtype, device=im.device)
             work = dist.all_gather_into_tensor(im_all, im_c, group=group, async_op=True)
-        # The local images' block does not need the exchange: score it while the gathers are in flight,
-        # then the rank ranges before and after this rank.
+        # The local images' block does not need the exchange: score it while the gather is in flight, then the other ranks' images.
         y = ops.pack_captions(s, s_len_t, g_glob)
         _mark('pack+issue_gathers')
         S_blk = torch.empty((W * B, B), dtype=torch.float32, device=im.device)
-        ops.scores_from_packed(xm, xe, y, g_loc, out=S_blk[r * B:(r + 1) * B])
+        e_scr = torch.empty(max(int(g_loc.e_bytes), 16), dtype=torch.uint8, device=im.device)
+        ops.scores_from_packed(xm, xe, y, g_loc, out=S_blk[r * B:(r + 1) * B], e_scratch=e_scr)
         _mark('local_block')
-        for w_ in gathers:
-            w_.wait()
+        gather.wait()
         _mark('gather_wait')
-        rank_scores_rows(xm_all, xe_all, y, S_blk, 0, r, B, R, T, D)
-        rank_scores_rows(xm_all, xe_all, y, S_blk, r + 1, W - 1 - r, B, R, T, D)
+        for k in range(1, W):
+            w_ = (r + k) % W
+            xm_w, xe_w = fs.rank_views(flat_all, w_)
+            ops.scores_from_packed(xm_w, xe_w, y, g_loc, out=S_blk[w_ * B:(w_ + 1) * B], e_scratch=e_scr)
+        il_all = fs.lengths(flat_all)
         _mark('remote_rows')
         parts = torch.empty((W * S_blk.shape[0], B), dtype=S_blk.dtype, device=im.device)
         dist.all_gather_into_tensor(parts, S_blk, group=group)
@@ -380,6 +422,9 @@ class _ShardedTriplet(torch.autograd.Function):
             ctx.save_for_backward(im_c, il_all, s, s_len_t, dS_full)
             ctx.exchange, ctx.im_shape, ctx.rank = ex, tuple(im.shape), r
         elif need:
+            # the dense backward's pair kernel reads all ranks' packed images as ONE operand: lay the segments' parts out contiguously
+            # (device copies, no collective)
+            xm_all, xe_all = fs.contiguous_operands(flat_all) if W > 1 else (xm, xe)
             ctx.save_for_backward(im_all, il_all, s, s_len_t, dS_full, xm_all, xe_all, y)
             ctx.g_glob, ctx.group = g_glob, group
         ctx.mark_non_differentiable(S_full)

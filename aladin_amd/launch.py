@@ -13,6 +13,7 @@ import socket
 import subprocess
 import sys
 import threading
+import time
 
 RANK_ENV = ('RANK', 'LOCAL_RANK', 'WORLD_SIZE')
 
@@ -45,7 +46,11 @@ def _is_result_line(line):
         return False
 
 
-_BIND_FAILURES = ('Address already in use', 'EADDRINUSE', 'address already in use', 'failed to bind')
+# what torch.distributed.run / the TCPStore print when the rendezvous port was taken between free_port() and their bind.  The retry
+# needs the rendezvous message itself, a failure within RETRY_WINDOW_S of the launch and NO rank output relayed yet (a
+# rank's own socket error after GPU work had started must not trigger a second full run with duplicated output)
+_BIND_FAILURES = ('The server socket has failed to listen', 'failed to bind to', 'EADDRINUSE')
+RETRY_WINDOW_S = 60.0
 
 
 def run_ranks(script, argv, nproc, env=None, python=None, out=None, err=None, timeout=None):
@@ -61,10 +66,10 @@ def run_ranks(script, argv, nproc, env=None, python=None, out=None, err=None, ti
     a launch that dies on the bind is repeated once on a fresh port."""
     out = sys.stdout if out is None else out
     err = sys.stderr if err is None else err
-    rc, result, err_tail = _run_ranks_once(script, argv, nproc, env, python, out, err, timeout)
-    if rc not in (0, 124) and result is None and any(sig in err_tail for sig in _BIND_FAILURES):
+    rc, result, err_tail, elapsed, n_out = _run_ranks_once(script, argv, nproc, env, python, out, err, timeout)
+    if rc not in (0, 124) and result is None and n_out == 0 and elapsed < RETRY_WINDOW_S and any(sig in err_tail for sig in _BIND_FAILURES):
         err.write('aladin_amd.launch: rendezvous port was taken, retrying once on a fresh port\n')
-        rc, result, err_tail = _run_ranks_once(script, argv, nproc, env, python, out, err, timeout)
+        rc, result, err_tail, _, _ = _run_ranks_once(script, argv, nproc, env, python, out, err, timeout)
     if result is not None:
         if rc == 0:
             out.write(result)
@@ -90,9 +95,12 @@ def _run_ranks_once(script, argv, nproc, env, python, out, err, timeout):
                             start_new_session=True)
     result = [None]
     err_tail = []
+    n_out = [0]
+    t_start = time.monotonic()
 
     def pump_out():
         for line in proc.stdout:
+            n_out[0] += 1
             if _is_result_line(line):
                 if result[0] is not None:          # an earlier candidate was ordinary output after all
                     out.write(result[0])
@@ -130,4 +138,4 @@ def _run_ranks_once(script, argv, nproc, env, python, out, err, timeout):
         rc = 124
     for th in threads:
         th.join(timeout=10)
-    return rc, result[0], ''.join(err_tail)
+    return rc, result[0], ''.join(err_tail), time.monotonic() - t_start, n_out[0]

@@ -182,13 +182,17 @@ def _rnorm_views(rnorm, geom):
     return rnorm[:n_img], rnorm[n_img:]
 
 
-def pack_images(im, im_len_t, geom, rnorm=None):
+def pack_images(im, im_len_t, geom, rnorm=None, out=None):
     """(xm, xe): L2-normalised, sliced, length-masked fp16 MFMA operands of the image sets.  rnorm (optional float32 tensor of
-    geom.rnorm_bytes / 4 elements): receives the image rows' inverse norms in its [xm | xe] part."""
+    geom.rnorm_bytes / 4 elements): receives the image rows' inverse norms in its [xm | xe] part.  out = (xm, xe): write into
+    the caller's buffers (the sharded step packs straight into its all-gather segment)."""
     lib = _lib.load()
     im = _rows_inner_contig(im)
-    xm = torch.empty(geom.xm_bytes // 2, dtype=torch.float16, device=im.device)
-    xe = torch.empty(max(geom.xe_bytes // 2, 8), dtype=torch.float16, device=im.device)
+    if out is not None:
+        xm, xe = out
+    else:
+        xm = torch.empty(geom.xm_bytes // 2, dtype=torch.float16, device=im.device)
+        xe = torch.empty(max(geom.xe_bytes // 2, 8), dtype=torch.float16, device=im.device)
     v, pk = _set_view(im, im_len_t), _packed_struct(xm, xe, None, rnorm)
     _lib.check(lib.aladin_align_pack(C.byref(v), None, C.byref(geom), C.byref(pk), _stream()), 'align_pack(images)')
     return xm, xe

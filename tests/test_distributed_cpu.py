@@ -283,3 +283,52 @@ def test_sharded_loss_heads_equal_the_single_process_step():
                 want = leaf.grad.numpy()[r * B:(r + 1) * B]
                 assert got is not None
                 np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-7)
+
+
+def _flat_worker(rank, world, port, ret):
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from aladin_amd.distributed import FlatSegments
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    B, xm_bytes, xe_bytes = 6, 2 * 1000, 2 * 70                    # deliberately not multiples of 256: the parts are padded
+    fs = FlatSegments(xm_bytes, xe_bytes, B)
+    flat, xm, xe, il = fs.alloc(torch.device('cpu'))
+    flat.zero_()
+    xm.copy_(torch.arange(xm.numel(), dtype=torch.float32).add(1000 * rank).to(torch.float16))
+    xe.copy_(torch.arange(xe.numel(), dtype=torch.float32).mul(-1).sub(rank).to(torch.float16))
+    il.copy_(torch.arange(B, dtype=torch.int32) + 10 * rank)
+    flat_all, work = fs.gather(flat, None, async_op=True)
+    work.wait()
+    got = {'il': fs.lengths(flat_all).tolist(), 'seg': fs.seg}
+    for w in range(world):
+        a, b = fs.rank_views(flat_all, w)
+        got[w] = (a.float().tolist(), b.float().tolist())
+    xm_all, xe_all = fs.contiguous_operands(flat_all)
+    got['cat'] = (xm_all.float().tolist(), xe_all.float().tolist())
+    ret[rank] = got
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize('world', [2, 3])
+def test_flat_segment_exchange(world):
+    """Round 5: the fast path's forward exchange is ONE all-gather of [xm | xe | image lengths] segments.  Under gloo: every rank
+    reads back every rank's parts in place, the lengths in rank order, and the contiguous re-layout the dense backward asks for."""
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 31500 + (os.getpid() % 2000) + world
+    mp.spawn(_flat_worker, args=(world, port, ret), nprocs=world, join=True)
+    B, n_xm, n_xe = 6, 1000, 70
+    want_il = [k + 10 * w for w in range(world) for k in range(B)]
+    xm_w = lambda w: torch.arange(n_xm, dtype=torch.float32).add(1000 * w).to(torch.float16).float().tolist()
+    xe_w = lambda w: torch.arange(n_xe, dtype=torch.float32).mul(-1).sub(w).to(torch.float16).float().tolist()
+    for r in range(world):
+        got = ret[r]
+        assert got['seg'] % 256 == 0 and got['il'] == want_il
+        for w in range(world):
+            assert got[w][0] == xm_w(w) and got[w][1] == xe_w(w)
+        assert got['cat'][0] == sum((xm_w(w) for w in range(world)), []) and got['cat'][1] == sum((xe_w(w) for w in range(world)), [])

@@ -209,8 +209,25 @@ def cpu_baseline_b256(threads, budget_s=60.0):
                 avail = int(line.split()[1]) / 2 ** 20
     except OSError:
         pass
+    # a container's memory cap does not show in /proc/meminfo: an OOM kill there takes the whole bench line with it
+    for lim in ('/sys/fs/cgroup/memory.max', '/sys/fs/cgroup/memory/memory.limit_in_bytes'):
+        try:
+            v = open(lim).read().strip()
+            if v.isdigit():
+                cap = int(v) / 2 ** 30
+                used = 0.0
+                for cur in ('/sys/fs/cgroup/memory.current', '/sys/fs/cgroup/memory/memory.usage_in_bytes'):
+                    try:
+                        used = int(open(cur).read().strip()) / 2 ** 30
+                        break
+                    except (OSError, ValueError):
+                        pass
+                avail = cap - used if avail is None else min(avail, cap - used)
+            break
+        except OSError:
+            continue
     if avail is not None and avail < 60.0:
-        raise MemoryError('only %.0f GiB of host memory available; the faithful B = 256 step needs ~40 GiB' % avail)
+        raise MemoryError('only %.0f GiB of host memory available (cgroup limit included); the faithful B = 256 step needs ~40 GiB' % avail)
     im, s, il, sl = synth.alignment_batch(256, 34, 50, 768, seed=1234, ragged=False)
     a, b = torch.from_numpy(im), torch.from_numpy(s)
     torch.set_num_threads(int(threads))

@@ -4,7 +4,7 @@ selects (ALADIN_LIB, ALADIN_SCORE_VARIANT ... of the diag build), saved for a bi
 
     python tools/check_variant.py save gpurun_out/S_base.pt
     ALADIN_LIB=aladin_amd/lib/libaladin_hip_diag.so ALADIN_SCORE_VARIANT=1 python tools/check_variant.py save gpurun_out/S_v1.pt
-    python tools/check_variant.py cmp gpurun_out/S_base.pt gpurun_out/S_v8.pt
+    python tools/check_variant.py cmp gpurun_out/S_base.pt gpurun_out/S_v1.pt
 """
 import os
 import sys
