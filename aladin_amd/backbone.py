@@ -297,7 +297,7 @@ class BertImgModel(nn.Module):
         """The two passes ALADIN makes per step (alad_model.py:124-140: captions alone, then tags + regions) as ONE pass over
         a batch of 2B sequences: the caption embeddings are zero-padded to the image pass's length and masked.  A training
         step of this model on an MI355X is bound by the NUMBER of kernels (thousands of launches of a few microseconds each,
-        tools/bench_e2e_config4.py), not by their work, so one pass of twice the batch costs about what one of the two did.
+        tools/experiments/bench_e2e_config4.py), not by their work, so one pass of twice the batch costs about what one of the two did.
         Masked positions get exp(-10000) = 0 attention weight exactly, every other operation is per position: the real
         positions' states equal those of the two separate passes up to GEMM summation order.
         -> (txt_sequence_output (B, T_txt, H), img_sequence_output (B, T_img + R, H))"""

@@ -90,11 +90,11 @@ class JointTextImageTransformerEncoder(nn.Module):
         """backbone_autocast: None (default: the backbone runs in fp32, as the reference trains) or a torch dtype
         (torch.bfloat16 / torch.float16): the two BERT passes run under torch.autocast -- 16-bit MFMA GEMMs instead of fp32
         ones; the hand-off, the matching head and the loss heads stay fp32.  An MI355X-side option, not reference behaviour:
-        the end-to-end step of the shipped YAML is 99 % backbone (tools/bench_e2e_config4.py)."""
+        the end-to-end step of the shipped YAML is 99 % backbone (tools/experiments/bench_e2e_config4.py)."""
         super().__init__()
         self.backbone_autocast = backbone_autocast
         # The backbone's forward_pair (both BERT passes as one pass of 2B sequences) halves the launches but pads the caption pass
-        # to the image pass's length: measured at bs 32 (tools/bench_e2e_config4.py) it pays when the step is launch-bound
+        # to the image pass's length: measured at bs 32 (tools/experiments/bench_e2e_config4.py) it pays when the step is launch-bound
         # (16-bit autocast: 32.1 -> 19.4 ms) and costs 5 % when the fp32 GEMMs dominate (33.5 -> 35.3 ms)
         self.batch_passes = backbone_autocast is not None
         m = config['model']

@@ -10,76 +10,14 @@ import torch
 
 from . import _lib
 
-
-_RAW_STREAM = getattr(torch._C, '_cuda_getCurrentRawStream', None)
-
-
-def _stream():
-    """hipStream_t of PyTorch's current stream (reference kernels run there too).  The raw getter is
-    ~10x cheaper than torch.cuda.current_stream(), which matters for the small-batch, launch-bound step."""
-    if _RAW_STREAM is not None:
-        return C.c_void_p(_RAW_STREAM(torch.cuda.current_device()))
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
-
-
-def _ptr(t):
-    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
-
-
-def _require_gpu(*tensors):
-    for t in tensors:
-        if not isinstance(t, torch.Tensor):
-            raise TypeError('aladin_amd: expected a torch.Tensor, got %r' % type(t))
-        if not t.is_cuda:
-            raise RuntimeError('aladin_amd: the alignment/matching path runs in HIP kernels on an MI355X only; '
-                               'got a %s tensor (no CPU fallback exists)' % t.device)
-        if t.dtype != torch.float32:
-            raise TypeError('aladin_amd: float32 expected, got %s' % t.dtype)
-        if t.device.index is not None and t.device.index != torch.cuda.current_device():
-            # kernels are enqueued on the CURRENT device's current stream (one process per GPU, DESIGN.md section 5)
-            raise RuntimeError('aladin_amd: tensor on %s but the current device is cuda:%d; call torch.cuda.set_device() '
-                               '(or use `with torch.cuda.device(...)`) first' % (t.device, torch.cuda.current_device()))
-
-
-def _rows_inner_contig(t):
-    """Keep permuted (S,B,D)->(B,S,D) views (reference alad/alad_model.py:377-378) without a copy
-    as long as the feature axis is contiguous and rows stay 16-byte aligned."""
-    if t.stride(-1) != 1 or any(st % 4 for st in t.stride()[:-1]) or t.data_ptr() % 16:
-        return t.contiguous()
-    return t
-
-
-_LEN_CACHE = {}
-
-
-def lengths_tensor(lens, device):
-    """Python list / tensor of lengths -> int32 device tensor (the reference passes lists).
-    Lists are cached by value so that a repeated batch shape costs no host->device copy."""
-    if isinstance(lens, torch.Tensor):
-        return lens.to(device=device, dtype=torch.int32, non_blocking=True)
-    key = (tuple(lens), device)
-    t = _LEN_CACHE.get(key)
-    if t is None:
-        if len(_LEN_CACHE) >= 256:
-            _LEN_CACHE.clear()
-        t = torch.tensor([int(x) for x in key[0]], dtype=torch.int32).to(device, non_blocking=True)
-        _LEN_CACHE[key] = t
-    return t
-
-
-def _ld(t):
-    """Leading dimension of a 2-D tensor whose rows are contiguous (stride(0) is arbitrary when there is one row)."""
-    return t.stride(0) if t.shape[0] > 1 else max(t.shape[1], 1)
+from ._ops_common import _RAW_STREAM, _stream, _ptr, _require_gpu, _rows_inner_contig, _LEN_CACHE, lengths_tensor, _ld, _workspace
+from .ops_losses import _DotScores, _hinge_raw        # (the other names of ops_losses / ops_heads / ops_retrieval: __getattr__ below)
 
 
 def _pair_kernel_covers(geom):
     """Shapes the fp16 pair kernel of the backward covers (csrc/align_bwd.hip: bwd_pair_argmax16_kernel): a 64-row block per
     pair = the image's 32 / 48 main rows + a window on its side rows, or its 64 main rows; at most 64 padded words."""
     return (geom.mrows in (32, 48) or (geom.mrows == 64 and geom.rem == 0)) and geom.tp16 <= 4
-
-
-def _workspace(nbytes, device):
-    return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -266,7 +204,7 @@ def _grad_like(x):
 DENSE_MIN_FRACTION = 0.4     # of the pairs carrying a gradient: below, the list path (cost ~ 3.2 ms x fraction at B = 256) beats the dense one (~1.4 ms)
 DENSE_MIN_PAIRS = 1 << 14    # below: the per-pair kernel is launch-bound and already faster (B = 64: 0.20 vs 0.26 ms)
 DENSE_ROWS_GEMM = True       # False: ALADIN_BWD_DENSE_GATHER -- the dense table with the per-row gather (bit-identical to the list path)
-DENSE_BACKWARD = True        # False: always one workgroup per gradient-carrying pair (the A/B switch of tests/ and tools/bench_dense_ds.py)
+DENSE_BACKWARD = True        # False: always one workgroup per gradient-carrying pair (the A/B switch of tests/ and tools/experiments/bench_dense_ds.py)
 
 
 class _DensityProbe:
@@ -327,7 +265,7 @@ DENSE_GEMM_FORCE = False     # tests / tools: the GEMM row step whatever the cap
 
 def _caption_fill(s_len, T, y_tail=2):
     """Mean share of a caption's 16-word tiles that holds real words (None: lengths only on the device).  The gather row
-    step costs ~ real words, the GEMM one the padded tiles: measured crossover (B = 256, tools/dense_backward_probe.py fill)
+    step costs ~ real words, the GEMM one the padded tiles: measured crossover (B = 256, tools/experiments/dense_backward_probe.py fill)
     at a fill of 0.42 for R' = 33 and 0.50 for R' = 50 -- COCO captions (~12 of 35 tokens) are on the gather side."""
     if isinstance(s_len, torch.Tensor):
         return None
@@ -467,25 +405,6 @@ class _AlignScores(torch.autograd.Function):
             dense = probe.step(torch.count_nonzero(dS), dS.numel())
         d_im, d_s = _align_backward(im, s, im_len_t, s_len_t, dS, packed=(ctx.geom, xm, xe, y, rnorm), dense=dense)
         return d_im, d_s, None, None, None, None
-
-
-def _hinge_raw(scores, margin, max_violation, want_grad, want_pairs=False, loss_out=None):
-    """-> (loss, dS or None, pairs or None); pairs = (int32 list of non-zero i*B+j, int32 count).
-    loss_out: a one-element float32 view the kernel writes the loss into (instead of a fresh scalar)."""
-    lib = _lib.load()
-    B = scores.shape[0]
-    sc = scores if scores.stride(1) == 1 else scores.contiguous()
-    dev = scores.device
-    loss = loss_out if loss_out is not None else torch.empty((), dtype=torch.float32, device=dev)
-    dS = torch.empty((B, B), dtype=torch.float32, device=dev) if want_grad else None
-    ws = _workspace(lib.aladin_hinge_workspace_bytes(B), dev)
-    pairs = None
-    if want_grad and want_pairs:
-        pairs = (torch.empty(B * B, dtype=torch.int32, device=dev), torch.empty(1, dtype=torch.int32, device=dev))
-    _lib.check(lib.aladin_hinge_fused(_ptr(sc), _ld(sc), B, float(margin), int(bool(max_violation)), _ptr(loss),
-                                      _ptr(dS), _ptr(pairs[0] if pairs else None), _ptr(pairs[1] if pairs else None),
-                                      _ptr(ws), _stream()), 'hinge_fused')
-    return loss, dS, pairs
 
 
 def _buf_views(buf, geom, offs):
@@ -877,642 +796,19 @@ def alignment_sum_scores(im_set, s_seq, im_len, s_len, mean=False):
 
 
 # ------------------------------------------------------------------------------------------------
-# hinge / listnet
+# One namespace for callers (`from aladin_amd import ops; ops.hinge_loss(...)`): the losses, the loss heads and the retrieval
+# functions live in ops_losses / ops_heads / ops_retrieval (round 5 split of a 1400-line module) and are looked up lazily, so that
+# ops_heads may import THIS module (it builds on the alignment nodes) without a cycle.
 # ------------------------------------------------------------------------------------------------
-class _Hinge(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, scores, margin, max_violation):
-        loss, ctx.dS, _ = _hinge_raw(scores, margin, max_violation, ctx.needs_input_grad[0])
-        return loss
-
-    @staticmethod
-    def backward(ctx, g):
-        return (ctx.dS * g if ctx.dS is not None else None), None, None
-
-
-def hinge_loss(scores, margin, max_violation):
-    """VSE++ hinge on a square score matrix; replaces reference alad/loss.py:42-67."""
-    _require_gpu(scores)
-    if scores.dim() != 2 or scores.shape[0] != scores.shape[1]:
-        raise ValueError('aladin_amd: the contrastive loss needs a square score matrix, got %s '
-                         '(the reference fails in diag/expand_as, alad/loss.py:43-45)' % (tuple(scores.shape),))
-    return _Hinge.apply(scores, margin, max_violation)
-
-
-class _ListNet(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, teacher, student, temperature, eps):
-        lib = _lib.load()
-        B = student.shape[0]
-        t = teacher if teacher.stride(1) == 1 else teacher.contiguous()
-        m = student if student.stride(1) == 1 else student.contiguous()
-        loss = torch.empty((), dtype=torch.float32, device=student.device)
-        dM = torch.empty((B, B), dtype=torch.float32, device=student.device) if ctx.needs_input_grad[1] else None
-        ws = _workspace(lib.aladin_listnet_workspace_bytes(B), student.device)
-        _lib.check(lib.aladin_listnet_fwd_bwd(_ptr(t), _ld(t), _ptr(m), _ld(m), B, float(temperature),
-                                              float(eps), _ptr(loss), _ptr(dM), _ptr(ws), _stream()), 'listnet_fwd_bwd')
-        ctx.dM = dM
-        return loss
-
-    @staticmethod
-    def backward(ctx, g):
-        return None, (ctx.dM * g if ctx.dM is not None else None), None, None
-
-
-def listnet_loss(teacher_scores, student_scores, temperature=6.0, eps=1e-10):
-    """ListNet distillation; replaces reference alad/loss.py:427-445 (teacher detached, :370)."""
-    _require_gpu(teacher_scores, student_scores)
-    if teacher_scores.shape != student_scores.shape or student_scores.dim() != 2 \
-            or student_scores.shape[0] != student_scores.shape[1]:
-        raise ValueError('aladin_amd: listnet needs two square score matrices of equal shape')
-    return _ListNet.apply(teacher_scores.detach(), student_scores, temperature, eps)
-
-
-class _DistillMode(torch.autograd.Function):
-    """mse / contrastive / ordinal distillation: forward computes loss and d student in one call."""
-
-    @staticmethod
-    def forward(ctx, teacher, student, wb, mode, margin, threshold, stride):
-        lib = _lib.load()
-        B = student.shape[0]
-        t = teacher if teacher.stride(1) == 1 else teacher.contiguous()
-        m = student if student.stride(1) == 1 else student.contiguous()
-        dev = student.device
-        loss = torch.empty((), dtype=torch.float32, device=dev)
-        dM = torch.empty((B, B), dtype=torch.float32, device=dev) if ctx.needs_input_grad[1] else None
-        ws = _workspace(lib.aladin_distill_workspace_bytes(B), dev)
-        ctx.dwb = None
-        if mode == 'mse':
-            w = wb.detach().to(torch.float32).contiguous()
-            ctx.dwb = torch.empty(2, dtype=torch.float32, device=dev) if ctx.needs_input_grad[2] else None
-            _lib.check(lib.aladin_distill_mse_fwd_bwd(_ptr(t), _ld(t), _ptr(m), _ld(m), B, _ptr(w), _ptr(loss), _ptr(dM),
-                                                      _ptr(ctx.dwb), _ptr(ws), _stream()), 'distill_mse_fwd_bwd')
-        elif mode == 'contrastive':
-            _lib.check(lib.aladin_distill_contrastive_fwd_bwd(_ptr(t), _ld(t), _ptr(m), _ld(m), B, float(margin), _ptr(loss),
-                                                              _ptr(dM), _ptr(ws), _stream()), 'distill_contrastive_fwd_bwd')
-        else:
-            _lib.check(lib.aladin_distill_ordinal_fwd_bwd(_ptr(t), _ld(t), _ptr(m), _ld(m), B, float(margin),
-                                                          float(threshold), int(stride), _ptr(loss), _ptr(dM), _ptr(ws),
-                                                          _stream()), 'distill_ordinal_fwd_bwd')
-        ctx.dM = dM
-        return loss
-
-    @staticmethod
-    def backward(ctx, g):
-        return (None, ctx.dM * g if ctx.dM is not None else None, ctx.dwb * g if ctx.dwb is not None else None,
-                None, None, None, None)
-
-
-def distillation_loss(teacher_scores, student_scores, mode, margin=0.2, threshold=0.1, stride=3, wb=None):
-    """DistillationLoss modes 'mse' / 'contrastive' / 'ordinal'; replaces reference alad/loss.py:371-425
-    (teacher detached, :370).  ``wb`` is the learnable (2,) pair of the 'mse' mode (:366)."""
-    _require_gpu(teacher_scores, student_scores)
-    if mode not in ('mse', 'contrastive', 'ordinal'):
-        raise ValueError('aladin_amd: unknown distillation mode %r' % (mode,))
-    if teacher_scores.shape != student_scores.shape or student_scores.dim() != 2 \
-            or student_scores.shape[0] != student_scores.shape[1]:
-        raise ValueError('aladin_amd: distillation needs two square score matrices of equal shape')
-    if mode == 'mse':
-        if wb is None or wb.numel() != 2:
-            raise ValueError("aladin_amd: mode 'mse' needs the (2,) parameter wb")
-        _require_gpu(wb)
-    elif mode == 'ordinal' and not 1 <= int(stride) < student_scores.shape[0]:
-        raise ValueError('aladin_amd: ordinal distillation needs 1 <= stride < B')
-    return _DistillMode.apply(teacher_scores.detach(), student_scores, wb, mode, margin, threshold, stride)
-
-
-class _OrderScores(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, im, s):
-        lib = _lib.load()
-        a = im if im.stride(1) == 1 else im.contiguous()
-        b = s if s.stride(1) == 1 else s.contiguous()
-        out = torch.empty((a.shape[0], b.shape[0]), dtype=torch.float32, device=a.device)
-        _lib.check(lib.aladin_order_sim_fwd(_ptr(a), a.stride(0), _ptr(b), b.stride(0), a.shape[0], b.shape[0], a.shape[1],
-                                            _ptr(out), out.stride(0), _stream()), 'order_sim_fwd')
-        ctx.save_for_backward(a, b, out)
-        return out
-
-    @staticmethod
-    def backward(ctx, g):
-        lib = _lib.load()
-        a, b, out = ctx.saved_tensors
-        g = g.contiguous()
-        d_im = torch.empty_like(a) if ctx.needs_input_grad[0] else None
-        d_s = torch.empty_like(b) if ctx.needs_input_grad[1] else None
-        _lib.check(lib.aladin_order_sim_bwd(_ptr(a), a.stride(0), _ptr(b), b.stride(0), a.shape[0], b.shape[0], a.shape[1],
-                                            _ptr(g), _ld(g), _ptr(out), out.stride(0), _ptr(d_im),
-                                            d_im.stride(0) if d_im is not None else 0, _ptr(d_s),
-                                            d_s.stride(0) if d_s is not None else 0, _stream()), 'order_sim_bwd')
-        return d_im, d_s
-
-
-def order_scores(im, s):
-    """-||max(s_j - im_i, 0)||; replaces order_sim, reference alad/loss.py:20-26."""
-    _require_gpu(im, s)
-    if im.dim() != 2 or s.dim() != 2 or im.shape[1] != s.shape[1]:
-        raise ValueError('aladin_amd: (Bi,D) and (Bc,D) embeddings expected')
-    return _OrderScores.apply(im, s)
-
-
-# ------------------------------------------------------------------------------------------------
-# dot-product scores (matching head)
-# ------------------------------------------------------------------------------------------------
-def _sgemm(M, N, K, A, a_rs, a_cs, B, b_rs, b_cs, out):
-    _lib.check(_lib.load().aladin_sgemm_strided(M, N, K, _ptr(A), a_rs, a_cs, _ptr(B), b_rs, b_cs, _ptr(out),
-                                                out.stride(0), _stream()), 'sgemm_strided')
-    return out
-
-
-class _DotScores(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, im, s):
-        ctx.save_for_backward(im, s)
-        out = torch.empty((im.shape[0], s.shape[0]), dtype=torch.float32, device=im.device)
-        # C[m][n] = sum_k im[m,k] * s[n,k]
-        return _sgemm(im.shape[0], s.shape[0], im.shape[1], im, im.stride(0), im.stride(1), s, s.stride(1), s.stride(0), out)
-
-    @staticmethod
-    def backward(ctx, dM):
-        im, s = ctx.saved_tensors
-        dM = dM.contiguous()
-        Bi, Bc, D = im.shape[0], s.shape[0], im.shape[1]
-        d_im = torch.empty((Bi, D), dtype=torch.float32, device=im.device)
-        d_s = torch.empty((Bc, D), dtype=torch.float32, device=im.device)
-        _sgemm(Bi, D, Bc, dM, dM.stride(0), 1, s, s.stride(0), s.stride(1), d_im)        # dM @ s
-        _sgemm(Bc, D, Bi, dM, 1, dM.stride(0), im, im.stride(0), im.stride(1), d_s)      # dM.T @ im
-        return d_im, d_s
-
-
-def dot_scores(im, s):
-    """im @ s.T in exact fp32 on the MFMA; replaces dot_sim, reference alad/loss.py:8-11."""
-    _require_gpu(im, s)
-    if im.dim() != 2 or s.dim() != 2 or im.shape[1] != s.shape[1]:
-        raise ValueError('aladin_amd: (Bi,D) and (Bc,D) embeddings expected')
-    return _DotScores.apply(im, s)
-
-
-# ------------------------------------------------------------------------------------------------
-# small-batch matching + distillation (B <= 64: the batch size of every shipped YAML is 32)
-# ------------------------------------------------------------------------------------------------
-SMALL_BATCH_MAX = 64
-HEAD_MATCH_HINGE, HEAD_ALIGN_HINGE, HEAD_LISTNET = 1, 2, 4      # ALADIN_HEAD_* of include/aladin_hip.h
-
-
-def _heads_small_fwd(im, s, S, margin, max_violation, flags, temperature, eps, weights, want_grads, want_pairs, align=None):
-    """Launch aladin_heads_small_fwd -> dict of its outputs (see include/aladin_hip.h).
-    align = (im_set, s_seq, im_len_t, s_len_t, packed): with the hardest-negative alignment hinge and the fp16 pair
-    kernel's shapes the element-wise pass shares its launch with the backward's pair recompute
-    (aladin_heads_small_fwd_argmax); out['table_ws'] then holds the argmax table and out['sets'] the sets in the row
-    layout the kernels were given."""
-    lib = _lib.load()
-    B = (im if im is not None else S).shape[0]
-    dev = (im if im is not None else S).device
-    D = im.shape[1] if im is not None else 1
-    out = {'M': torch.empty((B, B), dtype=torch.float32, device=dev) if flags & (HEAD_MATCH_HINGE | HEAD_LISTNET) else None,
-           'terms': torch.empty(3, dtype=torch.float32, device=dev),             # [matching, alignment, listnet]
-           'total': torch.empty((), dtype=torch.float32, device=dev)}
-    f32 = dict(dtype=torch.float32, device=dev)
-    # a head with weight 0 is computed for its logged value only (the distillation term before distill_epoch,
-    # alad_model.py:442-444): no gradient matrix is produced for it, and the kernels keep it out of the total
-    out['dMh'] = torch.empty((B, B), **f32) if (want_grads and flags & HEAD_MATCH_HINGE and weights[0] != 0) else None
-    out['dMl'] = torch.empty((B, B), **f32) if (want_grads and flags & HEAD_LISTNET and weights[2] != 0) else None
-    out['dS'] = torch.empty((B, B), **f32) if (want_grads and flags & HEAD_ALIGN_HINGE) else None
-    out['pairs'] = out['table_ws'] = out['sets'] = None
-    if (align is not None and out['dS'] is not None and max_violation and _pair_kernel_covers(align[4][0])
-            and not align[4][0].split):
-        im_set, s_seq, im_len_t, s_len_t, packed = align
-        geom = packed[0]
-        im_c, s_c = _rows_inner_contig(im_set), _rows_inner_contig(s_seq)
-        out['table_ws'] = torch.empty(lib.aladin_align_bwd_workspace_bytes(C.byref(geom), 0), dtype=torch.uint8, device=dev)
-        out['sets'] = (im_c, s_c)
-        ws = _workspace(lib.aladin_heads_small_workspace_bytes(B), dev)
-        vi, vs, pk = _set_view(im_c, im_len_t), _set_view(s_c, s_len_t), _packed_struct(*packed[1:5])
-        _lib.check(lib.aladin_heads_small_fwd_argmax(_ptr(im), _ld(im) if im is not None else 0, _ptr(s), _ld(s) if s is not None else 0,
-                                                     _ptr(S), _ld(S), D, float(margin), int(flags), float(temperature), float(eps),
-                                                     float(weights[0]), float(weights[1]), float(weights[2]), _ptr(out['M']),
-                                                     _ptr(out['terms']), _ptr(out['total']), _ptr(out['dMh']), _ptr(out['dMl']),
-                                                     _ptr(out['dS']), _ptr(ws), C.byref(vi), C.byref(vs), C.byref(geom), C.byref(pk),
-                                                     _ptr(out['table_ws']), _stream()), 'heads_small_fwd_argmax')
-        return out
-    if want_pairs and out['dS'] is not None:
-        out['pairs'] = (torch.empty(B * B, dtype=torch.int32, device=dev), torch.empty(1, dtype=torch.int32, device=dev))
-    ws = _workspace(lib.aladin_heads_small_workspace_bytes(B), dev)
-    _lib.check(lib.aladin_heads_small_fwd(_ptr(im), _ld(im) if im is not None else 0, _ptr(s), _ld(s) if s is not None else 0,
-                                          _ptr(S), _ld(S) if S is not None else 0, B, D, float(margin), int(bool(max_violation)),
-                                          int(flags), float(temperature), float(eps), float(weights[0]), float(weights[1]),
-                                          float(weights[2]), _ptr(out['M']), _ptr(out['terms']), _ptr(out['total']),
-                                          _ptr(out['dMh']), _ptr(out['dMl']), _ptr(out['dS']),
-                                          _ptr(out['pairs'][0] if out['pairs'] else None),
-                                          _ptr(out['pairs'][1] if out['pairs'] else None), _ptr(ws), _stream()), 'heads_small_fwd')
-    return out
-
-
-class _SmallMatchDistill(torch.autograd.Function):
-    """(hinge loss on M, listnet loss of M against the teacher, M) with M = im @ s.T, in two forward launches and
-    one backward launch (csrc/small_batch.hip).  Either loss may be switched off (returns a zero scalar)."""
-
-    @staticmethod
-    def forward(ctx, im, s, teacher, margin, max_violation, want_hinge, temperature, eps):
-        im = im if im.stride(1) == 1 else im.contiguous()
-        s = s if s.stride(1) == 1 else s.contiguous()
-        t = None
-        if teacher is not None:
-            t = teacher if teacher.stride(1) == 1 else teacher.contiguous()
-        flags = (HEAD_MATCH_HINGE if want_hinge else 0) | (HEAD_LISTNET if t is not None else 0)
-        need = any(ctx.needs_input_grad[:2])
-        o = _heads_small_fwd(im, s, t, margin, max_violation, flags, temperature, eps, (1.0, 1.0, 1.0), need, False)
-        ctx.save_for_backward(im, s, o['dMh'], o['dMl'])
-        ctx.set_materialize_grads(False)
-        return o['terms'][0], o['terms'][2], o['M']
-
-    @staticmethod
-    def backward(ctx, g_h, g_l, g_M):
-        im, s, dMh, dMl = ctx.saved_tensors
-        if (g_h is None or dMh is None) and (g_l is None or dMl is None) and g_M is None:
-            return (None,) * 8
-        B, D = im.shape
-        d_im = torch.empty((B, D), dtype=torch.float32, device=im.device) if ctx.needs_input_grad[0] else None
-        d_s = torch.empty((B, D), dtype=torch.float32, device=im.device) if ctx.needs_input_grad[1] else None
-        gh = g_h.to(torch.float32).contiguous() if (g_h is not None and dMh is not None) else None
-        gl = g_l.to(torch.float32).contiguous() if (g_l is not None and dMl is not None) else None
-        gM = (g_M if g_M.stride(1) == 1 else g_M.contiguous()) if g_M is not None else None
-        _lib.check(_lib.load().aladin_heads_small_bwd(_ptr(im), _ld(im), _ptr(s), _ld(s), B, D,
-                                                      _ptr(dMh if gh is not None else None), _ptr(gh), 1.0,
-                                                      _ptr(dMl if gl is not None else None), _ptr(gl), 1.0, _ptr(gM),
-                                                      _ld(gM) if gM is not None else 0, _ptr(None), 0.0, _ptr(None),
-                                                      _ptr(d_im), _ptr(d_s), _stream()), 'heads_small_bwd')
-        return d_im, d_s, None, None, None, None, None, None
-
-
-class _SmallHeads(torch.autograd.Function):
-    """The whole loss-head step at B <= 64 as ONE autograd node: alignment scores (pack, side GEMM, score kernel),
-    then the three heads and their fixed-weight sum (alad_model.py:450-453) in two launches; backward = one launch for
-    the matching side + the two alignment backward kernels.  No element-wise glue kernels at all.
-    Returns (total, terms[3] = matching / alignment / distillation, S, M); only `total` is differentiable."""
-
-    @staticmethod
-    def forward(ctx, img_emb, cap_emb, im, s, im_len_t, s_len_t, margin, max_violation, flags, weights, temperature, eps):
-        need_sets = any(ctx.needs_input_grad[2:4])
-        need_embs = any(ctx.needs_input_grad[0:2])
-        S, packed = None, None
-        if flags & (HEAD_ALIGN_HINGE | HEAD_LISTNET):
-            if need_sets and flags & HEAD_ALIGN_HINGE:
-                _check_backward_supported(im, s, 0, 2)
-            S, packed = _align_forward(im, s, im_len_t, s_len_t)
-        a = b = None
-        if flags & (HEAD_MATCH_HINGE | HEAD_LISTNET):
-            a = img_emb if img_emb.stride(1) == 1 else img_emb.contiguous()
-            b = cap_emb if cap_emb.stride(1) == 1 else cap_emb.contiguous()
-        align = (im, s, im_len_t, s_len_t, packed) if (packed is not None and need_sets and flags & HEAD_ALIGN_HINGE) else None
-        o = _heads_small_fwd(a, b, S, margin, max_violation, flags, temperature, eps, weights, need_sets or need_embs, True, align)
-        if o['sets'] is not None:
-            im, s = o['sets']
-        ctx.flags, ctx.weights = flags, weights
-        ctx.geom = packed[0] if packed is not None else None
-        ctx.pairs = o['pairs']
-        pk = packed[1:] if packed is not None else (None, None, None, None)
-        ctx.save_for_backward(a, b, im, s, im_len_t, s_len_t, pk[0], pk[1], pk[2], pk[3], o['dMh'], o['dMl'], o['dS'], o['table_ws'])
-        ctx.set_materialize_grads(False)
-        terms = o['terms']
-        ctx.mark_non_differentiable(*[t for t in (terms, S, o['M']) if t is not None])       # one call: it replaces the set
-        return o['total'], terms, S, o['M']
-
-    @staticmethod
-    def backward(ctx, g_total, _g_terms, _g_S, _g_M):
-        if g_total is None:
-            return (None,) * 12
-        a, b, im, s, im_len_t, s_len_t, xm, xe, y, rnorm, dMh, dMl, dS, table_ws = ctx.saved_tensors
-        flags, w = ctx.flags, ctx.weights
-        g = g_total.to(torch.float32).contiguous()
-        d_a = d_b = d_im = d_s = None
-        scale = torch.empty(1, dtype=torch.float32, device=g.device) if dS is not None else None
-        if a is not None:
-            B, D = a.shape
-            d_a = torch.empty((B, D), dtype=torch.float32, device=a.device) if ctx.needs_input_grad[0] else None
-            d_b = torch.empty((B, D), dtype=torch.float32, device=a.device) if ctx.needs_input_grad[1] else None
-            _lib.check(_lib.load().aladin_heads_small_bwd(_ptr(a), _ld(a), _ptr(b), _ld(b), B, D, _ptr(dMh), _ptr(g), float(w[0]),
-                                                          _ptr(dMl), _ptr(g), float(w[2]), _ptr(None), 0, _ptr(g), float(w[1]),
-                                                          _ptr(scale), _ptr(d_a), _ptr(d_b), _stream()), 'heads_small_bwd')
-        elif scale is not None:
-            scale = g * float(w[1])
-        if dS is not None and any(ctx.needs_input_grad[2:4]):
-            if table_ws is not None:
-                d_im, d_s = _triplet_backward(im, s, im_len_t, s_len_t, ctx.geom, _packed_struct(xm, xe, y, rnorm), dS, table_ws, scale,
-                                              base_workspace=True)
-            else:
-                d_im, d_s = _align_backward(im, s, im_len_t, s_len_t, dS, gscale=scale, packed=(ctx.geom, xm, xe, y, rnorm), pairs=ctx.pairs)
-        return d_a, d_b, d_im, d_s, None, None, None, None, None, None, None, None
-
-
-class _BigHeads(torch.autograd.Function):
-    """_SmallHeads for B > 64: the same single autograd node over the general kernels -- alignment scores + fused hinge,
-    exact-fp32 matching GEMM, hinge and ListNet on it, aladin_loss_total for the weighted sum; backward =
-    aladin_grad_combine (upstream gradient x weights x dLoss/dM, and the alignment backward's scale) + two GEMMs + the
-    alignment backward.  No element-wise torch kernels."""
-
-    @staticmethod
-    def forward(ctx, img_emb, cap_emb, im, s, im_len_t, s_len_t, margin, max_violation, flags, weights, temperature, eps):
-        lib = _lib.load()
-        need_sets = any(ctx.needs_input_grad[2:4])
-        need_embs = any(ctx.needs_input_grad[0:2])
-        dev = img_emb.device
-        B = img_emb.shape[0]
-        terms = torch.empty(3, dtype=torch.float32, device=dev)          # slots of absent heads are never read
-        S = packed = dS = pairs = table_ws = buf = None
-        dense = False
-        ctx.fill, _FILL_HINT[0] = _FILL_HINT[0], None
-        ctx.offs = None
-        if flags & (HEAD_ALIGN_HINGE | HEAD_LISTNET):
-            if need_sets and flags & HEAD_ALIGN_HINGE:
-                _check_backward_supported(im, s, 0, 2)
-            fused = (_triplet_forward(im, s, im_len_t, s_len_t, margin, loss_out=terms[1:2])
-                     if (flags & HEAD_ALIGN_HINGE) and need_sets and max_violation else None)
-            if fused is not None:                    # the alignment head's whole forward in one library call
-                _, S, (im, s, geom_f, buf, dS, table_ws, ctx.offs) = fused
-                packed = (geom_f, None, None, None, None)
-            else:
-                S, packed = _align_forward(im, s, im_len_t, s_len_t, norms=need_sets)
-                if flags & HEAD_ALIGN_HINGE:
-                    _, dS, pairs = _hinge_raw(S, margin, max_violation, need_sets, want_pairs=True, loss_out=terms[1:2])
-                    if need_sets and not max_violation:                 # sum of violations: the dense backward while dS is dense
-                        dense = _density_probe.step(pairs[1], B * B)
-        a = b = M = dMh = dMl = None
-        if flags & (HEAD_MATCH_HINGE | HEAD_LISTNET):
-            a = img_emb if img_emb.stride(1) == 1 else img_emb.contiguous()
-            b = cap_emb if cap_emb.stride(1) == 1 else cap_emb.contiguous()
-            M = torch.empty((B, B), dtype=torch.float32, device=dev)
-            _sgemm(B, B, a.shape[1], a, a.stride(0), a.stride(1), b, b.stride(1), b.stride(0), M)
-            if flags & HEAD_MATCH_HINGE:
-                _, dMh, _ = _hinge_raw(M, margin, max_violation, need_embs, loss_out=terms[0:1])
-            if flags & HEAD_LISTNET:
-                dMl = torch.empty((B, B), dtype=torch.float32, device=dev) if (need_embs and weights[2] != 0) else None
-                ws = _workspace(lib.aladin_listnet_workspace_bytes(B), dev)
-                _lib.check(lib.aladin_listnet_fwd_bwd(_ptr(S), _ld(S), _ptr(M), _ld(M), B, float(temperature), float(eps),
-                                                      C.c_void_p(terms.data_ptr() + 8), _ptr(dMl), _ptr(ws), _stream()),
-                           'listnet_fwd_bwd')
-        total = torch.empty((), dtype=torch.float32, device=dev)
-        tp = terms.data_ptr()
-        _lib.check(lib.aladin_loss_total(C.c_void_p(tp) if flags & HEAD_MATCH_HINGE else C.c_void_p(0), float(weights[0]),
-                                         C.c_void_p(tp + 4) if flags & HEAD_ALIGN_HINGE else C.c_void_p(0), float(weights[1]),
-                                         C.c_void_p(tp + 8) if flags & HEAD_LISTNET else C.c_void_p(0), float(weights[2]),
-                                         _ptr(total), _stream()), 'loss_total')
-        ctx.flags, ctx.weights = flags, weights
-        ctx.geom = packed[0] if packed is not None else None
-        ctx.pairs = pairs
-        ctx.dense = dense
-        pk = packed[1:] if packed is not None else (None, None, None, None)
-        ctx.save_for_backward(a, b, im, s, im_len_t, s_len_t, pk[0], pk[1], pk[2], pk[3], dMh, dMl, dS, table_ws, buf)
-        ctx.set_materialize_grads(False)
-        ctx.mark_non_differentiable(*[t for t in (terms, S, M) if t is not None])
-        return total, terms, S, M
-
-    @staticmethod
-    def backward(ctx, g_total, _g_terms, _g_S, _g_M):
-        if g_total is None:
-            return (None,) * 12
-        lib = _lib.load()
-        a, b, im, s, im_len_t, s_len_t, xm, xe, y, rnorm, dMh, dMl, dS, table_ws, buf = ctx.saved_tensors
-        w = ctx.weights
-        g = g_total.to(torch.float32).contiguous()
-        dev = g.device
-        d_a = d_b = d_im = d_s = None
-        want_m = (dMh is not None or dMl is not None) and any(ctx.needs_input_grad[0:2])
-        want_a = dS is not None and any(ctx.needs_input_grad[2:4])
-        C_tot = torch.empty_like(dMh if dMh is not None else dMl) if want_m else None
-        scale = torch.empty(1, dtype=torch.float32, device=dev) if want_a else None
-        if want_m or want_a:
-            n = C_tot.numel() if C_tot is not None else 0
-            _lib.check(lib.aladin_grad_combine(n, _ptr(g), float(w[0]), _ptr(dMh), float(w[2]), _ptr(dMl), _ptr(C_tot), float(w[1]),
-                                               _ptr(scale), _stream()), 'grad_combine')
-        if want_m:
-            B, D = a.shape
-            if ctx.needs_input_grad[0]:
-                d_a = torch.empty((B, D), dtype=torch.float32, device=dev)
-                _sgemm(B, D, B, C_tot, C_tot.stride(0), 1, b, b.stride(0), b.stride(1), d_a)          # C @ cap
-            if ctx.needs_input_grad[1]:
-                d_b = torch.empty((B, D), dtype=torch.float32, device=dev)
-                _sgemm(B, D, B, C_tot, 1, C_tot.stride(0), a, a.stride(0), a.stride(1), d_b)          # C.T @ img
-        if want_a and buf is not None:
-            d_im, d_s = _triplet_backward(im, s, im_len_t, s_len_t, ctx.geom, _packed_from_buf(buf, ctx.offs), dS, table_ws, scale)
-        elif want_a:
-            d_im, d_s = _align_backward(im, s, im_len_t, s_len_t, dS, gscale=scale, packed=(ctx.geom, xm, xe, y, rnorm), pairs=ctx.pairs,
-                                        dense=ctx.dense, fill=ctx.fill)
-        return d_a, d_b, d_im, d_s, None, None, None, None, None, None, None, None
-
-
-def small_batch_loss_heads(img_emb, cap_emb, im_set, s_seq, im_len, s_len, margin, max_violation, heads, weights,
-                           temperature=6.0, eps=1e-10):
-    """The loss heads of one training step in a single autograd node (three head launches at B <= SMALL_BATCH_MAX,
-    the general kernels above it -- either way no element-wise glue).
-    heads: subset of {'matching', 'alignment', 'distillation'}; weights: dict head -> fixed loss weight.
-    -> (total = sum_k w_k L_k  [differentiable], terms (3,) = matching / alignment / distillation values, S, M)."""
-    flags = (HEAD_MATCH_HINGE if 'matching' in heads else 0) | (HEAD_ALIGN_HINGE if 'alignment' in heads else 0) | \
-        (HEAD_LISTNET if 'distillation' in heads else 0)
-    if not flags:
-        raise ValueError('aladin_amd: no loss head selected')
-    _require_gpu(img_emb, cap_emb)
-    im_len_t = s_len_t = None
-    if flags & (HEAD_ALIGN_HINGE | HEAD_LISTNET):
-        im_len_t, s_len_t = _check_sets(im_set, s_seq, im_len, s_len)
-        if not (im_set.shape[0] == s_seq.shape[0] == img_emb.shape[0]):
-            raise ValueError('aladin_amd: the loss heads need one image set, one caption and one embedding pair per sample')
-    w = (float(weights.get('matching', 0.0)), float(weights.get('alignment', 0.0)), float(weights.get('distillation', 0.0)))
-    node = _SmallHeads if img_emb.shape[0] <= SMALL_BATCH_MAX else _BigHeads
-    _FILL_HINT[0] = _caption_fill(s_len, s_seq.shape[1]) if (node is _BigHeads and not max_violation and flags & HEAD_ALIGN_HINGE) else None
-    return node.apply(img_emb, cap_emb, im_set, s_seq, im_len_t, s_len_t, margin, max_violation, flags, w, temperature, eps)
-
-
-loss_heads = small_batch_loss_heads            # the single-node step at any batch size
-
-
-class _MatchHinge(torch.autograd.Function):
-    """(hinge loss on M, M) with M = im @ s.T (alad/loss.py:8-11 + :42-67) as ONE autograd node at any batch size: forward = the
-    exact-fp32 GEMM + the fused hinge, backward = aladin_grad_combine (g_loss * dLoss/dM + g_M in one launch) + two GEMMs.  Both
-    outputs are differentiable, as ContrastiveLoss(return_similarity_mat=True)'s are in the reference."""
-
-    @staticmethod
-    def forward(ctx, im, s, margin, max_violation):
-        a = im if im.stride(1) == 1 else im.contiguous()
-        b = s if s.stride(1) == 1 else s.contiguous()
-        B = a.shape[0]
-        M = torch.empty((B, B), dtype=torch.float32, device=a.device)
-        _sgemm(B, B, a.shape[1], a, a.stride(0), a.stride(1), b, b.stride(1), b.stride(0), M)
-        need = any(ctx.needs_input_grad[:2])
-        loss, dM, _ = _hinge_raw(M, margin, max_violation, need)
-        ctx.save_for_backward(a, b, dM)
-        ctx.set_materialize_grads(False)
-        return loss, M
-
-    @staticmethod
-    def backward(ctx, g_loss, g_M):
-        a, b, dM = ctx.saved_tensors
-        if (g_loss is None or dM is None) and g_M is None:
-            return None, None, None, None
-        lib = _lib.load()
-        B, D = a.shape
-        if g_loss is not None and dM is not None:
-            g = g_loss.to(torch.float32).contiguous()
-            gM = g_M.contiguous() if g_M is not None else None
-            C_tot = torch.empty_like(dM)
-            # C = g * (1 * dM) (+ g_M: the second matrix slot with weight 1 / g -- not expressible, so add it separately when present)
-            _lib.check(lib.aladin_grad_combine(C_tot.numel(), _ptr(g), 1.0, _ptr(dM), 0.0, _ptr(None), _ptr(C_tot), 0.0, _ptr(None),
-                                               _stream()), 'grad_combine')
-            if gM is not None:
-                C_tot = C_tot + gM
-        else:
-            C_tot = g_M.contiguous()
-        d_a = d_b = None
-        if ctx.needs_input_grad[0]:
-            d_a = torch.empty((B, D), dtype=torch.float32, device=a.device)
-            _sgemm(B, D, B, C_tot, C_tot.stride(0), 1, b, b.stride(0), b.stride(1), d_a)          # C @ cap
-        if ctx.needs_input_grad[1]:
-            d_b = torch.empty((B, D), dtype=torch.float32, device=a.device)
-            _sgemm(B, D, B, C_tot, 1, C_tot.stride(0), a, a.stride(0), a.stride(1), d_b)          # C.T @ img
-        return d_a, d_b, None, None
-
-
-def match_hinge(im, s, margin, max_violation):
-    """(loss, M) of ContrastiveLoss(measure='dot') in one autograd node -- the matching head as alad_model.py:380 calls it
-    every step.  B <= SMALL_BATCH_MAX: the small-batch kernels (two launches forward, one backward); above: GEMM + fused hinge."""
-    _require_gpu(im, s)
-    if im.dim() != 2 or s.dim() != 2 or im.shape != s.shape:
-        raise ValueError('aladin_amd: the contrastive loss needs a square score matrix: two (B, D) embedding matrices of equal shape '
-                         '(the reference fails in diag/expand_as, alad/loss.py:43-45); got %s and %s' % (tuple(im.shape), tuple(s.shape)))
-    if im.shape[0] <= SMALL_BATCH_MAX:
-        loss, _, M = _SmallMatchDistill.apply(im, s, None, margin, max_violation, True, 6.0, 1e-10)
-        return loss, M
-    return _MatchHinge.apply(im, s, margin, max_violation)
-
-
-def small_batch_match_distill(im, s, teacher, margin, max_violation, want_hinge=True, temperature=6.0, eps=1e-10):
-    """-> (hinge_loss, listnet_loss, M) for B <= SMALL_BATCH_MAX unit-norm global embeddings im, s (B, D):
-    M = im @ s.T (alad/loss.py:8-11), the VSE++ hinge on it (:42-67, if want_hinge) and the ListNet distillation from
-    `teacher` (:427-445, detached; None = no distillation) -- two launches per step instead of about twelve."""
-    _require_gpu(im, s)
-    if im.dim() != 2 or s.dim() != 2 or im.shape != s.shape:
-        raise ValueError('aladin_amd: two (B, D) embedding matrices of equal shape expected')
-    if im.shape[0] > SMALL_BATCH_MAX:
-        raise ValueError('aladin_amd: small_batch_match_distill takes B <= %d' % SMALL_BATCH_MAX)
-    if teacher is not None:
-        _require_gpu(teacher)
-        if tuple(teacher.shape) != (im.shape[0], im.shape[0]):
-            raise ValueError('aladin_amd: teacher scores must be (B, B)')
-        teacher = teacher.detach()
-    if not want_hinge and teacher is None:                    # scores only: the plain differentiable dot-product node
-        return im.new_zeros(()), im.new_zeros(()), dot_scores(im, s)
-    return _SmallMatchDistill.apply(im, s, teacher, margin, max_violation, want_hinge, temperature, eps)
-
-
-# ------------------------------------------------------------------------------------------------
-# retrieval
-# ------------------------------------------------------------------------------------------------
-def sim_matrix(img, cap):
-    """(n_img, n_cap) = img @ cap.T on the split-fp16 MFMA path (no autograd); replaces
-    ims.mm(caps.t()), reference alad/recall_auxiliary.py:30 and alad/evaluation.py:196,285."""
-    _require_gpu(img, cap)
-    lib = _lib.load()
-    img = img if img.stride(1) == 1 else img.contiguous()
-    cap = cap if cap.stride(1) == 1 else cap.contiguous()
-    n_img, D = img.shape
-    n_cap = cap.shape[0]
-    sim = torch.empty((n_img, n_cap), dtype=torch.float32, device=img.device)
-    ws = _workspace(lib.aladin_sim_workspace_bytes(n_img, n_cap, D), img.device)
-    _lib.check(lib.aladin_sim_matrix(_ptr(img), _ld(img), _ptr(cap), _ld(cap), n_img, n_cap, D, _ptr(sim),
-                                     _ld(sim), _ptr(ws), _stream()), 'sim_matrix')
-    return sim
-
-
-def recall_ranks(sim, caps_per_img=5):
-    """(rank_i2t, top1_i2t, rank_t2i, top1_t2i) int32 device tensors from a (n_img, 5*n_img) score
-    matrix; replaces the argsort/where loops of reference alad/recall_auxiliary.py:34-56."""
-    _require_gpu(sim)
-    lib = _lib.load()
-    sim = sim if sim.stride(1) == 1 else sim.contiguous()
-    n_img, n_cap = sim.shape
-    dev = sim.device
-    r_i2t = torch.empty(n_img, dtype=torch.int32, device=dev)
-    t_i2t = torch.empty(n_img, dtype=torch.int32, device=dev)
-    r_t2i = torch.empty(n_cap, dtype=torch.int32, device=dev)
-    t_t2i = torch.empty(n_cap, dtype=torch.int32, device=dev)
-    ws = _workspace(lib.aladin_recall_workspace_bytes(n_cap), dev)
-    _lib.check(lib.aladin_recall_ranks(_ptr(sim), _ld(sim), n_img, n_cap, caps_per_img, _ptr(r_i2t), _ptr(t_i2t),
-                                       _ptr(r_t2i), _ptr(t_t2i), _ptr(ws), _stream()), 'recall_ranks')
-    return r_i2t, t_i2t, r_t2i, t_t2i
-
-
-def retrieval_ranks(img, cap, caps_per_img=5, exact=False, return_stats=False):
-    """(rank_i2t, top1_i2t, rank_t2i, top1_t2i) straight from the (n_img, D) / (n_cap, D) embeddings:
-    sim_matrix + recall_ranks fused, the (n_img, n_cap) score matrix is never written.  Same bits as
-    the two-step path; replaces reference alad/recall_auxiliary.py:30-56 in one pass.
-    The kernel screens with the hi.hi third of the split product and continues to the exact score only the pairs a
-    rigorous per-pair bound leaves undecided (include/aladin_hip.h); exact=True forces the three-product path on
-    every tile (same outputs).  return_stats=True appends {'exact_tiles', 'listed_pairs', 'rescored_pairs', 'skipped_tiles', 'tiles'}
-    (one D2H copy): tiles continued in place, pairs listed, listed pairs whose chains were continued, tiles that skipped the screen."""
-    _require_gpu(img, cap)
-    if img.dim() != 2 or cap.dim() != 2 or img.shape[1] != cap.shape[1]:
-        raise ValueError('aladin_amd: (n_img,D) and (n_cap,D) embeddings expected')
-    lib = _lib.load()
-    img = img if img.stride(1) == 1 else img.contiguous()
-    cap = cap if cap.stride(1) == 1 else cap.contiguous()
-    n_img, n_cap, D = img.shape[0], cap.shape[0], img.shape[1]
-    dev = img.device
-    r_i2t = torch.empty(n_img, dtype=torch.int32, device=dev)
-    t_i2t = torch.empty(n_img, dtype=torch.int32, device=dev)
-    r_t2i = torch.empty(n_cap, dtype=torch.int32, device=dev)
-    t_t2i = torch.empty(n_cap, dtype=torch.int32, device=dev)
-    ws = _workspace(lib.aladin_retrieval_workspace_bytes(n_img, n_cap, D), dev)
-    fn = lib.aladin_retrieval_ranks_exact if exact else lib.aladin_retrieval_ranks
-    _lib.check(fn(_ptr(img), img.stride(0), _ptr(cap), cap.stride(0), n_img, n_cap, D, caps_per_img,
-                  _ptr(r_i2t), _ptr(t_i2t), _ptr(r_t2i), _ptr(t_t2i), _ptr(ws), _stream()), 'retrieval_ranks')
-    if return_stats:
-        off = lib.aladin_retrieval_stats_offset(n_img, n_cap, D)
-        st = ws[off:off + 36].view(torch.int32).cpu().tolist()
-        tiles = -(-n_img // 256) * -(-n_cap // 384)
-        return r_i2t, t_i2t, r_t2i, t_t2i, {'exact_tiles': st[0], 'listed_pairs': st[1], 'rescored_pairs': st[5], 'skipped_tiles': st[8],
-                                            'tiles': tiles}
-    return r_i2t, t_i2t, r_t2i, t_t2i
-
-
-def topk_indices(scores, k, dim=1):
-    """(n_q, k) int32 indices of each query's k best candidates, best first, ties -> lower index; queries are
-    the rows of `scores` (dim=1) or its columns (dim=0, read in place: no transpose).  Replaces the
-    `inds[i][0:50]` slices of the descending argsorts in reference alad/evaluation.py:303-309 (-1 past the
-    number of candidates)."""
-    _require_gpu(scores)
-    if scores.dim() != 2 or dim not in (0, 1):
-        raise ValueError('aladin_amd: topk_indices expects a 2-D score matrix and dim 0 or 1')
-    sc = scores if scores.stride(1) == 1 else scores.contiguous()
-    n_q, n_c = (sc.shape[0], sc.shape[1]) if dim == 1 else (sc.shape[1], sc.shape[0])
-    q_stride, c_stride = (_ld(sc), 1) if dim == 1 else (1, _ld(sc))
-    out = torch.empty((n_q, int(k)), dtype=torch.int32, device=sc.device)
-    _lib.check(_lib.load().aladin_topk(_ptr(sc), q_stride, c_stride, n_q, n_c, int(k), _ptr(out), _ptr(None), _stream()),
-               'topk')
-    return out
-
-
-class _L2Norm(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, x):
-        x = x if x.stride(1) == 1 else x.contiguous()
-        out = torch.empty((x.shape[0], x.shape[1]), dtype=torch.float32, device=x.device)
-        _lib.check(_lib.load().aladin_l2norm_fwd(_ptr(x), x.stride(0), x.shape[0], x.shape[1], _ptr(out), _stream()), 'l2norm_fwd')
-        ctx.save_for_backward(x)
-        return out
-
-    @staticmethod
-    def backward(ctx, g):
-        (x,) = ctx.saved_tensors
-        g = g if g.stride(1) == 1 else g.contiguous()
-        dx = torch.empty((x.shape[0], x.shape[1]), dtype=torch.float32, device=x.device)
-        _lib.check(_lib.load().aladin_l2norm_bwd(_ptr(x), x.stride(0), _ptr(g), _ld(g), x.shape[0], x.shape[1], _ptr(dx), _stream()),
-                   'l2norm_bwd')
-        return dx
-
-
-def l2norm_rows(x):
-    """X / sqrt(sum_dim1 X^2) without eps; replaces l2norm, reference alad/utils.py:134-139 (zero rows -> NaN)."""
-    _require_gpu(x)
-    if x.dim() != 2 or x.shape[0] < 1 or x.shape[1] < 1:
-        raise ValueError('aladin_amd: l2norm expects a non-empty (rows, D) matrix')
-    return _L2Norm.apply(x)
+_SUBMODULES = ('ops_losses', 'ops_heads', 'ops_retrieval')
+
+
+def __getattr__(name):
+    import importlib
+    if name.startswith('__'):
+        raise AttributeError(name)
+    for m in _SUBMODULES:
+        mod = importlib.import_module('.' + m, __package__)
+        if name in mod.__dict__:
+            return mod.__dict__[name]
+    raise AttributeError('module %r has no attribute %r' % (__name__, name))

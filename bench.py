@@ -310,9 +310,29 @@ def shipped_shape_step(dev):
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / 100
+    # the shape's score kernel alone (align_scores16_r48, 192 x 320 tile; the side GEMM's result reused), event-timed like the
+    # headline's: ALGORITHMIC flops (50 regions x 35 words per pair, not the 48 + 2 side rows x 40 columns the tiles hold)
+    from aladin_amd import ops
+    geom = ops.align_geometry(B, B, 51, 38, D)
+    packed = ops.pack_sets(a.detach(), b.detach(), ops.lengths_tensor(il, dev), ops.lengths_tensor(sl, dev), geom, norms=False)
+    out = torch.empty((B, B), dtype=torch.float32, device=dev)
+    e_scr = torch.empty(max(int(geom.e_bytes), 16), dtype=torch.uint8, device=dev)
+    ops.scores_from_packed(packed[1], packed[2], packed[3], geom, out, e_scr)
+    for _ in range(50):
+        ops.scores_from_packed(packed[1], packed[2], packed[3], geom, out, e_scr, reuse_side=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(200):
+        ops.scores_from_packed(packed[1], packed[2], packed[3], geom, out, e_scr, reuse_side=True)
+    e1.record()
+    torch.cuda.synchronize()
+    k_us = e0.elapsed_time(e1) / 200 * 1e3
+    k_flops = 2 * 50 * 35 * D * B * B
     return {'workload': 'triplet loss forward+backward at B=256, R=51, T=38, D=768 (50 regions + 35 tokens), eager launches',
             'ms_per_step': round(ms, 4), 'pairs_per_s': round(B * B / (ms * 1e-3), 1),
-            'flops_per_pair': 2 * 50 * 35 * D, 'tflops_algorithmic_fwd_equiv': round(2 * 50 * 35 * D * B * B / (ms * 1e-3) / 1e12, 1)}
+            'flops_per_pair': 2 * 50 * 35 * D, 'tflops_algorithmic_fwd_equiv': round(2 * 50 * 35 * D * B * B / (ms * 1e-3) / 1e12, 1),
+            'score_kernel': 'align_scores16_r48_kernel (48-row region class + 2 side rows, 40-word caption class)',
+            'score_kernel_us': round(k_us, 2), 'score_kernel_frac': round(k_flops / (k_us * 1e-6) / 1e12 / PEAK_TFLOPS, 4)}
 
 
 def stub_main(args, world, rank):

@@ -75,7 +75,7 @@ def test_bench_secondary_fields_are_in_the_line():
     assert 40.0 <= e['R@1_i2t'] <= 80.0 and 40.0 <= e['R@1_t2i'] <= 80.0 and e['rescored_pairs'] <= e['listed_pairs']
     assert e['by_data'][0]['ms'] <= e['ms'] and e['by_data'][2]['ms'] <= 1.08 * e['all_exact_ms']     # clean input cheaper; hard input never much above all-exact
     assert all(0 <= b['exact_tiles'] <= e['tiles'] for b in e['by_data'])
-    assert 0.1 < c['shipped_shape']['ms_per_step'] < 0.6
+    assert 0.1 < c['shipped_shape']['ms_per_step'] < 0.6 and 0.2 < c['shipped_shape']['score_kernel_frac'] < 0.8
     h = c['loss_heads_bs32']
     assert 0 < h['graph_replay_only_ms'] < h['graphed_step_ms'] < 1.0 and h['eager_ms'] > 0
     x = c['e2e_config4']

@@ -3,7 +3,7 @@
 # packers, ground-truth and re-score kernels; tools/bench_retrieval.py --profile) -> gpurun_out/<tag>/pmc_*; materialise with tools/materialise_profiles.py <tag> -> profiles/<tag>_pmc.json
 set -u
 TAG=${1:-r04_eval}
-ONLY=${2:-0.05}          # which data set of tools/bench_retrieval.py (substring of its name): the clean timing input by default
+ONLY=${2:-sigma=8}       # which data set of tools/bench_retrieval.py (substring of its name): the SURVEY 8(d) input (R@1 75 / 41 %) by default
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out/$TAG
 mkdir -p "$OUT"

@@ -5,7 +5,7 @@
 #   (clean input), phase stamps (diagnostic library, if built), the shipped-shape step with its kernel breakdown
 # usage: tools/collect_round.sh <tag>
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=$R/gpurun_out/$TAG
 mkdir -p "$O"
@@ -17,6 +17,6 @@ if [ -f aladin_amd/lib/libaladin_hip_diag.so ]; then
 fi
 bash tools/collect_shipped_shape.sh > /dev/null 2>&1; cp gpurun_out/shipped_shape.txt "$O/shipped_shape.txt"
 bash tools/collect_pmc.sh "$TAG" > "$O/collect_pmc.log" 2>&1
-bash tools/collect_eval_pmc.sh "${TAG}_eval" 0.05 > "$O/collect_eval_pmc.log" 2>&1
+bash tools/collect_eval_pmc.sh "${TAG}_eval" "sigma=8" > "$O/collect_eval_pmc.log" 2>&1
 bash tools/collect_retrieval_stats.sh "$TAG" > "$O/collect_retrieval_stats.log" 2>&1
 tail -2 "$O/bench_retrieval.txt"; head -c 400 "$O/bench_line_unprofiled.json"; echo

@@ -2,7 +2,7 @@
 # A/B of the 24- / 40-word caption classes (diagnostic library: ALADIN_ALIGN_CLASS40 = 1 / 0 = on / whole 16-word tiles) on
 # training steps and on the COCO-1k evaluation grid -> gpurun_out/ab_caption_classes.txt
 set -u
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 OUT=$R/gpurun_out/ab_caption_classes.txt
 mkdir -p "$R/gpurun_out"; : > "$OUT"
 export ALADIN_LIB=$R/aladin_amd/lib/libaladin_hip_diag.so

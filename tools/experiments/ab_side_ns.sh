@@ -2,7 +2,7 @@
 # A/B of the side GEMM's LDS ring depth (diagnostic library, ALADIN_SIDE_NS = 3 / 2) over the shapes that use it:
 # rocprofv3 averages of the side GEMM and the step -> gpurun_out/ab_side_ns.txt
 set -u
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 OUT=$R/gpurun_out/ab_side_ns.txt
 mkdir -p "$R/gpurun_out"; : > "$OUT"
 export ALADIN_LIB=$R/aladin_amd/lib/libaladin_hip_diag.so

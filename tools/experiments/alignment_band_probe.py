@@ -15,7 +15,7 @@ Prints the fractions, the measured |S16 - S_split| next to the band, and what a 
 import os
 import sys
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import torch
 
@@ -24,7 +24,7 @@ from aladin_amd import evaluation as E, ops, synth
 
 def main():
     fixture = sys.argv[1] if len(sys.argv) > 1 else 'eval_coco1k_d768'
-    g = np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests', 'golden', fixture + '.npz'))
+    g = np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), 'tests', 'golden', fixture + '.npz'))
     n_img, D = int(g['n_img']), int(g['D'])
     images, captions, il, cl = synth.eval_sets(n_img, D, int(g['seed']), base_weight=float(g['gen_base_weight']),
                                                img_len_range=tuple(int(v) for v in g['gen_img_len_range']),

@@ -8,7 +8,7 @@ import sys
 import time
 
 os.environ['ALADIN_ALIGN_SPREAD'] = os.environ.get('PROBE_SCHED', '26')      # 26: 16x16x32 kernel, 6: 32x32x16 kernel
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 # probes and knobs exist only in the diagnostic build (`make -C aladin_amd/csrc diag`), never in the product library
 os.environ.setdefault('ALADIN_LIB', os.path.join(ROOT, 'aladin_amd', 'lib', 'libaladin_hip_diag.so'))
 sys.path.insert(0, ROOT)

@@ -10,7 +10,7 @@ import json
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 os.environ.setdefault("ALADIN_LIB", os.path.join(ROOT, "aladin_amd", "lib", "libaladin_hip_diag.so"))
 import numpy as np

@@ -2,7 +2,7 @@
 # gpurun_out/<tag>* (merged back by gpurun after tools/collect_round.sh) -> the committed summaries under profiles/
 # usage: tools/materialise_round.sh <tag>
 set -eu
-TAG=${1:-r04}
+TAG=${1:-r05}
 R=$(cd "$(dirname "$0")/.." && pwd)
 cd "$R"
 O=gpurun_out/$TAG
