@@ -313,6 +313,7 @@ constexpr int SIM_RAW_WAVE = 192;                 // UNDECIDED scores and arg-ma
 // the analysis, [7] of those, tiles that overflowed their lists, [8] tiles that skipped the analysis (hopeless data, see sim_screen_kernel)
 enum { SIM_ST_EXACT = 0, SIM_ST_LISTED = 1, SIM_ST_RESCORED = 5, SIM_ST_ANALYSED = 6, SIM_ST_OVERFLOW = 7, SIM_ST_SKIPPED = 8 };
 constexpr int SIM_STATS_WORDS = 64;
+constexpr int SIM_RESCORE_SPLIT = 4;
 
 struct SimRankArgs {
   int cpi;
@@ -504,8 +505,9 @@ __device__ __forceinline__ void sim_rank_epilogue_exact(f32x4 (&acc)[SIM_RT][SIM
   }
 }
 
-// FORCE_EXACT: every tile takes the exact path (round 3's behaviour; tests compare the two)
-template <bool FORCE_EXACT>
+// MODE 0: screened; 1: every tile exact (no analysis code at all); 2: the screened kernel with every tile skipping its analysis
+// (diagnostic build: is the exact path of the MODE-0 code as fast as MODE 1's?)
+template <int MODE>
 __global__ __launch_bounds__(512) void sim_screen_kernel(const half_t* __restrict__ a, const half_t* __restrict__ b,
                                                          const float* __restrict__ scale, int n_img, int n_cap, int64_t ldk,
                                                          int kps, int n_nblk, int n_blocks, SimRankArgs ra) {
@@ -549,7 +551,7 @@ __global__ __launch_bounds__(512) void sim_screen_kernel(const half_t* __restric
         }
     }
   }
-  if constexpr (!FORCE_EXACT) {
+  if constexpr (MODE != 1) {
     // The analysis arrays live in the stage the LAST K step did not use: every wave left that stage before the last step's
     // barrier and nothing refills it any more, so no barrier is needed before writing them.
     char* ep = smem + ((kps & 1) ? Cfg::STAGE_BYTES : 0);
@@ -580,16 +582,22 @@ __global__ __launch_bounds__(512) void sim_screen_kernel(const half_t* __restric
     int* l_hits = l_rawn + Cfg::NWAVES;                              // [2] rows / columns of the tile with a score in reach of their ground truth
     SimRaw* l_raw = reinterpret_cast<SimRaw*>(l_hits + 2);            // [8 waves][SIM_RAW_WAVE]
     static_assert(Cfg::BM <= Cfg::THREADS && Cfg::BN <= Cfg::THREADS, "one row / column entry per thread");
+    static_assert(SIM_LIST_CAP % 256 == 0, "sim_rescore_kernel compacts the list in passes of its 256 threads");
     static_assert(10 * (Cfg::BM + Cfg::BN) * 4 + SIM_LIST_CAP * 16 + 16 + 4 * Cfg::NWAVES * 4 + Cfg::NWAVES * 4 + 8 + Cfg::NWAVES * SIM_RAW_WAVE * 8 <= Cfg::STAGE_BYTES,
                   "the analysis arrays share one operand stage");
     // Hopeless data (ground truths deep in the bulk: every column of every tile nominates candidates and the lists overflow):
     // the analysis would be paid for nothing.  Tiles count themselves as analysed / overflowed; once at least 32 have
-    // reported and 7 of 8 overflowed, a tile goes straight on to the exact path -- except every eighth, which keeps probing
-    // (data may differ between regions of the grid).  Both paths give the same integers; only the cost depends on the choice.
+    // reported and 7 of 8 overflowed, a tile goes straight on to the exact path -- except the tiles of every fourth ROUND of 256
+    // (by dispatch index), which keep probing (data may differ between regions of the grid).  Probing by round, not by tile:
+    // the workgroups of a round run in lockstep and share their operand panels through the L2 while they do; one tile in eight
+    // taking longer than its neighbours (this round's first form) put every tile out of phase: 700 vs 580 us all-exact with
+    // ground truths 2 sigma inside the bulk.  (A sample launch of 256 tiles followed by a launch-uniform decision for the rest
+    // was measured too: no better on such data, + 10 us on clean data for the second launch.)  Both paths give the same integers.
     if (tid == 0) {
       const int n_an = __hip_atomic_load(&ra.stats[SIM_ST_ANALYSED], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       const int n_ov = __hip_atomic_load(&ra.stats[SIM_ST_OVERFLOW], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      *l_listn = (n_an >= 32 && 8 * n_ov >= 7 * n_an && (blockIdx.x & 7) != 0) ? -1 : 0;
+      *l_listn = (n_an >= 32 && 8 * n_ov >= 7 * n_an && ((blockIdx.x >> 8) & 3) != 0) ? -1 : 0;
+      if constexpr (MODE == 2) *l_listn = -1;            // (diagnostic build) timing probe: every tile skips the analysis
     }
     // the tile's largest band factors bound every pair's band from above: the cheap test of phase 1
     const int e = tid;
@@ -911,37 +919,65 @@ __device__ __forceinline__ void sim_chain_global(const half_t* __restrict__ ap, 
 __global__ __launch_bounds__(256) void sim_rescore_kernel(const half_t* __restrict__ a, const half_t* __restrict__ b, int64_t ldk,
                                                           int kps, int n_tiles, SimRankArgs ra) {
   __shared__ SimEntry l_e[SIM_LIST_CAP];
-  __shared__ int l_n;
+  __shared__ int w_cnt[SIM_LIST_CAP / 256][4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int tile = blockIdx.x;
-  if (tile >= n_tiles) return;
+  // SIM_RESCORE_SPLIT workgroups per tile.  Each filters and compacts the tile's WHOLE list -- in list order, so that all of them
+  // build the same compacted list (ballot prefix sums, no atomics) -- and then takes the 16-pair groups whose index is its own modulo
+  // the split: a tile that fills its 512 entries was a 32-group chain for ONE workgroup (80 us on the critical path of a launch
+  // whose other tiles listed nothing), while splitting the list BEFORE compaction left every part with half-empty groups (a group
+  // costs 98 KB of operand rows however few of its 16 pairs are live: sigma 8 went 0.385 -> 0.454 ms).
+  // part-major block order: blocks [0, n_tiles) are part 0 of every tile.  (Tile-major -- part = blockIdx % 4 -- put the working
+  // part-0 blocks on blockIdx = 0 mod 4, i.e. on TWO of the eight XCDs: the kernel ran 165 instead of 58 us.)
+  const int tile = blockIdx.x % n_tiles, part = blockIdx.x / n_tiles;
+  if (part >= SIM_RESCORE_SPLIT) return;
   const int n = ra.list_cnt[tile];
-  if (n == 0) return;                                                   // workgroup-uniform
-  if (threadIdx.x == 0) l_n = 0;
-  __syncthreads();
-  // filter and compact: the chains cost 6 KB of operand rows per pair, so the 16-pair groups below should hold live pairs only
-  for (int q = threadIdx.x; q < n; q += 256) {
-    SimEntry e = ra.list[(int64_t)tile * SIM_LIST_CAP + q];
-    if (e.flags & (SIM_F_ROWARG | SIM_F_COLARG)) {
-      const float2 pr = ra.na[e.row], qt = ra.nb[e.col];
-      const float hi = e.s + fmaf(fabsf(e.s), 0x1p-14f, fmaf(pr.x, qt.x, pr.y * qt.y));
-      if (e.flags & SIM_F_ROWARG) {
-        const unsigned k = ra.lob_i2t[e.row];
-        if (k && hi < key_float(k)) e.flags &= ~SIM_F_ROWARG;
-      }
-      if (e.flags & SIM_F_COLARG) {
-        const unsigned k = ra.lob_t2i[e.col];
-        if (k && hi < key_float(k)) e.flags &= ~SIM_F_COLARG;
+  // only a HEAVY list is shared out (more than a quarter of the capacity: the case the split exists for); below, part 0 takes everything
+  // and the other parts leave at once -- every part filters the whole list, which is not free (sigma 6: + 19 us with every tile split)
+  const int split = n > SIM_LIST_CAP / 4 ? SIM_RESCORE_SPLIT : 1;
+  if (part >= split || n == 0) return;                                  // workgroup-uniform
+  SimEntry mine[SIM_LIST_CAP / 256];
+  int pre[SIM_LIST_CAP / 256];
+#pragma unroll
+  for (int pass = 0; pass < SIM_LIST_CAP / 256; ++pass) {
+    const int q = pass * 256 + (int)threadIdx.x;
+    SimEntry e = SimEntry{0, 0, 0.f, 0};
+    if (q < n) {
+      e = ra.list[(int64_t)tile * SIM_LIST_CAP + q];
+      if (e.flags & (SIM_F_ROWARG | SIM_F_COLARG)) {
+        const float2 pr = ra.na[e.row], qt = ra.nb[e.col];
+        const float hi = e.s + fmaf(fabsf(e.s), 0x1p-14f, fmaf(pr.x, qt.x, pr.y * qt.y));
+        if (e.flags & SIM_F_ROWARG) {
+          const unsigned k = ra.lob_i2t[e.row];
+          if (k && hi < key_float(k)) e.flags &= ~SIM_F_ROWARG;
+        }
+        if (e.flags & SIM_F_COLARG) {
+          const unsigned k = ra.lob_t2i[e.col];
+          if (k && hi < key_float(k)) e.flags &= ~SIM_F_COLARG;
+        }
       }
     }
-    if (e.flags) l_e[atomicAdd(&l_n, 1)] = e;
+    mine[pass] = e;
+    const unsigned long long live = __ballot(e.flags != 0);
+    pre[pass] = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(live >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)live, 0u));
+    if (lane == 0) w_cnt[pass][wave] = __popcll(live);
   }
   __syncthreads();
-  const int n_live = l_n;
-  if (threadIdx.x == 0 && n_live) atomicAdd(&ra.stats[SIM_ST_RESCORED], n_live);
+  int n_live = 0;
+#pragma unroll
+  for (int pass = 0; pass < SIM_LIST_CAP / 256; ++pass) {
+    int base = n_live;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      if (w < wave) base += w_cnt[pass][w];
+      n_live += w_cnt[pass][w];
+    }
+    if (mine[pass].flags) l_e[base + pre[pass]] = mine[pass];
+  }
+  __syncthreads();
+  if (threadIdx.x == 0 && part == 0 && n_live) atomicAdd(&ra.stats[SIM_ST_RESCORED], n_live);
   const int m = lane & 15;
   const int Dp = kps * 64;
-  for (int grp = wave; grp * 16 < n_live; grp += 4) {
+  for (int grp = part + split * wave; grp * 16 < n_live; grp += 4 * split) {
     const bool need = grp * 16 + m < n_live;
     SimEntry e = SimEntry{0, 0, 0.f, 0};
     if (need) e = l_e[grp * 16 + m];
@@ -1364,7 +1400,7 @@ static int retrieval_ranks_impl(const float* img, int64_t img_rs, const float* c
   // the exact path on every tile
   if (Dp / 16 > 1024) force_exact = true;
   static unsigned long long lds_reserved[2] = {0, 0};
-  const void* kern = force_exact ? (const void*)sim_screen_kernel<true> : (const void*)sim_screen_kernel<false>;
+  const void* kern = force_exact ? (const void*)sim_screen_kernel<1> : (const void*)sim_screen_kernel<0>;
   if ((rc = aladin_reserve_lds(kern, SimCfg::LDS_BYTES, &lds_reserved[force_exact ? 1 : 0], "sim_screen"))) return rc;
   const int n_mblk = Mp / SimCfg::BM, n_nblk = Np / SimCfg::BN, n_tiles = n_mblk * n_nblk;
   const int64_t ldk = (int64_t)2 * Dp;
@@ -1389,16 +1425,25 @@ static int retrieval_ranks_impl(const float* img, int64_t img_rs, const float* c
     hipLaunchKernelGGL(sim_gt_kernel, dim3(cdiv(tiles, 4)), dim3(256), 0, st, ws.a, ws.b, n_img, n_cap, caps_per_img, ldk, kps, rw.gt,
                        rw.best_i2t, rw.best_t2i);
   }
+#ifdef ALADIN_DIAG
+  static const char* probe_env = getenv("ALADIN_SIM_SKIP_PROBE");
+  if (!force_exact && probe_env && probe_env[0] == '1') {
+    static unsigned long long lds2 = 0;
+    if ((rc = aladin_reserve_lds((const void*)sim_screen_kernel<2>, SimCfg::LDS_BYTES, &lds2, "sim_screen<2>"))) return rc;
+    hipLaunchKernelGGL(sim_screen_kernel<2>, dim3(n_tiles), dim3(SimCfg::THREADS), SimCfg::LDS_BYTES, st, ws.a, ws.b, ws.scale, n_img, n_cap,
+                       ldk, kps, n_nblk, n_tiles, ra);
+  } else
+#endif
   if (force_exact)
-    hipLaunchKernelGGL(sim_screen_kernel<true>, dim3(n_tiles), dim3(SimCfg::THREADS), SimCfg::LDS_BYTES, st, ws.a, ws.b, ws.scale, n_img, n_cap,
+    hipLaunchKernelGGL(sim_screen_kernel<1>, dim3(n_tiles), dim3(SimCfg::THREADS), SimCfg::LDS_BYTES, st, ws.a, ws.b, ws.scale, n_img, n_cap,
                        ldk, kps, n_nblk, n_tiles, ra);
   else
-    hipLaunchKernelGGL(sim_screen_kernel<false>, dim3(n_tiles), dim3(SimCfg::THREADS), SimCfg::LDS_BYTES, st, ws.a, ws.b, ws.scale, n_img, n_cap,
+    hipLaunchKernelGGL(sim_screen_kernel<0>, dim3(n_tiles), dim3(SimCfg::THREADS), SimCfg::LDS_BYTES, st, ws.a, ws.b, ws.scale, n_img, n_cap,
                        ldk, kps, n_nblk, n_tiles, ra);
   rc = aladin_check_launch("sim_screen_kernel");
   if (rc) return rc;
   if (!force_exact) {
-    hipLaunchKernelGGL(sim_rescore_kernel, dim3(n_tiles), dim3(256), 0, st, ws.a, ws.b, ldk, kps, n_tiles, ra);
+    hipLaunchKernelGGL(sim_rescore_kernel, dim3(n_tiles * SIM_RESCORE_SPLIT), dim3(256), 0, st, ws.a, ws.b, ldk, kps, n_tiles, ra);
     rc = aladin_check_launch("sim_rescore_kernel");
     if (rc) return rc;
   }
