@@ -146,13 +146,16 @@ ALADIN_API int aladin_align_scores(const aladin_packed* packed, const aladin_ali
  * packed is NULL -- the recorded arg-max is the fp32 arg-max, as autograd's; (3) one wave per OUTPUT row gathers the partner
  * rows the table points at and applies the normalise backward.  d_im / d_s: fully written, no atomics.
  * workspace: aladin_align_bwd_workspace_bytes(geom, flags).  Split operands are rejected (forward only).
- *   ALADIN_BWD_PARTNERS_FP16  step 3 reads the unit vectors -- the partner rows AND the output row's own -- from the
- *       forward's packed fp16 operands and packed->rnorm instead of normalising the raw fp32 rows again: the raw sets are
- *       not read by step 3 at all (bwd_rows 43.9 -> ~27 us at B = 256, traffic past L2 302 -> ~185 MB).  One fp16
- *       rounding of those vectors leaves the gradients <= 2.5e-4 of their largest entry away from the reference's autograd
- *       (measured on every reference fixture; the test fails at 5e-4 = half of north_star's 1e-3) against 3e-5 without the
- *       flag.  Needs packed->xm, y, rnorm (and xe with side rows) of THIS problem.  The Python layer sets it by default
- *       since round 5 (ops.set_backward_precision('exact') clears it).  The arg-maxima are the exact fp32 ones either way.
+ *   ALADIN_BWD_PARTNERS_FP16  step 3 gathers the PARTNER rows (the unit vectors an output row's gradient is a weighted sum of)
+ *       from the forward's packed fp16 operands instead of normalising the raw fp32 rows again: half the bytes per partner, no norm
+ *       reduction (bwd_rows 43.5 -> 34.0 us at B = 256, traffic past L2 302 -> 217 MB).  One fp16 rounding of those vectors leaves
+ *       the gradients <= 4.3e-4 of their largest entry away from the reference's autograd on every reference fixture (the tests
+ *       fail at 5e-4 = half of north_star's 1e-3; profiles/r05_bwd_precision_probe.txt) against 3e-7 without the flag.  Needs
+ *       packed->xm, y, rnorm (and xe with side rows) of THIS problem.  The Python layer sets it by default since round 5
+ *       (ops.set_backward_precision('exact') clears it).  The arg-maxima are the exact fp32 ones either way.
+ *   ALADIN_BWD_OWN_ROW_FP16  (with ALADIN_BWD_PARTNERS_FP16) the output row's OWN unit vector and inverse norm come from the packed
+ *       operands and packed->rnorm too: the raw sets are not read by step 3 at all (30.4 us).  5.8e-4 on one D = 64 fixture whose
+ *       cosines are near 1 (= the partners' figure wherever D >= 128): past the 5e-4 gate, hence an opt-in ('fp16-own').
  *   ALADIN_BWD_DENSE  the caller states that (almost) every pair carries a gradient -- the sum-of-violations hinge
  *       (max_violation = False, alad/loss.py:60-67), or a gradient arriving on the score matrix itself.  The arg-max table of
  *       ALL pairs then comes from the forward's own tile kernel run in split precision (64 pairs per workgroup sharing their

@@ -1264,8 +1264,8 @@ def test_large_batch_equals_its_blocks():
 
 def test_fused_hinge_argmax_equals_the_list_path():
     """The training step derives the backward's pairs from the hinge statistics and runs the hinge's element-wise pass in
-    the pair kernel's launch (aladin_hinge_argmax_fused + aladin_align_bwd_rows); the list-driven form (aladin_hinge_fused
-    -> pair list -> aladin_align_bwd_packed_strided) must give the same loss, dS and gradients bit for bit -- including
+    the pair kernel's launch (aladin_align_triplet_fwd / _bwd: one library call per direction); the list-driven form (aladin_align_pack
+    + aladin_align_scores + aladin_hinge_fused -> pair list -> aladin_align_bwd) must give the same loss, dS and gradients bit for bit -- including
     when a row's and a column's hardest negative are the same pair, inactive terms and ragged lengths."""
     from aladin_amd import ops, synth
     # (51, 38): the shipped data shape, 50 regions + 35 tokens -- two region tiles per image (the second is the pair kernel's segment)
