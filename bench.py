@@ -114,17 +114,20 @@ def kernel_roofline(im, s, il, sl, groups=5, iters=100):
 
 
 def csrc_hash():
-    """sha256 over what the kernels are built from (aladin_amd/csrc/*.hip, *.hpp, the Makefile with its flags, include/aladin_hip.h;
-    sorted by name): what a committed PMC summary was collected on.  tools/materialise_profiles.py stamps it into profiles/*_pmc.json."""
-    import glob
-    import hashlib
-    h = hashlib.sha256()
-    csrc = os.path.join(ROOT, 'aladin_amd', 'csrc')
-    for f in sorted(glob.glob(os.path.join(csrc, '*.hip')) + glob.glob(os.path.join(csrc, '*.hpp')) + [os.path.join(csrc, 'Makefile')]) + \
-            [os.path.join(ROOT, 'include', 'aladin_hip.h')]:
-        h.update(os.path.basename(f).encode())
-        h.update(open(f, 'rb').read())
-    return h.hexdigest()[:16]
+    """sha256 over what the kernels are built from (tools/srchash.py: aladin_amd/csrc/*.hip, *.hpp, the Makefile with its flags,
+    include/aladin_hip.h): what a committed PMC summary was collected on, and what the Makefile stamps next to every library it links."""
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import srchash
+    return srchash.csrc_hash(ROOT)
+
+
+def library_sources():
+    """{'lib': path, 'built_from': stamp or None, 'tree': hash, 'current': bool}: is the loaded library the tree's sources?"""
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import srchash
+    from aladin_amd import _lib
+    stamp, tree = srchash.library_stamp(_lib.LIB_PATH), srchash.csrc_hash(ROOT)
+    return {'lib': os.path.relpath(_lib.LIB_PATH, ROOT), 'built_from': stamp, 'tree': tree, 'current': stamp == tree}
 
 
 PMC_EXTRA = {}
@@ -651,6 +654,9 @@ def main():
                     cfg[key] = fn(dev)
                 except Exception as exc:
                     cfg[key] = {'error': '%s: %s' % (type(exc).__name__, exc)}
+        # which binary was timed: the library's link-time source stamp against the tree (tools/srchash.py); `current` false = a
+        # library left over from an experiment, or built by hand -- the numbers of this line are then not the committed code's
+        cfg['library'] = library_sources()
         # the three fractions of the 16-bit MFMA peak side by side: the score kernel alone (`frac`), the forward chain
         # pack + side GEMM + score kernel (`forward_chain_frac`), the whole timed step forward + backward (`step_frac`)
         roof['step_frac'] = round(value * FLOPS_PER_PAIR / world / 1e12 / PEAK_TFLOPS, 4)

@@ -38,6 +38,8 @@ def _bench(*extra):
 def test_bench_single_gpu_line():
     d = _bench()
     assert d['config']['launch'] in ('hipgraph', 'eager') and d['config']['bwd_partners'] == 'fp16'
+    lib = d['config']['library']                     # the timed binary is the tree's sources (link-time stamp, tools/srchash.py)
+    assert lib['current'] is True and lib['built_from'] == lib['tree'], lib
     assert 0.1 < d['ms_per_step'] < 0.5
 
 

@@ -23,6 +23,23 @@ def test_library_exports_every_declared_symbol():
     assert lib.aladin_version() == _lib.ABI_VERSION
 
 
+def test_library_is_built_from_the_sources_of_this_tree():
+    """The Makefile stamps every library it links with a hash of the kernel sources, their Makefile and the header
+    (tools/srchash.py); a library left behind by an experiment, or sources edited without a rebuild, fail here -- before a GPU
+    run measures or tests the wrong binary.  (`__graft_entry__.build()` always leaves the two in step.)"""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import srchash
+    from aladin_amd import _lib
+    stamp = srchash.library_stamp(os.path.join(ROOT, 'aladin_amd', 'lib', 'libaladin_hip.so'))
+    assert stamp is not None, 'no source stamp next to the library: rebuild with make -C aladin_amd/csrc'
+    assert stamp == srchash.csrc_hash(ROOT), 'the library was built from other sources than this tree holds: make -C aladin_amd/csrc'
+    diag = os.path.join(ROOT, 'aladin_amd', 'lib', 'libaladin_hip_diag.so')
+    if os.path.exists(diag):
+        assert srchash.library_stamp(diag) == srchash.csrc_hash(ROOT), 'stale diagnostic library: make -C aladin_amd/csrc diag'
+    del _lib
+
+
 def test_library_exports_nothing_but_the_declared_symbols():
     """The converse: the product library's dynamic symbol table holds the header's entry points and nothing
     else -- no debug probes, no kernel handles, no C++ helpers (-fvisibility=hidden + csrc/exports.map) -- and

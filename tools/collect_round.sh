@@ -10,6 +10,10 @@ R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=$R/gpurun_out/$TAG
 mkdir -p "$O"
 cd "$R"
+# refuse to collect on a library that was not built from this tree's sources (link-time stamp, tools/srchash.py)
+if [ "$(cat aladin_amd/lib/libaladin_hip.so.srchash 2>/dev/null)" != "$(python3 tools/srchash.py)" ]; then
+  echo "collect_round: aladin_amd/lib/libaladin_hip.so is not built from this tree's sources (make -C aladin_amd/csrc all diag)"; exit 1
+fi
 python3 bench.py > "$O/bench_line_unprofiled.json" 2> "$O/bench.err"
 python3 tools/bench_retrieval.py > "$O/bench_retrieval.txt" 2>&1
 if [ -f aladin_amd/lib/libaladin_hip_diag.so ]; then
