@@ -24,18 +24,32 @@ for sigma, exact in ((3.0, False), (6.0, False), (8.0, False), (12.0, False), (1
     # workspace behind the statistics (retr_layout): lob_i2t (Mp words), lob_t2i (Np words), list_cnt (n_tiles words), lists
     lo = so + 256 + r256(20 * 256 * 4) + r256(66 * 384 * 4) + r256(n_tiles * 4)
     seg = ws[lo:lo + n_tiles * CAP * 16].view(torch.int64).view(n_tiles, 2 * CAP)[:, 2 * CAP - 12:].cpu().numpy().astype(np.float64)
+    # a tile that listed more than CAP - 6 pairs wrote list entries over its stamps: leave it out (counted below)
+    ref = np.median(seg[:, 0])
+    ok = (np.abs(seg[:, 0] - ref) < 1e8) & np.all((seg[:, 1:12] == 0) | ((seg[:, 1:12] >= seg[:, :1]) & (seg[:, 1:12] < seg[:, :1] + 1e6)), axis=1)
+    n_lost = int((~ok).sum())
+    seg = seg[ok]
     t0 = seg[:, 0].min()
-    d = np.diff(seg[:, :8], axis=1) / 100.0          # 100 MHz -> us
-    ep = np.round(np.median(np.diff(np.concatenate([seg[:, 6:7], seg[:, 8:12], seg[:, 7:8]], axis=1), axis=1) / 100.0, axis=0), 2).tolist()
-    print('   exact epilogue: init+barrier, rows, cols, barrier, global atomics:', ep)
-    print('   diag counters [exact tiles, listed pairs, cheap group tests, full group evaluations, waves in phase 2, rescored, analysed, overflowed, skipped]:', ws[so:so + 36].view(torch.int32).cpu().tolist())
-    if not exact:
-        listed = seg[:, 8] > 0
-        if listed.any():
-            print('   listed tiles: phase 2a (incl. barrier) / 2b+flush us, median:', round(float(np.median(seg[listed, 8] - seg[listed, 3]) / 100.0), 2), round(float(np.median(seg[listed, 4] - seg[listed, 8]) / 100.0), 2))
-    print('sigma', sigma, 'exact' if exact else 'screen', 'per-phase us (median over tiles):', np.round(np.median(d, axis=0), 2).tolist(),
-          'tile total median', round(float(np.median((seg[:, 7] if (exact or sigma > 10) else seg[:, 4]) - seg[:, 0]) / 100.0), 2),
-          'kernel span', round(float((seg.max() - t0) / 100.0), 1))
+    us = lambda a, b: (seg[:, a] - seg[:, b]) / 100.0     # 100 MHz -> us; slots: 0 start, 1 prefix GEMM done, 2 thresholds, 3 phase 1 / 1b, 8 phase 2a,
+    med = lambda v: round(float(np.median(v)), 2) if len(v) else None      # 4 phase 2b + flush | 5 continuation starts, 6 done, 7 epilogue done (epilogue: 8 init, 9 rows, 10 columns, 11 barrier)
+    done_exact = seg[:, 7] > 0                        # the tile continued its chains in place (or the launch was all-exact)
+    analysed = seg[:, 2] > 0
+    screened = analysed & ~done_exact                 # decided by the prefix: ends at slot 4
+    counters = ws[so:so + 36].view(torch.int32).cpu().tolist()
+    print('sigma', sigma, 'all-exact launch' if exact else 'screened launch', '| tiles: screened %d, analysed then exact %d, exact at once %d' %
+          (int(screened.sum()), int((analysed & done_exact).sum()), int((~analysed & done_exact).sum())),
+          '| counters [exact tiles, listed pairs, (diag) cheap group tests, full group evaluations, waves in phase 2, rescored, analysed, overflowed, skipped]:', counters)
+    if screened.any():
+        m = screened
+        p2a = m & (seg[:, 8] > 0)
+        print('   screened tiles, median us: prefix GEMM %s | loads + thresholds %s | phase 1 + 1b %s | phase 2a (incl. barrier) %s | phase 2b + flush %s | tile total %s' %
+              (med(us(1, 0)[m]), med(us(2, 1)[m]), med(us(3, 2)[m]), med(us(8, 3)[p2a]), med(us(4, 8)[p2a]), med(us(4, 0)[m])))
+    if done_exact.any():
+        m = done_exact
+        ma = m & analysed
+        print('   exact tiles, median us: prefix GEMM %s | analysis before giving up %s | continuation GEMM %s | epilogue %s (init + barrier %s, rows %s, columns %s, barrier %s, global atomics %s) | tile total %s' %
+              (med(us(1, 0)[m]), med(us(5, 1)[ma]), med(us(6, 5)[m]), med(us(7, 6)[m]), med(us(8, 6)[m]), med(us(9, 8)[m]), med(us(10, 9)[m]), med(us(11, 10)[m]), med(us(7, 11)[m]), med(us(7, 0)[m])))
+    print('   kernel span %.1f us' % float((seg[:, :12].max() - t0) / 100.0) + ('   (%d tiles left out: their lists overwrote the stamps)' % n_lost if n_lost else ''))
     if '--detail' in sys.argv:
         end = np.where(seg[:, 7] > 0, seg[:, 7], seg[:, 4])
         dur = (end - seg[:, 0]) / 100.0
