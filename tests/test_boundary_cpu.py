@@ -40,6 +40,33 @@ def test_library_is_built_from_the_sources_of_this_tree():
     del _lib
 
 
+def test_source_hash_follows_every_input_of_the_build(tmp_path):
+    """tools/srchash.py: one byte in a kernel source, a shared header, the Makefile or include/aladin_hip.h changes the hash; files
+    outside the build (a stray .txt) do not; a library without a stamp file reads as None."""
+    import shutil
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import srchash
+    root = tmp_path / 'tree'
+    shutil.copytree(os.path.join(ROOT, 'aladin_amd', 'csrc'), root / 'aladin_amd' / 'csrc')
+    os.makedirs(root / 'include')
+    shutil.copy(os.path.join(ROOT, 'include', 'aladin_hip.h'), root / 'include' / 'aladin_hip.h')
+    base = srchash.csrc_hash(str(root))
+    assert base == srchash.csrc_hash(ROOT) and len(base) == 16
+    for rel in ('aladin_amd/csrc/recall.hip', 'aladin_amd/csrc/common.hpp', 'aladin_amd/csrc/Makefile', 'include/aladin_hip.h'):
+        f = root / rel
+        keep = f.read_bytes()
+        f.write_bytes(keep + b'\n')
+        assert srchash.csrc_hash(str(root)) != base, rel
+        f.write_bytes(keep)
+        assert srchash.csrc_hash(str(root)) == base
+    (root / 'aladin_amd' / 'csrc' / 'notes.txt').write_text('not a build input')
+    assert srchash.csrc_hash(str(root)) == base
+    assert srchash.library_stamp(str(root / 'no_such_lib.so')) is None
+    (root / 'lib.so.srchash').write_text(base + '\n')
+    assert srchash.library_stamp(str(root / 'lib.so')) == base
+
+
 def test_library_exports_nothing_but_the_declared_symbols():
     """The converse: the product library's dynamic symbol table holds the header's entry points and nothing
     else -- no debug probes, no kernel handles, no C++ helpers (-fvisibility=hidden + csrc/exports.map) -- and
