@@ -21,6 +21,15 @@ import torch
 import torch.distributed as dist
 
 
+class _HostStamp:
+    def __init__(self):
+        import time
+        self.t = time.perf_counter()
+
+    def elapsed_time(self, other):
+        return (other.t - self.t) * 1e3
+
+
 class PhaseRecorder:
     """Device-side timeline of one sharded step, for bench.py --gpus N (config.phases_ms): mark(name) drops an
     event on the current stream at a phase boundary; summary() gives the mean milliseconds between consecutive
@@ -36,6 +45,8 @@ class PhaseRecorder:
 
     @staticmethod
     def _event():
+        if not torch.cuda.is_available():          # the CPU tier (gloo, tests/helpers/cpu_standins.py): host time stamps
+            return _HostStamp()
         ev = torch.cuda.Event(enable_timing=True)
         ev.record()
         return ev
@@ -50,7 +61,8 @@ class PhaseRecorder:
             self._cur = None
 
     def summary(self):
-        torch.cuda.synchronize()
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
         tot, order = {}, []
         for st in self.steps:
             for (_, e0), (name, e1) in zip(st[:-1], st[1:]):
@@ -79,6 +91,18 @@ def _world(group):
     return dist.get_world_size(group), dist.get_rank(group)
 
 
+def _reduce_scatter_rows(g, n, group):
+    """Sum over ranks of the (W*n, ...) tensor g, this rank's n rows of it.  RCCL: one reduce-scatter; gloo (the CPU tier) has none:
+    all-reduce + slice, the same sums."""
+    W, r = _world(group)
+    if dist.get_backend(group) == 'gloo':
+        dist.all_reduce(g, group=group)
+        return g[r * n:(r + 1) * n].clone()
+    out = torch.empty((n,) + tuple(g.shape[1:]), dtype=g.dtype, device=g.device)
+    dist.reduce_scatter_tensor(out, g, group=group)
+    return out
+
+
 class _AllGatherRows(torch.autograd.Function):
     """cat over ranks along dim 0; backward = reduce-scatter(sum) of the incoming gradient."""
 
@@ -96,12 +120,7 @@ class _AllGatherRows(torch.autograd.Function):
         W, r = _world(ctx.group)
         g = g.contiguous()
         n = g.shape[0] // W
-        if dist.get_backend(ctx.group) == 'gloo':            # gloo has no reduce_scatter
-            dist.all_reduce(g, group=ctx.group)
-            return g[r * n:(r + 1) * n].clone(), None
-        out = torch.empty((n,) + tuple(g.shape[1:]), dtype=g.dtype, device=g.device)
-        dist.reduce_scatter_tensor(out, g, group=ctx.group)
-        return out, None
+        return _reduce_scatter_rows(g, n, ctx.group), None
 
 
 class _GatherColumnBlocks(torch.autograd.Function):
@@ -459,9 +478,7 @@ class _ShardedTriplet(torch.autograd.Function):
         d_im_all, d_s = rank_backward_block(im_all, il_all, s, s_len_t, dS_full, r, ctx.g_glob, xm_all, xe_all, y,
                                             gscale=g_loss.to(torch.float32).contiguous())
         _mark('bwd_compute_dense')
-        B = s.shape[0]
-        d_im = torch.empty((B,) + tuple(d_im_all.shape[1:]), dtype=d_im_all.dtype, device=d_im_all.device)
-        dist.reduce_scatter_tensor(d_im, d_im_all, group=ctx.group)
+        d_im = _reduce_scatter_rows(d_im_all.contiguous(), s.shape[0], ctx.group)
         _mark('bwd_reduce_scatter')
         return d_im, d_s, None, None, None, None, None, None
 

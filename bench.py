@@ -49,6 +49,10 @@ def parse():
     ap.add_argument('--stub-step', action='store_true',
                     help='CPU self-test of the multi-rank protocol (tests/test_launch_cpu.py): gloo, a stub step, the same launcher, '
                          'argument parsing, barriers, MAX over ranks and JSON line -- no GPU, no kernels, no performance claim')
+    ap.add_argument('--cpu-standin', action='store_true',
+                    help='CPU self-test of the REAL multi-rank step loop (tests/test_launch_cpu.py): gloo, the fast sharded node of '
+                         'aladin_amd/distributed.py with the HIP entry points replaced by tests/helpers/cpu_standins.py, at a reduced shape '
+                         '(B=64/rank, D=16) -- exchange tuning, PhaseRecorder, watchdog and the JSON line as on the GPUs; no performance claim')
     ap.add_argument('--eager', action='store_true', help='do not capture the step in a HIP graph')
     ap.add_argument('--graph', action='store_true', help='always replay the captured HIP graph (default: the faster of graph / eager in a short trial)')
     ap.add_argument('--force-sharded', action='store_true',
@@ -422,6 +426,7 @@ def tick():
 
 
 def main():
+    global B, D
     args = parse()
     # before anything initialises the HIP runtime: the host driver only supports dmabuf IPC
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
@@ -453,17 +458,36 @@ def main():
                          % (args.gpus, rank, world))
     if args.stub_step:
         return stub_main(args, world, rank)
-    if not torch.cuda.is_available():
-        raise SystemExit('bench.py needs an MI355X (no GPU visible); there is no CPU fallback')
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
-    sharded = world > 1 or args.force_sharded
+    standin = args.cpu_standin
+    if standin:
+        # the real step loop below on CPU tensors under gloo, the HIP entry points replaced by torch restatements that keep the packed
+        # layout (tests/helpers/cpu_standins.py; nothing under oracle/): a protocol and bookkeeping self-test of the multi-GPU path at a
+        # reduced shape, labelled as such in the line -- never a measurement
+        B, D = 64, 16
+        torch.set_num_threads(1)
+        dev = torch.device('cpu')
+        sync = lambda: None
+        args.preroll_s, args.steps, args.warmup, args.repeats = 0.0, min(args.steps, 3), min(args.warmup, 1), min(args.repeats, 2)
+    else:
+        if not torch.cuda.is_available():
+            raise SystemExit('bench.py needs an MI355X (no GPU visible); there is no CPU fallback')
+        torch.cuda.set_device(local_rank)
+        dev = torch.device('cuda', local_rank)
+        sync = torch.cuda.synchronize
+    sharded = world > 1 or args.force_sharded or standin
     dist = None
     if sharded:
         import torch.distributed as dist
         import datetime
         limit = datetime.timedelta(seconds=120)             # a collective that does not complete in two minutes aborts the rank (RCCL watchdog)
-        if world == 1:
+        if standin:
+            if world == 1:
+                os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+                os.environ.setdefault('MASTER_PORT', '29672')
+                dist.init_process_group('gloo', rank=0, world_size=1, timeout=limit)
+            else:
+                dist.init_process_group('gloo', timeout=limit)
+        elif world == 1:
             os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
             os.environ.setdefault('MASTER_PORT', '29671')
             dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev, timeout=limit)
@@ -475,6 +499,10 @@ def main():
     from aladin_amd.loss import AlignmentContrastiveLoss
     from aladin_amd import distributed as AD
     ops.set_backward_precision(args.bwd_partners)
+    if standin:
+        sys.path.insert(0, os.path.join(ROOT, 'tests', 'helpers'))
+        import cpu_standins
+        cpu_standins.install()
 
     im_np, s_np, il, sl = synth.alignment_batch(B, R, T, D, seed=1234 + 17 * rank, ragged=False)
     im = torch.from_numpy(im_np).to(dev).requires_grad_(True)
@@ -501,7 +529,7 @@ def main():
     def fence():
         if sharded:
             dist.barrier()
-        torch.cuda.synchronize()
+        sync()
 
     def agree_max(x):
         if not sharded:
@@ -538,13 +566,14 @@ def main():
     if sharded and args.exchange == 'tune':
         # Both exchanges give the same gradients (tests/); which is faster depends on the world size and
         # the fabric.  Time a few untimed steps of each, agree on the MAX over ranks, keep the winner.
+        n_try, n_tune = (1, 2) if standin else (3, 8)
         for mode in ('dense', 'sparse'):
             exchange[0] = mode
             failed, elapsed = 0.0, float('inf')
             try:
-                for _ in range(3):
+                for _ in range(n_try):
                     step()
-                torch.cuda.synchronize()
+                sync()
             except Exception as exc:
                 print('bench: exchange %r failed on rank %d (%s); not used' % (mode, rank, exc), file=sys.stderr)
                 failed = 1.0
@@ -553,11 +582,11 @@ def main():
             if agree_max(failed) == 0.0:
                 fence()
                 t0 = time.perf_counter()
-                for _ in range(8):
+                for _ in range(n_tune):
                     step()
                 fence()
                 elapsed = agree_max(time.perf_counter() - t0)
-            tuned[mode] = elapsed / 8 * 1e3
+            tuned[mode] = elapsed / n_tune * 1e3
         if all(v == float('inf') for v in tuned.values()):
             raise SystemExit('bench: both backward exchanges failed; see stderr')
         exchange[0] = min(tuned, key=tuned.get)
@@ -589,7 +618,7 @@ def main():
     while time.perf_counter() - t_pre < args.preroll_s:
         for _ in range(50):
             run()
-        torch.cuda.synchronize()
+        sync()
         n_pre += 50
     # 2. warm-up
     for _ in range(args.warmup):
@@ -612,7 +641,7 @@ def main():
     if sharded:
         rec = AD.PhaseRecorder()
         AD.set_phase_recorder(rec)
-        for _ in range(10):
+        for _ in range(2 if standin else 10):
             rec.begin()
             step()
             rec.mark('autograd_tail')
@@ -628,24 +657,30 @@ def main():
         dist.barrier()
         if WATCHDOG[0] is not None:
             WATCHDOG[0].stop()                             # the measured part is over; what follows is rank 0's own (bounded) work
+    # the row step that RAN: the sharded step gathers no inverse norms, so whatever --bwd-partners says its backward reads the raw fp32
+    # sets (ops._bwd_flags: 0 without rnorm) -- ADVICE r5: do not label a multi-GPU line with the single-GPU default
+    bwd_mode = args.bwd_partners if not sharded else 'exact (the sharded step carries no inverse norms: its row step reads the raw fp32 sets; --bwd-partners has no effect)'
     if rank == 0:
-        roof = kernel_roofline(im.detach(), s.detach(), il, sl)
-        cfg = {'workload': 'configs[1]: alignment-head triplet loss forward+backward, B=256 synthetic '
+        roof = kernel_roofline(im.detach(), s.detach(), il, sl) if not standin else {'bound': 'mfma', 'note': 'not measured: CPU stand-ins'}
+        cfg = {'workload': ('CPU STAND-INS (tests/helpers/cpu_standins.py) under gloo at B=%d/rank, D=%d: the multi-rank step loop, not a measurement; ' % (B, D) if standin else '') +
+                           'configs[1]: alignment-head triplet loss forward+backward, B=256 synthetic '
                            'features per GPU (R=34,T=50,D=768, full lengths)' +
                            ('' if world == 1 else '; configs[3]: global %dx%d matrix, images all-gathered '
                             'over RCCL, caption-block sharding' % (B * world, B * world)),
-               'global_pairs_per_step': pairs, 'loss': float(loss.detach()), 'launch': launch, 'bwd_partners': args.bwd_partners, 'backward_seed': 'preallocated ones',
+               'global_pairs_per_step': pairs, 'loss': float(loss.detach()), 'launch': launch, 'bwd_partners': bwd_mode, 'backward_seed': 'preallocated ones',
                'launch_trial_ms': launch_trial, 'hip_env': {'DEBUG_CLR_GRAPH_PACKET_CAPTURE': os.environ.get('DEBUG_CLR_GRAPH_PACKET_CAPTURE')},
                'timing': {'preroll_s': args.preroll_s, 'preroll_steps': n_pre, 'repeats': len(region_ms), 'statistic': 'median',
                           'ms_per_step_min': round(min(region_ms), 4), 'ms_per_step_max': round(max(region_ms), 4)},
-               'step_tflops_algorithmic': round(value * FLOPS_PER_PAIR / 1e12, 2)}
+               'step_tflops_algorithmic': round(value * FLOPS_PER_PAIR / 1e12, 2) if not standin else None}
         if sharded:
             cfg['collectives'] = {'backend': dist.get_backend(), 'ranks': dist.get_world_size(),
                                   'launcher': 'self (aladin_amd.launch)' if os.environ.get('ALADIN_SELF_LAUNCHED') else 'external'}
             cfg['bwd_exchange'] = exchange[0]
             cfg['bwd_exchange_tuning_ms'] = {k: (round(v, 4) if v != float('inf') else None) for k, v in tuned.items()}
             cfg['phases_ms'] = phases          # rank 0's device timeline of one step (10-step mean), see PhaseRecorder
-        if world == 1 and not args.no_eval:
+        if standin:
+            cfg['standin_calls'] = dict(cpu_standins.CALLS)
+        if world == 1 and not args.no_eval and not standin:
             sys.path.insert(0, os.path.join(ROOT, 'tools'))
             import benchlib
             for key, fn in (('eval_config3', eval_config3), ('shipped_shape', shipped_shape_step), ('loss_heads_bs32', benchlib.loss_heads_bs32),
@@ -659,14 +694,15 @@ def main():
         cfg['library'] = library_sources()
         # the three fractions of the 16-bit MFMA peak side by side: the score kernel alone (`frac`), the forward chain
         # pack + side GEMM + score kernel (`forward_chain_frac`), the whole timed step forward + backward (`step_frac`)
-        roof['step_frac'] = round(value * FLOPS_PER_PAIR / world / 1e12 / PEAK_TFLOPS, 4)
+        if not standin:
+            roof['step_frac'] = round(value * FLOPS_PER_PAIR / world / 1e12 / PEAK_TFLOPS, 4)
         out = {
             'metric': 'alignment image-text pairs/sec (BxB scores, triplet loss fwd+bwd) at B=256/GPU,R=34,T=50,D=768',
-            'value': round(value, 1), 'unit': 'pairs/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'value': round(value, 1) if not standin else 0.0, 'unit': 'pairs/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(ms, 4), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f16', 'data': 'synthetic', 'config': cfg, 'roofline': roof,
+            'dtype': 'f16', 'data': 'synthetic' if not standin else 'cpu-standin', 'config': cfg, 'roofline': roof,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not standin:
             out['cpu_baseline'] = cpu_baseline(live_b256=not args.no_cpu_b256)
         print(json.dumps(out), flush=True)
     if sharded:

@@ -101,6 +101,43 @@ def test_bench_py_eight_ranks_stub_step():
     assert res['config']['stub_result_ok'] is True
 
 
+@pytest.mark.timeout(900)
+def test_bench_py_eight_ranks_cpu_standin_runs_the_real_sharded_step():
+    """the REAL step loop of bench.py at configs[3]'s world size -- the fast sharded node of aladin_amd/distributed.py,
+    the exchange tuning (dense AND pair-driven sparse backward), PhaseRecorder, the stall watchdog and the one JSON line -- under gloo
+    with the HIP entry points replaced by tests/helpers/cpu_standins.py (`--stub-step` above touches none of distributed.py).  The
+    loss of the global 512 x 512 batch must be the unsharded composition's on the concatenated batch."""
+    env = dict(os.environ, OMP_NUM_THREADS='1')
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '8', '--cpu-standin', '--steps', '2', '--warmup', '1'],
+                         env=env, capture_output=True, text=True, timeout=800)
+    assert out.returncode == 0, out.stderr[-2000:]
+    res = json.loads([l for l in out.stdout.splitlines() if l.strip()][-1])
+    cfg = res['config']
+    assert res['n_gpus'] == 8 and res['data'] == 'cpu-standin' and res['value'] == 0.0 and res['steps'] == 2
+    assert cfg['collectives'] == {'backend': 'gloo', 'ranks': 8, 'launcher': 'self (aladin_amd.launch)'}
+    assert set(cfg['bwd_exchange_tuning_ms']) == {'dense', 'sparse'} and all(v for v in cfg['bwd_exchange_tuning_ms'].values())
+    assert cfg['bwd_exchange'] == min(cfg['bwd_exchange_tuning_ms'], key=cfg['bwd_exchange_tuning_ms'].get)
+    phases = list(cfg['phases_ms'])
+    assert phases[:6] == ['pack+issue_gathers', 'local_block', 'gather_wait', 'remote_rows', 'S_allgather', 'hinge'] and phases[-1] == 'autograd_tail'
+    assert ('bwd_give_back' in phases) == (cfg['bwd_exchange'] == 'sparse') and ('bwd_reduce_scatter' in phases) == (cfg['bwd_exchange'] == 'dense')
+    calls = cfg['standin_calls']
+    assert calls['scores_from_packed'] == 8 * calls['pack_images'] and calls['align_backward'] == calls['hinge_raw'] == calls['pack_images']
+    assert cfg['bwd_partners'].startswith('exact')
+    # the global loss = the same stand-ins composed on ONE process over the concatenated batch (rank r's batch: seed 1234 + 17 r)
+    sys.path.insert(0, os.path.join(ROOT, 'tests', 'helpers'))
+    import numpy as np
+    import torch
+    import cpu_standins
+    from aladin_amd import synth
+    parts = [synth.alignment_batch(64, 34, 50, 16, seed=1234 + 17 * r, ragged=False) for r in range(8)]
+    im = torch.from_numpy(np.concatenate([p[0] for p in parts]))
+    s = torch.from_numpy(np.concatenate([p[1] for p in parts]))
+    loss, _, _, _ = cpu_standins.single_process_step(im, s, sum((p[2] for p in parts), []), sum((p[3] for p in parts), []))
+    np.testing.assert_allclose(cfg['loss'], float(loss), rtol=1e-5)
+
+
 def test_no_self_launch_inside_a_rank_or_for_one_gpu():
     from aladin_amd import launch
     assert launch.needs_self_launch(8, {})
