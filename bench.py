@@ -637,6 +637,40 @@ def main():
     pairs = (B * world) ** 2
     value = pairs / (ms * 1e-3)
 
+    # The same step with the EXACT backward row step (raw fp32 rows instead of fp16 partner rows), timed the same way (one region of
+    # K steps under the launch mode chosen above), so that the precision trade behind the headline is visible in the line
+    bwd_exact_ms = None
+    if not sharded and args.bwd_partners != 'exact':
+        old_mode = ops.set_backward_precision('exact')
+        try:
+            run_x = step
+            if launch == 'hipgraph':
+                for _ in range(3):
+                    step()
+                sync()
+                im.grad = None
+                s.grad = None
+                graph_x = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph_x):
+                    loss_x = crit(im, s, il, sl)
+                    loss_x.backward(gradient=seed)
+                run_x = graph_x.replay
+            for _ in range(max(args.warmup, 50)):
+                run_x()
+            reg = []
+            for _ in range(max(1, min(args.repeats, 3))):
+                fence()
+                t0 = time.perf_counter()
+                for _ in range(args.steps):
+                    run_x()
+                fence()
+                reg.append((time.perf_counter() - t0) / args.steps * 1e3)
+            bwd_exact_ms = round(statistics.median(reg), 4)
+        except Exception as exc:
+            bwd_exact_ms = 'error: %s' % exc
+        finally:
+            ops.set_backward_precision(old_mode)
+
     phases = None
     if sharded:
         rec = AD.PhaseRecorder()
@@ -667,7 +701,7 @@ def main():
                            'features per GPU (R=34,T=50,D=768, full lengths)' +
                            ('' if world == 1 else '; configs[3]: global %dx%d matrix, images all-gathered '
                             'over RCCL, caption-block sharding' % (B * world, B * world)),
-               'global_pairs_per_step': pairs, 'loss': float(loss.detach()), 'launch': launch, 'bwd_partners': bwd_mode, 'backward_seed': 'preallocated ones',
+               'global_pairs_per_step': pairs, 'loss': float(loss.detach()), 'launch': launch, 'bwd_partners': bwd_mode, 'bwd_exact_ms_per_step': bwd_exact_ms, 'backward_seed': 'preallocated ones',
                'launch_trial_ms': launch_trial, 'hip_env': {'DEBUG_CLR_GRAPH_PACKET_CAPTURE': os.environ.get('DEBUG_CLR_GRAPH_PACKET_CAPTURE')},
                'timing': {'preroll_s': args.preroll_s, 'preroll_steps': n_pre, 'repeats': len(region_ms), 'statistic': 'median',
                           'ms_per_step_min': round(min(region_ms), 4), 'ms_per_step_max': round(max(region_ms), 4)},

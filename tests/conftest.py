@@ -22,6 +22,19 @@ def pytest_sessionfinish(session, exitstatus):
     import json
     mod = sys.modules.get('test_gpu_parity')
     log = getattr(mod, 'SCORE_ERR_LOG', None)
+    glog = getattr(mod, 'GRAD_ERR_LOG', None)
+    grads = None
+    if glog:
+        # gradient VALUES vs reference / oracle per backward row mode (assert_grads_close): worst call per test, and the worst of each mode
+        worst = {}
+        for test, d in glog:
+            cur = worst.get(test)
+            if cur is None or d['max_err_over_max_ref'] > cur['max_err_over_max_ref']:
+                worst[test] = d
+        grads = {'note': 'gradients vs reference / oracle: max |err| / max |ref| per test; gate = the absolute term the test held on top of rtol 1e-3',
+                 'worst_by_mode': {m: max((v['max_err_over_max_ref'] for v in worst.values() if v['mode'] == m), default=None) for m in ('exact', 'fp16')},
+                 'worst_fp16_D_ge_64': max((v['max_err_over_max_ref'] for v in worst.values() if v['mode'] == 'fp16' and v['D'] >= 64), default=None),
+                 'tests': worst}
     if log:
         out = os.path.join(ROOT, 'gpurun_out')
         try:
@@ -36,7 +49,7 @@ def pytest_sessionfinish(session, exitstatus):
                            'max_frac_of_tol': max(v['frac_of_tol'] for v in worst.values()),
                            'max_err_over_max_ref': max(v['max_err_over_max_ref'] for v in worst.values()),
                            'max_rel_err_where_ref_ge_tenth_of_max': max(v['max_rel_err_where_ref_ge_tenth_of_max'] for v in worst.values()),
-                           'tests': worst}, f, indent=1)
+                           'tests': worst, 'gradients': grads}, f, indent=1)
         except OSError:
             pass
 

@@ -41,6 +41,9 @@ def test_bench_single_gpu_line():
     lib = d['config']['library']                     # the timed binary is the tree's sources (link-time stamp, tools/srchash.py)
     assert lib['current'] is True and lib['built_from'] == lib['tree'], lib
     assert 0.1 < d['ms_per_step'] < 0.5
+    # the precision trade behind the headline is in the line: the same step with the exact row step, timed the same way
+    x = d['config']['bwd_exact_ms_per_step']
+    assert isinstance(x, float) and 0.97 * d['ms_per_step'] < x < 0.6, x
 
 
 def test_bench_sharded_step_on_one_rank():
@@ -48,6 +51,7 @@ def test_bench_sharded_step_on_one_rank():
     d = _bench('--force-sharded')
     c = d['config']
     assert c['collectives'] == {'backend': 'nccl', 'ranks': 1, 'launcher': 'external'}
+    assert c['bwd_partners'].startswith(('exact', 'fp16')) and c['bwd_exact_ms_per_step'] is None
     assert c['bwd_exchange'] in ('dense', 'sparse') and set(c['bwd_exchange_tuning_ms']) == {'dense', 'sparse'}
     assert all(v is not None and v > 0 for v in c['bwd_exchange_tuning_ms'].values())          # both exchanges ran
     for phase in ('pack+issue_gathers', 'local_block', 'S_allgather', 'hinge', 'bwd_start'):
