@@ -203,13 +203,15 @@ def rank_scores_rows(xm_all, xe_all, y, S_blk, first, count, B, R, T, D):
     ops.scores_from_packed(xm_all[first * per_m:(first + count) * per_m], xe, y, g, out=S_blk[first * B:(first + count) * B])
 
 
-def rank_backward_block(im_all, il_all_t, s_local, s_len_t, dS_full, rank, g_glob, xm_all, xe_all, y, gscale=None):
-    """This rank's contribution: d(all image sets) restricted to its caption block, and d(its captions)."""
+def rank_backward_block(im_all, il_all_t, s_local, s_len_t, dS_full, rank, g_glob, xm_all, xe_all, y, gscale=None, rnorm=None):
+    """This rank's contribution: d(all image sets) restricted to its caption block, and d(its captions).
+    rnorm: the inverse norms of [xm_all rows | xe_all rows | y rows] (g_glob.rnorm_bytes) -- with them the row step follows
+    ops.set_backward_precision (fp16 partner rows by default), without them it reads the raw fp32 sets."""
     from . import ops
     B = s_local.shape[0]
     dS_blk = dS_full[:, rank * B:(rank + 1) * B].contiguous()
-    return ops._align_backward(im_all, s_local, il_all_t, s_len_t, dS_blk, gscale=gscale,
-                               packed=(g_glob, xm_all, xe_all, y))
+    packed = (g_glob, xm_all, xe_all, y) if rnorm is None else (g_glob, xm_all, xe_all, y, rnorm)
+    return ops._align_backward(im_all, s_local, il_all_t, s_len_t, dS_blk, gscale=gscale, packed=packed)
 
 
 class _PinnedPool:
@@ -338,18 +340,31 @@ class FlatSegments:
     """The one forward exchange of the fast path: every rank contributes ONE segment [xm | xe | image lengths] (256-byte aligned
     parts) to a single all-gather.  Pure tensor bookkeeping (device-agnostic: the gloo tests run it on CPU tensors)."""
 
-    def __init__(self, xm_bytes, xe_bytes, B):
+    def __init__(self, xm_bytes, xe_bytes, B, rn_rows=0):
+        """rn_rows > 0: the segment also carries the inverse norms of the rank's packed image rows ([xm rows | xe rows] fp32, what
+        aladin_align_pack writes into `rnorm`), so that the backward's fp16 row step has them for every rank's images."""
         up = lambda v: (int(v) + 255) // 256 * 256
         self.xm_b, self.xe_b, self.B = int(xm_bytes), max(int(xe_bytes), 16), int(B)
         self.o_xe = up(self.xm_b)
         self.o_il = self.o_xe + up(self.xe_b)
-        self.seg = self.o_il + up(4 * self.B)
+        self.o_rn = self.o_il + up(4 * self.B)
+        self.rn_b = 4 * int(rn_rows)
+        self.seg = self.o_rn + up(self.rn_b)
 
     def alloc(self, device):
         """-> (flat, xm, xe, il): this rank's segment and typed views of its parts (fp16, fp16, int32)."""
         flat = torch.empty(self.seg, dtype=torch.uint8, device=device)
         return flat, flat[:self.xm_b].view(torch.float16), flat[self.o_xe:self.o_xe + self.xe_b].view(torch.float16), \
             flat[self.o_il:self.o_il + 4 * self.B].view(torch.int32)
+
+    def rnorm_view(self, flat):
+        """this rank's inverse-norm part (fp32) of its own segment"""
+        return flat[self.o_rn:self.o_rn + self.rn_b].view(torch.float32)
+
+    def rnorms(self, flat_all):
+        """(W, rn_rows) fp32: every rank's inverse norms, in place"""
+        W = flat_all.numel() // self.seg
+        return flat_all.view(W, self.seg)[:, self.o_rn:self.o_rn + self.rn_b].view(torch.float32)
 
     def gather(self, flat, group, async_op=True):
         W, _ = _world(group)
@@ -392,22 +407,32 @@ class _ShardedTriplet(torch.autograd.Function):
         # ONE exchange for everything the forward needs from the other ranks (round 5; rounds 2-4 issued three gathers): each rank's
         # segment is [xm | xe | image lengths], packed straight into it; the remote images are then scored rank by rank from their
         # segments (a score depends only on its own image / caption rows, so any split gives the bits of one launch).
-        fs = FlatSegments(g_loc.xm_bytes, g_loc.xe_bytes, B)
-        flat, xm, xe, il_seg = fs.alloc(im.device)
-        il_seg.copy_(im_len_t)
-        ops.pack_images(im_c, im_len_t, g_loc, out=(xm, xe))
-        flat_all, gather = fs.gather(flat, group)
         need = any(ctx.needs_input_grad[:2])
         # <= 3 non-zeros of dS per row/column under max_violation: pair-driven exchange
         # (its fixed cost -- one host sync for the split sizes -- pays off once the dense form would move
         # >= 4 ranks' worth of fp32 sets; bench.py times both)
         sparse = (bool(max_violation) and W >= 4) if exchange == 'auto' else (exchange == 'sparse')
+        # dense exchange: the inverse norms of the packed rows travel with them when the backward's row step will take its partner rows
+        # from the packed fp16 operands (ops.set_backward_precision: the library default) -- 4 bytes per 1.5 KB row.  (The pair-driven
+        # exchange packs its compact problem again in the backward and gets them there.)
+        fp16_rows = need and not sparse and ops._BWD_PARTNERS[0] == 'fp16'
+        n_m, n_e = int(g_loc.xm_rows), int(g_loc.xe_rows)
+        fs = FlatSegments(g_loc.xm_bytes, g_loc.xe_bytes, B, rn_rows=(n_m + n_e) if fp16_rows and W > 1 else 0)
+        flat, xm, xe, il_seg = fs.alloc(im.device)
+        il_seg.copy_(im_len_t)
+        rn_glob = None
+        if fp16_rows:                          # [all ranks' xm rows | all ranks' xe rows | y rows]: the captions' part now, the images' after the gather
+            rn_glob = torch.empty(int(g_glob.rnorm_bytes) // 4, dtype=torch.float32, device=im.device)
+        # one rank: the local rows ARE the global ones -- their inverse norms go straight into place (no copies after the gather)
+        rn_img = None if not fp16_rows else (rn_glob if W == 1 else fs.rnorm_view(flat))
+        ops.pack_images(im_c, im_len_t, g_loc, rnorm=rn_img, out=(xm, xe))
+        flat_all, gather = fs.gather(flat, group)
         im_all, work = None, None
         if need and not sparse:                    # raw fp32 sets: only the exact backward reads them (the second and last gather)
             im_all = torch.empty((W * B, R, D), dtype=im.dtype, device=im.device)
             work = dist.all_gather_into_tensor(im_all, im_c, group=group, async_op=True)
         # The local images' block does not need the exchange: score it while the gather is in flight, then the other ranks' images.
-        y = ops.pack_captions(s, s_len_t, g_glob)
+        y = ops.pack_captions(s, s_len_t, g_glob, rnorm=rn_glob)
         _mark('pack+issue_gathers')
         S_blk = torch.empty((W * B, B), dtype=torch.float32, device=im.device)
         e_scr = torch.empty(max(int(g_loc.e_bytes), 16), dtype=torch.uint8, device=im.device)
@@ -444,7 +469,15 @@ class _ShardedTriplet(torch.autograd.Function):
             # the dense backward's pair kernel reads all ranks' packed images as ONE operand: lay the segments' parts out contiguously
             # (device copies, no collective)
             xm_all, xe_all = fs.contiguous_operands(flat_all) if W > 1 else (xm, xe)
-            ctx.save_for_backward(im_all, il_all, s, s_len_t, dS_full, xm_all, xe_all, y)
+            if rn_glob is not None:
+                if W > 1:
+                    rn_all = fs.rnorms(flat_all)
+                    rn_glob[:W * n_m].view(W, n_m).copy_(rn_all[:, :n_m])
+                    if n_e:
+                        rn_glob[W * n_m:W * (n_m + n_e)].view(W, n_e).copy_(rn_all[:, n_m:])
+                ctx.save_for_backward(im_all, il_all, s, s_len_t, dS_full, xm_all, xe_all, y, rn_glob)
+            else:
+                ctx.save_for_backward(im_all, il_all, s, s_len_t, dS_full, xm_all, xe_all, y)
             ctx.g_glob, ctx.group = g_glob, group
         ctx.mark_non_differentiable(S_full)
         ctx.set_materialize_grads(False)
@@ -465,18 +498,26 @@ class _ShardedTriplet(torch.autograd.Function):
             dS_need = dS_full.index_select(0, ex.need_idx)[:, r * B:(r + 1) * B].contiguous()
             _mark('bwd_sparse_fetch')
             if im_need.shape[0]:
-                d_im_need, d_s = ops._align_backward(im_need, s, il_need, s_len_t, dS_need, gscale=gscale)
+                # the compact problem (the images this caption block pairs with x its captions) packed again -- one launch over ~n_need x R
+                # + B x T rows -- so that its arg-maxima come from the fp16 MFMA pair kernel (re-decided exactly in fp32, like the single-GPU
+                # step's) and its row step can take the partner rows from the packed operands; without `packed` both run in fp32 throughout
+                packed = None
+                g_need = ops.align_geometry(im_need.shape[0], s.shape[0], im_need.shape[1], s.shape[1], s.shape[2])
+                if ops._pair_kernel_covers(g_need):
+                    packed = ops.pack_sets(im_need, s, il_need, s_len_t, g_need)
+                d_im_need, d_s = ops._align_backward(im_need, s, il_need, s_len_t, dS_need, gscale=gscale, packed=packed)
             else:                                  # no violation anywhere in this caption block
                 d_im_need, d_s = torch.zeros_like(im_need), torch.zeros_like(s)
             _mark('bwd_compute_compact')
             d_im = ctx.exchange.give_back(d_im_need, ctx.im_shape)
             _mark('bwd_give_back')
             return d_im, d_s, None, None, None, None, None, None
-        im_all, il_all, s, s_len_t, dS_full, xm_all, xe_all, y = ctx.saved_tensors
+        im_all, il_all, s, s_len_t, dS_full, xm_all, xe_all, y = ctx.saved_tensors[:8]
+        rn_glob = ctx.saved_tensors[8] if len(ctx.saved_tensors) > 8 else None
         W, r = _world(ctx.group)
         _mark('bwd_start')
         d_im_all, d_s = rank_backward_block(im_all, il_all, s, s_len_t, dS_full, r, ctx.g_glob, xm_all, xe_all, y,
-                                            gscale=g_loss.to(torch.float32).contiguous())
+                                            gscale=g_loss.to(torch.float32).contiguous(), rnorm=rn_glob)
         _mark('bwd_compute_dense')
         d_im = _reduce_scatter_rows(d_im_all.contiguous(), s.shape[0], ctx.group)
         _mark('bwd_reduce_scatter')

@@ -691,9 +691,10 @@ def main():
         dist.barrier()
         if WATCHDOG[0] is not None:
             WATCHDOG[0].stop()                             # the measured part is over; what follows is rank 0's own (bounded) work
-    # the row step that RAN: the sharded step gathers no inverse norms, so whatever --bwd-partners says its backward reads the raw fp32
-    # sets (ops._bwd_flags: 0 without rnorm) -- ADVICE r5: do not label a multi-GPU line with the single-GPU default
-    bwd_mode = args.bwd_partners if not sharded else 'exact (the sharded step carries no inverse norms: its row step reads the raw fp32 sets; --bwd-partners has no effect)'
+    # the row step that RAN (the multi-GPU line must not be labelled with a mode it does not run): since round 6 the sharded
+    # step carries the packed rows' inverse norms (dense exchange: in its all-gather segment; pair-driven exchange: by packing the
+    # compact problem in the backward), so ops.set_backward_precision applies to it as to the single-GPU node
+    bwd_mode = args.bwd_partners
     if rank == 0:
         roof = kernel_roofline(im.detach(), s.detach(), il, sl) if not standin else {'bound': 'mfma', 'note': 'not measured: CPU stand-ins'}
         cfg = {'workload': ('CPU STAND-INS (tests/helpers/cpu_standins.py) under gloo at B=%d/rank, D=%d: the multi-rank step loop, not a measurement; ' % (B, D) if standin else '') +

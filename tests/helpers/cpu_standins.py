@@ -167,11 +167,18 @@ def check_sets(im_set, s_seq, im_len, s_len):
     return as_t(im_len), as_t(s_len)
 
 
+def pack_sets(im, s, im_len_t, s_len_t, geom, norms=True):
+    _count('pack_sets')
+    xm, xe = pack_images(im, im_len_t, geom)
+    return geom, xm, xe, pack_captions(s, s_len_t, geom), None
+
+
 def install():
     """Replace the HIP-backed functions of aladin_amd.ops in THIS process (a test worker or a --cpu-standin bench rank)."""
     from aladin_amd import ops
     ops.pack_images = pack_images
     ops.pack_captions = pack_captions
+    ops.pack_sets = pack_sets
     ops.scores_from_packed = scores_from_packed
     ops._hinge_raw = hinge_raw
     ops._align_backward = align_backward

@@ -51,7 +51,7 @@ def test_bench_sharded_step_on_one_rank():
     d = _bench('--force-sharded')
     c = d['config']
     assert c['collectives'] == {'backend': 'nccl', 'ranks': 1, 'launcher': 'external'}
-    assert c['bwd_partners'].startswith(('exact', 'fp16')) and c['bwd_exact_ms_per_step'] is None
+    assert c['bwd_partners'] == 'fp16' and c['bwd_exact_ms_per_step'] is None
     assert c['bwd_exchange'] in ('dense', 'sparse') and set(c['bwd_exchange_tuning_ms']) == {'dense', 'sparse'}
     assert all(v is not None and v > 0 for v in c['bwd_exchange_tuning_ms'].values())          # both exchanges ran
     for phase in ('pack+issue_gathers', 'local_block', 'S_allgather', 'hinge', 'bwd_start'):

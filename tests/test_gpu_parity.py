@@ -1955,7 +1955,11 @@ def test_sharded_sparse_exchange_compact_backward_emulated(W, mv):
     np.testing.assert_allclose(torch.cat(d_caps).cpu().numpy(), b.grad.cpu().numpy(), rtol=1e-5, atol=1e-6 * scale)
 
 
-def test_sharded_fast_path_under_rccl_world1():
+def test_sharded_fast_path_under_rccl_world1(bwd_mode):
+    """The fast sharded node on the real backend (one rank) under BOTH backward row steps: since round 6 the node carries the packed
+    rows' inverse norms (dense exchange) / packs its compact problem (pair-driven exchange), so the library's default fp16 row step
+    runs in it as in the single-GPU node -- same scores and loss bit for bit, gradients equal to the single-device step's and
+    within the mode's gate of the oracle's."""
     import os
     import torch.distributed as dist
     from aladin_amd import synth
@@ -1978,6 +1982,10 @@ def test_sharded_fast_path_under_rccl_world1():
         loss2.backward()
         assert torch.equal(S1, S2) and torch.equal(loss1.detach(), loss2.detach())
         assert torch.equal(a1.grad, a2.grad) and torch.equal(b1.grad, b2.grad)
+        _, dS = O.hinge_loss(S2.detach().cpu().numpy(), 0.2, True, return_grad=True)
+        dim, ds = O.alignment_scores_backward(im, s, il, sl, dS)
+        assert_grads_close(a1.grad, dim, bwd_mode)
+        assert_grads_close(b1.grad, ds, bwd_mode)
         # the pair-driven exchange (what world > 1 runs under max_violation), forced: RCCL all-to-all + compact backward
         a3, b3 = T(im).requires_grad_(True), T(s).requires_grad_(True)
         loss3, S3 = sharded_alignment_loss_fast(a3, b3, il, sl, 0.2, True, exchange='sparse')
@@ -1986,6 +1994,8 @@ def test_sharded_fast_path_under_rccl_world1():
         scale = float(a2.grad.abs().max())
         np.testing.assert_allclose(a3.grad.cpu().numpy(), a2.grad.cpu().numpy(), rtol=1e-5, atol=1e-6 * scale)
         np.testing.assert_allclose(b3.grad.cpu().numpy(), b2.grad.cpu().numpy(), rtol=1e-5, atol=1e-6 * scale)
+        assert_grads_close(a3.grad, dim, bwd_mode)
+        assert_grads_close(b3.grad, ds, bwd_mode)
         with pytest.raises(ValueError):
             sharded_alignment_loss_fast(T(im[:10]), T(s[:10]), il[:10], sl[:10])
     finally:
