@@ -9,6 +9,8 @@ an INJECTED VinVL/Oscar `backbone` (the BERT itself is out of scope), or any `en
 the reference's 7-tuple (img_glob (B,D), cap_glob (B,D), img_set (R,B,D), cap_seq (T,B,D), img_len,
 cap_len, reg_loss) can be passed.  (Random-init stand-ins for smoke tests live in tests/standins.py.)
 """
+import os
+
 import torch
 from torch import nn
 
@@ -17,8 +19,18 @@ from .loss import AlignmentContrastiveLoss, ContrastiveLoss, DistillationLoss, d
 
 
 class ALADModel(nn.Module):
-    def __init__(self, config, oscar_checkpoint=None, encoder=None, backbone=None, shard_group=False, backbone_autocast=None):
-        """shard_group: False = single device (the reference, alad/train.py:251-255); None or a torch.distributed group =
+    def __init__(self, config, oscar_checkpoint=None, encoder=None, backbone=None, shard_group=False, backbone_autocast=None,
+                 graphed=None):
+        """graphed: True = the loss heads of a TRAINING step (forward_loss + the weighted sum + their backward down to the encoder's
+        four outputs) are captured once per batch shape into a HIP graph and replayed (aladin_amd.graphs.GraphedLossStep) -- the
+        import swap of INTEGRATION.md section 2 then costs the replay (~0.07 - 0.1 ms at the shipped bs 32) instead of ~0.2 ms of
+        eager launches, with NO change to the train loop: same `(loss, loss_dict)`, `loss.backward()` continues into the encoder,
+        and `model.logger` is current whenever it is READ (the logged terms leave the device by one asynchronous copy per step;
+        reading `model.logger` -- what alad/train.py:436,447 do -- waits for the outstanding ones first).  None (default): the
+        environment variable ALADIN_GRAPH_HEADS (unset / "0" = off).  Evaluation (no_grad), sharded steps and configurations outside
+        the shipped ones (`_fused_heads_ok`) run eagerly as before.  The values of the returned loss_dict live in the graph's static
+        buffers: they are the current step's until the next step of the same batch shape runs (the reference's loop never keeps them).
+        shard_group: False = single device (the reference, alad/train.py:251-255); None or a torch.distributed group =
         one process per GPU, the loss heads run on the GLOBAL batch (all ranks' samples) with the score matrices sharded
         by caption block (aladin_amd.distributed.sharded_loss_heads; BASELINE configs[3] for the shipped YAMLs).
         encoder: any module with the 7-tuple contract of JointTextImageTransformerEncoder; or backbone: the
@@ -54,9 +66,26 @@ class ALADModel(nn.Module):
             margin=training['margin'], measure=training['measure'], max_violation=training['max-violation'])
         self.Eiters = 0
         self.config = config
-        self.logger = None
+        self._logger = None
         self.pending_log = None
         self.shard_group = shard_group
+        self.graphed = bool(os.environ.get('ALADIN_GRAPH_HEADS', '') not in ('', '0')) if graphed is None else bool(graphed)
+        self._graph_step = None
+        self._graph_bypass = False                                    # set by GraphedLossStep while IT runs forward_loss_total
+
+    @property
+    def logger(self):
+        """The callers' LogCollector (alad/train.py:413, alad/evaluation.py:109 swap it in).  With graphed heads the logged terms
+        of the last steps may still be on their way to the host: reading the logger delivers them first."""
+        if self._graph_step is not None:
+            self._graph_step.flush()
+        return self._logger
+
+    @logger.setter
+    def logger(self, value):
+        if self._graph_step is not None:
+            self._graph_step.flush()                                  # outstanding values belong to the logger that was current
+        self._logger = value
 
     def forward_emb(self, example_imgs, example_txts):
         """reference alad_model.py:325-348 (host->device copies + encoder call)."""
@@ -139,10 +168,10 @@ class ALADModel(nn.Module):
     def flush_log(self):
         """Push the loss terms of the last forward_loss(log=False) call to `self.logger` (one device->host copy)."""
         logged, self.pending_log = getattr(self, 'pending_log', None), None
-        if self.logger is not None and logged:
+        if self._logger is not None and logged:
             vals = torch.stack([torch.as_tensor(t).detach().reshape(()).to(torch.float32) for _, t, _ in logged]).tolist()
             for (key, _, n), v in zip(logged, vals):
-                self.logger.update(key, v, n)
+                self._logger.update(key, v, n)
 
     def weighted_total(self, loss_dict, epoch=0, distill_epoch=2):
         """reference alad_model.py:442-453: drop the distillation term before `distill_epoch` (when another term
@@ -169,6 +198,13 @@ class ALADModel(nn.Module):
                 and ('alignment' not in types and 'distillation' not in types or self.alignment_criterion.aggregation == 'MrSw')
                 and ('distillation' not in types or self.distillation_loss.mode == 'listnet'))
 
+    def _graph_heads_now(self, img_emb, cap_emb, img_emb_set, cap_emb_seq, log):
+        """graphed=True applies to a training step of a shipped configuration: gradients wanted, nothing being captured already."""
+        return (self.graphed and not self._graph_bypass and log and torch.is_grad_enabled() and img_emb.is_cuda
+                and any(t.requires_grad for t in (img_emb, cap_emb, img_emb_set, cap_emb_seq))
+                and 'regularizehidden' not in self.losses_types and self._fused_heads_ok(img_emb)
+                and not torch.cuda.is_current_stream_capturing())
+
     def forward_loss_total(self, img_emb, cap_emb, img_emb_set, cap_emb_seq, img_lengths, cap_lengths, reg_loss, epoch=0,
                            distill_epoch=2, log=True):
         """forward_loss + the weighted sum of forward (alad_model.py:371-428 + :442-453) -> (loss, loss_dict).
@@ -178,6 +214,11 @@ class ALADModel(nn.Module):
         if self.shard_group is not False:
             return self._sharded_loss_total(img_emb, cap_emb, img_emb_set, cap_emb_seq, img_lengths, cap_lengths, epoch,
                                             distill_epoch, log)
+        if self._graph_heads_now(img_emb, cap_emb, img_emb_set, cap_emb_seq, log):
+            if self._graph_step is None:
+                from .graphs import GraphedLossStep
+                self._graph_step = GraphedLossStep(self, log='deferred')
+            return self._graph_step(img_emb, cap_emb, img_emb_set, cap_emb_seq, img_lengths, cap_lengths, reg_loss, epoch, distill_epoch)
         if not self._fused_heads_ok(img_emb):
             d = self.forward_loss(img_emb, cap_emb, img_emb_set, cap_emb_seq, img_lengths, cap_lengths, reg_loss, log=log)
             return self.weighted_total(d, epoch, distill_epoch), d
@@ -228,8 +269,8 @@ class ALADModel(nn.Module):
     def forward(self, example_imgs, example_txts, epoch=0, distill_epoch=2):
         """reference alad_model.py:430-454."""
         self.Eiters += 1
-        if self.logger is not None:
-            self.logger.update('Eit', self.Eiters)
+        if self._logger is not None:
+            self._logger.update('Eit', self.Eiters)
         img_emb_aggr, cap_emb_aggr, img_feats, cap_feats, img_lengths, cap_lengths, regul_loss = \
             self.forward_emb(example_imgs, example_txts)
         return self.forward_loss_total(img_emb_aggr, cap_emb_aggr, img_feats, cap_feats, img_lengths, cap_lengths, regul_loss,

@@ -97,8 +97,12 @@ class GraphedLossStep:
         m = self.model
         for t in e.inputs:
             t.grad = None
-        loss, losses = m.forward_loss_total(e.inputs[0], e.inputs[1], e.inputs[2], e.inputs[3], e.lens[0], e.lens[1], 0,
-                                            0 if epoch_before_distill else 1, 1, log=False)
+        m._graph_bypass = True                               # ALADModel(graphed=True) routes its training steps HERE: not recursively
+        try:
+            loss, losses = m.forward_loss_total(e.inputs[0], e.inputs[1], e.inputs[2], e.inputs[3], e.lens[0], e.lens[1], 0,
+                                                0 if epoch_before_distill else 1, 1, log=False)
+        finally:
+            m._graph_bypass = False
         e.logged = m.pending_log
         loss.backward()
         return loss, losses
@@ -154,7 +158,8 @@ class GraphedLossStep:
         self._drain(True)
 
     def _log(self, e):
-        logger = self.model.logger
+        # (the model's own slot, not its `logger` property: reading THAT delivers the outstanding values, i.e. waits for the device)
+        logger = self.model.__dict__['_logger'] if '_logger' in self.model.__dict__ else self.model.logger
         if logger is None or e.log_buf is None:
             return
         k = self._log_k % len(self._log_slots)

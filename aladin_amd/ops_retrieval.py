@@ -52,7 +52,10 @@ def retrieval_ranks(img, cap, caps_per_img=5, exact=False, return_stats=False):
     The kernel screens with the hi.hi third of the split product and continues to the exact score only the pairs a
     rigorous per-pair bound leaves undecided (include/aladin_hip.h); exact=True forces the three-product path on
     every tile (same outputs).  return_stats=True appends {'exact_tiles', 'listed_pairs', 'rescored_pairs', 'skipped_tiles', 'tiles'}
-    (one D2H copy): tiles continued in place, pairs listed, listed pairs whose chains were continued, tiles that skipped the screen."""
+    (one D2H copy): tiles continued in place, pairs listed, listed pairs whose chains were continued, tiles that skipped the screen.
+    The four outputs are deterministic; these statistics (and the call's duration) are NOT -- a tile decides whether to skip its
+    analysis from what earlier tiles of the same launch have reported so far, which depends on scheduling.  Only
+    rescored_pairs <= listed_pairs and skipped_tiles <= exact_tiles <= tiles hold run to run."""
     _require_gpu(img, cap)
     if img.dim() != 2 or cap.dim() != 2 or img.shape[1] != cap.shape[1]:
         raise ValueError('aladin_amd: (n_img,D) and (n_cap,D) embeddings expected')

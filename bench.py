@@ -231,6 +231,29 @@ def cpu_baseline(live_b256=True):
     return out
 
 
+def _kernel_us(fn, name_substr, iters=5):
+    """Average device time (us) of the kernels whose name contains `name_substr` over `iters` calls of fn, from torch's kernel trace."""
+    import torch
+    if any(k.startswith(('ROCPROF', 'ROCP_')) for k in os.environ) or 'rocprof' in os.environ.get('LD_PRELOAD', ''):
+        return None                                          # bench.py itself is being profiled (tools/collect_pmc.sh): one tracer at a time
+    try:
+        from torch.profiler import ProfilerActivity, profile
+        fn()
+        torch.cuda.synchronize()
+        with profile(activities=[ProfilerActivity.CUDA]) as prof:
+            for _ in range(iters):
+                fn()
+            torch.cuda.synchronize()
+        tot, cnt = 0.0, 0
+        for e in prof.key_averages():
+            if name_substr in e.key:
+                tot += float(getattr(e, 'device_time_total', 0.0) or getattr(e, 'cuda_time_total', 0.0))
+                cnt += int(e.count)
+        return round(tot / cnt, 2) if cnt else None
+    except Exception:
+        return None
+
+
 def eval_config3(dev):
     """Secondary field: BASELINE configs[2] -- 5000 img x 25000 cap x 768 matching-head retrieval, scores + ranks
     of both directions in one fused pass (aladin_retrieval_ranks; the 500 MB matrix is never written).
@@ -279,7 +302,16 @@ def eval_config3(dev):
         a, b = synth_pair(sigma)
         by_data.append(measure('synth.retrieval_embeddings(sigma=%g)' % sigma, a, b))
     ms = head['ms']
-    return {'workload': 'configs[2]: 5000x25000x768 matching-head retrieval, fused scores + i2t/t2i ranks', 'ms': ms,
+    # roofline-style fields for this path: the whole call's algorithmic flops (2 * 5000 * 25000 * 768: ONE product
+    # per pair, what the reference's mm contracts) over the call's time against the 16-bit MFMA peak, and the screening GEMM kernel's
+    # own duration (torch's kernel trace over a few calls; None when a profiler is already attached to this process)
+    a8, b8 = synth_pair(8.0)
+    screen_us = _kernel_us(lambda: ops.retrieval_ranks(a8, b8), 'sim_screen_kernel')
+    del a8, b8
+    frac = round(2 * 5000 * 25000 * D / (ms * 1e-3) / 1e12 / PEAK_TFLOPS, 4)
+    return {'workload': 'configs[2]: 5000x25000x768 matching-head retrieval, fused scores + i2t/t2i ranks', 'ms': ms, 'frac': frac,
+            'screen_kernel_us': screen_us,
+            'screen_kernel_frac': None if not screen_us else round(2 * 5000 * 25000 * D / (screen_us * 1e-6) / 1e12 / PEAK_TFLOPS, 4),
             'data': head['data'], 'R@1_i2t': head['R@1_i2t'], 'R@1_t2i': head['R@1_t2i'],
             'all_exact_ms': round(ms_exact, 4), 'tiles': 20 * 66, 'exact_tiles': head['exact_tiles'], 'listed_pairs': head['listed_pairs'],
             'rescored_pairs': head['rescored_pairs'],

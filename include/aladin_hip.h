@@ -50,10 +50,8 @@ ALADIN_API const char* aladin_last_error(void);
  * scoring:  pack(images) -> [all-gather] -> scores  <- pack(captions).  The training step of one
  * GPU is ONE call per direction: aladin_align_triplet_fwd / _bwd below.
  *
- * ABI 11 (round 5): one entry point per operation, arguments grouped in three small structs.  The
- * generations that had accumulated (three geometry calls, pack_images / pack_captions / pack_both,
- * scores / scores_ex, align_bwd / _packed / _packed_strided / _packed_strided_ex, bwd_rows / _rows_ex)
- * are gone; nothing else changed meaning.
+ * One entry point per operation; the alignment family takes its arguments in three small structs
+ * (aladin_set, aladin_set_grad, aladin_packed).
  * ------------------------------------------------------------------------------------------- */
 
 /* A batch of sets (B, N, D) fp32 in HBM: element [b][n][d] at data[b * stride_b + n * stride_r + d] (strides in floats,
@@ -148,14 +146,14 @@ ALADIN_API int aladin_align_scores(const aladin_packed* packed, const aladin_ali
  * workspace: aladin_align_bwd_workspace_bytes(geom, flags).  Split operands are rejected (forward only).
  *   ALADIN_BWD_PARTNERS_FP16  step 3 gathers the PARTNER rows (the unit vectors an output row's gradient is a weighted sum of)
  *       from the forward's packed fp16 operands instead of normalising the raw fp32 rows again: half the bytes per partner, no norm
- *       reduction (bwd_rows 43.5 -> 34.0 us at B = 256, traffic past L2 302 -> 217 MB).  One fp16 rounding of those vectors leaves
- *       the gradients <= 4.3e-4 of their largest entry away from the reference's autograd on every reference fixture (the tests
- *       fail at 5e-4 = half of north_star's 1e-3; profiles/r05_bwd_precision_probe.txt) against 3e-7 without the flag.  Needs
- *       packed->xm, y, rnorm (and xe with side rows) of THIS problem.  The Python layer sets it by default since round 5
- *       (ops.set_backward_precision('exact') clears it).  The arg-maxima are the exact fp32 ones either way.
+ *       reduction.  One fp16 rounding of those vectors (<= 2^-11 relative per component) leaves the gradients within 5e-4 of their
+ *       LARGEST entry of the reference's autograd for D >= 128 (3e-7 without the flag; element by element the error reaches
+ *       ~3e-3 of an entry a tenth of the largest -- a max-normalised bound).  Needs packed->xm, y, rnorm
+ *       (and xe with side rows) of THIS problem.  The Python layer sets it by default (ops.set_backward_precision('exact') clears
+ *       it).  The arg-maxima are the exact fp32 ones either way.
  *   ALADIN_BWD_OWN_ROW_FP16  (with ALADIN_BWD_PARTNERS_FP16) the output row's OWN unit vector and inverse norm come from the packed
- *       operands and packed->rnorm too: the raw sets are not read by step 3 at all (30.4 us).  5.8e-4 on one D = 64 fixture whose
- *       cosines are near 1 (= the partners' figure wherever D >= 128): past the 5e-4 gate, hence an opt-in ('fp16-own').
+ *       operands and packed->rnorm too: the raw sets are not read by step 3 at all.  Up to ~7e-4 of the largest entry when the
+ *       partners are aligned with the row (cosines near 1): an opt-in ('fp16-own').
  *   ALADIN_BWD_DENSE  the caller states that (almost) every pair carries a gradient -- the sum-of-violations hinge
  *       (max_violation = False, alad/loss.py:60-67), or a gradient arriving on the score matrix itself.  The arg-max table of
  *       ALL pairs then comes from the forward's own tile kernel run in split precision (64 pairs per workgroup sharing their
@@ -179,7 +177,7 @@ ALADIN_API int aladin_align_bwd(const aladin_set* im, const aladin_set* s, const
 
 /* The training step of AlignmentContrastiveLoss(max_violation=True, aggregation='MrSw') -- every shipped YAML,
  * alad/loss.py:79-159 through alad/alad_model.py:386 -- as ONE call per direction, so that an eager drop-in module costs one
- * FFI crossing where rounds 1-4 made six (pack, scores, workspace queries, hinge, argmax, rows).
+ * FFI crossing per direction.
  *   fwd: pack both sets (-> packed, kept by the caller for the backward), side GEMM + score kernel (-> S, Bi x Bi), the
  *        hinge's row / column statistics, then ONE kernel whose workgroups either recompute a non-zero pair of dloss/dS --
  *        the pairs follow from the statistics: (q, q), (q, hardest caption of image q), (hardest image of caption q, q) --
@@ -421,11 +419,14 @@ ALADIN_API int aladin_topk(const float* M, int64_t q_stride, int64_t c_stride, i
  * bounds of all tiles rule out), a whole tile in place when it holds more.  Cost: a third of the three-product GEMM
  * when ground truths stand clear of the bulk of the scores, ~0.6 of it at Recall@1 75 / 41 %, all of it when they
  * sit deep inside; the result never depends on it.
- * aladin_retrieval_ranks_exact: every tile takes the three-product path (the round-3 kernel; for A/B
- * runs and tests).  aladin_retrieval_stats_offset: byte offset, inside the workspace of the last call,
- * of int32[9]: [0] tiles continued in place, [1] pairs listed, [5] listed pairs whose chains were continued,
- * [6] tiles that ran the analysis, [7] of those, tiles that overflowed their list, [8] tiles that skipped it
- * ([2..4]: diagnostic build only). */
+ * aladin_retrieval_ranks_exact: every tile takes the three-product path (for A/B runs and tests).
+ * aladin_retrieval_stats_offset: byte offset, inside the workspace of the last call, of int32[9]: [0] tiles continued in
+ * place, [1] pairs listed, [5] listed pairs whose chains were continued, [6] tiles that ran the analysis, [7] of those,
+ * tiles that overflowed their list, [8] tiles that skipped it ([2..4]: diagnostic build only).
+ * The four rank / arg-max OUTPUTS are deterministic.  The STATISTICS, and the time a call takes, are not: a tile decides
+ * whether to skip its analysis from what the tiles that finished before it have reported so far (relaxed loads of [6], [7]
+ * while other tiles of the same launch update them), so which tiles skip -- and with it [0], [1], [5], [8] -- depends on
+ * scheduling.  Callers may rely on [5] <= [1], [7] <= [6], [0] >= [8] and on nothing else. */
 ALADIN_API size_t aladin_retrieval_workspace_bytes(int n_img, int n_cap, int D);
 ALADIN_API size_t aladin_retrieval_stats_offset(int n_img, int n_cap, int D);
 ALADIN_API int aladin_retrieval_ranks(const float* img, int64_t img_row_stride, const float* cap, int64_t cap_row_stride, int n_img,

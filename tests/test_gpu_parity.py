@@ -2221,6 +2221,55 @@ def test_graphed_loss_step_equals_eager(eval_precision, loss_type, weights, log)
     assert len(step._cache) == 2                                     # one graph per (shape, distillation active)
 
 
+@pytest.mark.parametrize('loss_type,weights', [('alignment-distillation', [1, 1]), ('alignment-distillation-matching', [1, 1, 0.1])])
+def test_model_graphed_flag_is_a_drop_in(eval_precision, loss_type, weights):
+    """ALADModel(config, graphed=True) (or ALADIN_GRAPH_HEADS=1): the reference's train loop UNCHANGED -- `loss, loss_dict = model(imgs,
+    txts, epoch=...)`, `loss.backward()`, `str(model.logger)` (alad/train.py:413-447) -- gets the graph replay.  Loss, terms, logger
+    entries (current whenever `model.logger` is read), Eiters and the gradients reaching the encoder outputs equal the eager model's
+    bit for bit; a no_grad call (validation) runs eagerly."""
+    if eval_precision != 'fp16':
+        pytest.skip('training step; run once')
+    from aladin_amd import synth
+    from aladin_amd.alad_model import ALADModel
+    from aladin_amd.evaluation import LogCollector
+    config = {'training': {'loss-type': loss_type, 'loss-weights': weights, 'margin': 0.2, 'measure': 'dot',
+                           'max-violation': True, 'alignment-mode': 'MrSw', 'distillation-mode': 'listnet'}}
+    B, R, Tn, D = 32, 51, 38, 768
+    models = [ALADModel(config, graphed=False), ALADModel(config, graphed=True)]
+    assert models[1].graphed and not models[0].graphed
+    for m in models:
+        m.logger = LogCollector()
+    for seed, epoch in ((1, 5), (2, 5), (3, 0), (4, 5)):
+        im, s, il, sl = synth.structured_alignment_batch(B, R, Tn, D, seed=seed, noise=3.0, ragged=True)
+        ge, gc = synth.global_embeddings(B, D, seed=seed + 50, noise=1.0)
+        outs = []
+        for m in models:
+            t = [T(ge).requires_grad_(True), T(gc).requires_grad_(True), T(im.transpose(1, 0, 2).copy()).requires_grad_(True),
+                 T(s.transpose(1, 0, 2).copy()).requires_grad_(True)]
+            m.forward_emb = lambda a, b, _t=t: (_t[0], _t[1], _t[2], _t[3], il, sl, 0)
+            loss, d = m(None, None, epoch=epoch, distill_epoch=2)            # the reference's call (alad/train.py:416)
+            loss.backward()
+            outs.append((loss.detach().clone(), {k: v.detach().clone() for k, v in d.items()}, [None if x.grad is None else x.grad.clone() for x in t],
+                         {k: (mm.val, mm.count) for k, mm in m.logger.meters.items()}, str(m.logger)))
+        (l0, d0, g0, log0, s0), (l1, d1, g1, log1, s1) = outs
+        assert torch.equal(l0, l1) and list(d0) == list(d1) and log0 == log1 and s0 == s1 and 'Eit' in log1
+        assert all(torch.equal(d0[k], d1[k]) for k in d0)
+        for a, b in zip(g0, g1):
+            if a is None or b is None:
+                assert (a is None or float(a.abs().max()) == 0.0) and (b is None or float(b.abs().max()) == 0.0)
+            else:
+                assert torch.equal(a, b)
+    assert models[1]._graph_step is not None and len(models[1]._graph_step._cache) == 2 and models[0]._graph_step is None
+    # validation: no gradients wanted -> the eager path (nothing to capture), same numbers
+    with torch.no_grad():
+        t = [T(ge), T(gc), T(im.transpose(1, 0, 2).copy()), T(s.transpose(1, 0, 2).copy())]
+        vals = []
+        for m in models:
+            m.forward_emb = lambda a, b, _t=t: (_t[0], _t[1], _t[2], _t[3], il, sl, 0)
+            vals.append(m(None, None, epoch=5)[0])
+        assert torch.equal(vals[0], vals[1]) and len(models[1]._graph_step._cache) == 2
+
+
 def test_graphed_loss_step_runs_ahead_safely(eval_precision):
     """With no logger nothing makes the host wait: many steps of the same shape with DIFFERENT lengths are issued back to
     back (the pinned length buffers rotate behind events), every loss must be its own batch's eager loss; and a

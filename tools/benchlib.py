@@ -86,11 +86,34 @@ def loss_heads_bs32(dev, R=51, Tn=38, B=32):
     def replay_only():
         next(iter(gstep._cache.values())).graph.replay()
 
+    # the import swap with NO change to the train loop (round 6): ALADModel(config, graphed=True) called as alad/train.py:416 calls it;
+    # `model_flag_logged_ms` additionally reads model.logger every step, as the reference's loop does for TensorBoard (:447)
+    from aladin_amd.evaluation import LogCollector
+    model_g = ALADModel(model.config, graphed=True)
+    model_g.logger = LogCollector()
+    model_g.forward_emb = lambda p, q: (x, y, a_s, b_s, il, sl, 0)
+    model_e = ALADModel(model.config, graphed=False)
+    model_e.logger = LogCollector()
+    model_e.forward_emb = model_g.forward_emb
+
+    def via_model(m, read_logger):
+        def run():
+            for t in (a_s, b_s, x, y):
+                t.grad = None
+            loss, _ = m(None, None, epoch=5, distill_epoch=2)
+            loss.backward(gradient=seed)
+            if read_logger:
+                str(m.logger)
+        return run
+
     graphed()
     out = {'workload': 'loss heads of alad-alignment-and-matching-distill.yaml at bs %d, R=%d, T=%d (50 regions + 35 tokens), D=768, '
                        'ragged lengths: matching + alignment hinge + listnet, forward + backward; wall clock per step' % (B, R, Tn),
            'eager_ms': round(_wall_ms(eager, 100), 4), 'graphed_step_ms': round(_wall_ms(graphed, 300), 4),
-           'graph_replay_only_ms': round(_wall_ms(replay_only, 500), 4)}
+           'graph_replay_only_ms': round(_wall_ms(replay_only, 500), 4),
+           'model_eager_ms': round(_wall_ms(via_model(model_e, False), 100), 4),
+           'model_flag_ms': round(_wall_ms(via_model(model_g, False), 300), 4),
+           'model_flag_logged_ms': round(_wall_ms(via_model(model_g, True), 300), 4)}
     gstep.flush()
     return out
 
