@@ -219,8 +219,10 @@ def cpu_baseline(live_b256=True):
             pass
     # SURVEY 8(d) judges the >= 10x target against the faithful dataflow AT B = 256: that is the headline `value` when it was
     # measured (live, or the committed one-off); the B = 16 sweep (BASELINE configs[0]) stays beside it as `b16`
+    # ... but ONLY when it was measured live on THIS host: the committed file is a round-2 box's number -- it stays in the
+    # line under `b256` with its `source`, and the live B = 16 sweep remains the headline
     b = out.get('b256')
-    if b and b.get('pairs_per_s_fwd_bwd'):
+    if b and b.get('pairs_per_s_fwd_bwd') and b.get('source') == 'live':
         out['b16'] = {'value': out['value'], 'cores': out['cores'], 'fwd_only_value': out.pop('fwd_only_value'), 'sample': out['sample'],
                       'sweep_ms': out.pop('sweep_ms')}
         out['value'] = b['pairs_per_s_fwd_bwd']
@@ -357,6 +359,27 @@ def shipped_shape_step(dev):
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / 100
+    # the same step replayed as a HIP graph -- the launch mode the headline step is timed in when the short trial favours it (the eager
+    # number above stays the field's `ms_per_step`: it is what rounds 3-5 reported)
+    graph_ms = None
+    try:
+        a.grad = None
+        b.grad = None
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            crit(a, b, il, sl).backward(gradient=seed)
+        for _ in range(20):
+            g.replay()
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(200):
+            g.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        graph_ms = round(e0.elapsed_time(e1) / 200, 4)
+        del g
+    except Exception:
+        pass
     # the shape's score kernel alone (align_scores16_r48, 192 x 320 tile; the side GEMM's result reused), event-timed like the
     # headline's: ALGORITHMIC flops (50 regions x 35 words per pair, not the 48 + 2 side rows x 40 columns the tiles hold)
     from aladin_amd import ops
@@ -376,7 +399,7 @@ def shipped_shape_step(dev):
     k_us = e0.elapsed_time(e1) / 200 * 1e3
     k_flops = 2 * 50 * 35 * D * B * B
     return {'workload': 'triplet loss forward+backward at B=256, R=51, T=38, D=768 (50 regions + 35 tokens), eager launches',
-            'ms_per_step': round(ms, 4), 'pairs_per_s': round(B * B / (ms * 1e-3), 1),
+            'ms_per_step': round(ms, 4), 'graph_ms_per_step': graph_ms, 'pairs_per_s': round(B * B / (ms * 1e-3), 1),
             'flops_per_pair': 2 * 50 * 35 * D, 'tflops_algorithmic_fwd_equiv': round(2 * 50 * 35 * D * B * B / (ms * 1e-3) / 1e12, 1),
             'score_kernel': 'align_scores16_r48_kernel (48-row region class + 2 side rows, 40-word caption class)',
             'score_kernel_us': round(k_us, 2), 'score_kernel_frac': round(k_flops / (k_us * 1e-6) / 1e12 / PEAK_TFLOPS, 4)}
