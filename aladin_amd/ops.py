@@ -155,14 +155,26 @@ def scores_from_packed(xm, xe, y, geom, out=None, e_scratch=None, reuse_side=Fal
     return S
 
 
+def _pad_features(im_set, s_seq):
+    """The backward kernels move rows as 16-byte float4 columns (D % 4 == 0).  The reference has no such limit: a set whose
+    feature size is not a multiple of 4 is padded with zero features here, OUTSIDE the autograd nodes -- zeros change neither
+    a norm nor a dot product, and autograd's own backward of the padding drops the extra gradient columns.  One copy of each set,
+    paid by odd feature sizes only (every shipped configuration has D = 768)."""
+    D = im_set.shape[-1]
+    if D % 4 == 0 or im_set.dim() != 3 or s_seq.dim() != 3 or s_seq.shape[-1] != D:
+        return im_set, s_seq
+    pad = 4 - D % 4
+    return torch.nn.functional.pad(im_set, (0, pad)), torch.nn.functional.pad(s_seq, (0, pad))
+
+
 def _check_backward_supported(im, s, x_tail, y_tail):
     """The limits of aladin_align_bwd (align_bwd.hip), checked when the FORWARD of a differentiable score
     matrix is requested, so that an unsupported shape fails here and not inside loss.backward()."""
     Bi, R, D = im.shape
     Bc, T, _ = s.shape
     if D % 4 != 0 or D > 1024:
-        raise ValueError('aladin_amd: differentiable alignment scores need D %% 4 == 0 and D <= 1024 (got D=%d); '
-                         'score under torch.no_grad() or pad the feature axis' % D)
+        raise ValueError('aladin_amd: differentiable alignment scores need D <= 1024 (got D=%d; the public entry points pad a '
+                         'feature size that is not a multiple of 4); score under torch.no_grad()' % D)
     if R - 1 - x_tail > 96 or T - 1 - y_tail > 96:          # = the packed geometry's own limits (aladin_align_geometry)
         raise ValueError('aladin_amd: alignment scores support at most 96 scored positions per set '
                          '(got %d on the max side, %d on the sum side)' % (R - 1 - x_tail, T - 1 - y_tail))
@@ -498,6 +510,8 @@ def alignment_triplet_loss(im_set, s_seq, im_len, s_len, margin, max_violation):
     if im_set.shape[0] != s_seq.shape[0]:
         raise ValueError('aladin_amd: the contrastive loss needs a square score matrix, got (%d, %d) '
                          '(the reference fails in diag/expand_as, alad/loss.py:43-45)' % (im_set.shape[0], s_seq.shape[0]))
+    if torch.is_grad_enabled() and (im_set.requires_grad or s_seq.requires_grad):
+        im_set, s_seq = _pad_features(im_set, s_seq)
     _FILL_HINT[0] = None if max_violation else _caption_fill(s_len, s_seq.shape[1])
     return _AlignTriplet.apply(im_set, s_seq, im_len_t, s_len_t, margin, max_violation)
 
@@ -710,6 +724,7 @@ def alignment_scores(im_set, s_seq, im_len, s_len, aggregation='MrSw', precision
     if precision not in (None, 'fp16'):
         raise ValueError('aladin_amd: differentiable alignment scores use fp16 operands (split precision is forward-only)')
     im_len_t, s_len_t = _check_sets(im_set, s_seq, im_len, s_len)
+    im_set, s_seq = _pad_features(im_set, s_seq)
     if aggregation == 'MrSw':
         return _AlignScores.apply(im_set, s_seq, im_len_t, s_len_t, 0, 2)
     if aggregation == 'MwSr':

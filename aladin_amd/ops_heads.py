@@ -278,6 +278,9 @@ def small_batch_loss_heads(img_emb, cap_emb, im_set, s_seq, im_len, s_len, margi
         im_len_t, s_len_t = _check_sets(im_set, s_seq, im_len, s_len)
         if not (im_set.shape[0] == s_seq.shape[0] == img_emb.shape[0]):
             raise ValueError('aladin_amd: the loss heads need one image set, one caption and one embedding pair per sample')
+        if torch.is_grad_enabled() and (im_set.requires_grad or s_seq.requires_grad):
+            from .ops import _pad_features
+            im_set, s_seq = _pad_features(im_set, s_seq)          # D % 4 != 0: zero features, dropped again by autograd
     w = (float(weights.get('matching', 0.0)), float(weights.get('alignment', 0.0)), float(weights.get('distillation', 0.0)))
     node = _SmallHeads if img_emb.shape[0] <= SMALL_BATCH_MAX else _BigHeads
     _FILL_HINT[0] = _caption_fill(s_len, s_seq.shape[1]) if (node is _BigHeads and not max_violation and flags & HEAD_ALIGN_HINGE) else None

@@ -364,11 +364,11 @@ def test_b256_structured_triplet_step_default_backward(fp16_partners, eval_preci
 
 
 def test_backward_limits_are_reported_at_forward_time():
-    """Shapes the backward kernels do not take (D % 4 != 0, D > 1024) fail when the differentiable forward is
-    requested -- not later inside loss.backward() -- and still score fine without autograd."""
+    """The one shape limit of the differentiable path (D > 1024) fails when the differentiable forward is requested -- not later
+    inside loss.backward() -- and still scores fine without autograd."""
     from aladin_amd import ops, synth
     from aladin_amd.loss import AlignmentContrastiveLoss
-    for D in (30, 1028):
+    for D in (1028, 1030):
         im, s, il, sl = synth.alignment_batch(4, 10, 12, D, seed=3, ragged=True)
         a, b = T(im).requires_grad_(True), T(s).requires_grad_(True)
         with pytest.raises(ValueError, match='differentiable'):
@@ -378,6 +378,33 @@ def test_backward_limits_are_reported_at_forward_time():
         with torch.no_grad():
             S = ops.alignment_scores(a, b, il, sl, precision='fp16')
         assert_scores_close(S.cpu().numpy(), O.alignment_scores(im, s, il, sl))
+
+
+@pytest.mark.parametrize('D', [30, 65, 127])
+def test_feature_sizes_that_are_not_multiples_of_four(D, bwd_mode):
+    """The reference takes any feature size; the backward kernels move float4 columns.  The public entry points pad such sets with
+    zero features outside their autograd nodes (ops._pad_features): scores, loss and gradients -- in the callers' own D -- against
+    the oracle, through the score node, the fused triplet node and the loss heads."""
+    from aladin_amd import ops, synth
+    from aladin_amd.loss import AlignmentContrastiveLoss
+    im, s, il, sl = synth.structured_alignment_batch(9, 20, 18, D, seed=40 + D, noise=3.0, ragged=True)
+    a, b = T(im).requires_grad_(True), T(s).requires_grad_(True)
+    S = ops.alignment_scores(a, b, il, sl)
+    assert_scores_close(S.detach().cpu().numpy(), O.alignment_scores(im, s, il, sl))
+    w = synth.normal(S.shape, 77).astype(np.float32)
+    (S * T(w)).sum().backward()
+    dim, ds = O.alignment_scores_backward(im, s, il, sl, w.astype(np.float64))
+    assert a.grad.shape == a.shape and b.grad.shape == b.shape
+    assert_grads_close(a.grad, dim, bwd_mode, exact_atol=5e-5)
+    assert_grads_close(b.grad, ds, bwd_mode, exact_atol=5e-5)
+    a2, b2 = T(im).requires_grad_(True), T(s).requires_grad_(True)
+    loss, S2 = AlignmentContrastiveLoss(0.2, 'dot', True, 'MrSw')(a2, b2, il, sl, return_similarity_mat=True)
+    loss.backward()
+    ref_loss, dS = O.hinge_loss(S2.detach().cpu().numpy(), 0.2, True, return_grad=True)
+    np.testing.assert_allclose(loss.item(), ref_loss, rtol=1e-5, atol=1e-6)
+    dim, ds = O.alignment_scores_backward(im, s, il, sl, dS)
+    assert_grads_close(a2.grad, dim, bwd_mode, exact_atol=5e-5)
+    assert_grads_close(b2.grad, ds, bwd_mode, exact_atol=5e-5)
 
 
 def test_alignment_scores_permuted_view_input():
