@@ -451,3 +451,90 @@ def test_fast_sharded_step_gloo(case):
             if want_sparse:
                 assert ret[empty_rank][exchange][6] == 0                                 # ... and its rank took the empty-need branch
             assert not np.any(ret[empty_rank][exchange][4])                              # no gradient on its captions
+
+
+# ------------------------------------------------------------------------------------------------
+# The loss heads of the shipped distillation YAMLs on the GLOBAL batch THROUGH THE FAST NODE (what ALADModel(shard_group=...) runs:
+# sharded_loss_heads with its default align_fn = sharded_alignment_loss_fast), world 4 -- where exchange='auto' takes the pair-driven
+# exchange -- at the shipped data shape.  HIP entry points of the alignment node: the CPU stand-ins; the (B, B)-matrix heads: torch.
+# ------------------------------------------------------------------------------------------------
+def _fast_heads_worker(rank, world, port, ret):
+    for p in (ROOT, os.path.join(ROOT, 'oracle'), os.path.join(ROOT, 'tests', 'helpers')):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as dist
+    import cpu_standins
+    import faithful_torch as FT
+    from aladin_amd.distributed import sharded_loss_heads
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    cpu_standins.install()
+    B, R, T, D = 32, 51, 38, 16
+    im, s, il, sl, ie, ce = _heads_inputs(world, B, R, T, D)
+    sl_ = slice(rank * B, (rank + 1) * B)
+    out = []
+    for heads, w in HEADS_CASES:
+        leaves = [torch.from_numpy(x[sl_].copy()).requires_grad_(True) for x in (ie, ce, im, s)]
+        total, terms, S_full, M_full = sharded_loss_heads(
+            leaves[0], leaves[1], leaves[2], leaves[3], il[sl_], sl[sl_], 0.2, True, heads, w,
+            dot_fn=lambda a, b: a @ b.t(), hinge_fn=FT.hinge_faithful, listnet_fn=_torch_listnet)
+        total.backward()
+        out.append((total.item(), {k: v.item() for k, v in terms.items()}, None if S_full is None or rank else S_full.numpy(),
+                    [None if t.grad is None else t.grad.numpy() for t in leaves], cpu_standins.CALLS.get('pack_sets', 0)))
+    ret[rank] = out
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_sharded_loss_heads_through_the_fast_node_world4():
+    for p in (os.path.join(ROOT, 'oracle'), os.path.join(ROOT, 'tests', 'helpers')):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import alad_oracle as O
+    import cpu_standins
+    import faithful_torch as FT
+    world, B, R, T, D = 4, 32, 51, 38, 16
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 37500 + (os.getpid() % 2000)
+    mp.spawn(_fast_heads_worker, args=(world, port, ret), nprocs=world, join=True)
+    im, s, il, sl, ie, ce = _heads_inputs(world, B, R, T, D)
+    S_ref = O.alignment_scores(im, s, il, sl)
+
+    def align_fn(a, b, al, bl):
+        # the single-process composition of the same stand-ins: fp16-rounded packed operands, exact backward
+        loss, S, d_a, d_b = cpu_standins.single_process_step(a.detach(), b.detach(), al, bl, 0.2, True)
+
+        class _Node(torch.autograd.Function):
+            @staticmethod
+            def forward(ctx, x, y):
+                return loss.clone()
+
+            @staticmethod
+            def backward(ctx, g):
+                return d_a * g, d_b * g
+        return _Node.apply(a, b), S
+    for case, (heads, w) in enumerate(HEADS_CASES):
+        leaves = [torch.from_numpy(x.copy()).requires_grad_(True) for x in (ie, ce, im, s)]
+        total, terms = _heads_total(leaves[0], leaves[1], leaves[2], leaves[3], il, sl, heads, w, align_fn)
+        total.backward()
+        for r in range(world):
+            tot_r, terms_r, S_r, grads_r, n_pack_sets = ret[r][case]
+            np.testing.assert_allclose(tot_r, total.item(), rtol=2e-5)
+            assert list(terms_r) == [k for k in ('matching', 'alignment', 'distillation') if k in heads]
+            for k in heads:
+                np.testing.assert_allclose(terms_r[k], terms[k].item(), rtol=2e-5)
+            if S_r is not None:
+                np.testing.assert_allclose(S_r, S_ref, rtol=1e-3, atol=3e-4 * np.abs(S_ref).max())
+            for got, leaf in zip(grads_r, leaves):
+                if leaf.grad is None:
+                    assert got is None or not np.any(got)
+                    continue
+                want = leaf.grad.numpy()[r * B:(r + 1) * B]
+                assert got is not None
+                np.testing.assert_allclose(got, want, rtol=2e-4, atol=2e-6 * max(1e-9, float(np.abs(want).max())) + 1e-9)
+        if 'alignment' in heads and w['alignment'] != 0:
+            assert ret[0][case][4] >= 1                    # world 4: the pair-driven exchange ran (it packs its compact problem)
