@@ -63,10 +63,22 @@ def main():
         im_need, il_need = im_all.index_select(0, need), il_all.index_select(0, need)
         dS_need = dS_full.index_select(0, need)[:, :B].contiguous()
         t_sparse = timed(lambda: ops._align_backward(im_need, caps[0], il_need, slt, dS_need))
+        # round 6: the pair-driven exchange packs its compact problem (one launch) so that the pair kernel runs on the fp16 MFMA and the
+        # row step can take its partner rows from the packed operands (ops.set_backward_precision)
+        g_need = ops.align_geometry(im_need.shape[0], B, R, T, D)
+
+        def compact_packed():
+            packed = ops.pack_sets(im_need, caps[0], il_need, slt, g_need)
+            return ops._align_backward(im_need, caps[0], il_need, slt, dS_need, packed=packed)
+        t_sparse_packed = {}
+        for mode in ('exact', 'fp16'):
+            old = ops.set_backward_precision(mode)
+            t_sparse_packed[mode] = round(timed(compact_packed), 3)
+            ops.set_backward_precision(old)
         print(json.dumps({'W': W, 'pack_ms': round(t_pack, 3), 'scores_block_ms': round(t_scores, 3), 'pack_captions_ms': round(t_packc, 4),
                           'side_plus_score_ms': round(t_side_score, 4), 'score_kernel_ms': round(t_score_only, 4),
                           'score_kernel_us_per_256x256_block': round(t_score_only * 1e3 / W, 2), 'hinge_ms': round(t_hinge, 3),
-                          'bwd_dense_ms': round(t_dense, 3), 'bwd_compact_ms': round(t_sparse, 3), 'images_needed': int(need.numel()),
+                          'bwd_dense_ms': round(t_dense, 3), 'bwd_compact_ms': round(t_sparse, 3), 'bwd_compact_packed_ms': t_sparse_packed, 'images_needed': int(need.numel()),
                           'of': W * B, 'dense_exchange_MB': round(2 * W * B * R * D * 4 / 2 ** 20, 1),
                           'sparse_exchange_MB': round(2 * int(need.numel()) * R * D * 4 / 2 ** 20 * (W - 1) / W, 1)}), flush=True)
 
