@@ -388,6 +388,18 @@ class FlatSegments:
             segs[:, self.o_xe:self.o_xe + self.xe_b].contiguous().view(-1).view(torch.float16)
 
 
+def place_image_rnorms(rn_glob, rn_ranks, n_m, n_e):
+    """The gathered ranks' inverse norms -> the global layout the backward reads.  rn_ranks: (W, n_m + n_e) fp32, rank w's packed image
+    rows [its xm rows | its xe rows] (what aladin_align_pack wrote for the LOCAL geometry); rn_glob: the GLOBAL geometry's buffer
+    [all ranks' xm rows | all ranks' xe rows | y rows] whose y part the caption packer fills.  A pure function of its arguments so that
+    one GPU can check it against the single-device layout (tests/test_gpu_parity.py: the emulated ranks)."""
+    W = rn_ranks.shape[0]
+    rn_glob[:W * n_m].view(W, n_m).copy_(rn_ranks[:, :n_m])
+    if n_e:
+        rn_glob[W * n_m:W * (n_m + n_e)].view(W, n_e).copy_(rn_ranks[:, n_m:n_m + n_e])
+    return rn_glob
+
+
 class _ShardedTriplet(torch.autograd.Function):
     @staticmethod
     def forward(ctx, im, s, im_len_t, s_len_t, margin, max_violation, group, exchange='auto'):
@@ -471,10 +483,7 @@ class _ShardedTriplet(torch.autograd.Function):
             xm_all, xe_all = fs.contiguous_operands(flat_all) if W > 1 else (xm, xe)
             if rn_glob is not None:
                 if W > 1:
-                    rn_all = fs.rnorms(flat_all)
-                    rn_glob[:W * n_m].view(W, n_m).copy_(rn_all[:, :n_m])
-                    if n_e:
-                        rn_glob[W * n_m:W * (n_m + n_e)].view(W, n_e).copy_(rn_all[:, n_m:])
+                    place_image_rnorms(rn_glob, fs.rnorms(flat_all), n_m, n_e)
                 ctx.save_for_backward(im_all, il_all, s, s_len_t, dS_full, xm_all, xe_all, y, rn_glob)
             else:
                 ctx.save_for_backward(im_all, il_all, s, s_len_t, dS_full, xm_all, xe_all, y)

@@ -1869,6 +1869,35 @@ def test_sharded_fast_path_rank_logic_emulated_world3(R, Tn):
     assert torch.equal(S_full, ref_S) and torch.equal(loss, ref_loss.detach())
     np.testing.assert_allclose(d_im_all.cpu().numpy(), a.grad.cpu().numpy(), rtol=1e-5, atol=1e-8)
     np.testing.assert_allclose(torch.cat(d_caps).cpu().numpy(), b.grad.cpu().numpy(), rtol=1e-5, atol=1e-8)
+    # Round 6: the DEFAULT row step in the sharded node -- every rank packs its images with their inverse norms ([its xm rows | its xe
+    # rows], local geometry), the node lays the gathered norms out for the global geometry (distributed.place_image_rnorms) and the
+    # caption packer adds the y part.  With three emulated ranks: the assembled buffer must be, bit for bit, what ONE pack of the
+    # concatenated batch writes, and the rank contributions under 'fp16' must sum to the single-device step's fp16 gradients.
+    n_m, n_e = int(g_loc.xm_rows), int(g_loc.xe_rows)
+    rn_ranks = torch.empty((W, n_m + n_e), dtype=torch.float32, device=d)
+    for r in range(W):
+        ops.pack_images(ims[r], ilt[r], g_loc, rnorm=rn_ranks[r])
+    old = ops.set_backward_precision('fp16')
+    try:
+        d_im16 = torch.zeros_like(im_all)
+        d_caps16 = []
+        for r in range(W):
+            rn_glob = torch.empty(int(g_glob.rnorm_bytes) // 4, dtype=torch.float32, device=d)
+            y_r = ops.pack_captions(caps[r], slt[r], g_glob, rnorm=rn_glob)
+            DD.place_image_rnorms(rn_glob, rn_ranks, n_m, n_e)
+            whole = ops.pack_sets(im_all, caps[r], il_all, slt[r], g_glob)             # (geom, xm, xe, y, rnorm) of the concatenated images
+            assert torch.equal(rn_glob, whole[4]) and torch.equal(y_r, whole[3]) and torch.equal(xm_all, whole[1])
+            gi, gs = DD.rank_backward_block(im_all, il_all, caps[r], slt[r], dS_full, r, g_glob, xm_all, xe_all, y_r, rnorm=rn_glob)
+            d_im16 += gi
+            d_caps16.append(gs)
+        a16, b16 = T(im).requires_grad_(True), T(s).requires_grad_(True)
+        AlignmentContrastiveLoss(0.2, 'dot', True, 'MrSw')(a16, b16, il, sl).backward()
+        assert not torch.equal(a16.grad, a.grad)                                        # the fp16 row step really is another arithmetic
+        scale = float(a16.grad.abs().max())
+        np.testing.assert_allclose(d_im16.cpu().numpy(), a16.grad.cpu().numpy(), rtol=1e-5, atol=1e-6 * scale)
+        np.testing.assert_allclose(torch.cat(d_caps16).cpu().numpy(), b16.grad.cpu().numpy(), rtol=1e-5, atol=1e-6 * scale)
+    finally:
+        ops.set_backward_precision(old)
 
 
 def test_config3_per_rank_block_and_eight_emulated_ranks(eval_precision):
