@@ -587,8 +587,9 @@ __global__ __launch_bounds__(512) void sim_screen_kernel(const half_t* __restric
                   "the analysis arrays share one operand stage");
     // Hopeless data (ground truths deep in the bulk: every column of every tile nominates candidates and the lists overflow):
     // the analysis would be paid for nothing.  Tiles count themselves as analysed / overflowed; once at least 32 have
-    // reported and 7 of 8 overflowed, a tile goes straight on to the exact path -- except the tiles of every fourth ROUND of 256
-    // (by dispatch index), which keep probing (data may differ between regions of the grid).  Probing by round, not by tile:
+    // reported and 7 of 8 overflowed, a tile goes straight on to the exact path -- except the tiles of every EIGHTH round of 256
+    // (by dispatch index), which keep probing (data may differ between regions of the grid; every fourth round until round 6:
+    // at configs[2]'s six rounds that was a second analysed round for nothing, 0.717 vs 0.687 ms on hopeless data).  Probing by round, not by tile:
     // the workgroups of a round run in lockstep and share their operand panels through the L2 while they do; one tile in eight
     // taking longer than its neighbours (this round's first form) put every tile out of phase: 700 vs 580 us all-exact with
     // ground truths 2 sigma inside the bulk.  (A sample launch of 256 tiles followed by a launch-uniform decision for the rest
@@ -596,7 +597,7 @@ __global__ __launch_bounds__(512) void sim_screen_kernel(const half_t* __restric
     if (tid == 0) {
       const int n_an = __hip_atomic_load(&ra.stats[SIM_ST_ANALYSED], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       const int n_ov = __hip_atomic_load(&ra.stats[SIM_ST_OVERFLOW], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      *l_listn = (n_an >= 32 && 8 * n_ov >= 7 * n_an && ((blockIdx.x >> 8) & 3) != 0) ? -1 : 0;
+      *l_listn = (n_an >= 32 && 8 * n_ov >= 7 * n_an && ((blockIdx.x >> 8) & 7) != 0) ? -1 : 0;
       if constexpr (MODE == 2) *l_listn = -1;            // (diagnostic build) timing probe: every tile skips the analysis
     }
     // the tile's largest band factors bound every pair's band from above: the cheap test of phase 1
