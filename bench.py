@@ -269,10 +269,16 @@ def eval_config3(dev):
     import torch
     from aladin_amd import ops, synth
 
-    def ev_ms(fn, iters=10, warm=3):
+    def ev_ms(fn, iters=10, warm=3, preroll_s=0.3):
+        # clock-settling pre-roll, as for the headline step: each data set is generated on the HOST for seconds while the GPU idles and
+        # drops its clock; three warm-up calls (~1 ms) do not bring it back (a clean-input run once read 0.39 ms instead of 0.28)
         for _ in range(warm):
             fn()
-        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < preroll_s:
+            for _ in range(10):
+                fn()
+            torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(iters):
