@@ -315,6 +315,12 @@ class SparseImageExchange:
         return self._need_idx
 
     def _all_to_all(self, send, out_splits, in_splits):
+        if send.is_cuda and dist.get_backend(self.group) == 'gloo':
+            # gloo has no device all-to-all: stage through the host.  (Only the one-GPU test of the real node across processes gets
+            # here -- tests/helpers/gpu_shard_worker.py; the 8-GPU run is RCCL.)
+            out = torch.empty((sum(out_splits),) + tuple(send.shape[1:]), dtype=send.dtype)
+            dist.all_to_all_single(out, send.contiguous().cpu(), output_split_sizes=out_splits, input_split_sizes=in_splits, group=self.group)
+            return out.to(send.device)
         out = torch.empty((sum(out_splits),) + tuple(send.shape[1:]), dtype=send.dtype, device=send.device)
         dist.all_to_all_single(out, send.contiguous(), output_split_sizes=out_splits, input_split_sizes=in_splits,
                                group=self.group)

@@ -53,6 +53,11 @@ def parse():
                     help='CPU self-test of the REAL multi-rank step loop (tests/test_launch_cpu.py): gloo, the fast sharded node of '
                          'aladin_amd/distributed.py with the HIP entry points replaced by tests/helpers/cpu_standins.py, at a reduced shape '
                          '(B=64/rank, D=16) -- exchange tuning, PhaseRecorder, watchdog and the JSON line as on the GPUs; no performance claim')
+    ap.add_argument('--shared-gpu', action='store_true',
+                    help='GPU self-test of the multi-rank step with the REAL kernels on a one-GPU box (tests/test_bench_gpu.py): every rank uses '
+                         'cuda:0 and the collectives go through gloo (RCCL refuses two ranks per device), B=64/rank -- the real step loop, both '
+                         'backward exchanges, PhaseRecorder, watchdog, JSON line; the ranks contend for one GPU, so no performance claim')
+    ap.add_argument('--selftest-batch', type=int, default=64, help='per-rank batch of --shared-gpu (a multiple of 64; 256 = configs[3]\'s own size)')
     ap.add_argument('--eager', action='store_true', help='do not capture the step in a HIP graph')
     ap.add_argument('--graph', action='store_true', help='always replay the captured HIP graph (default: the faster of graph / eager in a short trial)')
     ap.add_argument('--force-sharded', action='store_true',
@@ -527,7 +532,8 @@ def main():
                          % (args.gpus, rank, world))
     if args.stub_step:
         return stub_main(args, world, rank)
-    standin = args.cpu_standin
+    standin, shared = args.cpu_standin, args.shared_gpu and not args.cpu_standin
+    selftest = standin or shared                            # reduced protocol, labelled line, value 0: never a measurement
     if standin:
         # the real step loop below on CPU tensors under gloo, the HIP entry points replaced by torch restatements that keep the packed
         # layout (tests/helpers/cpu_standins.py; nothing under oracle/): a protocol and bookkeeping self-test of the multi-GPU path at a
@@ -540,16 +546,22 @@ def main():
     else:
         if not torch.cuda.is_available():
             raise SystemExit('bench.py needs an MI355X (no GPU visible); there is no CPU fallback')
+        if shared:
+            # all ranks on cuda:0 (separate processes, separate HIP contexts), gloo for the exchange: the real kernels inside the real
+            # node at W > 1 on the one-GPU boxes this build has ever had
+            B = int(args.selftest_batch)
+            local_rank = 0
+            args.preroll_s, args.steps, args.warmup, args.repeats = 0.0, min(args.steps, 5), min(args.warmup, 2), min(args.repeats, 2)
         torch.cuda.set_device(local_rank)
         dev = torch.device('cuda', local_rank)
         sync = torch.cuda.synchronize
-    sharded = world > 1 or args.force_sharded or standin
+    sharded = world > 1 or args.force_sharded or selftest
     dist = None
     if sharded:
         import torch.distributed as dist
         import datetime
         limit = datetime.timedelta(seconds=120)             # a collective that does not complete in two minutes aborts the rank (RCCL watchdog)
-        if standin:
+        if selftest:
             if world == 1:
                 os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
                 os.environ.setdefault('MASTER_PORT', '29672')
@@ -635,7 +647,7 @@ def main():
     if sharded and args.exchange == 'tune':
         # Both exchanges give the same gradients (tests/); which is faster depends on the world size and
         # the fabric.  Time a few untimed steps of each, agree on the MAX over ranks, keep the winner.
-        n_try, n_tune = (1, 2) if standin else (3, 8)
+        n_try, n_tune = (1, 2) if selftest else (3, 8)
         for mode in ('dense', 'sparse'):
             exchange[0] = mode
             failed, elapsed = 0.0, float('inf')
@@ -744,7 +756,7 @@ def main():
     if sharded:
         rec = AD.PhaseRecorder()
         AD.set_phase_recorder(rec)
-        for _ in range(2 if standin else 10):
+        for _ in range(2 if selftest else 10):
             rec.begin()
             step()
             rec.mark('autograd_tail')
@@ -765,17 +777,18 @@ def main():
     # compact problem in the backward), so ops.set_backward_precision applies to it as to the single-GPU node
     bwd_mode = args.bwd_partners
     if rank == 0:
-        roof = kernel_roofline(im.detach(), s.detach(), il, sl) if not standin else {'bound': 'mfma', 'note': 'not measured: CPU stand-ins'}
+        roof = kernel_roofline(im.detach(), s.detach(), il, sl) if not selftest else {'bound': 'mfma', 'note': 'not measured: self-test mode'}
         cfg = {'workload': ('CPU STAND-INS (tests/helpers/cpu_standins.py) under gloo at B=%d/rank, D=%d: the multi-rank step loop, not a measurement; ' % (B, D) if standin else '') +
+                           ('SHARED-GPU SELF-TEST: %d ranks on ONE GPU (real kernels, gloo exchange) at B=%d/rank: the multi-rank step loop, not a measurement; ' % (world, B) if shared else '') +
                            'configs[1]: alignment-head triplet loss forward+backward, B=256 synthetic '
                            'features per GPU (R=34,T=50,D=768, full lengths)' +
                            ('' if world == 1 else '; configs[3]: global %dx%d matrix, images all-gathered '
-                            'over RCCL, caption-block sharding' % (B * world, B * world)),
+                            'over %s, caption-block sharding' % (B * world, B * world, 'gloo (self-test)' if selftest else 'RCCL')),
                'global_pairs_per_step': pairs, 'loss': float(loss.detach()), 'launch': launch, 'bwd_partners': bwd_mode, 'bwd_exact_ms_per_step': bwd_exact_ms, 'backward_seed': 'preallocated ones',
                'launch_trial_ms': launch_trial, 'hip_env': {'DEBUG_CLR_GRAPH_PACKET_CAPTURE': os.environ.get('DEBUG_CLR_GRAPH_PACKET_CAPTURE')},
                'timing': {'preroll_s': args.preroll_s, 'preroll_steps': n_pre, 'repeats': len(region_ms), 'statistic': 'median',
                           'ms_per_step_min': round(min(region_ms), 4), 'ms_per_step_max': round(max(region_ms), 4)},
-               'step_tflops_algorithmic': round(value * FLOPS_PER_PAIR / 1e12, 2) if not standin else None}
+               'step_tflops_algorithmic': round(value * FLOPS_PER_PAIR / 1e12, 2) if not selftest else None}
         if sharded:
             cfg['collectives'] = {'backend': dist.get_backend(), 'ranks': dist.get_world_size(),
                                   'launcher': 'self (aladin_amd.launch)' if os.environ.get('ALADIN_SELF_LAUNCHED') else 'external'}
@@ -784,7 +797,7 @@ def main():
             cfg['phases_ms'] = phases          # rank 0's device timeline of one step (10-step mean), see PhaseRecorder
         if standin:
             cfg['standin_calls'] = dict(cpu_standins.CALLS)
-        if world == 1 and not args.no_eval and not standin:
+        if world == 1 and not args.no_eval and not selftest:
             sys.path.insert(0, os.path.join(ROOT, 'tools'))
             import benchlib
             for key, fn in (('eval_config3', eval_config3), ('shipped_shape', shipped_shape_step), ('loss_heads_bs32', benchlib.loss_heads_bs32),
@@ -803,15 +816,15 @@ def main():
         cfg['library'] = library_sources()
         # the three fractions of the 16-bit MFMA peak side by side: the score kernel alone (`frac`), the forward chain
         # pack + side GEMM + score kernel (`forward_chain_frac`), the whole timed step forward + backward (`step_frac`)
-        if not standin:
+        if not selftest:
             roof['step_frac'] = round(value * FLOPS_PER_PAIR / world / 1e12 / PEAK_TFLOPS, 4)
         out = {
             'metric': 'alignment image-text pairs/sec (BxB scores, triplet loss fwd+bwd) at B=256/GPU,R=34,T=50,D=768',
-            'value': round(value, 1) if not standin else 0.0, 'unit': 'pairs/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'value': round(value, 1) if not selftest else 0.0, 'unit': 'pairs/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(ms, 4), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f16', 'data': 'synthetic' if not standin else 'cpu-standin', 'config': cfg, 'roofline': roof,
+            'dtype': 'f16', 'data': 'cpu-standin' if standin else ('shared-gpu-selftest' if shared else 'synthetic'), 'config': cfg, 'roofline': roof,
         }
-        if world == 1 and not args.no_cpu_baseline and not standin:
+        if world == 1 and not args.no_cpu_baseline and not selftest:
             out['cpu_baseline'] = cpu_baseline(live_b256=not args.no_cpu_b256)
         print(json.dumps(out), flush=True)
     if sharded:

@@ -1,0 +1,39 @@
+"""Worker of tests/test_gpu_parity.py::test_fast_sharded_node_across_processes_on_one_gpu: one RANK of the fast sharded step with the REAL
+HIP kernels.  No node with more than one GPU has been available to this build, and RCCL refuses two ranks on one device -- so the ranks
+are separate processes that share cuda:0 and exchange through gloo (which stages device tensors through the host): every line of
+aladin_amd.distributed._ShardedTriplet runs at W > 1 on real operands -- segment views into ONE gathered buffer, remote blocks scored from
+their segments in place, the score-block permute, the dense exchange (reduce-scatter = all-reduce + slice under gloo) and the pair-driven
+one (all-to-all staged through the host under gloo) -- only the transport differs from the 8-GPU run."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def worker(rank, world, port, shape, exchanges, bwd_mode, ret):
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    import torch
+    import torch.distributed as dist
+    from aladin_amd import distributed as AD, ops, synth
+    torch.cuda.set_device(0)
+    dev = torch.device('cuda:0')
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    ops.set_backward_precision(bwd_mode)
+    B, R, T, D, ragged = shape
+    im, s, il, sl = synth.structured_alignment_batch(B * world, R, T, D, seed=4321 + world, noise=3.0, ragged=ragged)
+    blk = slice(rank * B, (rank + 1) * B)
+    out = {}
+    for exchange in exchanges:
+        a = torch.from_numpy(im[blk].copy()).to(dev).requires_grad_(True)
+        b = torch.from_numpy(s[blk].copy()).to(dev).requires_grad_(True)
+        loss, S = AD.sharded_alignment_loss_fast(a, b, il[blk], sl[blk], 0.2, True, exchange=exchange)
+        took_sparse = loss.grad_fn.exchange is not None
+        (loss * 0.5).backward()
+        torch.cuda.synchronize()
+        out[exchange] = (loss.detach().cpu(), S.cpu() if rank == 0 else None, float(S.double().sum()), a.grad.cpu(), b.grad.cpu(), took_sparse)
+    ret[rank] = out
+    dist.barrier()
+    dist.destroy_process_group()

@@ -59,6 +59,37 @@ def test_bench_sharded_step_on_one_rank():
     assert c['loss'] == d0['config']['loss']                           # the global-batch loss of one rank IS the single-device loss
 
 
+def test_bench_four_ranks_sharing_this_gpu_run_the_real_sharded_step():
+    """`bench.py --gpus 4 --shared-gpu`: the driver-facing script's multi-rank path with the REAL kernels on a one-GPU box -- self-launch
+    (aladin_amd.launch), four ranks on cuda:0, gloo for the exchange (RCCL refuses two ranks per device), the real step loop, exchange
+    tuning (dense reduce-scatter AND pair-driven all-to-all), PhaseRecorder, watchdog, ONE JSON line.  The global loss must be the
+    single-device loss of the concatenated 256-sample batch, bit for bit (every rank scores its caption block with the same kernels)."""
+    import numpy as np
+    import torch
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '4', '--shared-gpu', '--steps', '3', '--warmup', '1'],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = json.loads([l for l in p.stdout.splitlines() if l.strip()][-1])
+    c = d['config']
+    assert d['n_gpus'] == 4 and d['data'] == 'shared-gpu-selftest' and d['value'] == 0.0 and 'SHARED-GPU SELF-TEST' in c['workload']
+    assert c['collectives'] == {'backend': 'gloo', 'ranks': 4, 'launcher': 'self (aladin_amd.launch)'}
+    assert set(c['bwd_exchange_tuning_ms']) == {'dense', 'sparse'} and all(v for v in c['bwd_exchange_tuning_ms'].values())
+    assert c['bwd_partners'] == 'fp16' and c['library']['current'] is True
+    for phase in ('pack+issue_gathers', 'local_block', 'gather_wait', 'remote_rows', 'S_allgather', 'hinge', 'bwd_start'):
+        assert phase in c['phases_ms'], phase
+    from aladin_amd import synth
+    from aladin_amd.loss import AlignmentContrastiveLoss
+    parts = [synth.alignment_batch(64, 34, 50, 768, seed=1234 + 17 * r, ragged=False) for r in range(4)]
+    dev = torch.device('cuda:0')
+    im = torch.from_numpy(np.concatenate([q[0] for q in parts])).to(dev)
+    s = torch.from_numpy(np.concatenate([q[1] for q in parts])).to(dev)
+    loss = AlignmentContrastiveLoss(0.2, 'dot', True, 'MrSw')(im, s, sum((q[2] for q in parts), []), sum((q[3] for q in parts), []))
+    assert c['loss'] == float(loss)
+
+
 def _bench_raw(*args, timeout=900):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
     p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '20', '--warmup', '5', '--repeats', '1', '--preroll-s', '0.3'] + list(args),

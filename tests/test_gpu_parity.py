@@ -2059,6 +2059,51 @@ def test_sharded_fast_path_under_rccl_world1(bwd_mode):
             dist.destroy_process_group()
 
 
+@pytest.mark.parametrize('world,shape,exchanges,bwd_mode', [(2, (64, 34, 50, 768, True), ('dense', 'sparse', 'auto'), 'fp16'),
+                                                            (2, (64, 34, 50, 768, True), ('dense', 'sparse'), 'exact'),
+                                                            (4, (32, 51, 38, 256, True), ('auto', 'dense'), 'fp16'),
+                                                            (3, (64, 34, 50, 128, False), ('sparse',), 'fp16'),
+                                                            (8, (64, 34, 50, 256, False), ('auto',), 'fp16')])
+def test_fast_sharded_node_across_processes_on_one_gpu(world, shape, exchanges, bwd_mode, eval_precision):
+    """The fast sharded step with the REAL kernels at W = 2, 3, 4: the ranks are separate processes sharing this GPU, the collectives go
+    through gloo (RCCL refuses two ranks per device; no multi-GPU node exists for this build) -- tests/helpers/gpu_shard_worker.py.
+    Against the single-device step on the concatenated batch: the global score matrix and the loss BIT for bit on every rank, the
+    gradients of every rank's own samples to 1e-5 (dense and pair-driven exchange, both backward row steps), 'auto' taking the
+    pair-driven exchange from W = 4."""
+    if eval_precision != 'fp16':
+        pytest.skip('training step; run once')
+    import os
+    import sys
+    import torch.multiprocessing as mp
+    from aladin_amd import ops, synth
+    from aladin_amd.loss import AlignmentContrastiveLoss
+    ops.set_backward_precision(bwd_mode)                   # (restored by the autouse fixture) the single-device reference below runs in the ranks' mode
+    helpers = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'helpers')
+    if helpers not in sys.path:
+        sys.path.insert(0, helpers)
+    import gpu_shard_worker
+    B, R, Tn, D, ragged = shape
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 38500 + (os.getpid() % 2000) + world
+    mp.spawn(gpu_shard_worker.worker, args=(world, port, shape, exchanges, bwd_mode, ret), nprocs=world, join=True)
+    im, s, il, sl = synth.structured_alignment_batch(B * world, R, Tn, D, seed=4321 + world, noise=3.0, ragged=ragged)
+    a, b = T(im).requires_grad_(True), T(s).requires_grad_(True)
+    ref_loss, ref_S = AlignmentContrastiveLoss(0.2, 'dot', True, 'MrSw')(a, b, il, sl, return_similarity_mat=True)
+    (ref_loss * 0.5).backward()
+    ga, gb = a.grad.cpu().numpy(), b.grad.cpu().numpy()
+    scale = float(np.abs(ga).max())
+    for exchange in exchanges:
+        want_sparse = exchange == 'sparse' or (exchange == 'auto' and world >= 4)
+        assert torch.equal(ret[0][exchange][1], ref_S.detach().cpu())                       # the gathered global matrix = the single-device one, bit for bit
+        for r in range(world):
+            loss_r, _, S_sum, d_a, d_b, took_sparse = ret[r][exchange]
+            assert took_sparse == want_sparse
+            assert torch.equal(loss_r, ref_loss.detach().cpu()) and S_sum == ret[0][exchange][2]
+            np.testing.assert_allclose(d_a.numpy(), ga[r * B:(r + 1) * B], rtol=1e-5, atol=1e-6 * scale)
+            np.testing.assert_allclose(d_b.numpy(), gb[r * B:(r + 1) * B], rtol=1e-5, atol=1e-6 * scale)
+
+
 @pytest.mark.parametrize('loss_type,weights', [('alignment-distillation', [1, 1]), ('alignment-distillation-matching', [1, 1, 0.1]),
                                                ('matching', [1]), ('alignment', [1])])
 def test_sharded_model_step_under_rccl_world1(loss_type, weights, eval_precision):
