@@ -37,3 +37,40 @@ def worker(rank, world, port, shape, exchanges, bwd_mode, ret):
     ret[rank] = out
     dist.barrier()
     dist.destroy_process_group()
+
+
+def model_worker(rank, world, port, B, loss_type, weights, epochs, bwd_mode, ret):
+    """One rank of ALADModel(config, shard_group=None).forward_loss_total -- every loss head of the shipped YAMLs on the GLOBAL batch --
+    with the real kernels, ranks sharing cuda:0 over gloo."""
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    import torch
+    import torch.distributed as dist
+    from aladin_amd import ops, synth
+    from aladin_amd.alad_model import ALADModel
+    from aladin_amd.evaluation import LogCollector
+    torch.cuda.set_device(0)
+    dev = torch.device('cuda:0')
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    ops.set_backward_precision(bwd_mode)
+    config = {'training': {'loss-type': loss_type, 'loss-weights': weights, 'margin': 0.2, 'measure': 'dot',
+                           'max-violation': True, 'alignment-mode': 'MrSw', 'distillation-mode': 'listnet'}}
+    im, s, il, sl = synth.structured_alignment_batch(B * world, 34, 50, 768, seed=977, noise=3.0, ragged=True)
+    ie, ce = synth.global_embeddings(B * world, 768, seed=978, noise=3.0)
+    blk = slice(rank * B, (rank + 1) * B)
+    out = []
+    for epoch in epochs:
+        m = ALADModel(config, shard_group=None)
+        m.logger = LogCollector()
+        leaves = [torch.from_numpy(x[blk].copy()).to(dev).requires_grad_(True) for x in (ie, ce, im, s)]
+        loss, d = m.forward_loss_total(leaves[0], leaves[1], leaves[2].permute(1, 0, 2), leaves[3].permute(1, 0, 2), il[blk], sl[blk], 0,
+                                       epoch=epoch, distill_epoch=2)
+        loss.backward()
+        torch.cuda.synchronize()
+        out.append((float(loss), {k: float(v) for k, v in d.items()}, {k: (mm.val, mm.count) for k, mm in m.logger.meters.items()},
+                    [None if t.grad is None else t.grad.cpu() for t in leaves]))
+    ret[rank] = out
+    dist.barrier()
+    dist.destroy_process_group()

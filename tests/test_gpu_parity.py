@@ -2104,6 +2104,59 @@ def test_fast_sharded_node_across_processes_on_one_gpu(world, shape, exchanges, 
             np.testing.assert_allclose(d_b.numpy(), gb[r * B:(r + 1) * B], rtol=1e-5, atol=1e-6 * scale)
 
 
+@pytest.mark.parametrize('world,loss_type,weights,bwd_mode', [(2, 'alignment-distillation', [1, 1], 'fp16'),
+                                                              (4, 'alignment-distillation-matching', [1, 1, 0.1], 'exact')])
+def test_sharded_model_heads_across_processes_on_one_gpu(world, loss_type, weights, bwd_mode, eval_precision):
+    """ALADModel(config, shard_group=None) -- matching hinge, alignment hinge and ListNet of the GLOBAL batch (the shipped distillation
+    YAMLs across ranks) -- with the real kernels at W = 2 and 4: ranks as processes sharing this GPU over gloo.  Total, terms, logger
+    entries (n = the global batch) and every rank's gradients against the single-device model on the concatenated batch, before and
+    after the distillation epoch."""
+    if eval_precision != 'fp16':
+        pytest.skip('training step; run once')
+    import os
+    import sys
+    import torch.multiprocessing as mp
+    from aladin_amd import ops, synth
+    from aladin_amd.alad_model import ALADModel
+    from aladin_amd.evaluation import LogCollector
+    ops.set_backward_precision(bwd_mode)                   # (restored by the autouse fixture) the ranks are fresh processes: they are told the mode
+    helpers = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'helpers')
+    if helpers not in sys.path:
+        sys.path.insert(0, helpers)
+    import gpu_shard_worker
+    B, epochs = 64, (0, 5)
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 39500 + (os.getpid() % 2000) + world
+    mp.spawn(gpu_shard_worker.model_worker, args=(world, port, B, loss_type, weights, epochs, bwd_mode, ret), nprocs=world, join=True)
+    config = {'training': {'loss-type': loss_type, 'loss-weights': weights, 'margin': 0.2, 'measure': 'dot',
+                           'max-violation': True, 'alignment-mode': 'MrSw', 'distillation-mode': 'listnet'}}
+    im, s, il, sl = synth.structured_alignment_batch(B * world, 34, 50, 768, seed=977, noise=3.0, ragged=True)
+    ie, ce = synth.global_embeddings(B * world, 768, seed=978, noise=3.0)
+    for k, epoch in enumerate(epochs):
+        m = ALADModel(config)
+        m.logger = LogCollector()
+        leaves = [T(x).requires_grad_(True) for x in (ie, ce, im, s)]
+        loss, d = m.forward_loss_total(leaves[0], leaves[1], leaves[2].permute(1, 0, 2), leaves[3].permute(1, 0, 2), il, sl, 0, epoch=epoch, distill_epoch=2)
+        loss.backward()
+        for r in range(world):
+            loss_r, d_r, log_r, grads_r = ret[r][k]
+            np.testing.assert_allclose(loss_r, float(loss), rtol=2e-6)
+            assert list(d_r) == list(d)
+            for key in d:
+                np.testing.assert_allclose(d_r[key], float(d[key]), rtol=2e-6)
+            assert list(log_r) == list(m.logger.meters)
+            for key, mm in m.logger.meters.items():
+                np.testing.assert_allclose(log_r[key][0], mm.val, rtol=2e-6)
+                assert log_r[key][1] == mm.count                                        # n = the global batch size on every rank
+            for got, leaf in zip(grads_r, leaves):
+                if leaf.grad is None or got is None:
+                    assert (got is None or not bool(got.any())) and (leaf.grad is None or not bool(leaf.grad.any()))
+                    continue
+                want = leaf.grad[r * B:(r + 1) * B].cpu().numpy()
+                np.testing.assert_allclose(got.numpy(), want, rtol=1e-5, atol=1e-6 * float(np.abs(want).max()) + 1e-12)
+
+
 @pytest.mark.parametrize('loss_type,weights', [('alignment-distillation', [1, 1]), ('alignment-distillation-matching', [1, 1, 0.1]),
                                                ('matching', [1]), ('alignment', [1])])
 def test_sharded_model_step_under_rccl_world1(loss_type, weights, eval_precision):
