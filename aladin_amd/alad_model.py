@@ -83,7 +83,8 @@ class ALADModel(nn.Module):
 
     @logger.setter
     def logger(self, value):
-        if self._graph_step is not None:
+        # (alad/train.py:413 re-assigns the SAME collector every iteration: nothing to deliver then, and no host wait)
+        if self._graph_step is not None and value is not self._logger:
             self._graph_step.flush()                                  # outstanding values belong to the logger that was current
         self._logger = value
 
